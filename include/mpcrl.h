@@ -1,0 +1,122 @@
+/* mpcrl.h — C ABI of the MI355X-native batched MPC-as-policy engine (libmpcrl_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of MPC-Based-Reinforcement-Learning/mpc4rl:
+ *
+ *   reference interface replaced                               entry point here
+ *   --------------------------------------------------------   ---------------------------------
+ *   AcadosOcpSolver(ocp) + build_nlp(ocp)                      mpcrl_create
+ *     rlmpc/mpc/cartpole/acados.py:192-203,
+ *     rlmpc/mpc/linear_system/acados.py:20-22,126-129,
+ *     rlmpc/mpc/chain_mass/acados.py:27-29,45
+ *   ocp_solver.set(stage,"p",..) / cost_set(..)                mpcrl_set_theta
+ *     rlmpc/mpc/common/mpc.py:137-154,212-257
+ *   shared_lib.ocp_nlp_cost_model_set(.., "scaling", gamma^k)  mpcrl_set_gamma
+ *     rlmpc/mpc/common/mpc.py:259-285  (the reference's one raw C call)
+ *   ocp_solver.reset(); set(stage,"x",x0)                      mpcrl_reset
+ *     rlmpc/mpc/common/mpc.py:204-210
+ *   set(0,"lbx"/"ubx",x0) [+ constraints_set(0,"lbu"/"ubu",u0)];   mpcrl_solve
+ *   ocp_solver.solve(); get(0,"u"); get_cost(); update_nlp()
+ *     rlmpc/mpc/common/mpc.py:27-50,52-96,177-202 and
+ *     rlmpc/mpc/nlp.py:1341-1424 (dL_dp, dpi_dp)
+ *   ocp_solver.get(stage, "x"|"u"|"pi"|"lam"|"t"|"sl"|"su")   mpcrl_get_iterate
+ *   ocp_solver.set(stage, "x"|"u"|"pi", v) / load_iterate      mpcrl_set_iterate
+ *     rlmpc/mpc/nlp.py:1354-1372, rlmpc/examples/chain_mass.py:119-120
+ *
+ * Conventions
+ *   - plain C, no torch types.  Every array argument of mpcrl_solve / *_iterate / mpcrl_reset /
+ *     mpcrl_set_theta is a DEVICE pointer (HIP), double precision, row-major, owned by the caller.
+ *   - the handle owns the warm-start iterate and all workspace; mpcrl_solve allocates nothing and is
+ *     asynchronous on the given HIP stream.
+ *   - return value: 0 ok, < 0 API misuse (MPCRL_E_*).  Per-instance solver status goes to status[B]
+ *     with acados' numbering: 0 success, 1 NaN, 2 max-iter, 4 QP failure (reference: solve() returns
+ *     int status, update/q_update raise on != 0, rlmpc/mpc/common/mpc.py:81-83,197-198).
+ *   - one handle per (device, stream); handles are independent across GPUs; not re-entrant (stateful
+ *     warm start, like the reference's solver object).
+ */
+#ifndef MPCRL_H
+#define MPCRL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MPCRL_MODEL_CARTPOLE = 0, MPCRL_MODEL_LINEAR = 1, MPCRL_MODEL_CHAIN = 2 };
+/* how the stage-cost scaling c_k is built (rlmpc/mpc/nlp.py:1044-1055 vs 1083-1091) */
+enum { MPCRL_COST_NLS = 0, MPCRL_COST_EXTERNAL = 1 };
+/* mpcrl_solve flags */
+enum {
+    MPCRL_SENS_V = 1,  /* dV/dp (or dQ/dp with u0_fixed)  = dL/dp   nlp.py:1211,1401 */
+    MPCRL_SENS_PI = 2, /* du0* / dp                        nlp.py:1413-1424 */
+    MPCRL_RTI = 4,     /* one SQP iteration from the stored iterate (build-side mode; the reference always runs full SQP) */
+    MPCRL_COLD = 8     /* ignore the stored iterate: x_k = x0, u = 0, multipliers 0 (MPC.reset, mpc.py:204-210) */
+};
+enum { MPCRL_E_ARG = -1, MPCRL_E_MODEL = -2, MPCRL_E_HIP = -3, MPCRL_E_NOMEM = -4 };
+
+#define MPCRL_NO_BOUND 1e30 /* |bound| >= 1e29 means "absent" */
+
+typedef struct {
+    int32_t model;     /* MPCRL_MODEL_* */
+    int32_t N;         /* horizon */
+    int32_t nx, nu;    /* must match the model */
+    int32_t np;        /* length of the full parameter vector p (reference order, nlp.py:969-989) */
+    int32_t cost_kind; /* MPCRL_COST_* */
+    double dT;         /* tf / N  (nlp.py:1163-1164) */
+    double gamma;      /* discount factor */
+    double h;          /* RK4 sub-step */
+    int32_t rk_steps;  /* RK4 steps per shooting interval */
+    double tol;        /* NLP residual tolerance (acados default 1e-6; chain 1e-5) */
+    int32_t max_iter;  /* SQP iterations (nlp_solver_max_iter) */
+    /* box bounds, HOST pointers, stage-vector order v = [u; x] */
+    const double *lb0, *ub0; /* nu      : controls at stage 0 */
+    const double *lb, *ub;   /* nu + nx : stages 1..N-1 */
+    const double *lbe, *ube; /* nx      : stage N */
+    const int32_t *soft;     /* nu + nx : 1 = L1-soft bound (idxsbx), may be NULL */
+    const double *zl, *zu;   /* nu + nx : L1 weights of soft bounds, may be NULL */
+    const double *consts;    /* model constants, HOST pointer (layout: DESIGN.md "model constants") */
+    int32_t n_consts;
+} MpcrlProblemSpec;
+
+typedef struct MpcrlSolver *mpcrl_handle;
+
+/* Creates a solver for `batch` independent OCP instances on HIP device `device`.  Copies the spec. */
+int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_handle *out);
+int mpcrl_destroy(mpcrl_handle h);
+
+/* theta: device pointer to np doubles (per_instance = 0, shared) or batch*np (per_instance = 1). */
+int mpcrl_set_theta(mpcrl_handle h, const double *theta, int n_theta, int per_instance, void *stream);
+int mpcrl_set_gamma(mpcrl_handle h, double gamma);
+int mpcrl_set_options(mpcrl_handle h, double tol, int max_iter);
+
+/* Cold iterate: x_k := x0 for all k, u := 0, all multipliers 0. x0: [B, nx] device. */
+int mpcrl_reset(mpcrl_handle h, const double *x0, void *stream);
+
+/* Solves all instances.
+ *   x0        [B, nx]            initial states
+ *   u0_fixed  [B, nu] or NULL    NULL: policy / V mode; else Q(s,a) mode (lbu_0 = ubu_0 = u0)
+ *   u0_out    [B, nu]            u_0*
+ *   V         [B]                optimal cost (V or Q)
+ *   dV_dp     [B, np] or NULL    needs MPCRL_SENS_V
+ *   dpi_dp    [B, nu, np] or NULL needs MPCRL_SENS_PI
+ *   status    [B] int32          0 success, 1 NaN, 2 max-iter, 4 QP failure
+ *   iters     [B, 2] int32 or NULL   SQP iterations, total interior-point iterations
+ */
+int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int flags, double *u0_out, double *V,
+                double *dV_dp, double *dpi_dp, int32_t *status, int32_t *iters, void *stream);
+
+/* Iterate access (device arrays; any may be NULL).
+ *   x [B, N+1, nx]; u [B, N, nu]; pi [B, N, nx] (pi[k] multiplies F(x_k,u_k) - x_{k+1}, nlp.py:827,1180)
+ *   bnd [B, 10, N+1, nu+nx]: lam_l, lam_u, t_l, t_u, s_l, s_u, lam_sl, lam_su, t_sl, t_su
+ *   res [B, 4]: stationarity, equality, inequality, complementarity residual of the last solve */
+int mpcrl_get_iterate(mpcrl_handle h, double *x, double *u, double *pi, double *bnd, double *res, void *stream);
+int mpcrl_set_iterate(mpcrl_handle h, const double *x, const double *u, const double *pi, const double *bnd, void *stream);
+
+/* Bytes of device memory held by the handle; library version. */
+int64_t mpcrl_workspace_bytes(mpcrl_handle h);
+int mpcrl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCRL_H */

@@ -1,0 +1,62 @@
+"""ctypes binding of libmpcrl_hip.so (include/mpcrl.h).  Fails loudly when the library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpcrl_hip.so")
+
+SENS_V, SENS_PI, RTI, COLD = 1, 2, 4, 8
+MODEL_CARTPOLE, MODEL_LINEAR, MODEL_CHAIN = 0, 1, 2
+COST_NLS, COST_EXTERNAL = 0, 1
+NO_BOUND = 1e30
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class ProblemSpec(C.Structure):
+    """MpcrlProblemSpec of include/mpcrl.h."""
+    _fields_ = [
+        ("model", C.c_int32), ("N", C.c_int32), ("nx", C.c_int32), ("nu", C.c_int32), ("np", C.c_int32),
+        ("cost_kind", C.c_int32), ("dT", C.c_double), ("gamma", C.c_double), ("h", C.c_double), ("rk_steps", C.c_int32),
+        ("tol", C.c_double), ("max_iter", C.c_int32),
+        ("lb0", _dp), ("ub0", _dp), ("lb", _dp), ("ub", _dp), ("lbe", _dp), ("ube", _dp),
+        ("soft", _ip), ("zl", _dp), ("zu", _dp), ("consts", _dp), ("n_consts", C.c_int32),
+    ]
+
+
+EXPORTS = ["mpcrl_create", "mpcrl_destroy", "mpcrl_set_theta", "mpcrl_set_gamma", "mpcrl_set_options", "mpcrl_reset",
+           "mpcrl_solve", "mpcrl_get_iterate", "mpcrl_set_iterate", "mpcrl_workspace_bytes", "mpcrl_version"]
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises RuntimeError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"mpc4rl_amd: {LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.mpcrl_create.argtypes = [C.POINTER(ProblemSpec), C.c_int, C.c_int, C.POINTER(vp)]
+    lib.mpcrl_destroy.argtypes = [vp]
+    lib.mpcrl_set_theta.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    lib.mpcrl_set_gamma.argtypes = [vp, C.c_double]
+    lib.mpcrl_set_options.argtypes = [vp, C.c_double, C.c_int]
+    lib.mpcrl_reset.argtypes = [vp, vp, vp]
+    lib.mpcrl_solve.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    lib.mpcrl_get_iterate.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.mpcrl_set_iterate.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.mpcrl_workspace_bytes.argtypes = [vp]
+    lib.mpcrl_workspace_bytes.restype = C.c_int64
+    for name in EXPORTS:
+        if name != "mpcrl_workspace_bytes":
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib

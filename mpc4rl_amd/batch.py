@@ -1,0 +1,150 @@
+"""MPCBatch — the batched extension of the reference's MPC surface: B OCP instances per call.
+
+``rlmpc.td3.policies.Actor.forward`` loops ``mpc.get_action`` over the observation batch in Python
+(rlmpc/td3/policies.py:186-197) and the Q-learning example loops ``q_update``/``update`` over replay samples
+(rlmpc/examples/linear_system_mpc_qlearning.py:178-190).  Here each of those loops is ONE call that issues one
+kernel launch through the C ABI (include/mpcrl.h); inputs and outputs are torch tensors on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .problems import OcpDescription
+
+
+@dataclass
+class SolveResult:
+    u0: torch.Tensor                 # [B, nu]   u_0*
+    V: torch.Tensor                  # [B]       optimal cost (V, or Q when u0 was fixed)
+    status: torch.Tensor             # [B] int32 0 success, 1 NaN, 2 max-iter, 4 QP failure
+    iters: torch.Tensor              # [B, 2] int32  SQP iterations, interior-point iterations
+    dV_dp: Optional[torch.Tensor]    # [B, n_p]
+    dpi_dp: Optional[torch.Tensor]   # [B, nu, n_p]
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class MPCBatch:
+    """B independent instances of one OCP on one GPU.  The handle keeps the warm-start iterate of every
+    instance (like the reference's solver object keeps its single iterate)."""
+
+    def __init__(self, ocp: OcpDescription, batch: int, device: Optional[torch.device] = None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("mpc4rl_amd.MPCBatch needs a HIP device; there is no CPU fallback.")
+        self.ocp = ocp
+        self.B = int(batch)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.nx, self.nu, self.N, self.n_p = ocp.nx, ocp.nu, ocp.N, ocp.n_p
+        spec, keep = ocp.c_spec()
+        h = C.c_void_p()
+        rc = self.lib.mpcrl_create(C.byref(spec), self.B, self.device.index or 0, C.byref(h))
+        del keep
+        if rc != 0:
+            raise RuntimeError(f"mpcrl_create failed with {rc}")
+        self._h = h
+        self._theta = None
+        self.set_theta(torch.as_tensor(ocp.p0, dtype=torch.float64))
+        self.gamma = ocp.gamma
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self.lib.mpcrl_destroy(h)
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, t, shape) -> torch.Tensor:
+        t = torch.as_tensor(t, dtype=torch.float64, device=self.device).reshape(shape).contiguous()
+        return t
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed with {rc}")
+
+    # ------------------------------------------------------------------ parameters / options
+    def set_theta(self, theta) -> None:
+        """theta: [n_p] (shared) or [B, n_p] (per instance).  Mirrors MPC.set_p / set_parameter (mpc.py:137-154,233-257)."""
+        t = torch.as_tensor(theta, dtype=torch.float64, device=self.device).contiguous()
+        per = int(t.dim() == 2)
+        if t.shape[-1] != self.n_p or (per and t.shape[0] != self.B):
+            raise ValueError(f"theta must be [{self.n_p}] or [{self.B}, {self.n_p}]")
+        self._theta = t
+        with torch.cuda.device(self.device):
+            self._check(self.lib.mpcrl_set_theta(self._h, _ptr(t), self.n_p, per, self._stream()), "mpcrl_set_theta")
+
+    def get_theta(self) -> torch.Tensor:
+        return self._theta
+
+    def set_discount_factor(self, gamma: float) -> None:
+        """MPC.set_discount_factor (mpc.py:259-285)."""
+        self.gamma = float(gamma)
+        self._check(self.lib.mpcrl_set_gamma(self._h, float(gamma)), "mpcrl_set_gamma")
+
+    def set_options(self, tol: float = -1.0, max_iter: int = -1) -> None:
+        self._check(self.lib.mpcrl_set_options(self._h, float(tol), int(max_iter)), "mpcrl_set_options")
+
+    def reset(self, x0=None) -> None:
+        """MPC.reset (mpc.py:204-210): the next solve starts from x_k = x0, u = 0, multipliers 0."""
+        self._check(self.lib.mpcrl_reset(self._h, None, self._stream()), "mpcrl_reset")
+
+    # ------------------------------------------------------------------ the hot path
+    def solve(self, x0, u0=None, sens_v: bool = False, sens_pi: bool = False, rti: bool = False, cold: bool = False) -> SolveResult:
+        x0 = self._dev(x0, (self.B, self.nx))
+        u0f = None if u0 is None else self._dev(u0, (self.B, self.nu))
+        flags = (_lib.SENS_V if sens_v else 0) | (_lib.SENS_PI if sens_pi else 0) | (_lib.RTI if rti else 0) | \
+            (_lib.COLD if cold else 0)
+        kw = dict(dtype=torch.float64, device=self.device)
+        u0_out = torch.empty((self.B, self.nu), **kw)
+        V = torch.empty((self.B,), **kw)
+        dV = torch.empty((self.B, self.n_p), **kw) if sens_v else None
+        dpi = torch.empty((self.B, self.nu, self.n_p), **kw) if sens_pi else None
+        status = torch.empty((self.B,), dtype=torch.int32, device=self.device)
+        iters = torch.empty((self.B, 2), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.mpcrl_solve(self._h, _ptr(x0), _ptr(u0f), flags, _ptr(u0_out), _ptr(V), _ptr(dV), _ptr(dpi),
+                                      _ptr(status), _ptr(iters), self._stream())
+        self._check(rc, "mpcrl_solve")
+        return SolveResult(u0_out, V, status, iters, dV, dpi)
+
+    def get_action(self, x0) -> torch.Tensor:
+        """Batched MPC.get_action (mpc.py:27-50)."""
+        return self.solve(x0).u0
+
+    # ------------------------------------------------------------------ iterate access
+    def get_iterate(self):
+        """x [B,N+1,nx], u [B,N,nu], pi [B,N,nx], bnd [B,10,N+1,nu+nx], res [B,4] (layouts of include/mpcrl.h)."""
+        kw = dict(dtype=torch.float64, device=self.device)
+        nw = self.nx + self.nu
+        x = torch.empty((self.B, self.N + 1, self.nx), **kw)
+        u = torch.empty((self.B, self.N, self.nu), **kw)
+        pi = torch.empty((self.B, self.N, self.nx), **kw)
+        bnd = torch.empty((self.B, 10, self.N + 1, nw), **kw)
+        res = torch.empty((self.B, 4), **kw)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.mpcrl_get_iterate(self._h, _ptr(x), _ptr(u), _ptr(pi), _ptr(bnd), _ptr(res), self._stream()),
+                        "mpcrl_get_iterate")
+        return x, u, pi, bnd, res
+
+    def set_iterate(self, x, u, pi, bnd=None) -> None:
+        nw = self.nx + self.nu
+        x = self._dev(x, (self.B, self.N + 1, self.nx))
+        u = self._dev(u, (self.B, self.N, self.nu))
+        pi = self._dev(pi, (self.B, self.N, self.nx))
+        bnd = None if bnd is None else self._dev(bnd, (self.B, 10, self.N + 1, nw))
+        with torch.cuda.device(self.device):
+            self._check(self.lib.mpcrl_set_iterate(self._h, _ptr(x), _ptr(u), _ptr(pi), _ptr(bnd), self._stream()),
+                        "mpcrl_set_iterate")
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.mpcrl_workspace_bytes(self._h))

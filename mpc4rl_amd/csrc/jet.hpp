@@ -1,0 +1,221 @@
+// Forward-mode derivative scalars for the device-side model code (gfx950, fp64).
+//
+//   Jet1<N> : value + N first-order tangents.                                      A_k, B_k, dF/dtheta
+//   Jet2<N> : value, one "inner" tangent e (direction y), N "outer" tangents g_i,
+//             and the mixed second-order terms m_i = d/d eps ( d f / d v_i ) along y.   Hessian-vector products
+//
+// Jet2 is the flattened form of a dual-of-dual; carrying only ONE inner direction keeps the
+// register footprint at 2N+2 doubles per scalar, which is what lets a whole RK4 step of the stage
+// dynamics stay in VGPRs of a single lane.  All loops are compile-time so nothing is runtime-indexed.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mpcrl {
+
+#define MPCRL_DI __device__ __forceinline__
+
+template <int N>
+struct Jet1 {
+    double v;
+    double d[N];
+    MPCRL_DI Jet1() {}
+    MPCRL_DI Jet1(double c) : v(c) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) d[i] = 0.0;
+    }
+};
+
+template <int N>
+MPCRL_DI Jet1<N> operator+(const Jet1<N> &a, const Jet1<N> &b) {
+    Jet1<N> r;
+    r.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i];
+    return r;
+}
+template <int N>
+MPCRL_DI Jet1<N> operator-(const Jet1<N> &a, const Jet1<N> &b) {
+    Jet1<N> r;
+    r.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i];
+    return r;
+}
+template <int N>
+MPCRL_DI Jet1<N> operator*(const Jet1<N> &a, const Jet1<N> &b) {
+    Jet1<N> r;
+    r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = fma(a.d[i], b.v, a.v * b.d[i]);
+    return r;
+}
+template <int N>
+MPCRL_DI Jet1<N> operator/(const Jet1<N> &a, const Jet1<N> &b) {
+    Jet1<N> r;
+    const double inv = 1.0 / b.v;
+    r.v = a.v * inv;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+    return r;
+}
+template <int N>
+MPCRL_DI Jet1<N> operator*(double s, const Jet1<N> &a) {
+    Jet1<N> r;
+    r.v = s * a.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = s * a.d[i];
+    return r;
+}
+template <int N>
+MPCRL_DI Jet1<N> operator+(const Jet1<N> &a, double s) {
+    Jet1<N> r = a;
+    r.v += s;
+    return r;
+}
+template <int N>
+MPCRL_DI Jet1<N> operator-(double s, const Jet1<N> &a) {
+    Jet1<N> r;
+    r.v = s - a.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = -a.d[i];
+    return r;
+}
+template <int N>
+MPCRL_DI void jsincos(const Jet1<N> &a, Jet1<N> &s, Jet1<N> &c) {
+    double sv, cv;
+    sincos(a.v, &sv, &cv);
+    s.v = sv;
+    c.v = cv;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        s.d[i] = cv * a.d[i];
+        c.d[i] = -sv * a.d[i];
+    }
+}
+template <int N>
+MPCRL_DI Jet1<N> jsqrt(const Jet1<N> &a) {
+    Jet1<N> r;
+    r.v = sqrt(a.v);
+    const double h = 0.5 / r.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = h * a.d[i];
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int N>
+struct Jet2 {
+    double v, e;
+    double g[N], m[N];
+    MPCRL_DI Jet2() {}
+    MPCRL_DI Jet2(double c) : v(c), e(0.0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) g[i] = 0.0, m[i] = 0.0;
+    }
+};
+template <int N>
+MPCRL_DI Jet2<N> operator+(const Jet2<N> &a, const Jet2<N> &b) {
+    Jet2<N> r;
+    r.v = a.v + b.v;
+    r.e = a.e + b.e;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.g[i] = a.g[i] + b.g[i], r.m[i] = a.m[i] + b.m[i];
+    return r;
+}
+template <int N>
+MPCRL_DI Jet2<N> operator-(const Jet2<N> &a, const Jet2<N> &b) {
+    Jet2<N> r;
+    r.v = a.v - b.v;
+    r.e = a.e - b.e;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.g[i] = a.g[i] - b.g[i], r.m[i] = a.m[i] - b.m[i];
+    return r;
+}
+template <int N>
+MPCRL_DI Jet2<N> operator*(const Jet2<N> &a, const Jet2<N> &b) {
+    Jet2<N> r;
+    r.v = a.v * b.v;
+    r.e = fma(a.e, b.v, a.v * b.e);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        r.g[i] = fma(a.g[i], b.v, a.v * b.g[i]);
+        r.m[i] = fma(a.m[i], b.v, fma(a.g[i], b.e, fma(a.e, b.g[i], a.v * b.m[i])));
+    }
+    return r;
+}
+template <int N>
+MPCRL_DI Jet2<N> jrecip(const Jet2<N> &b) {
+    Jet2<N> r;
+    const double i1 = 1.0 / b.v, i2 = i1 * i1, i3 = 2.0 * i2 * i1;
+    r.v = i1;
+    r.e = -b.e * i2;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        r.g[i] = -b.g[i] * i2;
+        r.m[i] = fma(b.g[i] * b.e, i3, -b.m[i] * i2);
+    }
+    return r;
+}
+template <int N>
+MPCRL_DI Jet2<N> operator/(const Jet2<N> &a, const Jet2<N> &b) {
+    return a * jrecip(b);
+}
+template <int N>
+MPCRL_DI Jet2<N> operator*(double s, const Jet2<N> &a) {
+    Jet2<N> r;
+    r.v = s * a.v;
+    r.e = s * a.e;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.g[i] = s * a.g[i], r.m[i] = s * a.m[i];
+    return r;
+}
+template <int N>
+MPCRL_DI Jet2<N> operator+(const Jet2<N> &a, double s) {
+    Jet2<N> r = a;
+    r.v += s;
+    return r;
+}
+template <int N>
+MPCRL_DI Jet2<N> operator-(double s, const Jet2<N> &a) {
+    Jet2<N> r;
+    r.v = s - a.v;
+    r.e = -a.e;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.g[i] = -a.g[i], r.m[i] = -a.m[i];
+    return r;
+}
+template <int N>
+MPCRL_DI void jsincos(const Jet2<N> &a, Jet2<N> &s, Jet2<N> &c) {
+    double sv, cv;
+    sincos(a.v, &sv, &cv);
+    s.v = sv;
+    c.v = cv;
+    s.e = cv * a.e;
+    c.e = -sv * a.e;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        s.g[i] = cv * a.g[i];
+        c.g[i] = -sv * a.g[i];
+        s.m[i] = fma(cv, a.m[i], -sv * a.e * a.g[i]);
+        c.m[i] = -fma(sv, a.m[i], cv * a.e * a.g[i]);
+    }
+}
+template <int N>
+MPCRL_DI Jet2<N> jsqrt(const Jet2<N> &a) {
+    Jet2<N> r;
+    r.v = sqrt(a.v);
+    const double h = 0.5 / r.v, h2 = -0.5 * h / a.v;
+    r.e = h * a.e;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        r.g[i] = h * a.g[i];
+        r.m[i] = fma(h, a.m[i], h2 * a.e * a.g[i]);
+    }
+    return r;
+}
+
+// plain double overloads so model code can be instantiated for values only
+MPCRL_DI void jsincos(const double &a, double &s, double &c) { sincos(a, &s, &c); }
+MPCRL_DI double jsqrt(double a) { return sqrt(a); }
+
+}  // namespace mpcrl

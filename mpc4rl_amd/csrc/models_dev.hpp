@@ -1,0 +1,168 @@
+// Device-side problem descriptors of the small (register-resident) OCPs.
+//
+// Each model states the reference's problem data as code:
+//   Cartpole  rlmpc/mpc/cartpole/acados.py:71-92 (dynamics as written there: no `l` in temp / x_ddot),
+//             cost y = [x; u], NONLINEAR_LS with numeric W, yref (config/cartpole.yaml:25-51)
+//   Linear    rlmpc/mpc/linear_system/acados.py:27-70 (x+ = A x + B u + b, l = 1/2 y'y + f'y, l_0 = l + V_0,
+//             l_e = 1/2 x' P x with P = DARE(A,B,I,I) numeric)
+//
+// Interface used by small_kernel.hip (stage vector order v = [u; x]):
+//   NX, NU, NP          dims, length of the full parameter vector p (reference order, nlp.py:969-989)
+//   NTD, td_index(i)    parameters the DYNAMICS depend on, and where they sit in p
+//   NTC, tc_index(i)    parameters only the COST depends on
+//   ode<S>(x,u,th,f)    continuous dynamics (or the discrete map when DISCRETE) for S = double | Jet1 | Jet2
+//   cost_val / cost_grad / hess / cost_dp / cost_mixed    UNSCALED stage cost l_k and its derivatives
+#pragma once
+#include "jet.hpp"
+
+namespace mpcrl {
+
+constexpr int SMALL_MAXNW = 8;
+constexpr int SMALL_MAXC = 64;
+
+// Kernel-argument copy of MpcrlProblemSpec (include/mpcrl.h) for the small kernel.  Passed by value, so every
+// constant below is a scalar (SGPR) operand in the kernel.
+struct SmallSpec {
+    int N, np, cost_kind, rk_steps, max_iter;
+    double dT, gamma, h, tol;
+    double lb0[SMALL_MAXNW], ub0[SMALL_MAXNW];   // nu used
+    double lb[SMALL_MAXNW], ub[SMALL_MAXNW];     // nu + nx used, v = [u; x]
+    double lbe[SMALL_MAXNW], ube[SMALL_MAXNW];   // nx used
+    double zl[SMALL_MAXNW], zu[SMALL_MAXNW];
+    int soft[SMALL_MAXNW];
+    double consts[SMALL_MAXC];
+};
+
+struct CartpoleDev {
+    static constexpr int NX = 4, NU = 1, NW = 5, NP = 83, NTD = 3, NTC = 0;
+    static constexpr bool DISCRETE = false, HAS_SOFT = false;
+    MPCRL_DI static int td_index(int i) { return i; }
+    MPCRL_DI static int tc_index(int) { return 0; }
+    // consts: W (5x5 row-major, y = [x;u] order), yref(5), W_e (4x4), yref_e(4)
+    static constexpr int C_W = 0, C_YREF = 25, C_WE = 30, C_YREFE = 46;
+
+    template <class S>
+    MPCRL_DI static void ode(const S *x, const S *u, const S *th, S *f) {
+        const double g = 9.8;   // config/cartpole.yaml:75-78 (fixed)
+        S s, c;
+        jsincos(x[2], s, c);
+        const S mM = th[1] + th[0];
+        const S temp = (u[0] + th[1] * x[3] * x[3] * s) / mM;
+        const S thdd = (g * s - c * temp) / (th[2] * (4.0 / 3.0 - th[1] * c * c / mM));
+        f[0] = x[1];
+        f[1] = temp - th[1] * thdd * c / mM;
+        f[2] = x[3];
+        f[3] = thdd;
+    }
+    MPCRL_DI static int yi(int i) { return i < NU ? NX + i : i - NU; }   // v index -> y index
+    // symmetrised weight between stage-vector coordinates i, j
+    MPCRL_DI static double hess(bool term, int i, int j, const SmallSpec &sp, const double *) {
+        if (term) {
+            if (i < NU || j < NU) return 0.0;
+            return 0.5 * (sp.consts[C_WE + (i - NU) * 4 + (j - NU)] + sp.consts[C_WE + (j - NU) * 4 + (i - NU)]);
+        }
+        return 0.5 * (sp.consts[C_W + yi(i) * 5 + yi(j)] + sp.consts[C_W + yi(j) * 5 + yi(i)]);
+    }
+    MPCRL_DI static double resid(bool term, int i, const double *x, const double *u, const SmallSpec &sp) {
+        if (term) return i < NU ? 0.0 : x[i - NU] - sp.consts[C_YREFE + i - NU];
+        return (i < NU ? u[i] : x[i - NU]) - sp.consts[C_YREF + yi(i)];
+    }
+    // gradient (stage-vector order) and value of the unscaled stage cost
+    MPCRL_DI static double cost_grad(bool term, int, const double *x, const double *u, const SmallSpec &sp, const double *tc,
+                                     double *g) {
+        double val = 0.0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) a = fma(hess(term, i, j, sp, tc), resid(term, j, x, u, sp), a);
+            g[i] = a;
+            val = fma(0.5 * a, resid(term, i, x, u, sp), val);
+        }
+        return val;
+    }
+    // non-parameterised NLS mirror: the cost does not depend on p (nlp.py:1039-1055)
+    MPCRL_DI static void cost_dp(bool, int, const double *, const double *, double, double *) {}
+    MPCRL_DI static void cost_mixed(bool, const double *, double, double *) {}
+};
+
+struct LinearDev {
+    static constexpr int NX = 2, NU = 1, NW = 3, NP = 12, NTD = 8, NTC = 4;
+    static constexpr bool DISCRETE = true, HAS_SOFT = true;
+    MPCRL_DI static int td_index(int i) { return i; }
+    MPCRL_DI static int tc_index(int i) { return 8 + i; }   // V_0, f_0, f_1, f_2
+    // consts: P (2x2 row-major)
+    template <class S>
+    MPCRL_DI static void ode(const S *x, const S *u, const S *th, S *f) {
+        // A column-major in p (linear_system/acados.py:60-62,89-90)
+        f[0] = th[0] * x[0] + th[2] * x[1] + th[4] * u[0] + th[6];
+        f[1] = th[1] * x[0] + th[3] * x[1] + th[5] * u[0] + th[7];
+    }
+    MPCRL_DI static double hess(bool term, int i, int j, const SmallSpec &sp, const double *) {
+        if (!term) return i == j ? 1.0 : 0.0;
+        if (i < NU || j < NU) return 0.0;
+        return 0.5 * (sp.consts[(i - NU) * 2 + (j - NU)] + sp.consts[(j - NU) * 2 + (i - NU)]);
+    }
+    MPCRL_DI static double cost_grad(bool term, int k, const double *x, const double *u, const SmallSpec &sp, const double *tc,
+                                     double *g) {
+        if (!term) {   // l = 1/2 y'y + f'y (+ V_0 at k = 0), y = [x; u], f = tc[1..3]
+            g[0] = u[0] + tc[3];
+            g[1] = x[0] + tc[1];
+            g[2] = x[1] + tc[2];
+            const double v = 0.5 * (x[0] * x[0] + x[1] * x[1] + u[0] * u[0]) + tc[1] * x[0] + tc[2] * x[1] + tc[3] * u[0];
+            return k == 0 ? v + tc[0] : v;
+        }
+        const double p00 = sp.consts[0], p01 = 0.5 * (sp.consts[1] + sp.consts[2]), p11 = sp.consts[3];
+        g[0] = 0.0;
+        g[1] = p00 * x[0] + p01 * x[1];
+        g[2] = p01 * x[0] + p11 * x[1];
+        return 0.5 * (x[0] * g[1] + x[1] * g[2]);
+    }
+    // out[NTC] += sc * d l / d (V_0, f)
+    MPCRL_DI static void cost_dp(bool term, int k, const double *x, const double *u, double sc, double *out) {
+        if (term) return;
+        if (k == 0) out[0] += sc;
+        out[1] += sc * x[0];
+        out[2] += sc * x[1];
+        out[3] += sc * u[0];
+    }
+    // out[NTC] += sc * y' d2 l / dv d(V_0, f),  y in stage-vector order [u; x]
+    MPCRL_DI static void cost_mixed(bool term, const double *y, double sc, double *out) {
+        if (term) return;
+        out[1] += sc * y[1];
+        out[2] += sc * y[2];
+        out[3] += sc * y[0];
+    }
+};
+
+// discrete map F = RK4^steps(ode; h)  (rlmpc/common/integrator.py:6-33)
+template <class M, class S>
+MPCRL_DI void disc_map(const S *x, const S *u, const S *th, S *xn, double h, int steps) {
+    constexpr int NX = M::NX;
+    if constexpr (M::DISCRETE) {
+        M::template ode<S>(x, u, th, xn);
+    } else {
+        S xc[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xc[i] = x[i];
+        for (int s = 0; s < steps; ++s) {
+            S k1[NX], k2[NX], k3[NX], k4[NX], xt[NX];
+            M::template ode<S>(xc, u, th, k1);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xt[i] = xc[i] + (0.5 * h) * k1[i];
+            M::template ode<S>(xt, u, th, k2);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xt[i] = xc[i] + (0.5 * h) * k2[i];
+            M::template ode<S>(xt, u, th, k3);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xt[i] = xc[i] + h * k3[i];
+            M::template ode<S>(xt, u, th, k4);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xc[i] = xc[i] + (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xn[i] = xc[i];
+    }
+}
+
+}  // namespace mpcrl

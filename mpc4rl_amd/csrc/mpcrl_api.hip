@@ -1,0 +1,224 @@
+// mpcrl_api.hip — C ABI of libmpcrl_hip.so (include/mpcrl.h): handle management, workspace, kernel launches.
+// Everything here is host glue; the arithmetic lives in small_kernel.hpp (cartpole, linear system) and
+// chain_kernel.hpp (chain of masses).
+#include "../../include/mpcrl.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "small_kernel.hpp"
+
+using namespace mpcrl;
+
+struct MpcrlSolver {
+    int model, B, device, nx, nu, np, N;
+    SmallSpec small;
+    double *theta = nullptr;   // [np] or [B, np]
+    int theta_stride = 0;
+    double *X = nullptr, *U = nullptr, *PI = nullptr, *BND = nullptr, *RES = nullptr;
+    int64_t bytes = 0;
+    bool have_iterate = false;
+};
+
+#define HIP_OK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            fprintf(stderr, "mpcrl: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return MPCRL_E_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+namespace {
+
+template <class T>
+int dev_alloc(T **p, size_t n, int64_t &bytes) {
+    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e != hipSuccess) return MPCRL_E_NOMEM;
+    bytes += (int64_t)(n * sizeof(T));
+    return 0;
+}
+
+void copy_or_fill(double *dst, const double *src, int n, int cap, double fill) {
+    for (int i = 0; i < cap; ++i) dst[i] = (src && i < n) ? src[i] : fill;
+}
+
+int fill_small_spec(const MpcrlProblemSpec &s, SmallSpec &d) {
+    const int nw = s.nx + s.nu;
+    if (nw > SMALL_MAXNW || s.n_consts > SMALL_MAXC || s.N + 1 > 64 || s.N < 1) return MPCRL_E_ARG;
+    std::memset(&d, 0, sizeof(d));
+    d.N = s.N, d.np = s.np, d.cost_kind = s.cost_kind, d.rk_steps = s.rk_steps, d.max_iter = s.max_iter;
+    d.dT = s.dT, d.gamma = s.gamma, d.h = s.h, d.tol = s.tol;
+    copy_or_fill(d.lb0, s.lb0, s.nu, SMALL_MAXNW, -MPCRL_NO_BOUND);
+    copy_or_fill(d.ub0, s.ub0, s.nu, SMALL_MAXNW, MPCRL_NO_BOUND);
+    copy_or_fill(d.lb, s.lb, nw, SMALL_MAXNW, -MPCRL_NO_BOUND);
+    copy_or_fill(d.ub, s.ub, nw, SMALL_MAXNW, MPCRL_NO_BOUND);
+    copy_or_fill(d.lbe, s.lbe, s.nx, SMALL_MAXNW, -MPCRL_NO_BOUND);
+    copy_or_fill(d.ube, s.ube, s.nx, SMALL_MAXNW, MPCRL_NO_BOUND);
+    copy_or_fill(d.zl, s.zl, nw, SMALL_MAXNW, 0.0);
+    copy_or_fill(d.zu, s.zu, nw, SMALL_MAXNW, 0.0);
+    for (int i = 0; i < SMALL_MAXNW; ++i) d.soft[i] = (s.soft && i < nw) ? s.soft[i] : 0;
+    copy_or_fill(d.consts, s.consts, s.n_consts, SMALL_MAXC, 0.0);
+    return 0;
+}
+
+template <class M>
+int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
+    const int ipw = 64 / (h->N + 1);
+    const int blocks = (h->B + ipw - 1) / ipw;
+    hipLaunchKernelGGL(small_solve_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mpcrl_version(void) { return 100; }
+
+int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_handle *out) {
+    if (!spec || !out || batch <= 0) return MPCRL_E_ARG;
+    HIP_OK(hipSetDevice(device));
+    MpcrlSolver *h = new (std::nothrow) MpcrlSolver();
+    if (!h) return MPCRL_E_NOMEM;
+    h->model = spec->model, h->B = batch, h->device = device, h->nx = spec->nx, h->nu = spec->nu, h->np = spec->np, h->N = spec->N;
+    int rc = 0;
+    switch (spec->model) {
+        case MPCRL_MODEL_CARTPOLE:
+            if (spec->nx != CartpoleDev::NX || spec->nu != CartpoleDev::NU || spec->np != CartpoleDev::NP) rc = MPCRL_E_MODEL;
+            break;
+        case MPCRL_MODEL_LINEAR:
+            if (spec->nx != LinearDev::NX || spec->nu != LinearDev::NU || spec->np != LinearDev::NP) rc = MPCRL_E_MODEL;
+            break;
+        default: rc = MPCRL_E_MODEL;
+    }
+    if (!rc) rc = fill_small_spec(*spec, h->small);
+    if (rc) {
+        delete h;
+        return rc;
+    }
+    const size_t B = batch, N = spec->N, nx = spec->nx, nu = spec->nu, nw = nx + nu;
+    rc = dev_alloc(&h->X, B * (N + 1) * nx, h->bytes);
+    if (!rc) rc = dev_alloc(&h->U, B * N * nu, h->bytes);
+    if (!rc) rc = dev_alloc(&h->PI, B * N * nx, h->bytes);
+    if (!rc) rc = dev_alloc(&h->BND, B * 10 * (N + 1) * nw, h->bytes);
+    if (!rc) rc = dev_alloc(&h->RES, B * 4, h->bytes);
+    if (!rc) rc = dev_alloc(&h->theta, B * (size_t)spec->np, h->bytes);
+    if (rc) {
+        mpcrl_destroy(h);
+        return rc;
+    }
+    HIP_OK(hipMemset(h->theta, 0, B * (size_t)spec->np * sizeof(double)));
+    *out = h;
+    return 0;
+}
+
+int mpcrl_destroy(mpcrl_handle h) {
+    if (!h) return MPCRL_E_ARG;
+    hipSetDevice(h->device);
+    for (double *p : {h->X, h->U, h->PI, h->BND, h->RES, h->theta})
+        if (p) hipFree(p);
+    delete h;
+    return 0;
+}
+
+int64_t mpcrl_workspace_bytes(mpcrl_handle h) { return h ? h->bytes : 0; }
+
+int mpcrl_set_theta(mpcrl_handle h, const double *theta, int n_theta, int per_instance, void *stream) {
+    if (!h || !theta || n_theta != h->np) return MPCRL_E_ARG;
+    HIP_OK(hipSetDevice(h->device));
+    const size_t n = (size_t)h->np * (per_instance ? h->B : 1);
+    HIP_OK(hipMemcpyAsync(h->theta, theta, n * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    h->theta_stride = per_instance ? h->np : 0;
+    return 0;
+}
+
+int mpcrl_set_gamma(mpcrl_handle h, double gamma) {
+    if (!h) return MPCRL_E_ARG;
+    h->small.gamma = gamma;
+    return 0;
+}
+
+int mpcrl_set_options(mpcrl_handle h, double tol, int max_iter) {
+    if (!h) return MPCRL_E_ARG;
+    if (tol > 0) h->small.tol = tol;
+    if (max_iter >= 0) h->small.max_iter = max_iter;
+    return 0;
+}
+
+int mpcrl_reset(mpcrl_handle h, const double *x0, void *stream) {
+    if (!h) return MPCRL_E_ARG;
+    (void)x0, (void)stream;
+    h->have_iterate = false;   // the next solve builds the cold iterate x_k = x0, u = 0 itself
+    return 0;
+}
+
+int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int flags, double *u0_out, double *V, double *dV_dp,
+                double *dpi_dp, int32_t *status, int32_t *iters, void *stream) {
+    if (!h || !x0 || !u0_out || !V || !status) return MPCRL_E_ARG;
+    if ((flags & MPCRL_SENS_V) && !dV_dp) return MPCRL_E_ARG;
+    if ((flags & MPCRL_SENS_PI) && !dpi_dp) return MPCRL_E_ARG;
+    HIP_OK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (!h->have_iterate) flags |= MPCRL_COLD;
+    SmallArgs a;
+    a.B = h->B, a.flags = flags, a.theta_stride = h->theta_stride;
+    a.x0 = x0, a.u0fix = u0_fixed, a.theta = h->theta;
+    a.X = h->X, a.U = h->U, a.PI = h->PI, a.BND = h->BND, a.RES = h->RES;
+    a.u0_out = u0_out, a.V = V, a.dV = (flags & MPCRL_SENS_V) ? dV_dp : nullptr, a.dpi = (flags & MPCRL_SENS_PI) ? dpi_dp : nullptr;
+    a.status = status, a.iters = iters;
+    if (a.dV) HIP_OK(hipMemsetAsync(dV_dp, 0, (size_t)h->B * h->np * sizeof(double), st));
+    if (a.dpi) HIP_OK(hipMemsetAsync(dpi_dp, 0, (size_t)h->B * h->nu * h->np * sizeof(double), st));
+    int rc;
+    switch (h->model) {
+        case MPCRL_MODEL_CARTPOLE: rc = launch_small<CartpoleDev>(h, a, st); break;
+        case MPCRL_MODEL_LINEAR: rc = launch_small<LinearDev>(h, a, st); break;
+        default: rc = MPCRL_E_MODEL;
+    }
+    if (!rc) h->have_iterate = true;
+    return rc;
+}
+
+int mpcrl_get_iterate(mpcrl_handle h, double *x, double *u, double *pi, double *bnd, double *res, void *stream) {
+    if (!h) return MPCRL_E_ARG;
+    HIP_OK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t B = h->B, N = h->N, nx = h->nx, nu = h->nu, nw = nx + nu;
+    if (x) HIP_OK(hipMemcpyAsync(x, h->X, B * (N + 1) * nx * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (u) HIP_OK(hipMemcpyAsync(u, h->U, B * N * nu * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (pi) HIP_OK(hipMemcpyAsync(pi, h->PI, B * N * nx * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (bnd) HIP_OK(hipMemcpyAsync(bnd, h->BND, B * 10 * (N + 1) * nw * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (res) HIP_OK(hipMemcpyAsync(res, h->RES, B * 4 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+int mpcrl_set_iterate(mpcrl_handle h, const double *x, const double *u, const double *pi, const double *bnd, void *stream) {
+    if (!h || !x || !u || !pi) return MPCRL_E_ARG;
+    HIP_OK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t B = h->B, N = h->N, nx = h->nx, nu = h->nu, nw = nx + nu;
+    HIP_OK(hipMemcpyAsync(h->X, x, B * (N + 1) * nx * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIP_OK(hipMemcpyAsync(h->U, u, B * N * nu * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIP_OK(hipMemcpyAsync(h->PI, pi, B * N * nx * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (bnd)
+        HIP_OK(hipMemcpyAsync(h->BND, bnd, B * 10 * (N + 1) * nw * sizeof(double), hipMemcpyDeviceToDevice, st));
+    else {
+        // multipliers 0, slacks t = 1: the state MPCRL_COLD would build
+        std::vector<double> hb(10 * (N + 1) * nw, 0.0);
+        for (size_t j : {2, 3, 8, 9})
+            for (size_t i = 0; i < (N + 1) * nw; ++i) hb[j * (N + 1) * nw + i] = 1.0;
+        for (size_t b = 0; b < B; ++b)
+            HIP_OK(hipMemcpyAsync(h->BND + b * hb.size(), hb.data(), hb.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_OK(hipStreamSynchronize(st));
+    }
+    h->have_iterate = true;
+    return 0;
+}
+
+}  // extern "C"

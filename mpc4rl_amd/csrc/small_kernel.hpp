@@ -1,0 +1,968 @@
+// small_kernel.hpp — the register-resident SQP / Riccati-IPM / adjoint-sensitivity kernel for small OCPs
+// (cartpole nx=4 nu=1, linear system nx=2 nu=1) on gfx950.
+//
+// Replaces, for a whole batch at once, what the reference does per instance through
+//   ocp_solver.solve()            rlmpc/mpc/common/mpc.py:42,79,195     (acados SQP + HPIPM, not vendored)
+//   update_nlp(): dL_dp, dpi_dp   rlmpc/mpc/nlp.py:1399-1424            (dense 600x600 Jacobian + SuperLU)
+//
+// Mapping (MI355X-first, not a translation of anything):
+//   * one wavefront (64 lanes) per workgroup; ONE LANE PER SHOOTING STAGE: lane k of an instance owns
+//     x_k, u_k, the multiplier of the dynamics arriving at stage k, A_k, B_k, the bound multipliers of stage k
+//     and the Riccati factors of stage k, all in VGPRs.  floor(64/(N+1)) instances share a wave
+//     (cartpole N=20: 3 instances = 63 lanes).
+//   * everything that is independent per stage (RK4 + forward-mode Jacobians, residuals, barrier terms,
+//     step recovery, fraction-to-boundary, exact-Hessian second-order sweeps) runs stage-parallel with no
+//     memory traffic at all;
+//   * the Riccati recursion is the only serial part: (P, p) travel lane k+1 -> lane k with cross-lane
+//     moves, the forward sweep sends the state step lane k -> lane k+1;
+//   * per-instance reductions (residual norms, mu, step length) are segmented wave reductions.
+//   * HBM traffic is the algorithmic minimum: x0 in, iterate in/out, results out.
+//
+// The interior-point iteration (initial point, Mehrotra predictor-corrector, single step length,
+// fraction-to-boundary 0.995, stopping rule) is the one documented in DESIGN.md; its constants are below.
+#pragma once
+#include "models_dev.hpp"
+
+namespace mpcrl {
+
+constexpr int IPM_MAX_ITER = 60;
+constexpr double IPM_TOL_RES = 1e-9, IPM_TOL_MU = 1e-11, IPM_T_MIN = 1e-1, IPM_MU0 = 1.0, IPM_FRAC = 0.995;
+constexpr double NO_BOUND = 1e29;
+
+struct SmallArgs {
+    int B;                 // instances
+    int flags;             // MPCRL_* solve flags
+    int theta_stride;      // 0 = shared theta, np = per instance
+    const double *x0;      // [B, nx]
+    const double *u0fix;   // [B, nu] or null
+    const double *theta;   // [np] or [B, np]
+    double *X, *U, *PI, *BND, *RES;   // iterate workspace (in/out), layouts of mpcrl_get_iterate
+    double *u0_out, *V, *dV, *dpi;
+    int *status, *iters;
+};
+
+// ---- cross-lane helpers (wave64) -----------------------------------------------------------------
+MPCRL_DI double lane_dn(double v) { return __shfl_down(v, 1); }   // value of lane + 1
+MPCRL_DI double lane_up(double v) { return __shfl_up(v, 1); }     // value of lane - 1
+
+// segmented reductions over the LPI lanes of one instance; result broadcast to all of its lanes
+MPCRL_DI double seg_sum(double v, int k, int lpi, int base) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const double o = __shfl_down(v, s);
+        if (k + s < lpi) v += o;
+    }
+    return __shfl(v, base);
+}
+MPCRL_DI double seg_max(double v, int k, int lpi, int base) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const double o = __shfl_down(v, s);
+        if (k + s < lpi) v = fmax(v, o);
+    }
+    return __shfl(v, base);
+}
+MPCRL_DI double seg_min(double v, int k, int lpi, int base) { return -seg_max(-v, k, lpi, base); }
+
+template <class M>
+struct SmallSolver {
+    static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD, NTC = M::NTC, NP = M::NP;
+    static constexpr int NPK = NX * (NX + 1) / 2, NLK = NU * (NU + 1) / 2;
+    static constexpr bool SOFT = M::HAS_SOFT;
+    MPCRL_DI static constexpr int sym(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+    const SmallSpec &sp;
+    const int N, lpi, k, base;
+    const bool term, first;
+    bool qmode;
+    double ck;                    // cost scaling c_k of this stage
+    double thd[NTD], thc[NTC > 0 ? NTC : 1];
+    // NLP iterate of this stage
+    double x[NX], u[NU], nu_[NX];   // nu_ = multiplier of x_k = F(x_{k-1},u_{k-1})   (k >= 1)
+    // linearisation of the dynamics leaving this stage (k < N) and cost gradient
+    double A[NX * NX], Bm[NX * NU], r[NX], q[NW];
+    // inequality rows of this stage: [side 0 lower / 1 upper][coordinate of v = [u; x]]
+    double lam[2][NW], t[2][NW], aff[2][NW];
+    double s[2][SOFT ? NW : 1], lams[2][SOFT ? NW : 1], ts[2][SOFT ? NW : 1], affs[2][SOFT ? NW : 1];
+    // QP iterate and Newton step
+    double dx[NX], du[NU], nuq[NX], Dx[NX], Du[NU], Dnu[NX];
+    // Riccati factors of this stage
+    double K[NU * NX], Li[NLK], kff[NU], P[NPK], p[NX];
+    double rg[NW], rb[NX], rt[NW], Dg[NW];
+
+    MPCRL_DI SmallSolver(const SmallSpec &sp_, int k_, int lpi_, int base_)
+        : sp(sp_), N(sp_.N), lpi(lpi_), k(k_), base(base_), term(k_ == sp_.N), first(k_ == 0) {}
+
+    // ---- static problem data of this stage -------------------------------------------------------
+    MPCRL_DI double lbv(int i) const {
+        if (first) return (i < NU && !qmode) ? sp.lb0[i < NU ? i : 0] : -1e30;
+        if (term) return i >= NU ? sp.lbe[i >= NU ? i - NU : 0] : -1e30;
+        return sp.lb[i];
+    }
+    MPCRL_DI double ubv(int i) const {
+        if (first) return (i < NU && !qmode) ? sp.ub0[i < NU ? i : 0] : 1e30;
+        if (term) return i >= NU ? sp.ube[i >= NU ? i - NU : 0] : 1e30;
+        return sp.ub[i];
+    }
+    MPCRL_DI bool has(int sd, int i) const { return sd ? ubv(i) < NO_BOUND : lbv(i) > -NO_BOUND; }
+    MPCRL_DI bool softc(int i) const { return SOFT && !first && !term && sp.soft[i] != 0; }
+    MPCRL_DI double zw(int sd, int i) const { return (sd ? sp.zu[i] : sp.zl[i]) * sp.dT * pow(sp.gamma, (double)k); }
+    MPCRL_DI bool fixed(int i) const { return first && (i >= NU || qmode); }
+    MPCRL_DI double vc(int i) const { return i < NU ? u[i < NU ? i : 0] : x[i >= NU ? i - NU : 0]; }
+    MPCRL_DI double dvc(const double *ax, const double *au, int i) const {
+        return i < NU ? (term ? 0.0 : au[i < NU ? i : 0]) : ax[i >= NU ? i - NU : 0];
+    }
+    MPCRL_DI double BA(int m, int j) const { return j < NU ? Bm[m * NU + (j < NU ? j : 0)] : A[m * NX + (j >= NU ? j - NU : 0)]; }
+    // slack(v) of the bound row on side sd, coordinate i, at value v
+    MPCRL_DI double bslack(int sd, int i, double v) const {
+        const double sv = SOFT && softc(i) ? s[sd][SOFT ? i : 0] : 0.0;
+        return sd ? ubv(i) - v + sv : v + sv - lbv(i);
+    }
+
+    // ---- linearise the dynamics leaving this stage and the stage cost; returns c_k * l_k ---------
+    MPCRL_DI double linearize(const double *xnext) {
+        if (!term) {
+            Jet1<NW> jx[NX], ju[NU], jt[NTD], jn[NX];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) ju[i] = Jet1<NW>(u[i]), ju[i].d[i] = 1.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) jx[i] = Jet1<NW>(x[i]), jx[i].d[NU + i] = 1.0;
+#pragma unroll
+            for (int i = 0; i < NTD; ++i) jt[i] = Jet1<NW>(thd[i]);
+            disc_map<M, Jet1<NW>>(jx, ju, jt, jn, sp.h, sp.rk_steps);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                r[i] = jn[i].v - xnext[i];
+#pragma unroll
+                for (int j = 0; j < NU; ++j) Bm[i * NU + j] = jn[i].d[j];
+#pragma unroll
+                for (int j = 0; j < NX; ++j) A[i * NX + j] = jn[i].d[NU + j];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) r[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX * NX; ++i) A[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX * NU; ++i) Bm[i] = 0.0;
+        }
+        double val = M::cost_grad(term, k, x, u, sp, thc, q);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) q[i] *= ck;
+        val *= ck;
+        if constexpr (SOFT) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+                if (softc(i)) val += zw(0, i) * s[0][i] + zw(1, i) * s[1][i];
+        }
+        return val;
+    }
+
+    // (G' nu) contribution to the stationarity row of coordinate i: [B A]' nu_{k+1} - [0; nu_k]
+    MPCRL_DI double GTnu(const double *nu_next, const double *nu_own, int i) const {
+        double a = 0.0;
+        if (!term) {
+#pragma unroll
+            for (int m = 0; m < NX; ++m) a = fma(BA(m, i), nu_next[m], a);
+        }
+        if (i >= NU && !first) a -= nu_own[i >= NU ? i - NU : 0];
+        return a;
+    }
+
+    // ---- NLP residuals (stationarity, equality, inequality, complementarity), local maxima -------
+    MPCRL_DI void nlp_res_local(const double *nu_next, const double *x0, const double *u0f, double *res) const {
+        double rs = 0, re = 0, ri = 0, rc = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            if (term && i < NU) continue;
+            if (!fixed(i)) {
+                double g = q[i] + GTnu(nu_next, nu_, i);
+                if (has(0, i)) g -= lam[0][i];
+                if (has(1, i)) g += lam[1][i];
+                rs = fmax(rs, fabs(g));
+            }
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd)
+                if (has(sd, i)) {
+                    const double h = -bslack(sd, i, vc(i));
+                    ri = fmax(ri, h);
+                    rc = fmax(rc, fabs(lam[sd][i] * h));
+                    if constexpr (SOFT) {
+                        if (softc(i)) {
+                            ri = fmax(ri, -s[sd][i]);
+                            rc = fmax(rc, fabs(lams[sd][i] * s[sd][i]));
+                            rs = fmax(rs, fabs(zw(sd, i) - lam[sd][i] - lams[sd][i]));
+                        }
+                    }
+                }
+        }
+        if (!term) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) re = fmax(re, fabs(r[i]));
+        }
+        if (first) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) re = fmax(re, fabs(x[i] - x0[i]));
+            if (qmode) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) re = fmax(re, fabs(u[i] - u0f[i]));
+            }
+        }
+        res[0] = rs, res[1] = re, res[2] = ri, res[3] = rc;
+    }
+
+    // ---- one backward Riccati stage: (Pn, pn) of stage k+1  ->  K, Li, kff, P, p of this stage ----
+    // FACTOR = false re-uses K, Li and P (vector-only sweep for the corrector / extra right-hand sides).
+    // Hs(i,j): stage Hessian accessor (already scaled), Dg: barrier diagonal, g: modified gradient, bb: dynamics offset.
+    template <bool FACTOR, class HF>
+    MPCRL_DI bool riccati_stage(const double *Pn, const double *pn, HF Hs, const double *g, const double *bb) {
+        bool ok = true;
+        double cc[NX], mv[NW];
+        if (term) {
+            if constexpr (FACTOR) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) P[sym(i, j)] = Hs(NU + i, NU + j) + (i == j ? Dg[NU + i] : 0.0);
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) p[i] = g[NU + i];
+            return true;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double a = pn[i];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) a = fma(Pn[sym(i, j)], bb[j], a);
+            cc[i] = a;
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            double a = g[i];
+#pragma unroll
+            for (int m = 0; m < NX; ++m) a = fma(BA(m, i), cc[m], a);
+            mv[i] = a;
+        }
+        double Mm[NW * (NW + 1) / 2];
+        if constexpr (FACTOR) {
+            double T[NX * NW];
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int m = 0; m < NX; ++m) a = fma(Pn[sym(i, m)], BA(m, j), a);
+                    T[i * NW + j] = a;
+                }
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    double a = Hs(i, j) + (i == j ? Dg[i] : 0.0);
+#pragma unroll
+                    for (int m = 0; m < NX; ++m) a = fma(BA(m, i), T[m * NW + j], a);
+                    Mm[sym(i, j)] = a;
+                }
+            if (first && qmode) {
+#pragma unroll
+                for (int i = 0; i < NU * NX; ++i) K[i] = 0.0;
+#pragma unroll
+                for (int i = 0; i < NLK; ++i) Li[i] = 0.0;
+            } else {
+                // Cholesky R = L L' of the control block; Li holds L with the diagonal inverted
+#pragma unroll
+                for (int i = 0; i < NU; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) {
+                        double a = Mm[sym(i, j)];
+#pragma unroll
+                        for (int m = 0; m < j; ++m) a -= Li[sym(i, m)] * Li[sym(j, m)];
+                        if (i == j) {
+                            ok = ok && (a > 0.0);
+                            Li[sym(i, i)] = 1.0 / sqrt(a);
+                        } else
+                            Li[sym(i, j)] = a * Li[sym(j, j)];
+                    }
+#pragma unroll
+                for (int j = 0; j < NX; ++j) {   // K = R^{-1} S, S(i, j) = Mm(NU + j, i)
+                    double y[NU];
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) {
+                        double a = Mm[sym(NU + j, i)];
+#pragma unroll
+                        for (int m = 0; m < i; ++m) a -= Li[sym(i, m)] * y[m];
+                        y[i] = a * Li[sym(i, i)];
+                    }
+#pragma unroll
+                    for (int i = NU - 1; i >= 0; --i) {
+                        double a = y[i];
+#pragma unroll
+                        for (int m = i + 1; m < NU; ++m) a -= Li[sym(m, i)] * K[m * NX + j];
+                        K[i * NX + j] = a * Li[sym(i, i)];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    double a = Mm[sym(NU + i, NU + j)];
+#pragma unroll
+                    for (int m = 0; m < NU; ++m) a -= Mm[sym(NU + i, m)] * K[m * NX + j];
+                    P[sym(i, j)] = a;
+                }
+        }
+        if (first && qmode) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) kff[i] = 0.0;
+        } else {
+            double y[NU];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                double a = mv[i];
+#pragma unroll
+                for (int m = 0; m < i; ++m) a -= Li[sym(i, m)] * y[m];
+                y[i] = a * Li[sym(i, i)];
+            }
+#pragma unroll
+            for (int i = NU - 1; i >= 0; --i) {
+                double a = y[i];
+#pragma unroll
+                for (int m = i + 1; m < NU; ++m) a -= Li[sym(m, i)] * kff[m];
+                kff[i] = a * Li[sym(i, i)];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double a = mv[NU + i];
+#pragma unroll
+            for (int m = 0; m < NU; ++m) a -= K[m * NX + i] * mv[m];
+            p[i] = a;
+        }
+        return ok;
+    }
+
+    // ---- backward sweep over the horizon (serial in k; the lanes of all instances in the wave step together).
+    // (P, p) of stage k+1 arrive by a one-lane shift; each lane keeps the received P_{k+1} in Pnext so that the
+    // corrector / extra right-hand sides only need the vector recursion.
+    double Pnext[NPK];
+    template <bool FACTOR, class HF>
+    MPCRL_DI bool backward(HF Hs, const double *g, const double *bb) {
+        bool ok = true;
+        for (int kk = N; kk >= 0; --kk) {
+            double pn[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) pn[i] = lane_dn(p[i]);
+            if constexpr (FACTOR) {
+                double Pn[NPK];
+#pragma unroll
+                for (int i = 0; i < NPK; ++i) Pn[i] = lane_dn(P[i]);
+                if (k == kk) {
+#pragma unroll
+                    for (int i = 0; i < NPK; ++i) Pnext[i] = Pn[i];
+                    ok = riccati_stage<true>(Pnext, pn, Hs, g, bb) && ok;
+                }
+            } else {
+                if (k == kk) riccati_stage<false>(Pnext, pn, Hs, g, bb);
+            }
+        }
+        return ok;
+    }
+
+    // ---- forward sweep: Newton step (Dx, Du) and the multipliers Dnu of the arriving dynamics ------
+    MPCRL_DI void forward(const double *bb) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Dx[i] = 0.0, Dnu[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) Du[i] = 0.0;
+        double xn[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xn[i] = 0.0;
+        for (int kk = 0; kk < N; ++kk) {
+            if (k == kk) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    double a = -kff[i];
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) a = fma(-K[i * NX + j], Dx[j], a);
+                    Du[i] = a;
+                }
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    double a = bb[i];
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) a = fma(A[i * NX + j], Dx[j], a);
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) a = fma(Bm[i * NU + j], Du[j], a);
+                    xn[i] = a;
+                }
+            }
+            double xin[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xin[i] = lane_up(xn[i]);
+            if (k == kk + 1) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) Dx[i] = xin[i];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    double a = p[i];
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) a = fma(P[sym(i, j)], xin[j], a);
+                    Dnu[i] = a;
+                }
+            }
+        }
+    }
+
+    // ---- interior point: per-row Newton quantities ------------------------------------------------
+    // complementarity target r_m of a row (affine: lam t; corrector: lam t + dlam_aff dt_aff - sigma mu)
+    MPCRL_DI static double rm_(double l, double tt, double af, int pass, double smu) { return fma(l, tt, pass ? af - smu : 0.0); }
+
+    // barrier diagonal and right-hand-side term of coordinate i (both sides), Newton system of DESIGN.md §IPM
+    MPCRL_DI void barrier_terms(int i, double v, int pass, double smu, double &dg, double &er) const {
+        dg = 0.0, er = 0.0;
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd) {
+            if (!has(sd, i)) continue;
+            const double sg = sd ? -1.0 : 1.0;
+            const double l1 = lam[sd][i], t1 = t[sd][i];
+            const double w1 = l1 / t1;
+            const double rd1 = t1 - bslack(sd, i, v);
+            const double e1 = (rm_(l1, t1, aff[sd][i], pass, smu) - l1 * rd1) / t1;
+            if (SOFT && softc(i)) {
+                const int ii = SOFT ? i : 0;
+                const double l2 = lams[sd][ii], t2 = ts[sd][ii];
+                const double w2 = l2 / t2;
+                const double e2 = (rm_(l2, t2, affs[sd][ii], pass, smu) - l2 * (t2 - s[sd][ii])) / t2;
+                const double rgs = zw(sd, i) - l1 - l2;
+                dg += w1 * w2 / (w1 + w2);
+                er += sg * (e1 * w2 - w1 * (rgs + e2)) / (w1 + w2);
+            } else {
+                dg += w1;
+                er += sg * e1;
+            }
+        }
+    }
+    // steps of the rows of coordinate i, side sd, for a primal step dv of the coordinate
+    MPCRL_DI void row_steps(int i, int sd, double v, double dv, int pass, double smu, double &dt1, double &dl1, double &dt2,
+                            double &dl2, double &dss) const {
+        const double sg = sd ? -1.0 : 1.0;
+        const double l1 = lam[sd][i], t1 = t[sd][i];
+        const double rd1 = t1 - bslack(sd, i, v);
+        const double rm1 = rm_(l1, t1, aff[sd][i], pass, smu);
+        dss = 0.0, dt2 = 0.0, dl2 = 0.0;
+        if (SOFT && softc(i)) {
+            const int ii = SOFT ? i : 0;
+            const double l2 = lams[sd][ii], t2 = ts[sd][ii];
+            const double w1 = l1 / t1, w2 = l2 / t2;
+            const double rd2 = t2 - s[sd][ii];
+            const double rm2 = rm_(l2, t2, affs[sd][ii], pass, smu);
+            const double e1 = (rm1 - l1 * rd1) / t1, e2 = (rm2 - l2 * rd2) / t2;
+            const double rgs = zw(sd, i) - l1 - l2;
+            dss = -(rgs + e1 + e2 + sg * w1 * dv) / (w1 + w2);
+            dt2 = -rd2 + dss;
+            dl2 = (-rm2 - l2 * dt2) / t2;
+        }
+        dt1 = -rd1 + sg * dv + dss;
+        dl1 = (-rm1 - l1 * dt1) / t1;
+    }
+
+    // ---- Mehrotra predictor-corrector on the QP of the current linearisation -----------------------
+    // act: this instance takes part.  Returns true when converged; n_it counts iterations of this instance.
+    MPCRL_DI bool qp_solve(bool act, const double *x0, const double *u0f, int &n_it) {
+        auto Hs = [&](int i, int j) { return ck * M::hess(term, i, j, sp, thc); };
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) dx[i] = first ? x0[i] - x[i] : 0.0, nuq[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) du[i] = (first && qmode) ? u0f[i] - u[i] : 0.0;
+        }
+        double cnt = 0.0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            if (term && i < NU) continue;
+            const double v = vc(i) + dvc(dx, du, i);
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd) {
+                if (!has(sd, i)) continue;
+                cnt += 1.0;
+                if (SOFT && softc(i)) {
+                    cnt += 1.0;
+                    if (act) s[sd][SOFT ? i : 0] = 0.0, ts[sd][SOFT ? i : 0] = IPM_T_MIN, lams[sd][SOFT ? i : 0] = IPM_MU0 / IPM_T_MIN;
+                }
+                if (act) {
+                    const double sl = bslack(sd, i, v);
+                    t[sd][i] = fmax(sl, IPM_T_MIN);
+                    lam[sd][i] = IPM_MU0 / t[sd][i];
+                }
+            }
+        }
+        const double n_rows = seg_sum(cnt, k, lpi, base);
+        bool qlive = act, ok = false;
+        for (int it = 0;; ++it) {
+            // ---- residuals
+            double dxn[NX], nuqn[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) dxn[i] = lane_dn(dx[i]), nuqn[i] = lane_dn(nuq[i]);
+            double rloc = 0.0, muloc = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = 0.0;
+                if (!term) {
+                    a = r[i] - dxn[i];
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) a = fma(A[i * NX + j], dx[j], a);
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) a = fma(Bm[i * NU + j], du[j], a);
+                }
+                rb[i] = a;
+                rloc = fmax(rloc, fabs(a));
+            }
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                rg[i] = 0.0;
+                if (term && i < NU) continue;
+                double a = q[i] + GTnu(nuqn, nuq, i);
+#pragma unroll
+                for (int j = 0; j < NW; ++j) a = fma(Hs(i, j), dvc(dx, du, j), a);
+                if (has(0, i)) a -= lam[0][i];
+                if (has(1, i)) a += lam[1][i];
+                if (fixed(i)) a = 0.0;
+                rg[i] = a;
+                rloc = fmax(rloc, fabs(a));
+                const double v = vc(i) + dvc(dx, du, i);
+#pragma unroll
+                for (int sd = 0; sd < 2; ++sd) {
+                    if (!has(sd, i)) continue;
+                    rloc = fmax(rloc, fabs(t[sd][i] - bslack(sd, i, v)));
+                    muloc = fma(lam[sd][i], t[sd][i], muloc);
+                    if (SOFT && softc(i)) {
+                        const int ii = SOFT ? i : 0;
+                        rloc = fmax(rloc, fabs(ts[sd][ii] - s[sd][ii]));
+                        rloc = fmax(rloc, fabs(zw(sd, i) - lam[sd][i] - lams[sd][ii]));
+                        muloc = fma(lams[sd][ii], ts[sd][ii], muloc);
+                    }
+                }
+            }
+            const double rinf = seg_max(rloc, k, lpi, base);
+            const double mu = n_rows > 0.0 ? seg_sum(muloc, k, lpi, base) / n_rows : 0.0;
+            if (qlive) {
+                if (rinf <= IPM_TOL_RES && mu <= IPM_TOL_MU)
+                    qlive = false, ok = true;
+                else if (it >= IPM_MAX_ITER || !(rinf < 1e300))
+                    qlive = false;
+            }
+            if (!__any(qlive)) break;
+            if (qlive) ++n_it;
+            // ---- predictor
+            double eaff[NW];
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const double v = vc(i) + dvc(dx, du, i);
+                barrier_terms(i, v, 0, 0.0, Dg[i], eaff[i]);
+                rt[i] = rg[i] + eaff[i];
+            }
+            const bool okf = backward<true>(Hs, rt, rb);
+            if (seg_max(okf ? 0.0 : 1.0, k, lpi, base) > 0.5) qlive = false;   // non-positive pivot: QP failure
+            forward(rb);
+            double amax = 1.0, muaff = 0.0;
+            double daff[2][NW], dsaff[2][SOFT ? NW : 1];
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                if (term && i < NU) continue;
+                const double v = vc(i) + dvc(dx, du, i), dv = dvc(Dx, Du, i);
+#pragma unroll
+                for (int sd = 0; sd < 2; ++sd) {
+                    daff[sd][i] = 0.0;
+                    if (SOFT) dsaff[sd][SOFT ? i : 0] = 0.0;
+                    if (!has(sd, i)) continue;
+                    double dt1, dl1, dt2, dl2, dss;
+                    row_steps(i, sd, v, dv, 0, 0.0, dt1, dl1, dt2, dl2, dss);
+                    if (dl1 < 0.0) amax = fmin(amax, -lam[sd][i] / dl1);
+                    if (dt1 < 0.0) amax = fmin(amax, -t[sd][i] / dt1);
+                    daff[sd][i] = dl1 * dt1;
+                    if (SOFT && softc(i)) {
+                        const int ii = SOFT ? i : 0;
+                        if (dl2 < 0.0) amax = fmin(amax, -lams[sd][ii] / dl2);
+                        if (dt2 < 0.0) amax = fmin(amax, -ts[sd][ii] / dt2);
+                        dsaff[sd][ii] = dl2 * dt2;
+                    }
+                }
+            }
+            const double a_aff = seg_min(amax, k, lpi, base);
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                if (term && i < NU) continue;
+                const double v = vc(i) + dvc(dx, du, i), dv = dvc(Dx, Du, i);
+#pragma unroll
+                for (int sd = 0; sd < 2; ++sd) {
+                    if (!has(sd, i)) continue;
+                    double dt1, dl1, dt2, dl2, dss;
+                    row_steps(i, sd, v, dv, 0, 0.0, dt1, dl1, dt2, dl2, dss);
+                    muaff = fma(fma(a_aff, dl1, lam[sd][i]), fma(a_aff, dt1, t[sd][i]), muaff);
+                    if (SOFT && softc(i)) {
+                        const int ii = SOFT ? i : 0;
+                        muaff = fma(fma(a_aff, dl2, lams[sd][ii]), fma(a_aff, dt2, ts[sd][ii]), muaff);
+                    }
+                }
+            }
+            const double mu_aff = n_rows > 0.0 ? seg_sum(muaff, k, lpi, base) / n_rows : 0.0;
+            const double ratio = mu > 0.0 ? mu_aff / mu : 0.0;
+            const double smu = ratio * ratio * ratio * mu;
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+#pragma unroll
+                for (int sd = 0; sd < 2; ++sd) {
+                    aff[sd][i] = daff[sd][i];
+                    if (SOFT) affs[sd][SOFT ? i : 0] = dsaff[sd][SOFT ? i : 0];
+                }
+            // ---- corrector (same factorisation, vector sweep only)
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const double v = vc(i) + dvc(dx, du, i);
+                double dgi, ec;
+                barrier_terms(i, v, 1, smu, dgi, ec);
+                rt[i] = rg[i] + ec;
+            }
+            backward<false>(Hs, rt, rb);
+            forward(rb);
+            amax = 1.0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                if (term && i < NU) continue;
+                const double v = vc(i) + dvc(dx, du, i), dv = dvc(Dx, Du, i);
+#pragma unroll
+                for (int sd = 0; sd < 2; ++sd) {
+                    if (!has(sd, i)) continue;
+                    double dt1, dl1, dt2, dl2, dss;
+                    row_steps(i, sd, v, dv, 1, smu, dt1, dl1, dt2, dl2, dss);
+                    if (dl1 < 0.0) amax = fmin(amax, -lam[sd][i] / dl1);
+                    if (dt1 < 0.0) amax = fmin(amax, -t[sd][i] / dt1);
+                    if (SOFT && softc(i)) {
+                        const int ii = SOFT ? i : 0;
+                        if (dl2 < 0.0) amax = fmin(amax, -lams[sd][ii] / dl2);
+                        if (dt2 < 0.0) amax = fmin(amax, -ts[sd][ii] / dt2);
+                    }
+                }
+            }
+            const double alpha = fmin(1.0, IPM_FRAC * seg_min(amax, k, lpi, base));
+            if (qlive) {
+                // rows of (i, sd) only read their own side's state, so they can be advanced in place
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    if (term && i < NU) continue;
+                    const double v = vc(i) + dvc(dx, du, i), dv = dvc(Dx, Du, i);
+#pragma unroll
+                    for (int sd = 0; sd < 2; ++sd) {
+                        if (!has(sd, i)) continue;
+                        double dt1, dl1, dt2, dl2, dss;
+                        row_steps(i, sd, v, dv, 1, smu, dt1, dl1, dt2, dl2, dss);
+                        lam[sd][i] = fma(alpha, dl1, lam[sd][i]);
+                        t[sd][i] = fma(alpha, dt1, t[sd][i]);
+                        if (SOFT && softc(i)) {
+                            const int ii = SOFT ? i : 0;
+                            lams[sd][ii] = fma(alpha, dl2, lams[sd][ii]);
+                            ts[sd][ii] = fma(alpha, dt2, ts[sd][ii]);
+                            s[sd][ii] = fma(alpha, dss, s[sd][ii]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NX; ++i) dx[i] = fma(alpha, Dx[i], dx[i]), nuq[i] = fma(alpha, Dnu[i], nuq[i]);
+#pragma unroll
+                for (int i = 0; i < NU; ++i) du[i] = fma(alpha, Du[i], du[i]);
+            }
+        }
+        return ok;
+    }
+
+    // ---- sensitivities: dV/dp = dL/dp (nlp.py:1211,1401) and du0*/dp (nlp.py:1413-1424) by an adjoint solve --
+    // nun: multiplier nu_{k+1} of the dynamics leaving this stage.  dVa / dpia: per-instance output rows.
+    MPCRL_DI void sensitivities(int flags, bool valid, const double *nun, double *dVa, double *dpia) {
+        double Fth[NX * NTD];
+        if (!term) {
+            Jet1<NTD> jx[NX], ju[NU], jt[NTD], jn[NX];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) ju[i] = Jet1<NTD>(u[i]);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) jx[i] = Jet1<NTD>(x[i]);
+#pragma unroll
+            for (int i = 0; i < NTD; ++i) jt[i] = Jet1<NTD>(thd[i]), jt[i].d[i] = 1.0;
+            disc_map<M, Jet1<NTD>>(jx, ju, jt, jn, sp.h, sp.rk_steps);
+#pragma unroll
+            for (int m = 0; m < NX; ++m)
+#pragma unroll
+                for (int d = 0; d < NTD; ++d) Fth[m * NTD + d] = jn[m].d[d];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX * NTD; ++i) Fth[i] = 0.0;
+        }
+        if ((flags & 1) && dVa) {
+            double cpart[NTC > 0 ? NTC : 1];
+#pragma unroll
+            for (int i = 0; i < (NTC > 0 ? NTC : 1); ++i) cpart[i] = 0.0;
+            M::cost_dp(term, k, x, u, ck, cpart);
+#pragma unroll
+            for (int d = 0; d < NTD; ++d) {
+                double a = 0.0;
+#pragma unroll
+                for (int m = 0; m < NX; ++m) a = fma(nun[m], Fth[m * NTD + d], a);
+                a = seg_sum(a, k, lpi, base);
+                if (first && valid) dVa[M::td_index(d)] = a;
+            }
+#pragma unroll
+            for (int d = 0; d < NTC; ++d) {
+                const double a = seg_sum(cpart[d], k, lpi, base);
+                if (first && valid) dVa[M::tc_index(d)] = a;
+            }
+        }
+        if (!((flags & 2) && dpia) || qmode) return;   // Q-mode: u_0 is pinned (mpc.py:71-76), du0/dp = 0
+        // exact Lagrangian Hessian of the stage (nlp.py:1202,1224): c hess l + sum_m nu_{k+1,m} hess F_m
+        double Hx[NW * (NW + 1) / 2];
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) Hx[sym(i, j)] = ck * M::hess(term, i, j, sp, thc);
+        if (!term) {
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                Jet2<NW> jx[NX], ju[NU], jt[NTD], jn[NX];
+#pragma unroll
+                for (int i = 0; i < NU; ++i) ju[i] = Jet2<NW>(u[i]), ju[i].g[i] = 1.0;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) jx[i] = Jet2<NW>(x[i]), jx[i].g[NU + i] = 1.0;
+#pragma unroll
+                for (int i = 0; i < NTD; ++i) jt[i] = Jet2<NW>(thd[i]);
+                if (j < NU)
+                    ju[j < NU ? j : 0].e = 1.0;
+                else
+                    jx[j >= NU ? j - NU : 0].e = 1.0;
+                disc_map<M, Jet2<NW>>(jx, ju, jt, jn, sp.h, sp.rk_steps);
+#pragma unroll
+                for (int i = j; i < NW; ++i) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int m = 0; m < NX; ++m) a = fma(nun[m], jn[m].m[i], a);
+                    Hx[sym(i, j)] += a;
+                }
+            }
+        }
+        // barrier diagonal from the final (lam, t) of the BOUND rows; slacks are constants of the mirror (quirk q1)
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            double d = 0.0;
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd)
+                if (has(sd, i)) d += lam[sd][i] / t[sd][i];
+            Dg[i] = d;
+        }
+        auto Hs = [&](int i, int j) { return Hx[sym(i, j)]; };
+        double zero[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) zero[i] = 0.0;
+        bool okall = true;
+#pragma unroll
+        for (int iu = 0; iu < NU; ++iu) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) rt[i] = (first && i == iu) ? -1.0 : 0.0;
+            if (iu == 0) {
+                const bool okf = backward<true>(Hs, rt, zero);
+                okall = seg_max(okf ? 0.0 : 1.0, k, lpi, base) < 0.5;
+            } else
+                backward<false>(Hs, rt, zero);
+            forward(zero);
+            double ynn[NX], yv[NW];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) ynn[i] = lane_dn(Dnu[i]);
+#pragma unroll
+            for (int i = 0; i < NW; ++i) yv[i] = dvc(Dx, Du, i);
+            double outd[NTD], outc[NTC > 0 ? NTC : 1];
+#pragma unroll
+            for (int d = 0; d < NTD; ++d) outd[d] = 0.0;
+#pragma unroll
+            for (int d = 0; d < (NTC > 0 ? NTC : 1); ++d) outc[d] = 0.0;
+            M::cost_mixed(term, yv, ck, outc);
+            if (!term) {
+                Jet2<NTD> jx[NX], ju[NU], jt[NTD], jn[NX];
+#pragma unroll
+                for (int i = 0; i < NU; ++i) ju[i] = Jet2<NTD>(u[i]), ju[i].e = yv[i];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) jx[i] = Jet2<NTD>(x[i]), jx[i].e = yv[NU + i];
+#pragma unroll
+                for (int i = 0; i < NTD; ++i) jt[i] = Jet2<NTD>(thd[i]), jt[i].g[i] = 1.0;
+                disc_map<M, Jet2<NTD>>(jx, ju, jt, jn, sp.h, sp.rk_steps);
+#pragma unroll
+                for (int d = 0; d < NTD; ++d) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int m = 0; m < NX; ++m) a = fma(nun[m], jn[m].m[d], fma(ynn[m], Fth[m * NTD + d], a));
+                    outd[d] = a;
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < NTD; ++d) {
+                const double a = seg_sum(outd[d], k, lpi, base);
+                if (first && valid) dpia[iu * NP + M::td_index(d)] = okall ? -a : NAN;
+            }
+#pragma unroll
+            for (int d = 0; d < NTC; ++d) {
+                const double a = seg_sum(outc[d], k, lpi, base);
+                if (first && valid) dpia[iu * NP + M::tc_index(d)] = okall ? -a : NAN;
+            }
+        }
+    }
+};
+
+// =====================================================================================================
+// kernel: floor(64/(N+1)) instances per 64-lane workgroup
+// =====================================================================================================
+template <class M>
+__global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, const SmallArgs a) {
+    constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NP = M::NP, NTD = M::NTD, NTC = M::NTC;
+    constexpr bool SOFT = M::HAS_SOFT;
+    const int lane = threadIdx.x;
+    const int N = sp.N, lpi = N + 1, ipw = 64 / lpi;
+    const int slot = lane / lpi, k = lane - slot * lpi, base = slot * lpi;
+    long inst = (long)blockIdx.x * ipw + slot;
+    const bool valid = slot < ipw && inst < a.B;
+    if (!valid) inst = a.B - 1;   // dead lanes shadow the last instance and never store
+    SmallSolver<M> S(sp, k, lpi, base);
+    const bool term = S.term, first = S.first;
+    S.qmode = a.u0fix != nullptr;
+    if (sp.cost_kind == 0)
+        S.ck = term ? 1.0 : sp.dT;                                                        // nlp.py:1044-1055
+    else
+        S.ck = first ? sp.dT : (term ? pow(sp.gamma, (double)N) : pow(sp.gamma, (double)k) * sp.dT);   // nlp.py:1083-1091
+    const double *th = a.theta + (size_t)inst * a.theta_stride;
+#pragma unroll
+    for (int i = 0; i < NTD; ++i) S.thd[i] = th[M::td_index(i)];
+#pragma unroll
+    for (int i = 0; i < NTC; ++i) S.thc[i] = th[M::tc_index(i)];
+    double x0[NX], u0f[NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x0[i] = a.x0[inst * NX + i];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) u0f[i] = S.qmode ? a.u0fix[inst * NU + i] : 0.0;
+    // ---- iterate: stored (warm) or the reference's cold start (MPC.reset, mpc.py:204-210)
+    const size_t nb = (size_t)(N + 1) * NW;
+    double *bnd = a.BND + (size_t)inst * 10 * nb + (size_t)k * NW;
+    if (a.flags & 8) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) S.x[i] = x0[i], S.nu_[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) S.u[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            S.lam[0][i] = S.lam[1][i] = 0.0, S.t[0][i] = S.t[1][i] = 1.0, S.aff[0][i] = S.aff[1][i] = 0.0;
+            if constexpr (SOFT) S.s[0][i] = S.s[1][i] = 0.0, S.lams[0][i] = S.lams[1][i] = 0.0, S.ts[0][i] = S.ts[1][i] = 1.0,
+                                S.affs[0][i] = S.affs[1][i] = 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            S.x[i] = a.X[(inst * (N + 1) + k) * NX + i];
+            S.nu_[i] = first ? 0.0 : a.PI[(inst * N + k - 1) * NX + i];
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) S.u[i] = term ? 0.0 : a.U[(inst * N + k) * NU + i];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            S.lam[0][i] = bnd[0 * nb + i], S.lam[1][i] = bnd[1 * nb + i], S.t[0][i] = bnd[2 * nb + i], S.t[1][i] = bnd[3 * nb + i];
+            S.aff[0][i] = S.aff[1][i] = 0.0;
+            if constexpr (SOFT) {
+                S.s[0][i] = bnd[4 * nb + i], S.s[1][i] = bnd[5 * nb + i], S.lams[0][i] = bnd[6 * nb + i], S.lams[1][i] = bnd[7 * nb + i];
+                S.ts[0][i] = bnd[8 * nb + i], S.ts[1][i] = bnd[9 * nb + i], S.affs[0][i] = S.affs[1][i] = 0.0;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < S.NPK; ++i) S.P[i] = 0.0, S.Pnext[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) S.p[i] = 0.0, S.dx[i] = 0.0, S.nuq[i] = 0.0, S.Dx[i] = 0.0, S.Dnu[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) S.du[i] = 0.0, S.Du[i] = 0.0, S.kff[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NU * NX; ++i) S.K[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < S.NLK; ++i) S.Li[i] = 0.0;
+
+    // ---- full-step SQP (the reference requests no globalisation; config/cartpole.yaml:8-14)
+    const int max_iter = (a.flags & 4) ? 1 : sp.max_iter;
+    bool live = valid;
+    int status = 2, n_sqp = 0, n_ipm = 0;
+    double Vout = 0.0, res_out[4] = {0, 0, 0, 0};
+    double nun[NX];
+    for (int it = 0;; ++it) {
+        double xn[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xn[i] = lane_dn(S.x[i]), nun[i] = lane_dn(S.nu_[i]);
+        const double cl = S.linearize(xn);
+        double rl[4];
+        S.nlp_res_local(nun, x0, u0f, rl);
+        const double cost = seg_sum(cl, k, lpi, base);
+        double res[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) res[j] = seg_max(rl[j], k, lpi, base);
+        const double rmax = fmax(fmax(res[0], res[1]), fmax(res[2], res[3]));
+        if (live) {
+            Vout = cost, n_sqp = it;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) res_out[j] = res[j];
+            if (!(rmax < 1e300))
+                status = 1, live = false;
+            else if (rmax < sp.tol)
+                status = 0, live = false;
+            else if (it >= max_iter)
+                status = 2, live = false;
+        }
+        if (!__any(live)) break;
+        const bool ok = S.qp_solve(live, x0, u0f, n_ipm);
+        if (live && !ok) status = 4, live = false;
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) S.x[i] += S.dx[i], S.nu_[i] = S.nuq[i];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) S.u[i] += S.du[i];
+        }
+    }
+    // ---- results
+    if (valid && first) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) a.u0_out[inst * NU + i] = S.u[i];
+        a.V[inst] = Vout;
+        a.status[inst] = status;
+        if (a.iters) a.iters[inst * 2] = n_sqp, a.iters[inst * 2 + 1] = n_ipm;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a.RES[inst * 4 + j] = res_out[j];
+    }
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            a.X[(inst * (N + 1) + k) * NX + i] = S.x[i];
+            if (!first) a.PI[(inst * N + k - 1) * NX + i] = S.nu_[i];
+        }
+        if (!term) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) a.U[(inst * N + k) * NU + i] = S.u[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            bnd[0 * nb + i] = S.has(0, i) ? S.lam[0][i] : 0.0, bnd[1 * nb + i] = S.has(1, i) ? S.lam[1][i] : 0.0;
+            bnd[2 * nb + i] = S.has(0, i) ? S.t[0][i] : 1.0, bnd[3 * nb + i] = S.has(1, i) ? S.t[1][i] : 1.0;
+            if constexpr (SOFT) {
+                bnd[4 * nb + i] = S.s[0][i], bnd[5 * nb + i] = S.s[1][i], bnd[6 * nb + i] = S.lams[0][i], bnd[7 * nb + i] = S.lams[1][i];
+                bnd[8 * nb + i] = S.ts[0][i], bnd[9 * nb + i] = S.ts[1][i];
+            }
+        }
+    }
+    if (a.flags & 3) {
+        // sensitivities at the final iterate (status 0, or 2 in RTI mode); other instances get NaN-free zeros
+        const bool sv = valid && (status == 0 || status == 2);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) nun[i] = lane_dn(S.nu_[i]);
+        S.sensitivities(a.flags, sv, nun, a.dV ? a.dV + inst * NP : nullptr, a.dpi ? a.dpi + inst * NU * NP : nullptr);
+    }
+}
+
+}  // namespace mpcrl

@@ -1,0 +1,124 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle port on the same seeded inputs.
+
+Tolerances: the engine and the oracle run the same iteration in fp64, so iterates agree to ~1e-10; the bar
+from BASELINE.json's north_star is 1e-6 relative on u0*, V, dV/dp, du0*/dp and that is what is asserted
+(tighter values are printed)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+
+
+def rel_err(a, b, floor=1.0):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+
+
+def cartpole_x0(B, seed=0):
+    """BASELINE config 2/3 inputs: theta ~ U(0.9 pi, 1.1 pi), rest 0 (continuous_cartpole/environment.py:178-180)
+    for the first half, near-upright states (non-saturated u0, non-trivial du0/dp) for the second half."""
+    rng = np.random.default_rng(seed)
+    x0 = np.zeros((B, 4))
+    h = B // 2
+    x0[:h, 2] = rng.uniform(0.9 * np.pi, 1.1 * np.pi, h)
+    x0[h:] = rng.uniform(-1, 1, (B - h, 4)) * np.array([0.5, 1.0, 0.3, 1.0])
+    return x0
+
+
+def run_both(ocp, P, oracle_port, x0, u0=None, theta=None, **kw):
+    from mpc4rl_amd import MPCBatch
+    B = x0.shape[0]
+    mpc = MPCBatch(ocp, B)
+    if theta is not None:
+        mpc.set_theta(torch.as_tensor(theta))
+    r = mpc.solve(x0, u0, sens_v=True, sens_pi=True, cold=True)
+    torch.cuda.synchronize()
+    ref = oracle_port.solve(P, x0, p=theta, u0fix=u0, **kw)
+    return mpc, r, ref
+
+
+def check(r, ref, need_strict=None):
+    st = r.status.cpu().numpy()
+    assert np.array_equal(st, ref.status), (st, ref.status)
+    ok = st == 0
+    assert ok.mean() > 0.9
+    it = r.iters.cpu().numpy()
+    assert np.array_equal(it[ok, 0], ref.sqp_iter[ok])
+    errs = {
+        "u0": rel_err(r.u0.cpu().numpy()[ok], ref.u0[ok]),
+        "V": rel_err(r.V.cpu().numpy()[ok], ref.V[ok]),
+        "dV": rel_err(r.dV_dp.cpu().numpy()[ok], ref.dV[ok]),
+    }
+    sel = ok if need_strict is None else ok & need_strict
+    errs["dpi"] = rel_err(r.dpi_dp.cpu().numpy()[sel], ref.dpi[sel])
+    print(errs, "ipm iters equal:", np.array_equal(it[ok, 1], ref.ipm_iter[ok]))
+    for k, v in errs.items():
+        assert v < RTOL, (k, v)
+    return errs
+
+
+def test_cartpole_solve_and_sens_vs_oracle(oracle_port):
+    from mpc4rl_amd import cartpole_ocp
+    from oracle.problems import make_cartpole
+    x0 = cartpole_x0(256)
+    mpc, r, ref = run_both(cartpole_ocp(), make_cartpole(), oracle_port, x0)
+    check(r, ref)
+    x, u, pi, bnd, res = [t.cpu().numpy() for t in mpc.get_iterate()]
+    ok = ref.status == 0
+    assert rel_err(x[ok], ref.X[ok]) < RTOL and rel_err(u[ok], ref.U[ok]) < RTOL and rel_err(pi[ok], ref.PI[ok]) < RTOL
+    assert np.all(res[ok] < 1e-6)          # assert_kkt_residual, nlp.py:1295-1299
+
+
+def test_cartpole_q_mode_vs_oracle(oracle_port):
+    from mpc4rl_amd import cartpole_ocp
+    from oracle.problems import make_cartpole
+    B = 64
+    rng = np.random.default_rng(1)
+    x0 = cartpole_x0(B, 1)
+    u0 = rng.uniform(-30, 30, (B, 1))
+    u0[0] = -30.0                          # scripts/cartpole_mpc_sensitivities.py:80-81
+    x0[0] = [0.0, 0.0, np.pi / 2, 0.0]
+    _, r, ref = run_both(cartpole_ocp(), make_cartpole(), oracle_port, x0, u0)
+    check(r, ref)
+    assert np.allclose(r.u0.cpu().numpy(), u0)
+    assert np.all(r.dpi_dp.cpu().numpy() == 0.0)
+
+
+def test_cartpole_per_instance_theta(oracle_port):
+    from mpc4rl_amd import cartpole_ocp
+    from oracle.problems import make_cartpole
+    B = 96
+    P = make_cartpole()
+    rng = np.random.default_rng(2)
+    theta = np.tile(P.p0, (B, 1))
+    theta[:, :3] *= rng.uniform(0.9, 1.1, (B, 3))
+    _, r, ref = run_both(cartpole_ocp(), P, oracle_port, cartpole_x0(B, 2), theta=theta)
+    check(r, ref)
+
+
+def test_linear_system_vs_oracle(oracle_port):
+    from mpc4rl_amd import linear_system_ocp
+    from oracle.problems import make_linear_system
+    B = 64
+    rng = np.random.default_rng(3)
+    x0 = np.column_stack([rng.uniform(0.15, 0.85, B), rng.uniform(-0.5, 0.5, B)])
+    x0[0] = [0.5, 0.5]                     # linear_system/environment.py:46
+    x0[1] = [0.2, 0.2]                     # scripts/linear_system_mpc_nlp.py:18
+    for gamma in (0.99, 0.9):
+        _, r, ref = run_both(linear_system_ocp(discount_factor=gamma), make_linear_system(gamma=gamma), oracle_port, x0)
+        # du0/dp is ill-defined where a soft bound is active (quirk q1, LICQ fails): compare where slacks are 0
+        s = np.abs(ref.BND[:, 4:6]).reshape(B, -1).max(axis=1)
+        check(r, ref, need_strict=s < 1e-9)
+
+
+def test_linear_system_q_mode(oracle_port):
+    from mpc4rl_amd import linear_system_ocp
+    from oracle.problems import make_linear_system
+    x0 = np.tile([0.2, 0.2], (8, 1))
+    u0 = np.linspace(-0.9, 0.9, 8).reshape(8, 1)
+    u0[0] = -0.5                           # scripts/linear_system_mpc_nlp.py:18
+    _, r, ref = run_both(linear_system_ocp(), make_linear_system(), oracle_port, x0, u0)
+    check(r, ref)
