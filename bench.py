@@ -1,0 +1,168 @@
+"""bench.py — headline benchmark: MPC + KKT-sensitivity solves per second, cartpole N=20, batch 4096 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch of synthetic inputs already resident in HBM: 4096
+cartpole OCPs (BASELINE.json config 3: cold-start full SQP to tol 1e-6 + dV/dp + du0*/dp) per GPU, one
+kernel launch through the C ABI.  With N > 1 the batch is sharded (weak scaling, 4096 per rank) and the
+step ends with the single all-reduce of the accumulated theta-gradient that a data-parallel RL update
+needs.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+B_PER_GPU = 4096
+N_THETA = 3             # cartpole model parameters (M, m, l)
+
+
+def algorithmic_bytes_per_solve(N, nx, nu, n_theta, sens):
+    """8*[nx + 2*I + nu + 1 + s_V*n_theta + s_pi*nu*n_theta] + 4, I = (N+1)nx + N nu + N nx."""
+    iterate = (N + 1) * nx + N * nu + N * nx
+    return 8 * (nx + 2 * iterate + nu + 1 + (n_theta + nu * n_theta if sens else 0)) + 4
+
+
+def make_inputs(B, rank):
+    """rng = default_rng(0); theta ~ U(0.9 pi, 1.1 pi), other states 0 (reference reset distribution)."""
+    rng = np.random.default_rng(rank)
+    x0 = np.zeros((B, 4))
+    x0[:, 2] = rng.uniform(0.9 * np.pi, 1.1 * np.pi, B)
+    return x0
+
+
+def cpu_baseline(x0_np, sens):
+    """The oracle's C++ port ("port") on this box's host cores, on a bounded sample of the same workload."""
+    from oracle import cpu_port
+    from oracle.problems import make_cartpole
+    P = make_cartpole()
+    cores = os.cpu_count() or 1
+    flags = (cpu_port.SENS_V | cpu_port.SENS_PI) if sens else 0
+    cpu_port.solve(P, x0_np[:64], flags=flags, nthreads=cores)        # warm-up (page in, spawn threads)
+    n = min(len(x0_np), 4096)
+    reps, t_total, solved = 0, 0.0, 0
+    while t_total < 3.0 and reps < 8:
+        t0 = time.perf_counter()
+        r = cpu_port.solve(P, x0_np[:n], flags=flags, nthreads=cores)
+        t_total += time.perf_counter() - t0
+        solved += n
+        reps += 1
+    return {"value": solved / t_total, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x {n} instances of the same workload (oracle/cpu C++ port, OpenMP over instances, "
+                      f"mean SQP iters {float(r.sqp_iter.mean()):.2f}, mean IPM iters {float(r.ipm_iter.mean()):.1f})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU)
+    ap.add_argument("--no-sens", action="store_true", help="forward solve only (BASELINE config 2)")
+    ap.add_argument("--rti", action="store_true", help="one SQP iteration from the stored iterate (build-side mode)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    ocp = cartpole_ocp()
+    B = args.batch
+    sens = not args.no_sens
+    mpc = MPCBatch(ocp, B, device=dev)
+    x0_np = make_inputs(B, rank)
+    x0 = torch.as_tensor(x0_np, device=dev)
+    grad = torch.zeros(N_THETA + 2, dtype=torch.float64, device=dev)
+
+    def step():
+        # cold start every step (MPC.reset semantics) so that every step does the same, full work
+        r = mpc.solve(x0, sens_v=sens, sens_pi=sens, cold=not args.rti, rti=args.rti)
+        if world > 1 and sens:
+            # data-parallel RL update: one all-reduce of [sum_i dV_i/dtheta, sum_i V_i, count]
+            grad[:N_THETA] = r.dV_dp[:, :N_THETA].sum(0)
+            grad[N_THETA] = r.V.sum()
+            grad[N_THETA + 1] = float(B)
+            dist.all_reduce(grad)
+        return r
+
+    if args.rti:
+        mpc.solve(x0, cold=True)            # converge once; RTI steps then start from that iterate
+    for _ in range(args.warmup):
+        r = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        r = step()
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    status = r.status.cpu().numpy()
+    iters = r.iters.cpu().numpy()
+    if rank == 0:
+        solves = B * world * args.steps
+        bytes_per = algorithmic_bytes_per_solve(ocp.N, ocp.nx, ocp.nu, N_THETA, sens)
+        achieved = bytes_per * B / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "MPC+KKT-sens solves/sec, cartpole N=20 batch=4096" if sens else "MPC solves/sec, cartpole N=20 batch=4096",
+            "value": solves / elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": ("cartpole N=20 nx=4 nu=1, %d instances/GPU, %s" % (
+                B, "RTI (1 SQP iteration, warm)" if args.rti else "cold-start full-step SQP to tol 1e-6")) +
+                (" + dV/dp + du0*/dp (BASELINE config 3)" if sens else " (BASELINE config 2)"),
+                "batch_per_gpu": B, "parallelism": f"instances sharded over {world} GPU(s)" +
+                ("; one all-reduce of the theta-gradient per step" if world > 1 and sens else ""),
+                "converged_fraction": float((status == 0).mean()), "sqp_iters_mean": float(iters[:, 0].mean()),
+                "sqp_iters_max": int(iters[:, 0].max()), "ipm_iters_mean": float(iters[:, 1].mean()),
+                "ipm_iters_max": int(iters[:, 1].max())},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_solve": bytes_per},
+        }
+        if world == 1 and not args.no_cpu:
+            try:
+                out["cpu_baseline"] = cpu_baseline(x0_np, sens)
+            except Exception as e:   # the bench line must still come out
+                out["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
