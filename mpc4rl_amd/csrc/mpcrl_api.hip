@@ -73,6 +73,10 @@ int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
     const int blocks = (h->B + ipw - 1) / ipw;
     hipLaunchKernelGGL(small_solve_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
     HIP_OK(hipGetLastError());
+    if (a.flags & (MPCRL_SENS_V | MPCRL_SENS_PI)) {
+        hipLaunchKernelGGL(small_sens_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
+        HIP_OK(hipGetLastError());
+    }
     return 0;
 }
 

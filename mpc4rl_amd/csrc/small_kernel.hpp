@@ -888,7 +888,8 @@ __global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, con
     for (int i = 0; i < S.NLK; ++i) S.Li[i] = 0.0;
 
     // ---- full-step SQP (the reference requests no globalisation; config/cartpole.yaml:8-14)
-    const int max_iter = (a.flags & 4) ? 1 : sp.max_iter;
+    const bool rti = (a.flags & 4) != 0;
+    const int max_iter = rti ? 1 : sp.max_iter;
     bool live = valid;
     int status = 2, n_sqp = 0, n_ipm = 0;
     double Vout = 0.0, res_out[4] = {0, 0, 0, 0};
@@ -911,7 +912,7 @@ __global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, con
             for (int j = 0; j < 4; ++j) res_out[j] = res[j];
             if (!(rmax < 1e300))
                 status = 1, live = false;
-            else if (rmax < sp.tol)
+            else if (rmax < sp.tol && !(rti && it == 0))
                 status = 0, live = false;
             else if (it >= max_iter)
                 status = 2, live = false;
@@ -956,13 +957,56 @@ __global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, con
             }
         }
     }
-    if (a.flags & 3) {
-        // sensitivities at the final iterate (status 0, or 2 in RTI mode); other instances get NaN-free zeros
-        const bool sv = valid && (status == 0 || status == 2);
+}
+
+// =====================================================================================================
+// sensitivity kernel: re-reads the converged iterate (x, u, nu, lam, t) written by small_solve_kernel.
+// Kept separate so that the second-order jets do not set the register budget of the SQP loop.
+// =====================================================================================================
+template <class M>
+__global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, const SmallArgs a) {
+    constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NP = M::NP, NTD = M::NTD, NTC = M::NTC;
+    const int lane = threadIdx.x;
+    const int N = sp.N, lpi = N + 1, ipw = 64 / lpi;
+    const int slot = lane / lpi, k = lane - slot * lpi, base = slot * lpi;
+    long inst = (long)blockIdx.x * ipw + slot;
+    const bool valid = slot < ipw && inst < a.B;
+    if (!valid) inst = a.B - 1;
+    SmallSolver<M> S(sp, k, lpi, base);
+    const bool term = S.term, first = S.first;
+    S.qmode = a.u0fix != nullptr;
+    if (sp.cost_kind == 0)
+        S.ck = term ? 1.0 : sp.dT;
+    else
+        S.ck = first ? sp.dT : (term ? pow(sp.gamma, (double)N) : pow(sp.gamma, (double)k) * sp.dT);
+    const double *th = a.theta + (size_t)inst * a.theta_stride;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) nun[i] = lane_dn(S.nu_[i]);
-        S.sensitivities(a.flags, sv, nun, a.dV ? a.dV + inst * NP : nullptr, a.dpi ? a.dpi + inst * NU * NP : nullptr);
+    for (int i = 0; i < NTD; ++i) S.thd[i] = th[M::td_index(i)];
+#pragma unroll
+    for (int i = 0; i < NTC; ++i) S.thc[i] = th[M::tc_index(i)];
+    const size_t nb = (size_t)(N + 1) * NW;
+    const double *bnd = a.BND + (size_t)inst * 10 * nb + (size_t)k * NW;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        S.x[i] = a.X[(inst * (N + 1) + k) * NX + i];
+        S.nu_[i] = first ? 0.0 : a.PI[(inst * N + k - 1) * NX + i];
     }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) S.u[i] = term ? 0.0 : a.U[(inst * N + k) * NU + i];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) S.lam[0][i] = bnd[0 * nb + i], S.lam[1][i] = bnd[1 * nb + i], S.t[0][i] = bnd[2 * nb + i], S.t[1][i] = bnd[3 * nb + i];
+    // the dynamics Jacobians of the final iterate are needed by the adjoint Riccati sweep
+    double xn[NX], nun[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xn[i] = lane_dn(S.x[i]), nun[i] = lane_dn(S.nu_[i]);
+    S.linearize(xn);
+#pragma unroll
+    for (int i = 0; i < S.NPK; ++i) S.P[i] = 0.0, S.Pnext[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) S.p[i] = 0.0;
+    const int status = a.status[inst];
+    const bool sv = valid && (status == 0 || status == 2);
+    S.sensitivities(a.flags, sv, nun, a.dV ? a.dV + inst * NP : nullptr, a.dpi ? a.dpi + inst * NU * NP : nullptr);
 }
 
 }  // namespace mpcrl

@@ -1,0 +1,52 @@
+"""Multi-GPU data parallelism for the MPC-as-policy engine: one process per GPU, instances sharded, ONE collective.
+
+The OCP instances of a batch are independent given theta, so the solve itself needs no
+communication.  The only exchange of a data-parallel RL update is the accumulated theta-gradient
+(rlmpc/examples/linear_system_mpc_qlearning.py:193-205: ``dp = mean_i(lr * td_i * dQ_dp_i)``): every rank
+contributes ``[sum_i w_i g_i (n_theta), sum_i w_i, count]`` in fp64 and all ranks apply the identical update.
+Backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous split of ``total`` instances over ``world`` ranks (remainder to the low ranks)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allreduce_weighted_grad(grad: torch.Tensor, weight: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
+                            deterministic: bool = False) -> Tuple[torch.Tensor, torch.Tensor, int]:
+    """grad [b, n_theta] (e.g. dQ/dp rows), weight [b] (e.g. lr * td error) of the LOCAL shard.
+
+    Returns (sum_i w_i g_i over ALL ranks [n_theta], sum_i w_i, total count) with a single all-reduce of
+    n_theta + 2 doubles.  ``deterministic=True`` uses all-gather + fixed-order summation instead so the result is
+    bitwise independent of the reduction tree."""
+    g = grad.to(torch.float64)
+    w = weight.to(torch.float64).reshape(-1)
+    n_theta = g.shape[1]
+    buf = torch.empty(n_theta + 2, dtype=torch.float64, device=g.device)
+    buf[:n_theta] = (w[:, None] * g).sum(0)
+    buf[n_theta] = w.sum()
+    buf[n_theta + 1] = float(g.shape[0])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if deterministic:
+            parts = [torch.empty_like(buf) for _ in range(dist.get_world_size(group))]
+            dist.all_gather(parts, buf, group=group)
+            buf = torch.stack(parts).sum(0)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf[:n_theta], buf[n_theta], int(round(float(buf[n_theta + 1].item())))
+
+
+def mean_update(grad: torch.Tensor, weight: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
+                deterministic: bool = False) -> torch.Tensor:
+    """``mean_i(w_i * g_i)`` over all instances on all ranks — the parameter step of the Q-learning example."""
+    s, _, n = allreduce_weighted_grad(grad, weight, group, deterministic)
+    return s / max(n, 1)
