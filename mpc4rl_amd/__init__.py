@@ -7,9 +7,9 @@ HIP kernel launch.  The arithmetic lives in ``csrc/`` behind the C ABI of ``incl
 PyTorch is used for device memory and streams only.  There is no CPU fallback: importing the solver
 classes without ``libmpcrl_hip.so`` raises.
 """
-from .problems import OcpDescription, cartpole_ocp, linear_system_ocp  # noqa: F401
+from .problems import OcpDescription, cartpole_ocp, chain_mass_ocp, linear_system_ocp  # noqa: F401
 from .batch import MPCBatch, SolveResult  # noqa: F401
-from .mpc import MPC, CartpoleMPC, LinearSystemMPC  # noqa: F401
+from .mpc import MPC, CartpoleMPC, ChainMassMPC, LinearSystemMPC  # noqa: F401
 
-__all__ = ["OcpDescription", "cartpole_ocp", "linear_system_ocp", "MPCBatch", "SolveResult", "MPC", "CartpoleMPC",
-           "LinearSystemMPC"]
+__all__ = ["OcpDescription", "cartpole_ocp", "linear_system_ocp", "chain_mass_ocp", "MPCBatch", "SolveResult", "MPC", "CartpoleMPC",
+           "LinearSystemMPC", "ChainMassMPC"]

@@ -135,6 +135,72 @@ struct LinearDev {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------
+// Chain of masses (rlmpc/mpc/chain_mass/ocp_utils.py:59-147,253-277), NMASS = n_mass.
+// x = [pos (3(M+1)); vel (3M)], u = velocity of the last mass, M = n_mass - 2 free masses.
+// p = [m (NL), D (3 NL), L (3 NL), C (3 NL), Q (nx*nx col-major), R (nu*nu col-major), w (3 M)]   (ocp_utils.py:353-371)
+// dynamics parameters th = [m, D, L, C, w]; consts = x_ss (NX).
+// ---------------------------------------------------------------------------------------------------
+template <int NMASS>
+struct ChainDev {
+    static constexpr int M = NMASS - 2, NL = NMASS - 1;
+    static constexpr int NX = (2 * M + 1) * 3, NU = 3, NW = NX + NU;
+    static constexpr int OFF_Q = 10 * NL, OFF_R = OFF_Q + NX * NX, OFF_W = OFF_R + NU * NU;
+    static constexpr int NP = OFF_W + 3 * M, NTD = 10 * NL + 3 * M;
+    MPCRL_DI static int td_index(int i) { return i < 10 * NL ? i : OFF_W + (i - 10 * NL); }
+
+    template <class S>
+    MPCRL_DI static void ode(const S *x, const S *u, const S *th, S *f) {
+        const S *pos = x, *vel = x + 3 * (M + 1);
+        const S *m = th, *D = th + NL, *L = th + 4 * NL, *C = th + 7 * NL, *w = th + 10 * NL;
+        S *acc = f + 3 * (M + 1);
+        for (int i = 0; i < 3 * M; ++i) acc[i] = (i % 3 == 2) ? w[i] + (-9.81) : w[i];
+        for (int i = 0; i <= M; ++i) {
+            S dist[3];
+            for (int j = 0; j < 3; ++j) dist[j] = i ? pos[3 * i + j] - pos[3 * (i - 1) + j] : pos[j];
+            const S nrm = jsqrt(dist[0] * dist[0] + dist[1] * dist[1] + dist[2] * dist[2]);
+            for (int j = 0; j < 3; ++j) {
+                const S Fs = D[3 * i + j] / m[i] * (1.0 - L[3 * i + j] / nrm) * dist[j];
+                const S vr = i < M ? vel[3 * i + j] : u[j];
+                const S dv = i ? vr - vel[3 * (i - 1) + j] : vr;
+                const S Ft = Fs + C[3 * i + j] * dv;
+                if (i < M) acc[3 * i + j] = acc[3 * i + j] - Ft;
+                if (i > 0) acc[3 * (i - 1) + j] = acc[3 * (i - 1) + j] + Ft;
+            }
+        }
+        for (int i = 0; i < 3 * M; ++i) f[i] = vel[i];
+        for (int j = 0; j < 3; ++j) f[3 * M + j] = u[j];
+    }
+    // symmetrised cost weights from p (Q, R column-major; ocp_utils.py:267,273)
+    MPCRL_DI static double Qs(const double *p, int i, int j) { return 0.5 * (p[OFF_Q + j * NX + i] + p[OFF_Q + i * NX + j]); }
+    MPCRL_DI static double Rs(const double *p, int i, int j) { return 0.5 * (p[OFF_R + j * NU + i] + p[OFF_R + i * NU + j]); }
+    // Hessian of the unscaled stage cost between stage-vector coordinates (v = [u; x])
+    MPCRL_DI static double hess(bool term, int i, int j, const double *p) {
+        if (i < NU && j < NU) return term ? 0.0 : Rs(p, i, j);
+        if (i >= NU && j >= NU) return Qs(p, i - NU, j - NU);
+        return 0.0;
+    }
+};
+
+// RK4^steps with the minimum of live state (used with large NX where the arrays live in scratch)
+template <class M, class S>
+MPCRL_DI void disc_map_lean(const S *x, const S *u, const S *th, S *xn, double h, int steps) {
+    constexpr int NX = M::NX;
+    S xc[NX], acc[NX], xt[NX], kk[NX];
+    for (int i = 0; i < NX; ++i) xc[i] = x[i];
+    for (int s = 0; s < steps; ++s) {
+        M::template ode<S>(xc, u, th, kk);
+        for (int i = 0; i < NX; ++i) acc[i] = kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
+        M::template ode<S>(xt, u, th, kk);
+        for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
+        M::template ode<S>(xt, u, th, kk);
+        for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + h * kk[i];
+        M::template ode<S>(xt, u, th, kk);
+        for (int i = 0; i < NX; ++i) xc[i] = xc[i] + (h / 6.0) * (acc[i] + kk[i]);
+    }
+    for (int i = 0; i < NX; ++i) xn[i] = xc[i];
+}
+
 // discrete map F = RK4^steps(ode; h)  (rlmpc/common/integrator.py:6-33)
 template <class M, class S>
 MPCRL_DI void disc_map(const S *x, const S *u, const S *th, S *xn, double h, int steps) {

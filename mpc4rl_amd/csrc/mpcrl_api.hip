@@ -11,13 +11,18 @@
 #include <new>
 #include <vector>
 
-#include "small_kernel.hpp"
+#include "large_kernel.hpp"
 
 using namespace mpcrl;
 
 struct MpcrlSolver {
     int model, B, device, nx, nu, np, N;
     SmallSpec small;
+    LargeSpec large;
+    bool is_large = false;
+    int n_mass = 0;
+    double *ws = nullptr, *consts_dev = nullptr;
+    size_t ws_stride = 0;
     double *theta = nullptr;   // [np] or [B, np]
     int theta_stride = 0;
     double *X = nullptr, *U = nullptr, *PI = nullptr, *BND = nullptr, *RES = nullptr;
@@ -67,6 +72,36 @@ int fill_small_spec(const MpcrlProblemSpec &s, SmallSpec &d) {
     return 0;
 }
 
+int fill_large_spec(const MpcrlProblemSpec &s, LargeSpec &d) {
+    const int nw = s.nx + s.nu;
+    if (nw > LARGE_MAXNW || s.nu > 4 || s.N + 1 > 64 || s.N < 1) return MPCRL_E_ARG;
+    if (s.soft)
+        for (int i = 0; i < nw; ++i)
+            if (s.soft[i]) return MPCRL_E_ARG;   // hard bounds only in the large kernel
+    std::memset(&d, 0, sizeof(d));
+    d.N = s.N, d.np = s.np, d.cost_kind = s.cost_kind, d.rk_steps = s.rk_steps, d.max_iter = s.max_iter;
+    d.dT = s.dT, d.gamma = s.gamma, d.h = s.h, d.tol = s.tol;
+    copy_or_fill(d.lb0, s.lb0, s.nu, 4, -MPCRL_NO_BOUND);
+    copy_or_fill(d.ub0, s.ub0, s.nu, 4, MPCRL_NO_BOUND);
+    copy_or_fill(d.lb, s.lb, nw, LARGE_MAXNW, -MPCRL_NO_BOUND);
+    copy_or_fill(d.ub, s.ub, nw, LARGE_MAXNW, MPCRL_NO_BOUND);
+    copy_or_fill(d.lbe, s.lbe, s.nx, LARGE_MAXNW, -MPCRL_NO_BOUND);
+    copy_or_fill(d.ube, s.ube, s.nx, LARGE_MAXNW, MPCRL_NO_BOUND);
+    return 0;
+}
+
+template <class M>
+int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
+    a.ws = h->ws, a.ws_stride = h->ws_stride;
+    hipLaunchKernelGGL(large_solve_kernel<M>, dim3(h->B), dim3(LARGE_NT), 0, st, h->large, a);
+    HIP_OK(hipGetLastError());
+    if (a.flags & (MPCRL_SENS_V | MPCRL_SENS_PI)) {
+        hipLaunchKernelGGL(large_sens_kernel<M>, dim3(h->B), dim3(LARGE_NT), 0, st, h->large, a);
+        HIP_OK(hipGetLastError());
+    }
+    return 0;
+}
+
 template <class M>
 int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
     const int ipw = 64 / (h->N + 1);
@@ -100,9 +135,19 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
         case MPCRL_MODEL_LINEAR:
             if (spec->nx != LinearDev::NX || spec->nu != LinearDev::NU || spec->np != LinearDev::NP) rc = MPCRL_E_MODEL;
             break;
+        case MPCRL_MODEL_CHAIN:
+            h->is_large = true;
+            h->n_mass = (spec->nx / 3 - 1) / 2 + 2;
+            if (spec->nu != 3 || !(h->n_mass == 3 || h->n_mass == 5 || h->n_mass == 7) || spec->nx != (2 * (h->n_mass - 2) + 1) * 3 ||
+                spec->n_consts != spec->nx)
+                rc = MPCRL_E_MODEL;
+            else if ((h->n_mass == 3 && spec->np != ChainDev<3>::NP) || (h->n_mass == 5 && spec->np != ChainDev<5>::NP) ||
+                     (h->n_mass == 7 && spec->np != ChainDev<7>::NP))
+                rc = MPCRL_E_MODEL;
+            break;
         default: rc = MPCRL_E_MODEL;
     }
-    if (!rc) rc = fill_small_spec(*spec, h->small);
+    if (!rc) rc = h->is_large ? fill_large_spec(*spec, h->large) : fill_small_spec(*spec, h->small);
     if (rc) {
         delete h;
         return rc;
@@ -114,6 +159,16 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
     if (!rc) rc = dev_alloc(&h->BND, B * 10 * (N + 1) * nw, h->bytes);
     if (!rc) rc = dev_alloc(&h->RES, B * 4, h->bytes);
     if (!rc) rc = dev_alloc(&h->theta, B * (size_t)spec->np, h->bytes);
+    if (!rc && h->is_large) {
+        h->ws_stride = h->n_mass == 3 ? LargeLayout<ChainDev<3>>(spec->N).total
+                                      : (h->n_mass == 5 ? LargeLayout<ChainDev<5>>(spec->N).total : LargeLayout<ChainDev<7>>(spec->N).total);
+        rc = dev_alloc(&h->ws, B * h->ws_stride, h->bytes);
+        if (!rc) rc = dev_alloc(&h->consts_dev, (size_t)spec->n_consts, h->bytes);
+        if (!rc) {
+            HIP_OK(hipMemcpy(h->consts_dev, spec->consts, spec->n_consts * sizeof(double), hipMemcpyHostToDevice));
+            h->large.consts = h->consts_dev;
+        }
+    }
     if (rc) {
         mpcrl_destroy(h);
         return rc;
@@ -126,7 +181,7 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
 int mpcrl_destroy(mpcrl_handle h) {
     if (!h) return MPCRL_E_ARG;
     hipSetDevice(h->device);
-    for (double *p : {h->X, h->U, h->PI, h->BND, h->RES, h->theta})
+    for (double *p : {h->X, h->U, h->PI, h->BND, h->RES, h->theta, h->ws, h->consts_dev})
         if (p) hipFree(p);
     delete h;
     return 0;
@@ -145,14 +200,14 @@ int mpcrl_set_theta(mpcrl_handle h, const double *theta, int n_theta, int per_in
 
 int mpcrl_set_gamma(mpcrl_handle h, double gamma) {
     if (!h) return MPCRL_E_ARG;
-    h->small.gamma = gamma;
+    h->small.gamma = gamma, h->large.gamma = gamma;
     return 0;
 }
 
 int mpcrl_set_options(mpcrl_handle h, double tol, int max_iter) {
     if (!h) return MPCRL_E_ARG;
-    if (tol > 0) h->small.tol = tol;
-    if (max_iter >= 0) h->small.max_iter = max_iter;
+    if (tol > 0) h->small.tol = tol, h->large.tol = tol;
+    if (max_iter >= 0) h->small.max_iter = max_iter, h->large.max_iter = max_iter;
     return 0;
 }
 
@@ -180,11 +235,19 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
     if (a.dV) HIP_OK(hipMemsetAsync(dV_dp, 0, (size_t)h->B * h->np * sizeof(double), st));
     if (a.dpi) HIP_OK(hipMemsetAsync(dpi_dp, 0, (size_t)h->B * h->nu * h->np * sizeof(double), st));
     int rc;
-    switch (h->model) {
-        case MPCRL_MODEL_CARTPOLE: rc = launch_small<CartpoleDev>(h, a, st); break;
-        case MPCRL_MODEL_LINEAR: rc = launch_small<LinearDev>(h, a, st); break;
-        default: rc = MPCRL_E_MODEL;
-    }
+    if (h->is_large) {
+        LargeArgs la;
+        la.B = a.B, la.flags = a.flags, la.theta_stride = a.theta_stride, la.x0 = a.x0, la.u0fix = a.u0fix, la.theta = a.theta;
+        la.X = a.X, la.U = a.U, la.PI = a.PI, la.BND = a.BND, la.RES = a.RES, la.ws = nullptr, la.ws_stride = 0;
+        la.u0_out = a.u0_out, la.V = a.V, la.dV = a.dV, la.dpi = a.dpi, la.status = a.status, la.iters = a.iters;
+        rc = h->n_mass == 3 ? launch_large<ChainDev<3>>(h, la, st)
+                            : (h->n_mass == 5 ? launch_large<ChainDev<5>>(h, la, st) : launch_large<ChainDev<7>>(h, la, st));
+    } else
+        switch (h->model) {
+            case MPCRL_MODEL_CARTPOLE: rc = launch_small<CartpoleDev>(h, a, st); break;
+            case MPCRL_MODEL_LINEAR: rc = launch_small<LinearDev>(h, a, st); break;
+            default: rc = MPCRL_E_MODEL;
+        }
     if (!rc) h->have_iterate = true;
     return rc;
 }

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from .batch import MPCBatch
-from .problems import OcpDescription, cartpole_ocp, linear_system_ocp
+from .problems import OcpDescription, cartpole_ocp, chain_mass_ocp, linear_system_ocp
 
 
 class _ParamView:
@@ -316,3 +316,14 @@ class LinearSystemMPC(MPC):
 
     def __init__(self, param: Optional[dict] = None, discount_factor: float = 0.99, **kw):
         super().__init__(linear_system_ocp(param, discount_factor), gamma=discount_factor, **kw)
+
+
+class ChainMassMPC(MPC):
+    """rlmpc/mpc/chain_mass/acados.py:18-29 (``AcadosMPC(param, discount_factor)``; param = get_chain_params())."""
+
+    def __init__(self, param: Optional[dict] = None, discount_factor: float = 1.0, **kw):
+        param = {} if param is None else param
+        ocp = chain_mass_ocp(n_mass=param.get("n_mass", 5), N=param.get("N", 40), Ts=param.get("Ts", 0.2), m=param.get("m", 0.033),
+                             D=param.get("D", 1.0), L=param.get("L", 0.033), C=param.get("C", 0.1),
+                             max_iter=param.get("nlp_iter", 50), tol=param.get("nlp_tol", 1e-5))
+        super().__init__(ocp, gamma=discount_factor, **kw)

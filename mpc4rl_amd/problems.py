@@ -132,3 +132,87 @@ def linear_system_ocp(param: Optional[dict] = None, discount_factor: float = 0.9
         lbu=np.array([-1.0]), ubu=np.array([1.0]), idxbx=np.arange(2), lbx=np.array([0.0, -1.0]), ubx=np.array([1.0, 1.0]),
         idxsbx=np.array([0]), zl=np.array([1e2]), zu=np.array([1e2]), consts=P.reshape(-1).copy(), gamma=discount_factor,
         tol=1e-6, max_iter=100, x0=np.array([0.5, 0.5]), n_model_p=12)
+
+
+# ---------------------------------------------------------------------------------------------------
+# chain of masses (rlmpc/mpc/chain_mass/ocp_utils.py:59-147,195-376, rlmpc/examples/chain_mass.py:17-25)
+# ---------------------------------------------------------------------------------------------------
+def chain_param_layout(n_mass: int):
+    """Offsets of m, D, L, C, Q, R, w inside p (define_param_struct_symSX, ocp_utils.py:353-371)."""
+    M, nl = n_mass - 2, n_mass - 1
+    nx, nu = (2 * M + 1) * 3, 3
+    off, o = {}, 0
+    for key, sz in [("m", nl), ("D", 3 * nl), ("L", 3 * nl), ("C", 3 * nl), ("Q", nx * nx), ("R", nu * nu), ("w", 3 * M)]:
+        off[key] = (o, o + sz)
+        o += sz
+    return M, nl, nx, nu, off, o
+
+
+def _chain_accel(n_mass, pos, vel, u, p):
+    """Accelerations of the free masses (ocp_utils.py:72-125), numpy."""
+    M, nl, nx, nu, off, _ = chain_param_layout(n_mass)
+    m = p[off["m"][0]: off["m"][1]]
+    D = p[off["D"][0]: off["D"][1]].reshape(nl, 3)
+    L = p[off["L"][0]: off["L"][1]].reshape(nl, 3)
+    C = p[off["C"][0]: off["C"][1]].reshape(nl, 3)
+    w = p[off["w"][0]: off["w"][1]].reshape(M, 3)
+    dist = pos - np.vstack([np.zeros((1, 3)), pos[:-1]])
+    nrm = np.sqrt((dist * dist).sum(axis=1, keepdims=True))
+    Fs = D / m[:, None] * (1.0 - L / nrm) * dist
+    dv = np.vstack([vel, u[None, :]]) - np.vstack([np.zeros((1, 3)), vel])
+    Ft = Fs + C * dv
+    return -Ft[:M] + Ft[1:] + np.array([0.0, 0.0, -9.81])[None, :] + w
+
+
+def chain_steady_state(n_mass: int, p: np.ndarray, x_end: np.ndarray) -> np.ndarray:
+    """x_ss with f = 0, u = 0 and the last mass at x_end (compute_parametric_steady_state, ocp_utils.py:150-192;
+    the reference mis-uses IPOPT as a root finder, here: Newton with a finite-difference Jacobian)."""
+    M = n_mass - 2
+    pos = np.zeros((M + 1, 3))
+    pos[:, 0] = np.linspace(0.0, x_end[0], M + 2)[1:]
+    pos[M] = x_end
+
+    def resid(free):
+        q = pos.copy()
+        q[:M] = free.reshape(M, 3)
+        return _chain_accel(n_mass, q, np.zeros((M, 3)), np.zeros(3), p).reshape(-1)
+
+    free = pos[:M].reshape(-1).copy()
+    for _ in range(100):
+        r = resid(free)
+        J = np.empty((3 * M, 3 * M))
+        for j in range(3 * M):
+            e = np.zeros(3 * M)
+            e[j] = 1e-7
+            J[:, j] = (resid(free + e) - resid(free - e)) / 2e-7
+        step = np.linalg.solve(J, -r)
+        free = free + step
+        if np.abs(step).max() < 1e-15:
+            break
+    assert np.abs(resid(free)).max() < 1e-10, "chain steady state did not converge"
+    return np.concatenate([free, x_end, np.zeros(3 * M)])
+
+
+def chain_mass_ocp(n_mass: int = 5, N: int = 40, Ts: float = 0.2, m: float = 0.033, D: float = 1.0, L: float = 0.033,
+                   C: float = 0.1, max_iter: int = 50, tol: float = 1e-5) -> OcpDescription:
+    """Chain-of-masses OCP with get_chain_params() defaults (ocp_utils.py:319-341; random_scale = 0)."""
+    M, nl, nx, nu, off, n_p = chain_param_layout(n_mass)
+    p0 = np.zeros(n_p)
+    for key, val in (("m", m), ("D", D), ("L", L), ("C", C)):
+        p0[off[key][0]: off[key][1]] = val
+    q_diag = np.ones(nx)
+    q_diag[3 * M: 3 * M + 3] = M + 1                                  # ocp_utils.py:268-270
+    p0[off["Q"][0]: off["Q"][1]] = (2.0 * np.diag(q_diag)).flatten("F")
+    p0[off["R"][0]: off["R"][1]] = (2.0 * 1e-2 * np.eye(nu)).flatten("F")   # ocp_utils.py:274
+    x_end = np.array([L * (n_mass - 1) * 6, 0.0, 0.0])               # ocp_utils.py:249
+    x_ss = chain_steady_state(n_mass, p0, x_end)
+    labels = [f"m_{i}" for i in range(nl)]
+    for key in ("D", "L", "C"):
+        labels += [f"{key}_{i}_{j}" for i in range(nl) for j in range(3)]
+    labels += [f"Q_{i}" for i in range(nx * nx)] + [f"R_{i}" for i in range(nu * nu)] + [f"w_{i}_{j}" for i in range(M) for j in range(3)]
+    x0 = np.zeros(nx)
+    x0[: 3 * (M + 1): 3] = np.linspace(0.0, L * (M + 1) * 6, M + 2)[1:]   # examples/chain_mass.py:17-25
+    return OcpDescription(
+        name=f"chain_mass_{n_mass}", model=_lib.MODEL_CHAIN, N=N, nx=nx, nu=nu, dT=Ts, cost_kind=_lib.COST_EXTERNAL, h=Ts / 2,
+        rk_steps=2, p0=p0, p_labels=labels, x_labels=[f"x_{i}" for i in range(nx)], u_labels=[f"u_{i}" for i in range(nu)],
+        lbu=-np.ones(nu), ubu=np.ones(nu), consts=x_ss, gamma=1.0, tol=tol, max_iter=max_iter, x0=x0, n_model_p=n_p)

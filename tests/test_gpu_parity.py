@@ -122,3 +122,68 @@ def test_linear_system_q_mode(oracle_port):
     u0[0] = -0.5                           # scripts/linear_system_mpc_nlp.py:18
     _, r, ref = run_both(linear_system_ocp(), make_linear_system(), oracle_port, x0, u0)
     check(r, ref)
+
+
+def test_chain_mass_sweep_vs_oracle(oracle_port):
+    """The harness of the reference's tests/test_chain_mass.py (rlmpc/examples/chain_mass.py:133-174): C_3_0 swept over
+    [0.5, 1.5] x nominal in 10 points, x0 = masses equally spaced on the x axis; u0* and du0*/dp per point — here the
+    ten points are ONE batched call with per-instance parameters."""
+    from mpc4rl_amd import chain_mass_ocp
+    from oracle.problems import make_chain_mass
+    ocp, P = chain_mass_ocp(), make_chain_mass()
+    p_idx = ocp.p_labels.index("C_3_0")
+    vals = np.linspace(0.5 * ocp.p0[p_idx], 1.5 * ocp.p0[p_idx], 10)
+    theta = np.tile(ocp.p0, (10, 1))
+    theta[:, p_idx] = vals
+    x0 = np.tile(ocp.x0, (10, 1))
+    _, r, ref = run_both(ocp, P, oracle_port, x0, theta=theta)
+    st = r.status.cpu().numpy()
+    assert np.all(st == 0) and np.array_equal(st, ref.status)
+    assert np.array_equal(r.iters.cpu().numpy()[:, 0], ref.sqp_iter)
+    assert rel_err(r.u0.cpu().numpy(), ref.u0) < RTOL and rel_err(r.V.cpu().numpy(), ref.V) < RTOL
+    assert rel_err(r.dV_dp.cpu().numpy(), ref.dV) < RTOL
+    dpi, dref = r.dpi_dp.cpu().numpy(), ref.dpi
+    assert rel_err(dpi, dref, floor=np.abs(dref).max()) < RTOL
+    assert rel_err(dpi[:, :, p_idx], dref[:, :, p_idx], floor=np.abs(dref[:, :, p_idx]).max()) < RTOL   # the swept column
+    # first-order consistency of the sweep (what the reference's plot_results shows): FD of u0* along the sweep vs du0*/dp
+    fd = np.gradient(r.u0.cpu().numpy(), vals, axis=0)
+    assert np.abs(fd[1:-1] - dpi[1:-1, :, p_idx]).max() < 5e-3 * max(1.0, np.abs(dpi[:, :, p_idx]).max())
+
+
+def test_chain_mass_vs_golden():
+    from mpc4rl_amd import MPCBatch, chain_mass_ocp
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g4_chain5.npz"))
+    ocp = chain_mass_ocp()
+    theta = np.tile(ocp.p0, (len(g["p_vals"]), 1))
+    theta[:, int(g["p_idx"])] = g["p_vals"]
+    mpc = MPCBatch(ocp, len(theta))
+    mpc.set_theta(torch.as_tensor(theta))
+    r = mpc.solve(g["x0"], sens_v=True, sens_pi=True, cold=True)
+    assert np.all(r.status.cpu().numpy() == 0)
+    assert rel_err(r.u0.cpu().numpy(), g["u0"]) < RTOL and rel_err(r.V.cpu().numpy(), g["V"]) < RTOL
+    assert rel_err(r.dV_dp.cpu().numpy(), g["dV"]) < RTOL
+    assert rel_err(r.dpi_dp.cpu().numpy(), g["dpi"], floor=np.abs(g["dpi"]).max()) < RTOL
+
+
+def test_golden_cartpole_and_linear_on_gpu():
+    """HIP path against the committed golden vectors (dense Python oracle + autograd mirror)."""
+    import os
+    from mpc4rl_amd import MPCBatch, cartpole_ocp, linear_system_ocp
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "g3_cartpole.npz"))
+    mpc = MPCBatch(cartpole_ocp(), len(g["x0"]))
+    mpc.set_theta(torch.as_tensor(g["theta"]))
+    r = mpc.solve(g["x0"], sens_v=True, sens_pi=True, cold=True)
+    assert np.all(r.status.cpu().numpy() == 0)
+    for k, a in (("u0", r.u0), ("V", r.V), ("dV", r.dV_dp), ("dpi", r.dpi_dp)):
+        assert rel_err(a.cpu().numpy(), g[k]) < RTOL, k
+    for tag in ("g099", "g09"):
+        g = np.load(os.path.join(gold, f"g2_linear_{tag}.npz"))
+        mpc = MPCBatch(linear_system_ocp(discount_factor=float(g["gamma"])), len(g["x0"]))
+        r = mpc.solve(g["x0"], sens_v=True, sens_pi=True, cold=True)
+        assert np.all(r.status.cpu().numpy() == 0)
+        strict = g["smax"] < 1e-9
+        for k, a in (("u0", r.u0), ("V", r.V), ("dV", r.dV_dp)):
+            assert rel_err(a.cpu().numpy(), g[k]) < RTOL, k
+        assert rel_err(r.dpi_dp.cpu().numpy()[strict], g["dpi"][strict]) < RTOL
