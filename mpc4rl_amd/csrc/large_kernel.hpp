@@ -414,10 +414,11 @@ struct LargeSolver {
     MPCRL_DI double &AFF(int sd, int e) { return aff[sd * (N + 1) * NW + e]; }
     MPCRL_DI double bslack(int sd, int k, int i, double v) const { return sd ? ubv(k, i) - v : v - lbv(k, i); }
 
-    MPCRL_DI bool qp_solve(const double *x0, const double *u0f, int &n_it) {
+    MPCRL_DI bool qp_solve(const double *x0, const double *u0f, int &n_it, double warm_mu) {
+        const bool warm = warm_mu > 0.0;
         auto Hs = [&](int k, int i, int j) { return ck(k) * M::hess(k == N, i, j, th); };
         const int ne = (N + 1) * NW;
-        for (int e = tid; e < (N + 1) * NX; e += NT) dx[e] = e < NX ? x0[e] - X[e] : 0.0, nuq[e] = 0.0;
+        for (int e = tid; e < (N + 1) * NX; e += NT) dx[e] = e < NX ? x0[e] - X[e] : 0.0, nuq[e] = warm ? NUv[e] : 0.0;
         for (int e = tid; e < N * NU; e += NT) du[e] = (qmode && e < NU) ? u0f[e] - U[e] : 0.0;
         __syncthreads();
         double cnt = 0.0;
@@ -428,8 +429,19 @@ struct LargeSolver {
             for (int sd = 0; sd < 2; ++sd)
                 if (has(sd, k, i)) {
                     cnt += 1.0;
-                    TT(sd, e) = fmax(bslack(sd, k, i, v), IPM_T_MIN);
-                    LAM(sd, e) = IPM_MU0 / TT(sd, e);
+                    if (warm) {
+                        double l = LAM(sd, e), tt = fmax(bslack(sd, k, i, v), TT(sd, e));
+                        if (l * tt < warm_mu) {
+                            if (l >= tt)
+                                tt = warm_mu / l;
+                            else
+                                l = warm_mu / tt;
+                        }
+                        LAM(sd, e) = l, TT(sd, e) = tt;
+                    } else {
+                        TT(sd, e) = fmax(bslack(sd, k, i, v), IPM_T_MIN);
+                        LAM(sd, e) = IPM_MU0 / TT(sd, e);
+                    }
                 }
         }
         const double n_rows = block_sum(cnt);
@@ -607,6 +619,13 @@ __global__ void __launch_bounds__(LARGE_NT) large_solve_kernel(const LargeSpec s
     const int max_iter = rti ? 1 : sp.max_iter;
     int status = 2, n_sqp = 0, n_ipm = 0;
     double cost = 0.0, res[4] = {0, 0, 0, 0};
+    double stepn = -1.0;   // perturbation seen by the next QP (< 0: cold)
+    if (!(a.flags & 8)) {
+        double sl = 0.0;
+        if (tid < NX) sl = fabs(x0[tid] - S.X[tid]);
+        if (S.qmode && tid < NU) sl = fmax(sl, fabs(u0f[tid] - S.U[tid]));
+        stepn = S.block_max(sl);
+    }
     for (int it = 0;; ++it) {
         S.linearize_dyn();
         const double cl = S.linearize_cost();
@@ -627,9 +646,16 @@ __global__ void __launch_bounds__(LARGE_NT) large_solve_kernel(const LargeSpec s
             status = 2;
             break;
         }
-        if (!S.qp_solve(x0, u0f, n_ipm)) {
+        const double warm_mu = stepn < 0.0 ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
+        if (!S.qp_solve(x0, u0f, n_ipm, warm_mu)) {
             status = 4;
             break;
+        }
+        {
+            double sl = 0.0;
+            for (int e = tid; e < (N + 1) * NX; e += LARGE_NT) sl = fmax(sl, fabs(S.dx[e]));
+            for (int e = tid; e < N * NU; e += LARGE_NT) sl = fmax(sl, fabs(S.du[e]));
+            stepn = S.block_max(sl);
         }
         for (int e = tid; e < (N + 1) * NX; e += LARGE_NT) S.X[e] += S.dx[e], S.NUv[e] = S.nuq[e];
         for (int e = tid; e < N * NU; e += LARGE_NT) S.U[e] += S.du[e];

@@ -28,6 +28,8 @@ namespace mpcrl {
 constexpr int IPM_MAX_ITER = 60;
 constexpr double IPM_TOL_RES = 1e-9, IPM_TOL_MU = 1e-11, IPM_T_MIN = 1e-1, IPM_MU0 = 1.0, IPM_FRAC = 0.995;
 constexpr double NO_BOUND = 1e29;
+// warm start of the interior point method from the previous QP: mu_w = clamp(C * step^2, MIN, MAX)   
+constexpr double IPM_WARM_C = 1e-4, IPM_WARM_MIN = 1e-10, IPM_WARM_MAX = 1e-2;
 
 struct SmallArgs {
     int B;                 // instances
@@ -470,14 +472,24 @@ struct SmallSolver {
 
     // ---- Mehrotra predictor-corrector on the QP of the current linearisation -----------------------
     // act: this instance takes part.  Returns true when converged; n_it counts iterations of this instance.
-    MPCRL_DI bool qp_solve(bool act, const double *x0, const double *u0f, int &n_it) {
+    // warm_mu > 0: start from the rows and multipliers of the previous QP, every complementarity product raised to >= warm_mu.
+    MPCRL_DI bool qp_solve(bool act, const double *x0, const double *u0f, int &n_it, double warm_mu) {
         auto Hs = [&](int i, int j) { return ck * M::hess(term, i, j, sp, thc); };
+        const bool warm = warm_mu > 0.0;
         if (act) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) dx[i] = first ? x0[i] - x[i] : 0.0, nuq[i] = 0.0;
+            for (int i = 0; i < NX; ++i) dx[i] = first ? x0[i] - x[i] : 0.0, nuq[i] = warm ? nu_[i] : 0.0;
 #pragma unroll
             for (int i = 0; i < NU; ++i) du[i] = (first && qmode) ? u0f[i] - u[i] : 0.0;
         }
+        auto recentre = [&](double &l, double &tt) {
+            if (l * tt < warm_mu) {
+                if (l >= tt)
+                    tt = warm_mu / l;
+                else
+                    l = warm_mu / tt;
+            }
+        };
         double cnt = 0.0;
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
@@ -489,12 +501,26 @@ struct SmallSolver {
                 cnt += 1.0;
                 if (SOFT && softc(i)) {
                     cnt += 1.0;
-                    if (act) s[sd][SOFT ? i : 0] = 0.0, ts[sd][SOFT ? i : 0] = IPM_T_MIN, lams[sd][SOFT ? i : 0] = IPM_MU0 / IPM_T_MIN;
+                    const int ii = SOFT ? i : 0;
+                    if (act) {
+                        if (warm) {
+                            double l = lams[sd][ii], tt = fmax(s[sd][ii], ts[sd][ii]);
+                            recentre(l, tt);
+                            lams[sd][ii] = l, ts[sd][ii] = tt;
+                        } else
+                            s[sd][ii] = 0.0, ts[sd][ii] = IPM_T_MIN, lams[sd][ii] = IPM_MU0 / IPM_T_MIN;
+                    }
                 }
                 if (act) {
                     const double sl = bslack(sd, i, v);
-                    t[sd][i] = fmax(sl, IPM_T_MIN);
-                    lam[sd][i] = IPM_MU0 / t[sd][i];
+                    if (warm) {
+                        double l = lam[sd][i], tt = fmax(sl, t[sd][i]);
+                        recentre(l, tt);
+                        lam[sd][i] = l, t[sd][i] = tt;
+                    } else {
+                        t[sd][i] = fmax(sl, IPM_T_MIN);
+                        lam[sd][i] = IPM_MU0 / t[sd][i];
+                    }
                 }
             }
         }
@@ -892,6 +918,20 @@ __global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, con
     const int max_iter = rti ? 1 : sp.max_iter;
     bool live = valid;
     int status = 2, n_sqp = 0, n_ipm = 0;
+    // size of the perturbation the next QP sees (< 0: nothing to start from): change of the pinned x0 / u0 for a warm call
+    double stepn = -1.0;
+    if (!(a.flags & 8)) {
+        double sl = 0.0;
+        if (first) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) sl = fmax(sl, fabs(x0[i] - S.x[i]));
+            if (S.qmode) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) sl = fmax(sl, fabs(u0f[i] - S.u[i]));
+            }
+        }
+        stepn = seg_max(sl, k, lpi, base);
+    }
     double Vout = 0.0, res_out[4] = {0, 0, 0, 0};
     double nun[NX];
     for (int it = 0;; ++it) {
@@ -918,8 +958,19 @@ __global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, con
                 status = 2, live = false;
         }
         if (!__any(live)) break;
-        const bool ok = S.qp_solve(live, x0, u0f, n_ipm);
+        const double warm_mu = stepn < 0.0 ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
+        const bool ok = S.qp_solve(live, x0, u0f, n_ipm, warm_mu);
         if (live && !ok) status = 4, live = false;
+        {
+            double sl = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) sl = fmax(sl, fabs(S.dx[i]));
+            if (!term) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) sl = fmax(sl, fabs(S.du[i]));
+            }
+            stepn = seg_max(sl, k, lpi, base);
+        }
         if (live) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) S.x[i] += S.dx[i], S.nu_[i] = S.nuq[i];

@@ -312,14 +312,31 @@ struct Solver {
     }
 
     // ---- Mehrotra predictor-corrector (the iteration of oracle/sqp_dense.py:ipm_dense); returns iterations
-    int qp_solve(const double *x0, const double *u0fix, bool &ok) {
+    // warm_mu > 0: start from the rows (lam, t, s) and multipliers of the previous QP, re-centred so that every
+    // complementarity product is at least warm_mu (the smaller factor of the pair is raised); warm_mu = 0: cold start.
+    int qp_solve(const double *x0, const double *u0fix, bool &ok, double warm_mu) {
         std::fill(dx.begin(), dx.end(), 0.0), std::fill(du.begin(), du.end(), 0.0), std::fill(pi_qp.begin(), pi_qp.end(), 0.0);
+        if (warm_mu > 0.0) pi_qp = PI;
         for (int i = 0; i < NX; ++i) dx[i] = x0[i] - X[i];
         if (u0fix)
             for (int i = 0; i < NU; ++i) du[i] = u0fix[i] - U[i];
         for (int e = 0; e < n; ++e) {
             if (skip(e)) continue;
             const double v = vcoord(e / NW, e % NW) + dvc(dx, du, e / NW, e % NW);
+            if (warm_mu > 0.0) {
+                for (int j = 0; j < 4; ++j)
+                    if (active(j, e)) {
+                        double l = lam[j][e], tt = std::max(row_slack(j, e, v), t[j][e]);
+                        if (l * tt < warm_mu) {
+                            if (l >= tt)
+                                tt = warm_mu / l;
+                            else
+                                l = warm_mu / tt;
+                        }
+                        lam[j][e] = l, t[j][e] = tt;
+                    }
+                continue;
+            }
             s[0][e] = s[1][e] = 0;
             for (int j = 0; j < 4; ++j)
                 if (active(j, e)) t[j][e] = std::max(row_slack(j, e, v), IPM_T_MIN), lam[j][e] = IPM_MU0 / t[j][e];
@@ -475,6 +492,14 @@ struct Solver {
         }
         n_ipm = 0;
         int status = 2;
+        // size of the perturbation the next QP sees: change of the pinned initial state (warm call), then the last step
+        double stepn = -1.0;   // < 0: no previous QP to start from
+        if (warm) {
+            stepn = 0.0;
+            for (int i = 0; i < NX; ++i) stepn = std::max(stepn, std::fabs(x0[i] - X[i]));
+            if (u0fix)
+                for (int i = 0; i < NU; ++i) stepn = std::max(stepn, std::fabs(u0fix[i] - U[i]));
+        }
         for (n_sqp = 0;; ++n_sqp) {
             cost = linearize();
             nlp_residuals(x0, u0fix, res);
@@ -483,8 +508,12 @@ struct Solver {
             if (rmax < tol) return 0;
             if (n_sqp == max_iter) return 2;
             bool ok;
-            n_ipm += qp_solve(x0, u0fix, ok);
+            const double warm_mu = stepn < 0.0 ? 0.0 : std::min(IPM_WARM_MAX, std::max(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
+            n_ipm += qp_solve(x0, u0fix, ok, warm_mu);
             if (!ok) return 4;
+            stepn = 0.0;
+            for (double v : dx) stepn = std::max(stepn, std::fabs(v));
+            for (double v : du) stepn = std::max(stepn, std::fabs(v));
             for (size_t i = 0; i < X.size(); ++i) X[i] += dx[i];
             for (size_t i = 0; i < U.size(); ++i) U[i] += du[i];
             PI = pi_qp;

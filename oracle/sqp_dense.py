@@ -38,6 +38,10 @@ IPM_TOL_MU = 1e-11      # average complementarity
 IPM_T_MIN = 1e-1        # lower clip of the initial slack
 IPM_MU0 = 1.0           # lambda_0 = mu0 / t_0
 IPM_FRAC = 0.995        # fraction to the boundary
+# warm start of QP j >= 1 (and of the first QP of a warm call) from the previous QP's rows and multipliers:
+# every complementarity product is raised to at least mu_w = clamp(IPM_WARM_C * step^2, MIN, MAX), step = inf-norm of
+# the previous primal step (or of the change of the pinned x0 / u0 for a warm call)
+IPM_WARM_C, IPM_WARM_MIN, IPM_WARM_MAX = 1e-4, 1e-10, 1e-2
 
 
 @dataclass
@@ -172,18 +176,28 @@ class Linearizer:
         return val, g, H
 
 
-def ipm_dense(H, g, G, b, C, d, v0):
+def ipm_dense(H, g, G, b, C, d, v0, warm=None, free=None):
     """Mehrotra predictor-corrector on  min 1/2 v'Hv + g'v  s.t. Gv = b, Cv + t = d, t >= 0.
+    warm = (mu_w, lam_prev, t_prev, pi_prev) or None.  free: mask of the variables that are not pinned by an equality
+    row of their own (x_0, and u_0 in Q-mode); the stationarity rows of pinned variables only define the multiplier of
+    that row and are left out of the stopping test (the structured implementations eliminate them).
     Returns v, pi, lam, t, iterations, ok."""
     n, me, mi = H.shape[0], G.shape[0], C.shape[0]
     v = v0.copy()
-    pi = np.zeros(me)
+    pi = np.zeros(me) if warm is None else warm[3].copy()
     if mi == 0:
         K = np.block([[H, G.T], [G, np.zeros((me, me))]])
         sol = np.linalg.solve(K, np.concatenate([-g, b]))
         return sol[:n], sol[n:], np.zeros(0), np.zeros(0), 1, True
-    t = np.maximum(d - C @ v, IPM_T_MIN)
-    lam = IPM_MU0 / t
+    if warm is None:
+        t = np.maximum(d - C @ v, IPM_T_MIN)
+        lam = IPM_MU0 / t
+    else:
+        mu_w, lam, t = warm[0], warm[1].copy(), np.maximum(d - C @ v, warm[2])
+        low = lam * t < mu_w
+        big_l = lam >= t
+        t = np.where(low & big_l, mu_w / np.where(lam > 0, lam, 1.0), t)
+        lam = np.where(low & ~big_l, mu_w / t, lam)
     ok = False
     it = 0
     for it in range(IPM_MAX_ITER + 1):
@@ -191,7 +205,7 @@ def ipm_dense(H, g, G, b, C, d, v0):
         r_b = G @ v - b
         r_d = C @ v + t - d
         mu = float(lam @ t) / mi
-        rinf = max(np.abs(r_g).max(), np.abs(r_b).max() if me else 0.0, np.abs(r_d).max())
+        rinf = max(np.abs(r_g if free is None else r_g[free]).max(), np.abs(r_b).max() if me else 0.0, np.abs(r_d).max())
         if rinf <= IPM_TOL_RES and mu <= IPM_TOL_MU:
             ok = True
             break
@@ -301,6 +315,13 @@ def solve(prob: Problem, x0, p=None, u0fix=None, gamma=None, warm: Optional[Solu
     status, ipm_total = 2, 0
     res = np.full(4, np.inf)
     it = 0
+    stepn = -1.0                      # < 0: no previous QP to start from
+    piq = None
+    if warm is not None:
+        stepn = float(np.abs(x0 - X[0]).max())
+        if u0fix is not None:
+            stepn = max(stepn, float(np.abs(np.asarray(u0fix, float).reshape(nu) - U[0]).max()))
+        piq = np.concatenate([pi0, pi.reshape(-1)] + ([np.zeros(nu)] if u0fix is not None else []))
     for it in range(max_iter + 1):
         A, B, Fv = lin.dynamics(X, U, p)
         cost, gcost, Hc = lin.cost(X, U, p, c)
@@ -354,7 +375,16 @@ def solve(prob: Problem, x0, p=None, u0fix=None, gamma=None, warm: Optional[Solu
         v0[st.ix(0): st.ix(0) + nx] = x0 - X[0]
         if u0fix is not None:
             v0[:nu] = u0fix - U[0]
-        v, piq, lam, t, nit, ok = ipm_dense(H, g, G, b, C, d, v0)
+        wrm = None
+        if stepn >= 0.0:
+            v0[st.nw:] = S
+            wrm = (min(IPM_WARM_MAX, max(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn)), lam, t, piq)
+        free = np.ones(st.nv, bool)
+        free[st.ix(0): st.ix(0) + nx] = False
+        if u0fix is not None:
+            free[:nu] = False
+        v, piq, lam, t, nit, ok = ipm_dense(H, g, G, b, C, d, v0, wrm, free)
+        stepn = float(np.abs(v[: st.nw]).max())
         ipm_total += nit
         if not ok:
             status = 4
