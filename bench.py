@@ -62,6 +62,52 @@ def cpu_baseline(x0_np, sens):
                       f"mean SQP iters {float(r.sqp_iter.mean()):.2f}, mean IPM iters {float(r.ipm_iter.mean()):.1f})"}
 
 
+def chain_bench(args):
+    """BASELINE config 4: chain_mass n_mass = 5 (nx=21) / 7 (nx=33), N=40, batch 1024, GN-SQP tol 1e-5 + sensitivities.
+    x0 = masses on the x axis (examples/chain_mass.py:17-25) + N(0, 1e-2) velocity perturbation, seed 0."""
+    from mpc4rl_amd import MPCBatch, chain_mass_ocp
+    n_mass = 5 if args.workload == "chain5" else 7
+    ocp = chain_mass_ocp(n_mass=n_mass)
+    B = args.batch if args.batch != B_PER_GPU else 1024
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(0)
+    x0 = np.tile(ocp.x0, (B, 1))
+    M = n_mass - 2
+    x0[:, 3 * (M + 1):] += rng.normal(0.0, 1e-2, (B, 3 * M))
+    mpc = MPCBatch(ocp, B, device=dev)
+    x0t = torch.as_tensor(x0, device=dev)
+    sens = not args.no_sens
+    for _ in range(args.warmup):
+        r = mpc.solve(x0t, sens_v=sens, sens_pi=sens, cold=True)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        r = mpc.solve(x0t, sens_v=sens, sens_pi=sens, cold=True)
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    it = r.iters.cpu().numpy()
+    # SURVEY.md §8d: iterate + outputs, plus the streamed stage factors of every Riccati sweep
+    nx, nu, N, n_th = ocp.nx, ocp.nu, ocp.N, ocp.n_p
+    b_alg = algorithmic_bytes_per_solve(N, nx, nu, n_th, sens)
+    b_sweep = 2 * 8 * N * ((nx + nu) ** 2 + (nx + nu))
+    sweeps = float(it[:, 1].mean()) + (1 + nu if sens else 0)
+    achieved = (b_alg + sweeps * b_sweep) * B / (kern_ms * 1e-3) / 1e9
+    out = {"metric": f"MPC+KKT-sens solves/sec, chain_mass n_mass={n_mass} N=40 batch={B}", "value": B * args.steps / elapsed,
+           "unit": "solves/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"chain_mass n_mass={n_mass} nx={nx} nu={nu} N={N}, {B} instances, cold-start GN-SQP tol 1e-5"
+                                  + (" + dV/dp + du0*/dp (499-dim p)" if sens else ""),
+                      "converged_fraction": float((r.status == 0).float().mean().item()), "sqp_iters_mean": float(it[:, 0].mean()),
+                      "ipm_iters_mean": float(it[:, 1].mean())},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": None, "kernel_ms": kern_ms, "algorithmic_bytes_per_solve": b_alg + sweeps * b_sweep}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,7 +117,11 @@ def main():
     ap.add_argument("--no-sens", action="store_true", help="forward solve only (BASELINE config 2)")
     ap.add_argument("--rti", action="store_true", help="one SQP iteration from the stored iterate (build-side mode)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", default="cartpole", choices=["cartpole", "chain5", "chain7"],
+                    help="cartpole = the headline metric (default); chain5/chain7 = BASELINE config 4 (not the headline line)")
     args = ap.parse_args()
+    if args.workload != "cartpole":
+        return chain_bench(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -9,6 +9,10 @@ classes without ``libmpcrl_hip.so`` raises.
 """
 from .problems import OcpDescription, cartpole_ocp, chain_mass_ocp, linear_system_ocp  # noqa: F401
 from .batch import MPCBatch, SolveResult  # noqa: F401
+from .envs import BatchedCartPoleSwingUpEnv, BatchedLinearSystemEnv  # noqa: F401
+from .qlearning import BatchedQLearning  # noqa: F401
+from .td3 import ContinuousCritic, MPCActor  # noqa: F401
+from .config import cartpole_ocp_from_config, read_config, store_iterate, load_iterate  # noqa: F401
 from .mpc import MPC, CartpoleMPC, ChainMassMPC, LinearSystemMPC  # noqa: F401
 
 __all__ = ["OcpDescription", "cartpole_ocp", "linear_system_ocp", "chain_mass_ocp", "MPCBatch", "SolveResult", "MPC", "CartpoleMPC",

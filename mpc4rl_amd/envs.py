@@ -1,0 +1,100 @@
+"""Batched torch environments: the step either side of the MPC hot path, producing x0[B, nx] on the device.
+
+Restates (no gymnasium dependency, tensors in / tensors out, B environments per call):
+  * ContinuousCartPoleSwingUpEnv   rlmpc/gym/continuous_cartpole/environment.py:19-200
+      Euler, tau = 0.02, force = action * force_mag (30), gravity 9.8, masscart 1.0, masspole 0.1, length 0.5;
+      reset: theta ~ U(0.9 pi, 1.1 pi), other states 0 (178-180); reward = x^2 + theta^2 (193-194);
+      terminated when |x| < 0.1, |x_dot| < 0.1, |theta| < 2 deg, |theta_dot| < 0.1 all hold (84-103)
+  * LinearSystemEnv                rlmpc/gym/linear_system/environment.py:6-66
+      s+ = A s + B a + [U(lb_noise, ub_noise), 0]; reset to [0.5, 0.5]; cost = 1/2 s's + 1/2 a'a + 100 per violated side
+The reference's own numpy VectorEnv (environment.py:302-458) computes the reward from env 0's action and resets to
+exactly [0, 0, pi, 0]; the single-env semantics above are the ones reproduced here, per environment.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+
+class BatchedCartPoleSwingUpEnv:
+    def __init__(self, num_envs: int, device="cpu", force_mag: float = 30.0, max_episode_steps: int = 500, seed: int = 0,
+                 dtype=torch.float64):
+        self.num_envs, self.device, self.dtype = num_envs, torch.device(device), dtype
+        self.gravity, self.masscart, self.masspole, self.length = 9.8, 1.0, 0.1, 0.5
+        self.total_mass = self.masspole + self.masscart
+        self.polemass_length = self.masspole * self.length
+        self.force_mag, self.tau = force_mag, 0.02
+        self.x_threshold, self.theta_threshold = 0.1, math.radians(2.0)
+        self.max_episode_steps = max_episode_steps
+        self.gen = torch.Generator(device=self.device).manual_seed(seed)
+        self.state = torch.zeros(num_envs, 4, dtype=dtype, device=self.device)
+        self.steps = torch.zeros(num_envs, dtype=torch.int64, device=self.device)
+
+    def _sample(self, n: int) -> torch.Tensor:
+        s = torch.zeros(n, 4, dtype=self.dtype, device=self.device)
+        s[:, 2] = (0.9 + 0.2 * torch.rand(n, generator=self.gen, dtype=self.dtype, device=self.device)) * math.pi
+        return s
+
+    def reset(self, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if mask is None:
+            self.state = self._sample(self.num_envs)
+            self.steps.zero_()
+        else:
+            n = int(mask.sum().item())
+            if n:
+                self.state[mask] = self._sample(n)
+                self.steps[mask] = 0
+        return self.state.clone()
+
+    def is_terminal(self, s: torch.Tensor) -> torch.Tensor:
+        return (s[:, 0].abs() < self.x_threshold) & (s[:, 1].abs() < 0.1) & (s[:, 2].abs() < self.theta_threshold) & (s[:, 3].abs() < 0.1)
+
+    def step(self, action: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """action: [B, 1] in [-1, 1] (what CartpoleMPC.get_action returns).  Returns obs, reward, terminated, truncated."""
+        a = action.to(self.dtype).reshape(self.num_envs)
+        x, x_dot, th, th_dot = self.state.unbind(1)
+        force = a * self.force_mag
+        c, s = torch.cos(th), torch.sin(th)
+        temp = (force + self.polemass_length * th_dot ** 2 * s) / self.total_mass
+        thacc = (self.gravity * s - c * temp) / (self.length * (4.0 / 3.0 - self.masspole * c ** 2 / self.total_mass))
+        xacc = temp - self.polemass_length * thacc * c / self.total_mass
+        self.state = torch.stack([x + self.tau * x_dot, x_dot + self.tau * xacc, th + self.tau * th_dot, th_dot + self.tau * thacc], 1)
+        self.steps += 1
+        terminated = self.is_terminal(self.state)
+        reward = self.state[:, 0] ** 2 + self.state[:, 2] ** 2
+        truncated = self.steps >= self.max_episode_steps
+        return self.state.clone(), reward, terminated, truncated
+
+
+class BatchedLinearSystemEnv:
+    def __init__(self, num_envs: int, device="cpu", lb_noise: float = -0.1, ub_noise: float = 0.0, A=None, B=None,
+                 min_observation=(-0.0, -1.0), max_observation=(1.0, 1.0), seed: int = 0, dtype=torch.float64):
+        self.num_envs, self.device, self.dtype = num_envs, torch.device(device), dtype
+        kw = dict(dtype=dtype, device=self.device)
+        self.A = torch.tensor([[0.9, 0.35], [0.0, 1.1]] if A is None else A, **kw)     # environment.py:15
+        self.B = torch.tensor([[0.0813], [0.2]] if B is None else B, **kw)
+        self.lb_noise, self.ub_noise = lb_noise, ub_noise
+        self.low, self.high = torch.tensor(min_observation, **kw), torch.tensor(max_observation, **kw)
+        self.gen = torch.Generator(device=self.device).manual_seed(seed)
+        self.state = torch.zeros(num_envs, 2, **kw)
+
+    def reset(self) -> torch.Tensor:
+        self.state = torch.tensor([0.5, 0.5], dtype=self.dtype, device=self.device).repeat(self.num_envs, 1)   # environment.py:46
+        return self.state.clone()
+
+    def cost(self, state: torch.Tensor, action: torch.Tensor) -> torch.Tensor:
+        lower = ((self.low - state).clamp(min=0) > 0).any(1).to(self.dtype) * 1e2
+        upper = ((state - self.high).clamp(min=0) > 0).any(1).to(self.dtype) * 1e2
+        return 0.5 * (state * state).sum(1) + 0.5 * (action * action).sum(1) + lower + upper
+
+    def step(self, action: torch.Tensor):
+        a = action.to(self.dtype).reshape(self.num_envs, 1)
+        noise = torch.zeros(self.num_envs, 2, dtype=self.dtype, device=self.device)
+        noise[:, 0] = self.lb_noise + (self.ub_noise - self.lb_noise) * torch.rand(self.num_envs, generator=self.gen, dtype=self.dtype,
+                                                                                      device=self.device)
+        self.state = self.state @ self.A.T + a @ self.B.T + noise
+        reward = self.cost(self.state, a)
+        done = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        return self.state.clone(), reward, done, done.clone()

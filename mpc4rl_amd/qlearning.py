@@ -1,0 +1,81 @@
+"""Batched MPC Q-learning: the reference's documented use of the hot path, with the per-sample loops turned into batches.
+
+rlmpc/examples/linear_system_mpc_qlearning.py:153-205 per episode:
+    roll out EPISODE_LENGTH steps with  a = mpc.get_action(s)                          (160-167)
+    for every stored sample i:  mpc.q_update(s_i, a_i) -> Q_i, dQ/dp_i ;  mpc.update(s_i) -> V_i      (178-190)
+    td_i = cost_i + gamma * V_{i+1} - Q_i                                               (193)
+    p   += mean_i( LR * td_i * dQ/dp_i )                                                (203-205)
+The samples of an episode are independent given p, and so are parallel environments: here the roll-out is ONE
+``MPCBatch.solve`` per time step over E environments and the learning sweep is TWO batched solves over all E*T samples.
+With several ranks every rank learns from its own environments and the parameter step is all-reduced
+(mpc4rl_amd.distributed), so all ranks hold identical parameters.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import torch
+
+from .batch import MPCBatch
+from .distributed import mean_update
+
+
+@dataclass
+class EpisodeStats:
+    total_cost: float
+    td_error_mean: float
+    step: torch.Tensor          # parameter step that was applied
+    converged_fraction: float
+
+
+class BatchedQLearning:
+    """Q-learning of the MPC parameters with E parallel environments and episodes of T steps.
+
+    ``rollout_mpc`` solves E instances (policy), ``sample_mpc`` solves E*(T-1) instances (Q and V of every transition)."""
+
+    def __init__(self, ocp, env, episode_length: int, lr: float = 1e-4, gamma: Optional[float] = None,
+                 scale_action: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
+                 unscale_action: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, device=None, group=None):
+        self.ocp, self.env, self.T, self.lr = ocp, env, episode_length, lr
+        self.gamma = ocp.gamma if gamma is None else gamma
+        self.E = env.num_envs
+        self.rollout_mpc = MPCBatch(ocp, self.E, device)
+        self.sample_mpc = MPCBatch(ocp, self.E * (episode_length - 1), device)
+        for m in (self.rollout_mpc, self.sample_mpc):
+            m.set_discount_factor(self.gamma)
+        self.theta = torch.as_tensor(ocp.p0, dtype=torch.float64, device=self.rollout_mpc.device).clone()
+        self.scale_action = scale_action or (lambda u: u)
+        self.unscale_action = unscale_action or (lambda a: a)
+        self.group = group
+
+    def run_episode(self) -> EpisodeStats:
+        dev = self.rollout_mpc.device
+        obs = self.env.reset().to(dev)
+        self.rollout_mpc.reset()
+        S, A, C = [], [], []
+        for _ in range(self.T):
+            u = self.rollout_mpc.get_action(obs)                  # [E, nu], one launch (mpc.get_action, 160-161)
+            a = self.scale_action(u)
+            nxt, cost, _, _ = self.env.step(a.to(self.env.device))
+            S.append(obs), A.append(u), C.append(cost.to(dev))
+            obs = nxt.to(dev)
+        S, A, C = torch.stack(S), torch.stack(A), torch.stack(C)      # [T, E, .]
+        n = self.T - 1                                                # replay_buffer.size() - 1 samples (172)
+        s = S[:n].reshape(n * self.E, -1)
+        a = A[:n].reshape(n * self.E, -1)
+        self.sample_mpc.reset()
+        rq = self.sample_mpc.solve(s, u0=a, sens_v=True, cold=True)   # Q(s_i, a_i), dQ/dp_i   (q_update, 181-187)
+        rv = self.sample_mpc.solve(s, cold=True)                      # V(s_i)               (update, 189-190)
+        ok = ((rq.status == 0) & (rv.status == 0)).reshape(n, self.E)
+        q, v = rq.V.reshape(n, self.E), rv.V.reshape(n, self.E)
+        dq = rq.dV_dp.reshape(n, self.E, -1)
+        td = C[: n - 1] + self.gamma * v[1:] - q[:-1]                 # (193)
+        valid = (ok[:-1] & ok[1:]).to(td.dtype)
+        w = (self.lr * td * valid).reshape(-1)
+        g = dq[: n - 1].reshape(-1, dq.shape[-1])
+        step = mean_update(g, w, self.group)                          # mean_i(LR * td_i * dQ/dp_i), all ranks (203)
+        self.theta = self.theta + step
+        for m in (self.rollout_mpc, self.sample_mpc):
+            m.set_theta(self.theta)                                   # mpc.set_parameter (204-205)
+        return EpisodeStats(float(C.sum().item()) / self.E, float(td.mean().item()), step, float(valid.mean().item()))

@@ -25,8 +25,7 @@ from typing import Callable, List, Optional
 import numpy as np
 import torch
 
-torch.set_default_dtype(torch.float64)
-DT = torch.float64
+DT = torch.float64   # every tensor below is created from float64 numpy data or with an explicit dtype (no global default is touched)
 
 
 @dataclass
@@ -241,8 +240,8 @@ def chain_steady_state(n_mass: int, p: np.ndarray, x_end: np.ndarray) -> np.ndar
 
     def resid(fr):
         # ode output = [vel (3M), u (3), f (3M)]  -> accelerations are the last 3M entries
-        x = torch.cat([fr, torch.tensor(x_end), torch.zeros(3 * M)])
-        return ode(x, torch.zeros(3), pt)[3 * M + 3:]
+        x = torch.cat([fr, torch.tensor(x_end), torch.zeros(3 * M, dtype=DT)])
+        return ode(x, torch.zeros(3, dtype=DT), pt)[3 * M + 3:]
 
     for _ in range(100):
         r = resid(free)
