@@ -89,6 +89,10 @@ int mpcrl_set_theta(mpcrl_handle h, const double *theta, int n_theta, int per_in
 int mpcrl_set_gamma(mpcrl_handle h, double gamma);
 int mpcrl_set_options(mpcrl_handle h, double tol, int max_iter);
 
+/* Scheduling hint (no effect on results): perm[B] int32 on the device, a permutation of 0..B-1 — slot i of a launch works on
+ * instance perm[i], so that instances expected to need similar iteration counts share a wavefront. NULL = identity. */
+int mpcrl_set_order(mpcrl_handle h, const int32_t *perm, void *stream);
+
 /* Cold iterate: x_k := x0 for all k, u := 0, all multipliers 0. x0: [B, nx] device. */
 int mpcrl_reset(mpcrl_handle h, const double *x0, void *stream);
 

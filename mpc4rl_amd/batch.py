@@ -99,9 +99,22 @@ class MPCBatch:
         self._check(self.lib.mpcrl_reset(self._h, None, self._stream()), "mpcrl_reset")
 
     # ------------------------------------------------------------------ the hot path
-    def solve(self, x0, u0=None, sens_v: bool = False, sens_pi: bool = False, rti: bool = False, cold: bool = False) -> SolveResult:
+    def _pack_order(self, x0: torch.Tensor) -> None:
+        """Scheduling hint: instances that share a wavefront run in lock-step for the maximum of their iteration counts, so
+        neighbours should be similar problems.  Order the batch along the coordinate of x0 with the largest spread."""
+        if self.B < 128:
+            return
+        dim = torch.argmax(x0.max(0).values - x0.min(0).values).reshape(1)     # stays on the device: no host sync
+        perm = torch.argsort(torch.index_select(x0, 1, dim).reshape(-1)).to(torch.int32)
+        self._check(self.lib.mpcrl_set_order(self._h, _ptr(perm), self._stream()), "mpcrl_set_order")
+
+    def solve(self, x0, u0=None, sens_v: bool = False, sens_pi: bool = False, rti: bool = False, cold: bool = False,
+              reorder: bool = True) -> SolveResult:
         x0 = self._dev(x0, (self.B, self.nx))
         u0f = None if u0 is None else self._dev(u0, (self.B, self.nu))
+        if reorder:
+            with torch.cuda.device(self.device):
+                self._pack_order(x0)
         flags = (_lib.SENS_V if sens_v else 0) | (_lib.SENS_PI if sens_pi else 0) | (_lib.RTI if rti else 0) | \
             (_lib.COLD if cold else 0)
         kw = dict(dtype=torch.float64, device=self.device)

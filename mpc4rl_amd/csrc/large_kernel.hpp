@@ -29,6 +29,7 @@ struct LargeSpec {
 
 struct LargeArgs {
     int B, flags, theta_stride;
+    const int *perm;
     const double *x0, *u0fix, *theta;
     double *X, *U, *PI, *BND, *RES;   // iterate (layouts of mpcrl_get_iterate)
     double *ws;                       // per-instance workspace, ws_stride doubles each
@@ -585,7 +586,7 @@ __global__ void __launch_bounds__(LARGE_NT) large_solve_kernel(const LargeSpec s
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU;
     __shared__ double sP[NX * NX], sBA[NX * NW], sT[NX * NW], sM[NW * NW];
     __shared__ double sp_[NX], scc[NX], smv[NW], sK[NU * NX + NU], sL[NU * NU], sred[16], sck[64];
-    const int tid = threadIdx.x, inst = blockIdx.x, N = sp.N;
+    const int tid = threadIdx.x, inst = a.perm ? a.perm[blockIdx.x] : blockIdx.x, N = sp.N;
     LargeSolver<M> S(sp, tid);
     S.sP = sP, S.sBA = sBA, S.sT = sT, S.sM = sM, S.sp_ = sp_, S.scc = scc, S.smv = smv, S.sK = sK, S.sL = sL, S.sred = sred;
     S.th = a.theta + (size_t)inst * a.theta_stride;
@@ -688,7 +689,7 @@ __global__ void __launch_bounds__(LARGE_NT) large_sens_kernel(const LargeSpec sp
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD, NP = M::NP, NT = LARGE_NT;
     __shared__ double sP[NX * NX], sBA[NX * NW], sT[NX * NW], sM[NW * NW];
     __shared__ double sp_[NX], scc[NX], smv[NW], sK[NU * NX + NU], sL[NU * NU], sred[16], sck[64];
-    const int tid = threadIdx.x, inst = blockIdx.x, N = sp.N;
+    const int tid = threadIdx.x, inst = a.perm ? a.perm[blockIdx.x] : blockIdx.x, N = sp.N;
     LargeSolver<M> S(sp, tid);
     S.sP = sP, S.sBA = sBA, S.sT = sT, S.sM = sM, S.sp_ = sp_, S.scc = scc, S.smv = smv, S.sK = sK, S.sL = sL, S.sred = sred;
     S.th = a.theta + (size_t)inst * a.theta_stride;

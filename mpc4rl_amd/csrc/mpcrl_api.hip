@@ -22,6 +22,8 @@ struct MpcrlSolver {
     bool is_large = false;
     int n_mass = 0;
     double *ws = nullptr, *consts_dev = nullptr;
+    int *perm = nullptr;
+    bool have_perm = false;
     size_t ws_stride = 0;
     double *theta = nullptr;   // [np] or [B, np]
     int theta_stride = 0;
@@ -159,6 +161,7 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
     if (!rc) rc = dev_alloc(&h->BND, B * 10 * (N + 1) * nw, h->bytes);
     if (!rc) rc = dev_alloc(&h->RES, B * 4, h->bytes);
     if (!rc) rc = dev_alloc(&h->theta, B * (size_t)spec->np, h->bytes);
+    if (!rc) rc = dev_alloc(&h->perm, B, h->bytes);
     if (!rc && h->is_large) {
         h->ws_stride = h->n_mass == 3 ? LargeLayout<ChainDev<3>>(spec->N).total
                                       : (h->n_mass == 5 ? LargeLayout<ChainDev<5>>(spec->N).total : LargeLayout<ChainDev<7>>(spec->N).total);
@@ -183,6 +186,7 @@ int mpcrl_destroy(mpcrl_handle h) {
     hipSetDevice(h->device);
     for (double *p : {h->X, h->U, h->PI, h->BND, h->RES, h->theta, h->ws, h->consts_dev})
         if (p) hipFree(p);
+    if (h->perm) hipFree(h->perm);
     delete h;
     return 0;
 }
@@ -211,6 +215,14 @@ int mpcrl_set_options(mpcrl_handle h, double tol, int max_iter) {
     return 0;
 }
 
+int mpcrl_set_order(mpcrl_handle h, const int32_t *perm, void *stream) {
+    if (!h) return MPCRL_E_ARG;
+    HIP_OK(hipSetDevice(h->device));
+    if (perm) HIP_OK(hipMemcpyAsync(h->perm, perm, (size_t)h->B * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    h->have_perm = perm != nullptr;
+    return 0;
+}
+
 int mpcrl_reset(mpcrl_handle h, const double *x0, void *stream) {
     if (!h) return MPCRL_E_ARG;
     (void)x0, (void)stream;
@@ -227,7 +239,7 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
     hipStream_t st = (hipStream_t)stream;
     if (!h->have_iterate) flags |= MPCRL_COLD;
     SmallArgs a;
-    a.B = h->B, a.flags = flags, a.theta_stride = h->theta_stride;
+    a.B = h->B, a.flags = flags, a.theta_stride = h->theta_stride, a.perm = h->have_perm ? h->perm : nullptr;
     a.x0 = x0, a.u0fix = u0_fixed, a.theta = h->theta;
     a.X = h->X, a.U = h->U, a.PI = h->PI, a.BND = h->BND, a.RES = h->RES;
     a.u0_out = u0_out, a.V = V, a.dV = (flags & MPCRL_SENS_V) ? dV_dp : nullptr, a.dpi = (flags & MPCRL_SENS_PI) ? dpi_dp : nullptr;
@@ -237,7 +249,7 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
     int rc;
     if (h->is_large) {
         LargeArgs la;
-        la.B = a.B, la.flags = a.flags, la.theta_stride = a.theta_stride, la.x0 = a.x0, la.u0fix = a.u0fix, la.theta = a.theta;
+        la.B = a.B, la.flags = a.flags, la.theta_stride = a.theta_stride, la.perm = a.perm, la.x0 = a.x0, la.u0fix = a.u0fix, la.theta = a.theta;
         la.X = a.X, la.U = a.U, la.PI = a.PI, la.BND = a.BND, la.RES = a.RES, la.ws = nullptr, la.ws_stride = 0;
         la.u0_out = a.u0_out, la.V = a.V, la.dV = a.dV, la.dpi = a.dpi, la.status = a.status, la.iters = a.iters;
         rc = h->n_mass == 3 ? launch_large<ChainDev<3>>(h, la, st)

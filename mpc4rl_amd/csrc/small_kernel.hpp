@@ -35,6 +35,7 @@ struct SmallArgs {
     int B;                 // instances
     int flags;             // MPCRL_* solve flags
     int theta_stride;      // 0 = shared theta, np = per instance
+    const int *perm;       // packing order: slot i of the launch works on instance perm[i] (null = identity)
     const double *x0;      // [B, nx]
     const double *u0fix;   // [B, nu] or null
     const double *theta;   // [np] or [B, np]
@@ -351,23 +352,46 @@ struct SmallSolver {
     double Pnext[NPK];
     template <bool FACTOR, class HF>
     MPCRL_DI bool backward(HF Hs, const double *g, const double *bb) {
+        // Every lane executes every stage step (full EXEC mask: a wave64 fp64 op with <= 8 active lanes is ~4x slower on
+        // gfx950 than with >= 12, scratch_bench/exec_mask.hip) and only the lane whose turn it is commits the result.
         bool ok = true;
         for (int kk = N; kk >= 0; --kk) {
             double pn[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) pn[i] = lane_dn(p[i]);
+            const bool mine = k == kk;
+            double sK[NU * NX], sLi[NLK], skff[NU], sP[NPK], sp[NX];
+#pragma unroll
+            for (int i = 0; i < NU * NX; ++i) sK[i] = K[i];
+#pragma unroll
+            for (int i = 0; i < NLK; ++i) sLi[i] = Li[i];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) skff[i] = kff[i];
+#pragma unroll
+            for (int i = 0; i < NPK; ++i) sP[i] = P[i];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) sp[i] = p[i];
             if constexpr (FACTOR) {
                 double Pn[NPK];
 #pragma unroll
                 for (int i = 0; i < NPK; ++i) Pn[i] = lane_dn(P[i]);
-                if (k == kk) {
+                const bool okk = riccati_stage<true>(Pn, pn, Hs, g, bb);
+                ok = ok && (okk || !mine);
 #pragma unroll
-                    for (int i = 0; i < NPK; ++i) Pnext[i] = Pn[i];
-                    ok = riccati_stage<true>(Pnext, pn, Hs, g, bb) && ok;
-                }
+                for (int i = 0; i < NPK; ++i) Pnext[i] = mine ? Pn[i] : Pnext[i];
             } else {
-                if (k == kk) riccati_stage<false>(Pnext, pn, Hs, g, bb);
+                riccati_stage<false>(Pnext, pn, Hs, g, bb);
             }
+#pragma unroll
+            for (int i = 0; i < NU * NX; ++i) K[i] = mine ? K[i] : sK[i];
+#pragma unroll
+            for (int i = 0; i < NLK; ++i) Li[i] = mine ? Li[i] : sLi[i];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) kff[i] = mine ? kff[i] : skff[i];
+#pragma unroll
+            for (int i = 0; i < NPK; ++i) P[i] = mine ? P[i] : sP[i];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) p[i] = mine ? p[i] : sp[i];
         }
         return ok;
     }
@@ -382,38 +406,39 @@ struct SmallSolver {
 #pragma unroll
         for (int i = 0; i < NX; ++i) xn[i] = 0.0;
         for (int kk = 0; kk < N; ++kk) {
-            if (k == kk) {
+            const bool mine = k == kk, next = k == kk + 1;
+            double tu[NU], tx[NX];
 #pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    double a = -kff[i];
+            for (int i = 0; i < NU; ++i) {
+                double a = -kff[i];
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) a = fma(-K[i * NX + j], Dx[j], a);
-                    Du[i] = a;
-                }
-#pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    double a = bb[i];
-#pragma unroll
-                    for (int j = 0; j < NX; ++j) a = fma(A[i * NX + j], Dx[j], a);
-#pragma unroll
-                    for (int j = 0; j < NU; ++j) a = fma(Bm[i * NU + j], Du[j], a);
-                    xn[i] = a;
-                }
+                for (int j = 0; j < NX; ++j) a = fma(-K[i * NX + j], Dx[j], a);
+                tu[i] = a;
             }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = bb[i];
+#pragma unroll
+                for (int j = 0; j < NX; ++j) a = fma(A[i * NX + j], Dx[j], a);
+#pragma unroll
+                for (int j = 0; j < NU; ++j) a = fma(Bm[i * NU + j], tu[j], a);
+                tx[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) Du[i] = mine ? tu[i] : Du[i];
             double xin[NX];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) xin[i] = lane_up(xn[i]);
-            if (k == kk + 1) {
+            for (int i = 0; i < NX; ++i) xin[i] = lane_up(tx[i]);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) Dx[i] = xin[i];
+            for (int i = 0; i < NX; ++i) Dx[i] = next ? xin[i] : Dx[i];
+        }
+        // multipliers of the arriving dynamics: local to each stage once Dx is known
 #pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    double a = p[i];
+        for (int i = 0; i < NX; ++i) {
+            double a = p[i];
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) a = fma(P[sym(i, j)], xin[j], a);
-                    Dnu[i] = a;
-                }
-            }
+            for (int j = 0; j < NX; ++j) a = fma(P[sym(i, j)], Dx[j], a);
+            Dnu[i] = first ? 0.0 : a;
         }
     }
 
@@ -853,6 +878,7 @@ __global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, con
     long inst = (long)blockIdx.x * ipw + slot;
     const bool valid = slot < ipw && inst < a.B;
     if (!valid) inst = a.B - 1;   // dead lanes shadow the last instance and never store
+    if (a.perm) inst = a.perm[inst];
     SmallSolver<M> S(sp, k, lpi, base);
     const bool term = S.term, first = S.first;
     S.qmode = a.u0fix != nullptr;
@@ -1023,6 +1049,7 @@ __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, cons
     long inst = (long)blockIdx.x * ipw + slot;
     const bool valid = slot < ipw && inst < a.B;
     if (!valid) inst = a.B - 1;
+    if (a.perm) inst = a.perm[inst];
     SmallSolver<M> S(sp, k, lpi, base);
     const bool term = S.term, first = S.first;
     S.qmode = a.u0fix != nullptr;
