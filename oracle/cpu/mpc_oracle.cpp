@@ -19,7 +19,7 @@ struct Solver {
     static constexpr int NX = Mdl::NX, NU = Mdl::NU, NW = NX + NU, NTD = Mdl::NTD, NP = Mdl::NP;
     const OracleSpec &sp;
     const int N, n;
-    const double *p;        // full parameter vector of this instance
+    const double *p;        // full parameter vector of this instance (rebound per instance by bind())
     double th[NTD];         // dynamics parameters
     std::vector<double> c;  // cost scaling c_k
     std::vector<double> X, U, PI;                       // iterate; PI[k] multiplies F(x_k,u_k) - x_{k+1}
@@ -32,6 +32,10 @@ struct Solver {
     bool qmode = false;
     int n_rows = 0;
 
+    void bind(const double *p_) {
+        p = p_;
+        for (int i = 0; i < NTD; ++i) th[i] = p[Mdl::td_index(i)];
+    }
     Solver(const OracleSpec &sp_, const double *p_) : sp(sp_), N(sp_.N), n((sp_.N + 1) * NW), p(p_) {
         for (int i = 0; i < NTD; ++i) th[i] = p[Mdl::td_index(i)];
         c.resize(N + 1);
@@ -622,10 +626,15 @@ int run(const OracleSpec *sp, int Bn, const double *x0, const double *u0fix, con
     const int N = sp->N, n = (N + 1) * NW;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel
+#endif
+    {
+    Solver<Mdl> S(*sp, p);   // one workspace per thread, re-used for every instance the thread picks up
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
 #endif
     for (int b = 0; b < Bn; ++b) {
-        Solver<Mdl> S(*sp, ppi ? p + (size_t)b * NP : p);
+        S.bind(ppi ? p + (size_t)b * NP : p);
         const bool warm = flags & ORACLE_WARM;
         if (warm) {
             std::copy(X + (size_t)b * (N + 1) * NX, X + (size_t)(b + 1) * (N + 1) * NX, S.X.begin());
@@ -662,6 +671,7 @@ int run(const OracleSpec *sp, int Bn, const double *x0, const double *u0fix, con
         }
         if ((flags & (ORACLE_SENS_V | ORACLE_SENS_PI)) && (st == 0 || st == 2))
             S.sensitivities(flags, dV ? dV + (size_t)b * NP : nullptr, dpi ? dpi + (size_t)b * NU * NP : nullptr);
+    }
     }
     return 0;
 }

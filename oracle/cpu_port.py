@@ -94,7 +94,7 @@ class PortResult:
 
 
 def solve(P: Problem, x0, p=None, u0fix=None, gamma=None, flags=SENS_V | SENS_PI, warm: Optional[PortResult] = None,
-          max_iter=None, tol=None, nthreads=0) -> PortResult:
+          max_iter=None, tol=None, nthreads=0, want_bnd=True) -> PortResult:
     x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, float)))
     B = x0.shape[0]
     nw = P.nu + P.nx
@@ -120,7 +120,7 @@ def solve(P: Problem, x0, p=None, u0fix=None, gamma=None, flags=SENS_V | SENS_PI
         X, U, PI, BND = warm.X.copy(), warm.U.copy(), warm.PI.copy(), warm.BND.copy()
     else:
         X, U, PI = np.zeros((B, P.N + 1, P.nx)), np.zeros((B, P.N, P.nu)), np.zeros((B, P.N, P.nx))
-        BND = np.zeros((B, 10, P.N + 1, nw))
+        BND = np.zeros((B, 10, P.N + 1, nw)) if want_bnd else None
     u0 = np.zeros((B, P.nu))
     V = np.zeros(B)
     dV = np.zeros((B, P.n_p)) if flags & SENS_V else None
@@ -132,7 +132,7 @@ def solve(P: Problem, x0, p=None, u0fix=None, gamma=None, flags=SENS_V | SENS_PI
         uf = np.ascontiguousarray(np.atleast_2d(np.asarray(u0fix, float)))
         assert uf.shape == (B, P.nu)
     rc = lib().mpc_oracle_solve(
-        C.byref(sp), B, dptr(x0), dptr(uf) if uf is not None else None, dptr(pp), per, flags, dptr(X), dptr(U), dptr(PI), dptr(BND),
+        C.byref(sp), B, dptr(x0), dptr(uf) if uf is not None else None, dptr(pp), per, flags, dptr(X), dptr(U), dptr(PI), dptr(BND) if BND is not None else None,
         dptr(u0), dptr(V), dptr(dV) if dV is not None else None, dptr(dpi) if dpi is not None else None,
         status.ctypes.data_as(_ip), nsqp.ctypes.data_as(_ip), nipm.ctypes.data_as(_ip), dptr(res), int(nthreads))
     if rc != 0:
