@@ -187,3 +187,55 @@ def test_golden_cartpole_and_linear_on_gpu():
         for k, a in (("u0", r.u0), ("V", r.V), ("dV", r.dV_dp)):
             assert rel_err(a.cpu().numpy(), g[k]) < RTOL, k
         assert rel_err(r.dpi_dp.cpu().numpy()[strict], g["dpi"][strict]) < RTOL
+
+
+@pytest.mark.parametrize("B", [1, 2, 4, 100, 4097])
+def test_ragged_batch_sizes(oracle_port, B):
+    """Batch sizes that do not fill the last wavefront (3 instances per wave), a single instance, and > 4096."""
+    from mpc4rl_amd import cartpole_ocp
+    from oracle.problems import make_cartpole
+    x0 = cartpole_x0(B, seed=7)
+    mpc, r, ref = run_both(cartpole_ocp(), make_cartpole(), oracle_port, x0, nthreads=8)
+    st = r.status.cpu().numpy()
+    assert np.array_equal(st, ref.status)
+    assert rel_err(r.u0.cpu().numpy(), ref.u0) < RTOL and rel_err(r.V.cpu().numpy(), ref.V) < RTOL
+    assert rel_err(r.dV_dp.cpu().numpy(), ref.dV) < RTOL and rel_err(r.dpi_dp.cpu().numpy(), ref.dpi) < RTOL
+    assert np.array_equal(r.iters.cpu().numpy()[:, 0], ref.sqp_iter)
+
+
+def test_status_codes_and_reorder_invariance(oracle_port):
+    """max-iter status for every instance; the packing-order hint must not change any result bit."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    x0 = cartpole_x0(300, seed=9)
+    mpc = MPCBatch(cartpole_ocp(max_iter=3), 300)
+    r = mpc.solve(x0, cold=True)
+    assert set(np.unique(r.status.cpu().numpy())) <= {0, 2} and int((r.status == 2).sum()) > 0
+    assert int(r.iters[:, 0].max()) == 3
+    a = MPCBatch(cartpole_ocp(), 300)
+    ra = a.solve(x0, sens_v=True, sens_pi=True, cold=True, reorder=True)
+    b = MPCBatch(cartpole_ocp(), 300)
+    rb = b.solve(x0, sens_v=True, sens_pi=True, cold=True, reorder=False)
+    for t1, t2 in ((ra.u0, rb.u0), (ra.V, rb.V), (ra.dV_dp, rb.dV_dp), (ra.dpi_dp, rb.dpi_dp), (ra.status, rb.status), (ra.iters, rb.iters)):
+        assert torch.equal(t1, t2)
+
+
+def test_full_size_properties_cartpole():
+    """BASELINE full size (4096): size-independent properties instead of an oracle run — every instance converges, the KKT
+    residuals are below tol, a second call from the stored iterate needs zero iterations and reproduces the outputs,
+    V is invariant to a permutation of the batch, and u0 respects its bounds."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    B = 4096
+    rng = np.random.default_rng(0)
+    x0 = np.zeros((B, 4))
+    x0[:, 2] = rng.uniform(0.9 * np.pi, 1.1 * np.pi, B)
+    mpc = MPCBatch(cartpole_ocp(), B)
+    r = mpc.solve(x0, sens_v=True, sens_pi=True, cold=True)
+    assert bool((r.status == 0).all())
+    res = mpc.get_iterate()[4]
+    assert float(res.max()) < 1e-6
+    assert float(r.u0.abs().max()) <= 30.0 + 1e-9
+    r2 = mpc.solve(x0, sens_v=True, sens_pi=True)
+    assert int(r2.iters[:, 0].max()) == 0 and torch.allclose(r2.V, r.V, rtol=1e-14) and torch.allclose(r2.dV_dp, r.dV_dp, rtol=1e-12)
+    perm = rng.permutation(B)
+    rp = MPCBatch(cartpole_ocp(), B).solve(x0[perm], cold=True)
+    assert torch.equal(rp.V, r.V[torch.as_tensor(perm, device=r.V.device)])
