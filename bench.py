@@ -41,6 +41,17 @@ def make_inputs(B, rank):
     return x0
 
 
+def measured_traffic(B, sens, rti):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in
+    separate rocprofv3 runs of this command); only valid for the default workload, else null."""
+    try:
+        if B != B_PER_GPU or not sens or rti:
+            return None
+        return float(json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))["traffic_bytes_per_step"])
+    except Exception:
+        return None
+
+
 def usable_cores():
     """Host threads this process may actually use: the cgroup CPU quota if there is one (the GPU boxes expose 256 logical
     CPUs but grant a quota of 16), else the affinity mask."""
@@ -220,7 +231,7 @@ def main():
                 "sqp_iters_max": int(iters[:, 0].max()), "ipm_iters_mean": float(iters[:, 1].mean()),
                 "ipm_iters_max": int(iters[:, 1].max())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B, sens, args.rti),
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_solve": bytes_per},
         }
         if world == 1 and not args.no_cpu:
