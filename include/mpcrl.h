@@ -93,6 +93,11 @@ int mpcrl_set_options(mpcrl_handle h, double tol, int max_iter);
  * instance perm[i], so that instances expected to need similar iteration counts share a wavefront. NULL = identity. */
 int mpcrl_set_order(mpcrl_handle h, const int32_t *perm, void *stream);
 
+/* Kernel variant (no effect on results).  AUTO = one lane per stage, everything in registers (the default for every model);
+ * COOPERATIVE = cartpole N=20 only: a 7-wave workgroup per 16 instances with the Riccati sweeps of all of them on one wave. */
+enum { MPCRL_VARIANT_AUTO = 0, MPCRL_VARIANT_COOPERATIVE = 1 };
+int mpcrl_set_variant(mpcrl_handle h, int variant);
+
 /* Cold iterate: x_k := x0 for all k, u := 0, all multipliers 0. x0: [B, nx] device. */
 int mpcrl_reset(mpcrl_handle h, const double *x0, void *stream);
 

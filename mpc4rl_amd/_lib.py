@@ -27,7 +27,7 @@ class ProblemSpec(C.Structure):
     ]
 
 
-EXPORTS = ["mpcrl_create", "mpcrl_destroy", "mpcrl_set_theta", "mpcrl_set_gamma", "mpcrl_set_options", "mpcrl_set_order", "mpcrl_reset",
+EXPORTS = ["mpcrl_create", "mpcrl_destroy", "mpcrl_set_theta", "mpcrl_set_gamma", "mpcrl_set_options", "mpcrl_set_order", "mpcrl_set_variant", "mpcrl_reset",
            "mpcrl_solve", "mpcrl_get_iterate", "mpcrl_set_iterate", "mpcrl_workspace_bytes", "mpcrl_version"]
 
 _lib = None
@@ -50,6 +50,7 @@ def load():
     lib.mpcrl_set_gamma.argtypes = [vp, C.c_double]
     lib.mpcrl_set_options.argtypes = [vp, C.c_double, C.c_int]
     lib.mpcrl_set_order.argtypes = [vp, vp, vp]
+    lib.mpcrl_set_variant.argtypes = [vp, C.c_int]
     lib.mpcrl_reset.argtypes = [vp, vp, vp]
     lib.mpcrl_solve.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     lib.mpcrl_get_iterate.argtypes = [vp, vp, vp, vp, vp, vp, vp]

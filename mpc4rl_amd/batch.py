@@ -94,6 +94,10 @@ class MPCBatch:
     def set_options(self, tol: float = -1.0, max_iter: int = -1) -> None:
         self._check(self.lib.mpcrl_set_options(self._h, float(tol), int(max_iter)), "mpcrl_set_options")
 
+    def set_variant(self, variant: int) -> None:
+        """0 = default (lane per stage), 1 = cooperative sweeps (cartpole N=20 only; experiment)."""
+        self._check(self.lib.mpcrl_set_variant(self._h, int(variant)), "mpcrl_set_variant")
+
     def reset(self, x0=None) -> None:
         """MPC.reset (mpc.py:204-210): the next solve starts from x_k = x0, u = 0, multipliers 0."""
         self._check(self.lib.mpcrl_reset(self._h, None, self._stream()), "mpcrl_reset")

@@ -67,9 +67,32 @@ MPCRL_DI double seg_max(double v, int k, int lpi, int base) {
 }
 MPCRL_DI double seg_min(double v, int k, int lpi, int base) { return -seg_max(-v, k, lpi, base); }
 
-template <class M>
+// Cooperative mode (coop_solve_kernel): a workgroup of COOP_WAVES waves owns COOP_G instances.  The stage-parallel phases stay
+// on the stage lanes; the serial Riccati sweeps of ALL instances of the workgroup run side by side on COOP_G lanes of the last
+// wave, exchanging per-stage data through LDS (one slot of SLOTP doubles per (instance, stage)).
+struct NoCoop {
+    static constexpr bool ON = false;
+};
+struct CoopCtx {
+    static constexpr bool ON = true;
+    double *lds;        // slots
+    double *okbuf;      // [COOP_G] factorisation-ok flags (1.0 / 0.0)
+    int *flags_ipm;     // [COOP_WAVES] workgroup-any scratch
+    int g;              // instance index inside the workgroup (stage lanes)
+    bool stage_lane;    // this lane owns a (g, k) stage slot
+    bool sweep_lane;    // this lane runs the sweeps of instance gs
+    int gs, wave, nwave;
+};
+constexpr int COOP_G = 16, COOP_STAGE_WAVES = 6, COOP_WAVES = 7;   // 6 waves of stage lanes (3 instances each, the last one 1) + 1 sweep wave
+
+template <class M, class C = NoCoop>
 struct SmallSolver {
     static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD, NTC = M::NTC, NP = M::NP;
+    C coop;
+    // LDS slot layout of one (instance, stage) in cooperative mode
+    static constexpr int oA = 0, oB = oA + NX * NX, oDg = oB + NX * NU, oRt = oDg + NW, oRb = oRt + NW, oK = oRb + NX,
+                         oKff = oK + NU * NX, oLi = oKff + NU, oP = oLi + NU * (NU + 1) / 2, oPv = oP + NX * (NX + 1) / 2,
+                         SLOT = oPv + NX, SLOTP = SLOT | 1;
     static constexpr int NPK = NX * (NX + 1) / 2, NLK = NU * (NU + 1) / 2;
     static constexpr bool SOFT = M::HAS_SOFT;
     MPCRL_DI static constexpr int sym(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
@@ -442,6 +465,288 @@ struct SmallSolver {
         }
     }
 
+    // ---- workgroup-wide "any" (cooperative mode) / wave-wide (default) ---------------------------------
+    MPCRL_DI bool any_lane(bool v) {
+        if constexpr (C::ON) {
+            const bool w = __any(v);
+            if ((threadIdx.x & 63) == 0) coop.flags_ipm[coop.wave] = w ? 1 : 0;
+            __syncthreads();
+            int r = 0;
+            for (int i = 0; i < coop.nwave; ++i) r |= coop.flags_ipm[i];
+            return r != 0;
+        } else
+            return __any(v);
+    }
+    MPCRL_DI double *slot(int g, int kk) const { return coop.lds + (size_t)(g * lpi + kk) * SLOTP; }
+
+    // stage lanes publish the dynamics Jacobians of the current linearisation (once per SQP iteration)
+    MPCRL_DI void coop_publish_AB() {
+        if constexpr (C::ON) {
+            if (coop.stage_lane) {
+                double *sl = slot(coop.g, k);
+#pragma unroll
+                for (int i = 0; i < NX * NX; ++i) sl[oA + i] = A[i];
+#pragma unroll
+                for (int i = 0; i < NX * NU; ++i) sl[oB + i] = Bm[i];
+            }
+        }
+    }
+
+    // serial sweeps of one instance on one lane; per-stage data in LDS.  FACTOR: matrix + vector recursion, else vector only.
+    template <bool FACTOR>
+    MPCRL_DI bool coop_sweep(int gs) {
+        bool ok = true;
+        double Pc[NPK], pc[NX];
+        {   // terminal stage
+            double *sl = slot(gs, N);
+            const double ckN = sp.cost_kind == 0 ? 1.0 : pow(sp.gamma, (double)N);
+            if constexpr (FACTOR) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) {
+                        Pc[sym(i, j)] = ckN * M::hess(true, NU + i, NU + j, sp, thc) + (i == j ? sl[oDg + NU + i] : 0.0);
+                        sl[oP + sym(i, j)] = Pc[sym(i, j)];
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NPK; ++i) Pc[i] = sl[oP + i];
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) pc[i] = sl[oRt + NU + i], sl[oPv + i] = pc[i];
+        }
+        double ckk_next = sp.cost_kind == 0 ? sp.dT : pow(sp.gamma, (double)N) * sp.dT;   // gamma^(k+1) dT, updated as k decreases
+        for (int kk = N - 1; kk >= 0; --kk) {
+            double *sl = slot(gs, kk);
+            const double ckk = sp.cost_kind == 0 ? sp.dT : (kk == 0 ? sp.dT : ckk_next / sp.gamma);
+            ckk_next = kk == 0 ? ckk_next : ckk;
+            const bool pin = kk == 0 && qmode;
+            double BAv[NX * NW], g[NW], bb[NX], cc[NX], mv[NW];
+#pragma unroll
+            for (int m = 0; m < NX; ++m) {
+#pragma unroll
+                for (int j = 0; j < NU; ++j) BAv[m * NW + j] = sl[oB + m * NU + j];
+#pragma unroll
+                for (int j = 0; j < NX; ++j) BAv[m * NW + NU + j] = sl[oA + m * NX + j];
+            }
+#pragma unroll
+            for (int i = 0; i < NW; ++i) g[i] = sl[oRt + i];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) bb[i] = sl[oRb + i];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = pc[i];
+#pragma unroll
+                for (int j = 0; j < NX; ++j) a = fma(Pc[sym(i, j)], bb[j], a);
+                cc[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                double a = g[i];
+#pragma unroll
+                for (int m = 0; m < NX; ++m) a = fma(BAv[m * NW + i], cc[m], a);
+                mv[i] = a;
+            }
+            double Kc[NU * NX], Lc[NLK], kf[NU];
+            if constexpr (FACTOR) {
+                double T[NX * NW], Mm[NW * (NW + 1) / 2];
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) {
+                        double a = 0.0;
+#pragma unroll
+                        for (int m = 0; m < NX; ++m) a = fma(Pc[sym(i, m)], BAv[m * NW + j], a);
+                        T[i * NW + j] = a;
+                    }
+#pragma unroll
+                for (int i = 0; i < NW; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) {
+                        double a = ckk * M::hess(false, i, j, sp, thc) + (i == j ? sl[oDg + i] : 0.0);
+#pragma unroll
+                        for (int m = 0; m < NX; ++m) a = fma(BAv[m * NW + i], T[m * NW + j], a);
+                        Mm[sym(i, j)] = a;
+                    }
+#pragma unroll
+                for (int i = 0; i < NU; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) {
+                        double a = Mm[sym(i, j)];
+#pragma unroll
+                        for (int m = 0; m < j; ++m) a -= Lc[sym(i, m)] * Lc[sym(j, m)];
+                        if (i == j) {
+                            ok = ok && (a > 0.0 || pin);
+                            Lc[sym(i, i)] = 1.0 / sqrt(a);
+                        } else
+                            Lc[sym(i, j)] = a * Lc[sym(j, j)];
+                    }
+#pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    double y[NU];
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) {
+                        double a = Mm[sym(NU + j, i)];
+#pragma unroll
+                        for (int m = 0; m < i; ++m) a -= Lc[sym(i, m)] * y[m];
+                        y[i] = a * Lc[sym(i, i)];
+                    }
+#pragma unroll
+                    for (int i = NU - 1; i >= 0; --i) {
+                        double a = y[i];
+#pragma unroll
+                        for (int m = i + 1; m < NU; ++m) a -= Lc[sym(m, i)] * Kc[m * NX + j];
+                        Kc[i * NX + j] = pin ? 0.0 : a * Lc[sym(i, i)];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) {
+                        double a = Mm[sym(NU + i, NU + j)];
+#pragma unroll
+                        for (int m = 0; m < NU; ++m) a -= Mm[sym(NU + i, m)] * Kc[m * NX + j];
+                        Pc[sym(i, j)] = a;
+                    }
+#pragma unroll
+                for (int i = 0; i < NU * NX; ++i) sl[oK + i] = Kc[i];
+#pragma unroll
+                for (int i = 0; i < NLK; ++i) sl[oLi + i] = Lc[i];
+#pragma unroll
+                for (int i = 0; i < NPK; ++i) sl[oP + i] = Pc[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < NU * NX; ++i) Kc[i] = sl[oK + i];
+#pragma unroll
+                for (int i = 0; i < NLK; ++i) Lc[i] = sl[oLi + i];
+#pragma unroll
+                for (int i = 0; i < NPK; ++i) Pc[i] = sl[oP + i];
+            }
+            {
+                double y[NU];
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    double a = mv[i];
+#pragma unroll
+                    for (int m = 0; m < i; ++m) a -= Lc[sym(i, m)] * y[m];
+                    y[i] = a * Lc[sym(i, i)];
+                }
+#pragma unroll
+                for (int i = NU - 1; i >= 0; --i) {
+                    double a = y[i];
+#pragma unroll
+                    for (int m = i + 1; m < NU; ++m) a -= Lc[sym(m, i)] * kf[m];
+                    kf[i] = pin ? 0.0 : a * Lc[sym(i, i)];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = mv[NU + i];
+#pragma unroll
+                for (int m = 0; m < NU; ++m) a -= Kc[m * NX + i] * mv[m];
+                pc[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) sl[oKff + i] = kf[i];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) sl[oPv + i] = pc[i];
+        }
+        // forward sweep; Du, Dx overwrite the (consumed) gradient slots
+        double dxc[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dxc[i] = 0.0;
+        for (int kk = 0; kk < N; ++kk) {
+            double *sl = slot(gs, kk);
+            double duc[NU], xn[NX];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                double a = -sl[oKff + i];
+#pragma unroll
+                for (int j = 0; j < NX; ++j) a = fma(-sl[oK + i * NX + j], dxc[j], a);
+                duc[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = sl[oRb + i];
+#pragma unroll
+                for (int j = 0; j < NX; ++j) a = fma(sl[oA + i * NX + j], dxc[j], a);
+#pragma unroll
+                for (int j = 0; j < NU; ++j) a = fma(sl[oB + i * NU + j], duc[j], a);
+                xn[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) sl[oRt + i] = duc[i];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) sl[oRt + NU + i] = dxc[i], dxc[i] = xn[i];
+        }
+        {
+            double *sl = slot(gs, N);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) sl[oRt + NU + i] = dxc[i];
+        }
+        return ok;
+    }
+
+    // program of the sweep wave: mirrors the barrier sequence of the stage waves (SQP loop / IPM loop / two KKT solves)
+    MPCRL_DI void coop_sweep_program(const int *flags_sqp) {
+        for (;;) {
+            __syncthreads();   // (a) SQP-level any(live)
+            int r = 0;
+            for (int i = 0; i < coop.nwave; ++i) r |= flags_sqp[i];
+            if (!r) break;
+            for (;;) {
+                __syncthreads();   // (b) IPM-level any(qlive)
+                int q = 0;
+                for (int i = 0; i < coop.nwave; ++i) q |= coop.flags_ipm[i];
+                if (!q) break;
+                __syncthreads();
+                if (coop.sweep_lane) {
+                    const bool ok = coop_sweep<true>(coop.gs);
+                    coop.okbuf[coop.gs] = ok ? 1.0 : 0.0;
+                }
+                __syncthreads();
+                __syncthreads();
+                if (coop.sweep_lane) coop_sweep<false>(coop.gs);
+                __syncthreads();
+            }
+        }
+    }
+
+    // stage-lane side of one KKT solve: publish, let the sweep lanes work, collect the Newton step
+    template <bool FACTOR>
+    MPCRL_DI bool coop_kkt(const double *g, const double *bb) {
+        if (coop.stage_lane) {
+            double *sl = slot(coop.g, k);
+            if constexpr (FACTOR) {
+#pragma unroll
+                for (int i = 0; i < NW; ++i) sl[oDg + i] = Dg[i];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) sl[oRb + i] = bb[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NW; ++i) sl[oRt + i] = g[i];
+        }
+        __syncthreads();   // inputs published -> the sweep wave (coop_sweep_program) works between these two barriers
+        __syncthreads();
+        bool okr = true;
+        if (coop.stage_lane) {
+            const double *sl = slot(coop.g, k);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) Du[i] = term ? 0.0 : sl[oRt + i];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) Dx[i] = sl[oRt + NU + i];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = sl[oPv + i];
+#pragma unroll
+                for (int j = 0; j < NX; ++j) a = fma(sl[oP + sym(i, j)], Dx[j], a);
+                Dnu[i] = first ? 0.0 : a;
+            }
+            okr = coop.okbuf[coop.g] > 0.5;
+        }
+        return okr;
+    }
+
     // ---- interior point: per-row Newton quantities ------------------------------------------------
     // complementarity target r_m of a row (affine: lam t; corrector: lam t + dlam_aff dt_aff - sigma mu)
     MPCRL_DI static double rm_(double l, double tt, double af, int pass, double smu) { return fma(l, tt, pass ? af - smu : 0.0); }
@@ -604,7 +909,7 @@ struct SmallSolver {
                 else if (it >= IPM_MAX_ITER || !(rinf < 1e300))
                     qlive = false;
             }
-            if (!__any(qlive)) break;
+            if (!any_lane(qlive)) break;
             if (qlive) ++n_it;
             // ---- predictor
             double eaff[NW];
@@ -614,9 +919,14 @@ struct SmallSolver {
                 barrier_terms(i, v, 0, 0.0, Dg[i], eaff[i]);
                 rt[i] = rg[i] + eaff[i];
             }
-            const bool okf = backward<true>(Hs, rt, rb);
+            bool okf;
+            if constexpr (C::ON)
+                okf = coop_kkt<true>(rt, rb);
+            else {
+                okf = backward<true>(Hs, rt, rb);
+                forward(rb);
+            }
             if (seg_max(okf ? 0.0 : 1.0, k, lpi, base) > 0.5) qlive = false;   // non-positive pivot: QP failure
-            forward(rb);
             double amax = 1.0, muaff = 0.0;
             double daff[2][NW], dsaff[2][SOFT ? NW : 1];
 #pragma unroll
@@ -676,8 +986,12 @@ struct SmallSolver {
                 barrier_terms(i, v, 1, smu, dgi, ec);
                 rt[i] = rg[i] + ec;
             }
-            backward<false>(Hs, rt, rb);
-            forward(rb);
+            if constexpr (C::ON)
+                coop_kkt<false>(rt, rb);
+            else {
+                backward<false>(Hs, rt, rb);
+                forward(rb);
+            }
             amax = 1.0;
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
@@ -984,6 +1298,205 @@ __global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, con
                 status = 2, live = false;
         }
         if (!__any(live)) break;
+        const double warm_mu = stepn < 0.0 ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
+        const bool ok = S.qp_solve(live, x0, u0f, n_ipm, warm_mu);
+        if (live && !ok) status = 4, live = false;
+        {
+            double sl = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) sl = fmax(sl, fabs(S.dx[i]));
+            if (!term) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) sl = fmax(sl, fabs(S.du[i]));
+            }
+            stepn = seg_max(sl, k, lpi, base);
+        }
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) S.x[i] += S.dx[i], S.nu_[i] = S.nuq[i];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) S.u[i] += S.du[i];
+        }
+    }
+    // ---- results
+    if (valid && first) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) a.u0_out[inst * NU + i] = S.u[i];
+        a.V[inst] = Vout;
+        a.status[inst] = status;
+        if (a.iters) a.iters[inst * 2] = n_sqp, a.iters[inst * 2 + 1] = n_ipm;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a.RES[inst * 4 + j] = res_out[j];
+    }
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            a.X[(inst * (N + 1) + k) * NX + i] = S.x[i];
+            if (!first) a.PI[(inst * N + k - 1) * NX + i] = S.nu_[i];
+        }
+        if (!term) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) a.U[(inst * N + k) * NU + i] = S.u[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            bnd[0 * nb + i] = S.has(0, i) ? S.lam[0][i] : 0.0, bnd[1 * nb + i] = S.has(1, i) ? S.lam[1][i] : 0.0;
+            bnd[2 * nb + i] = S.has(0, i) ? S.t[0][i] : 1.0, bnd[3 * nb + i] = S.has(1, i) ? S.t[1][i] : 1.0;
+            if constexpr (SOFT) {
+                bnd[4 * nb + i] = S.s[0][i], bnd[5 * nb + i] = S.s[1][i], bnd[6 * nb + i] = S.lams[0][i], bnd[7 * nb + i] = S.lams[1][i];
+                bnd[8 * nb + i] = S.ts[0][i], bnd[9 * nb + i] = S.ts[1][i];
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// cooperative kernel: COOP_G instances per workgroup of COOP_WAVES waves; sweeps of all instances on 16 lanes of the last wave.
+// Needs N + 1 = 21 stage lanes per instance (3 per wave) — the cartpole benchmark horizon; other horizons use small_solve_kernel.
+// =====================================================================================================
+template <class M>
+__global__ void __launch_bounds__(64 * COOP_WAVES) coop_solve_kernel(const SmallSpec sp, const SmallArgs a) {
+    constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NP = M::NP, NTD = M::NTD, NTC = M::NTC;
+    constexpr bool SOFT = M::HAS_SOFT;
+    using Solver = SmallSolver<M, CoopCtx>;
+    __shared__ double coop_lds[COOP_G * 21 * Solver::SLOTP];
+    __shared__ double coop_ok[COOP_G];
+    __shared__ int coop_flags[2 * COOP_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int N = sp.N, lpi = N + 1, ipw = 64 / lpi;
+    const int slot = lane / lpi, k = lane - slot * lpi, base = slot * lpi;
+    const int g = wave * ipw + slot;
+    const bool stage_lane = slot < ipw && g < COOP_G && wave < COOP_STAGE_WAVES;
+    long inst = (long)blockIdx.x * COOP_G + g;
+    const bool valid = stage_lane && inst < a.B;
+    if (!valid) inst = a.B - 1;   // dead lanes shadow the last instance and never store
+    if (a.perm) inst = a.perm[inst];
+    Solver S(sp, k, lpi, base);
+    S.coop.lds = coop_lds, S.coop.okbuf = coop_ok, S.coop.flags_ipm = coop_flags + COOP_WAVES, S.coop.g = stage_lane ? g : 0;
+    S.coop.stage_lane = stage_lane && wave < COOP_STAGE_WAVES, S.coop.wave = wave, S.coop.nwave = COOP_WAVES;
+    S.coop.gs = lane;
+    S.coop.sweep_lane = wave == COOP_WAVES - 1 && lane < COOP_G && (long)blockIdx.x * COOP_G + lane < a.B;
+    if (threadIdx.x < 2 * COOP_WAVES) coop_flags[threadIdx.x] = 0;
+    __syncthreads();
+    if (wave == COOP_WAVES - 1) {   // warp-specialised: this wave only runs the serial sweeps of the workgroup's instances
+        S.qmode = a.u0fix != nullptr;
+#pragma unroll
+        for (int i = 0; i < M::NTC; ++i) S.thc[i] = 0.0;
+        S.coop_sweep_program(coop_flags);
+        return;
+    }
+    const bool term = S.term, first = S.first;
+    S.qmode = a.u0fix != nullptr;
+    if (sp.cost_kind == 0)
+        S.ck = term ? 1.0 : sp.dT;                                                        // nlp.py:1044-1055
+    else
+        S.ck = first ? sp.dT : (term ? pow(sp.gamma, (double)N) : pow(sp.gamma, (double)k) * sp.dT);   // nlp.py:1083-1091
+    const double *th = a.theta + (size_t)inst * a.theta_stride;
+#pragma unroll
+    for (int i = 0; i < NTD; ++i) S.thd[i] = th[M::td_index(i)];
+#pragma unroll
+    for (int i = 0; i < NTC; ++i) S.thc[i] = th[M::tc_index(i)];
+    double x0[NX], u0f[NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x0[i] = a.x0[inst * NX + i];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) u0f[i] = S.qmode ? a.u0fix[inst * NU + i] : 0.0;
+    // ---- iterate: stored (warm) or the reference's cold start (MPC.reset, mpc.py:204-210)
+    const size_t nb = (size_t)(N + 1) * NW;
+    double *bnd = a.BND + (size_t)inst * 10 * nb + (size_t)k * NW;
+    if (a.flags & 8) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) S.x[i] = x0[i], S.nu_[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) S.u[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            S.lam[0][i] = S.lam[1][i] = 0.0, S.t[0][i] = S.t[1][i] = 1.0, S.aff[0][i] = S.aff[1][i] = 0.0;
+            if constexpr (SOFT) S.s[0][i] = S.s[1][i] = 0.0, S.lams[0][i] = S.lams[1][i] = 0.0, S.ts[0][i] = S.ts[1][i] = 1.0,
+                                S.affs[0][i] = S.affs[1][i] = 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            S.x[i] = a.X[(inst * (N + 1) + k) * NX + i];
+            S.nu_[i] = first ? 0.0 : a.PI[(inst * N + k - 1) * NX + i];
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) S.u[i] = term ? 0.0 : a.U[(inst * N + k) * NU + i];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            S.lam[0][i] = bnd[0 * nb + i], S.lam[1][i] = bnd[1 * nb + i], S.t[0][i] = bnd[2 * nb + i], S.t[1][i] = bnd[3 * nb + i];
+            S.aff[0][i] = S.aff[1][i] = 0.0;
+            if constexpr (SOFT) {
+                S.s[0][i] = bnd[4 * nb + i], S.s[1][i] = bnd[5 * nb + i], S.lams[0][i] = bnd[6 * nb + i], S.lams[1][i] = bnd[7 * nb + i];
+                S.ts[0][i] = bnd[8 * nb + i], S.ts[1][i] = bnd[9 * nb + i], S.affs[0][i] = S.affs[1][i] = 0.0;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < S.NPK; ++i) S.P[i] = 0.0, S.Pnext[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) S.p[i] = 0.0, S.dx[i] = 0.0, S.nuq[i] = 0.0, S.Dx[i] = 0.0, S.Dnu[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) S.du[i] = 0.0, S.Du[i] = 0.0, S.kff[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NU * NX; ++i) S.K[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < S.NLK; ++i) S.Li[i] = 0.0;
+
+    // ---- full-step SQP (the reference requests no globalisation; config/cartpole.yaml:8-14)
+    const bool rti = (a.flags & 4) != 0;
+    const int max_iter = rti ? 1 : sp.max_iter;
+    bool live = valid;
+    int status = 2, n_sqp = 0, n_ipm = 0;
+    // size of the perturbation the next QP sees (< 0: nothing to start from): change of the pinned x0 / u0 for a warm call
+    double stepn = -1.0;
+    if (!(a.flags & 8)) {
+        double sl = 0.0;
+        if (first) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) sl = fmax(sl, fabs(x0[i] - S.x[i]));
+            if (S.qmode) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) sl = fmax(sl, fabs(u0f[i] - S.u[i]));
+            }
+        }
+        stepn = seg_max(sl, k, lpi, base);
+    }
+    double Vout = 0.0, res_out[4] = {0, 0, 0, 0};
+    double nun[NX];
+    for (int it = 0;; ++it) {
+        double xn[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xn[i] = lane_dn(S.x[i]), nun[i] = lane_dn(S.nu_[i]);
+        const double cl = S.linearize(xn);
+        S.coop_publish_AB();
+        double rl[4];
+        S.nlp_res_local(nun, x0, u0f, rl);
+        const double cost = seg_sum(cl, k, lpi, base);
+        double res[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) res[j] = seg_max(rl[j], k, lpi, base);
+        const double rmax = fmax(fmax(res[0], res[1]), fmax(res[2], res[3]));
+        if (live) {
+            Vout = cost, n_sqp = it;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) res_out[j] = res[j];
+            if (!(rmax < 1e300))
+                status = 1, live = false;
+            else if (rmax < sp.tol && !(rti && it == 0))
+                status = 0, live = false;
+            else if (it >= max_iter)
+                status = 2, live = false;
+        }
+        {   // workgroup-wide any(live)
+            const bool w = __any(live);
+            if (lane == 0) coop_flags[wave] = w ? 1 : 0;
+            __syncthreads();
+            int r = 0;
+            for (int i = 0; i < COOP_WAVES; ++i) r |= coop_flags[i];
+            if (!r) break;
+        }
         const double warm_mu = stepn < 0.0 ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
         const bool ok = S.qp_solve(live, x0, u0f, n_ipm, warm_mu);
         if (live && !ok) status = 4, live = false;

@@ -239,3 +239,16 @@ def test_full_size_properties_cartpole():
     perm = rng.permutation(B)
     rp = MPCBatch(cartpole_ocp(), B).solve(x0[perm], cold=True)
     assert torch.equal(rp.V, r.V[torch.as_tensor(perm, device=r.V.device)])
+
+
+def test_cooperative_variant_matches_default(oracle_port):
+    """The experimental cooperative kernel (16 instances per 7-wave workgroup, sweeps on one wave) must agree with the oracle."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    from oracle.problems import make_cartpole
+    B = 100
+    x0 = cartpole_x0(B, seed=11)
+    mpc = MPCBatch(cartpole_ocp(), B)
+    mpc.set_variant(1)
+    r = mpc.solve(x0, sens_v=True, sens_pi=True, cold=True)
+    ref = oracle_port.solve(make_cartpole(), x0)
+    check(r, ref)
