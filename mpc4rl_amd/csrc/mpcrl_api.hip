@@ -44,6 +44,23 @@ struct MpcrlSolver {
 
 namespace {
 
+// switches to the handle's device for the duration of a call and restores the caller's device afterwards
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+#define ON_DEVICE(dev)            \
+    DeviceGuard guard_((dev));    \
+    if (!guard_.ok) return MPCRL_E_HIP
+
 template <class T>
 int dev_alloc(T **p, size_t n, int64_t &bytes) {
     hipError_t e = hipMalloc((void **)p, n * sizeof(T));
@@ -131,7 +148,7 @@ int mpcrl_version(void) { return 100; }
 
 int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_handle *out) {
     if (!spec || !out || batch <= 0) return MPCRL_E_ARG;
-    HIP_OK(hipSetDevice(device));
+    ON_DEVICE(device);
     MpcrlSolver *h = new (std::nothrow) MpcrlSolver();
     if (!h) return MPCRL_E_NOMEM;
     h->model = spec->model, h->B = batch, h->device = device, h->nx = spec->nx, h->nu = spec->nu, h->np = spec->np, h->N = spec->N;
@@ -189,7 +206,7 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
 
 int mpcrl_destroy(mpcrl_handle h) {
     if (!h) return MPCRL_E_ARG;
-    hipSetDevice(h->device);
+    DeviceGuard guard_(h->device);
     for (double *p : {h->X, h->U, h->PI, h->BND, h->RES, h->theta, h->ws, h->consts_dev})
         if (p) hipFree(p);
     if (h->perm) hipFree(h->perm);
@@ -201,7 +218,7 @@ int64_t mpcrl_workspace_bytes(mpcrl_handle h) { return h ? h->bytes : 0; }
 
 int mpcrl_set_theta(mpcrl_handle h, const double *theta, int n_theta, int per_instance, void *stream) {
     if (!h || !theta || n_theta != h->np) return MPCRL_E_ARG;
-    HIP_OK(hipSetDevice(h->device));
+    ON_DEVICE(h->device);
     const size_t n = (size_t)h->np * (per_instance ? h->B : 1);
     HIP_OK(hipMemcpyAsync(h->theta, theta, n * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     h->theta_stride = per_instance ? h->np : 0;
@@ -223,7 +240,7 @@ int mpcrl_set_options(mpcrl_handle h, double tol, int max_iter) {
 
 int mpcrl_set_order(mpcrl_handle h, const int32_t *perm, void *stream) {
     if (!h) return MPCRL_E_ARG;
-    HIP_OK(hipSetDevice(h->device));
+    ON_DEVICE(h->device);
     if (perm) HIP_OK(hipMemcpyAsync(h->perm, perm, (size_t)h->B * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     h->have_perm = perm != nullptr;
     return 0;
@@ -247,7 +264,7 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
     if (!h || !x0 || !u0_out || !V || !status) return MPCRL_E_ARG;
     if ((flags & MPCRL_SENS_V) && !dV_dp) return MPCRL_E_ARG;
     if ((flags & MPCRL_SENS_PI) && !dpi_dp) return MPCRL_E_ARG;
-    HIP_OK(hipSetDevice(h->device));
+    ON_DEVICE(h->device);
     hipStream_t st = (hipStream_t)stream;
     if (!h->have_iterate) flags |= MPCRL_COLD;
     SmallArgs a;
@@ -278,7 +295,7 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
 
 int mpcrl_get_iterate(mpcrl_handle h, double *x, double *u, double *pi, double *bnd, double *res, void *stream) {
     if (!h) return MPCRL_E_ARG;
-    HIP_OK(hipSetDevice(h->device));
+    ON_DEVICE(h->device);
     hipStream_t st = (hipStream_t)stream;
     const size_t B = h->B, N = h->N, nx = h->nx, nu = h->nu, nw = nx + nu;
     if (x) HIP_OK(hipMemcpyAsync(x, h->X, B * (N + 1) * nx * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -291,7 +308,7 @@ int mpcrl_get_iterate(mpcrl_handle h, double *x, double *u, double *pi, double *
 
 int mpcrl_set_iterate(mpcrl_handle h, const double *x, const double *u, const double *pi, const double *bnd, void *stream) {
     if (!h || !x || !u || !pi) return MPCRL_E_ARG;
-    HIP_OK(hipSetDevice(h->device));
+    ON_DEVICE(h->device);
     hipStream_t st = (hipStream_t)stream;
     const size_t B = h->B, N = h->N, nx = h->nx, nu = h->nu, nw = nx + nu;
     HIP_OK(hipMemcpyAsync(h->X, x, B * (N + 1) * nx * sizeof(double), hipMemcpyDeviceToDevice, st));
