@@ -258,8 +258,10 @@ struct SmallSolver {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             double a = pn[i];
+            if constexpr (FACTOR) {   // vector-only sweeps receive p_{k+1} + P_{k+1} bb already summed by the lane that owns P_{k+1}
 #pragma unroll
-            for (int j = 0; j < NX; ++j) a = fma(Pn[sym(i, j)], bb[j], a);
+                for (int j = 0; j < NX; ++j) a = fma(Pn[sym(i, j)], bb[j], a);
+            }
             cc[i] = a;
         }
 #pragma unroll
@@ -297,6 +299,10 @@ struct SmallSolver {
                 for (int i = 0; i < NLK; ++i) Li[i] = 0.0;
             } else {
                 // Cholesky R = L L' of the control block; Li holds L with the diagonal inverted
+                if constexpr (NU == 1) {
+                    ok = ok && (Mm[0] > 0.0);
+                    Li[0] = 1.0 / Mm[0];   // scalar pivot: keep 1/R itself, no square root
+                } else
 #pragma unroll
                 for (int i = 0; i < NU; ++i)
 #pragma unroll
@@ -310,6 +316,10 @@ struct SmallSolver {
                         } else
                             Li[sym(i, j)] = a * Li[sym(j, j)];
                     }
+                if constexpr (NU == 1) {
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) K[j] = Mm[sym(NU + j, 0)] * Li[0];
+                } else
 #pragma unroll
                 for (int j = 0; j < NX; ++j) {   // K = R^{-1} S, S(i, j) = Mm(NU + j, i)
                     double y[NU];
@@ -342,6 +352,8 @@ struct SmallSolver {
         if (first && qmode) {
 #pragma unroll
             for (int i = 0; i < NU; ++i) kff[i] = 0.0;
+        } else if constexpr (NU == 1) {
+            kff[0] = mv[0] * Li[0];
         } else {
             double y[NU];
 #pragma unroll
@@ -370,18 +382,32 @@ struct SmallSolver {
     }
 
     // ---- backward sweep over the horizon (serial in k; the lanes of all instances in the wave step together).
-    // (P, p) of stage k+1 arrive by a one-lane shift; each lane keeps the received P_{k+1} in Pnext so that the
-    // corrector / extra right-hand sides only need the vector recursion.
-    double Pnext[NPK];
+    // (P, p) of stage k+1 arrive by a one-lane shift.  For the vector-only sweeps (corrector, extra right-hand sides) the
+    // product P_{k+1} bb_k is formed beforehand, stage-parallel, by the lane that owns P_{k+1}, so only NX values travel.
     template <bool FACTOR, class HF>
     MPCRL_DI bool backward(HF Hs, const double *g, const double *bb) {
-        // Every lane executes every stage step (full EXEC mask: a wave64 fp64 op with <= 8 active lanes is ~4x slower on
-        // gfx950 than with >= 12, scratch_bench/exec_mask.hip) and only the lane whose turn it is commits the result.
+        // Every lane executes every stage step (full EXEC mask) and only the lane whose turn it is commits the result.
         bool ok = true;
+        double hb[NX];
+        if constexpr (!FACTOR) {
+            double bbp[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) bbp[i] = lane_up(bb[i]);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = 0.0;
+#pragma unroll
+                for (int j = 0; j < NX; ++j) a = fma(P[sym(i, j)], bbp[j], a);
+                hb[i] = a;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) hb[i] = 0.0;
+        }
         for (int kk = N; kk >= 0; --kk) {
             double pn[NX];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) pn[i] = lane_dn(p[i]);
+            for (int i = 0; i < NX; ++i) pn[i] = lane_dn(p[i] + hb[i]);
             const bool mine = k == kk;
             double sK[NU * NX], sLi[NLK], skff[NU], sP[NPK], sp[NX];
 #pragma unroll
@@ -394,16 +420,16 @@ struct SmallSolver {
             for (int i = 0; i < NPK; ++i) sP[i] = P[i];
 #pragma unroll
             for (int i = 0; i < NX; ++i) sp[i] = p[i];
+            double Pn[NPK];
             if constexpr (FACTOR) {
-                double Pn[NPK];
 #pragma unroll
                 for (int i = 0; i < NPK; ++i) Pn[i] = lane_dn(P[i]);
                 const bool okk = riccati_stage<true>(Pn, pn, Hs, g, bb);
                 ok = ok && (okk || !mine);
-#pragma unroll
-                for (int i = 0; i < NPK; ++i) Pnext[i] = mine ? Pn[i] : Pnext[i];
             } else {
-                riccati_stage<false>(Pnext, pn, Hs, g, bb);
+#pragma unroll
+                for (int i = 0; i < NPK; ++i) Pn[i] = 0.0;
+                riccati_stage<false>(Pn, pn, Hs, g, bb);
             }
 #pragma unroll
             for (int i = 0; i < NU * NX; ++i) K[i] = mine ? K[i] : sK[i];
@@ -1243,7 +1269,7 @@ __global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, con
         }
     }
 #pragma unroll
-    for (int i = 0; i < S.NPK; ++i) S.P[i] = 0.0, S.Pnext[i] = 0.0;
+    for (int i = 0; i < S.NPK; ++i) S.P[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < NX; ++i) S.p[i] = 0.0, S.dx[i] = 0.0, S.nuq[i] = 0.0, S.Dx[i] = 0.0, S.Dnu[i] = 0.0;
 #pragma unroll
@@ -1434,7 +1460,7 @@ __global__ void __launch_bounds__(64 * COOP_WAVES) coop_solve_kernel(const Small
         }
     }
 #pragma unroll
-    for (int i = 0; i < S.NPK; ++i) S.P[i] = 0.0, S.Pnext[i] = 0.0;
+    for (int i = 0; i < S.NPK; ++i) S.P[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < NX; ++i) S.p[i] = 0.0, S.dx[i] = 0.0, S.nuq[i] = 0.0, S.Dx[i] = 0.0, S.Dnu[i] = 0.0;
 #pragma unroll
@@ -1592,7 +1618,7 @@ __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, cons
     for (int i = 0; i < NX; ++i) xn[i] = lane_dn(S.x[i]), nun[i] = lane_dn(S.nu_[i]);
     S.linearize(xn);
 #pragma unroll
-    for (int i = 0; i < S.NPK; ++i) S.P[i] = 0.0, S.Pnext[i] = 0.0;
+    for (int i = 0; i < S.NPK; ++i) S.P[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < NX; ++i) S.p[i] = 0.0;
     const int status = a.status[inst];
