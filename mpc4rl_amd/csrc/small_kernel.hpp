@@ -45,8 +45,20 @@ struct SmallArgs {
 };
 
 // ---- cross-lane helpers (wave64) -----------------------------------------------------------------
-MPCRL_DI double lane_dn(double v) { return __shfl_down(v, 1); }   // value of lane + 1
-MPCRL_DI double lane_up(double v) { return __shfl_up(v, 1); }     // value of lane - 1
+// One-lane shifts across the whole wave as DPP moves (gfx9 wave_shl:1 / wave_shr:1): a VALU op instead of the LDS-crossbar
+// round trip of ds_bpermute that __shfl_down/__shfl_up compile to; same edge behaviour (the last / first lane keeps its own value).
+MPCRL_DI double lane_dn(double v) {   // value of lane + 1
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+MPCRL_DI double lane_up(double v) {   // value of lane - 1
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 
 // segmented reductions over the LPI lanes of one instance; result broadcast to all of its lanes
 MPCRL_DI double seg_sum(double v, int k, int lpi, int base) {
