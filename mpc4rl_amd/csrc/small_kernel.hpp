@@ -60,6 +60,14 @@ MPCRL_DI double lane_up(double v) {   // value of lane - 1
     return __hiloint2double(hi, lo);
 }
 
+// 1/x from the hardware seed plus two Newton steps (~1 ulp); x is a strictly positive, normal number wherever this is used
+// (slacks, multipliers, pivots), so the range / denormal handling of an IEEE division (~13 instructions) is not needed.
+MPCRL_DI double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
 // segmented reductions over the LPI lanes of one instance; result broadcast to all of its lanes
 MPCRL_DI double seg_sum(double v, int k, int lpi, int base) {
 #pragma unroll
@@ -313,7 +321,7 @@ struct SmallSolver {
                 // Cholesky R = L L' of the control block; Li holds L with the diagonal inverted
                 if constexpr (NU == 1) {
                     ok = ok && (Mm[0] > 0.0);
-                    Li[0] = 1.0 / Mm[0];   // scalar pivot: keep 1/R itself, no square root
+                    Li[0] = fast_rcp(Mm[0]);   // scalar pivot: keep 1/R itself, no square root
                 } else
 #pragma unroll
                 for (int i = 0; i < NU; ++i)
@@ -796,46 +804,50 @@ struct SmallSolver {
         for (int sd = 0; sd < 2; ++sd) {
             if (!has(sd, i)) continue;
             const double sg = sd ? -1.0 : 1.0;
-            const double l1 = lam[sd][i], t1 = t[sd][i];
-            const double w1 = l1 / t1;
+            const double l1 = lam[sd][i], t1 = t[sd][i], it1 = fast_rcp(t1);
+            const double w1 = l1 * it1;
             const double rd1 = t1 - bslack(sd, i, v);
-            const double e1 = (rm_(l1, t1, aff[sd][i], pass, smu) - l1 * rd1) / t1;
+            const double e1 = (rm_(l1, t1, aff[sd][i], pass, smu) - l1 * rd1) * it1;
             if (SOFT && softc(i)) {
                 const int ii = SOFT ? i : 0;
-                const double l2 = lams[sd][ii], t2 = ts[sd][ii];
-                const double w2 = l2 / t2;
-                const double e2 = (rm_(l2, t2, affs[sd][ii], pass, smu) - l2 * (t2 - s[sd][ii])) / t2;
+                const double l2 = lams[sd][ii], t2 = ts[sd][ii], it2 = fast_rcp(t2);
+                const double w2 = l2 * it2;
+                const double e2 = (rm_(l2, t2, affs[sd][ii], pass, smu) - l2 * (t2 - s[sd][ii])) * it2;
                 const double rgs = zw(sd, i) - l1 - l2;
-                dg += w1 * w2 / (w1 + w2);
-                er += sg * (e1 * w2 - w1 * (rgs + e2)) / (w1 + w2);
+                const double iw = fast_rcp(w1 + w2);
+                dg += w1 * w2 * iw;
+                er += sg * (e1 * w2 - w1 * (rgs + e2)) * iw;
             } else {
                 dg += w1;
                 er += sg * e1;
             }
         }
     }
-    // steps of the rows of coordinate i, side sd, for a primal step dv of the coordinate
+    // steps of the rows of coordinate i, side sd, for a primal step dv of the coordinate.  rat = the largest of -dlam/lam and
+    // -dt/t over these rows: the step to the boundary is 1 / max(rat), so no division is needed per row.
     MPCRL_DI void row_steps(int i, int sd, double v, double dv, int pass, double smu, double &dt1, double &dl1, double &dt2,
-                            double &dl2, double &dss) const {
+                            double &dl2, double &dss, double &rat) const {
         const double sg = sd ? -1.0 : 1.0;
-        const double l1 = lam[sd][i], t1 = t[sd][i];
+        const double l1 = lam[sd][i], t1 = t[sd][i], it1 = fast_rcp(t1);
         const double rd1 = t1 - bslack(sd, i, v);
         const double rm1 = rm_(l1, t1, aff[sd][i], pass, smu);
-        dss = 0.0, dt2 = 0.0, dl2 = 0.0;
+        dss = 0.0, dt2 = 0.0, dl2 = 0.0, rat = 0.0;
         if (SOFT && softc(i)) {
             const int ii = SOFT ? i : 0;
-            const double l2 = lams[sd][ii], t2 = ts[sd][ii];
-            const double w1 = l1 / t1, w2 = l2 / t2;
+            const double l2 = lams[sd][ii], t2 = ts[sd][ii], it2 = fast_rcp(t2);
+            const double w1 = l1 * it1, w2 = l2 * it2;
             const double rd2 = t2 - s[sd][ii];
             const double rm2 = rm_(l2, t2, affs[sd][ii], pass, smu);
-            const double e1 = (rm1 - l1 * rd1) / t1, e2 = (rm2 - l2 * rd2) / t2;
+            const double e1 = (rm1 - l1 * rd1) * it1, e2 = (rm2 - l2 * rd2) * it2;
             const double rgs = zw(sd, i) - l1 - l2;
-            dss = -(rgs + e1 + e2 + sg * w1 * dv) / (w1 + w2);
+            dss = -(rgs + e1 + e2 + sg * w1 * dv) * fast_rcp(w1 + w2);
             dt2 = -rd2 + dss;
-            dl2 = (-rm2 - l2 * dt2) / t2;
+            dl2 = (-rm2 - l2 * dt2) * it2;
+            rat = fmax(-dl2 * fast_rcp(l2), -dt2 * it2);
         }
         dt1 = -rd1 + sg * dv + dss;
-        dl1 = (-rm1 - l1 * dt1) / t1;
+        dl1 = (-rm1 - l1 * dt1) * it1;
+        rat = fmax(rat, fmax(-dl1 * fast_rcp(l1), -dt1 * it1));
     }
 
     // ---- Mehrotra predictor-corrector on the QP of the current linearisation -----------------------
@@ -965,7 +977,7 @@ struct SmallSolver {
                 forward(rb);
             }
             if (seg_max(okf ? 0.0 : 1.0, k, lpi, base) > 0.5) qlive = false;   // non-positive pivot: QP failure
-            double amax = 1.0, muaff = 0.0;
+            double rmax = 1.0, muaff = 0.0;   // rmax = 1 / (step to the boundary), at least 1
             double daff[2][NW], dsaff[2][SOFT ? NW : 1];
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
@@ -976,20 +988,14 @@ struct SmallSolver {
                     daff[sd][i] = 0.0;
                     if (SOFT) dsaff[sd][SOFT ? i : 0] = 0.0;
                     if (!has(sd, i)) continue;
-                    double dt1, dl1, dt2, dl2, dss;
-                    row_steps(i, sd, v, dv, 0, 0.0, dt1, dl1, dt2, dl2, dss);
-                    if (dl1 < 0.0) amax = fmin(amax, -lam[sd][i] / dl1);
-                    if (dt1 < 0.0) amax = fmin(amax, -t[sd][i] / dt1);
+                    double dt1, dl1, dt2, dl2, dss, rat;
+                    row_steps(i, sd, v, dv, 0, 0.0, dt1, dl1, dt2, dl2, dss, rat);
+                    rmax = fmax(rmax, rat);
                     daff[sd][i] = dl1 * dt1;
-                    if (SOFT && softc(i)) {
-                        const int ii = SOFT ? i : 0;
-                        if (dl2 < 0.0) amax = fmin(amax, -lams[sd][ii] / dl2);
-                        if (dt2 < 0.0) amax = fmin(amax, -ts[sd][ii] / dt2);
-                        dsaff[sd][ii] = dl2 * dt2;
-                    }
+                    if (SOFT && softc(i)) dsaff[sd][SOFT ? i : 0] = dl2 * dt2;
                 }
             }
-            const double a_aff = seg_min(amax, k, lpi, base);
+            const double a_aff = 1.0 / seg_max(rmax, k, lpi, base);
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 if (term && i < NU) continue;
@@ -997,8 +1003,8 @@ struct SmallSolver {
 #pragma unroll
                 for (int sd = 0; sd < 2; ++sd) {
                     if (!has(sd, i)) continue;
-                    double dt1, dl1, dt2, dl2, dss;
-                    row_steps(i, sd, v, dv, 0, 0.0, dt1, dl1, dt2, dl2, dss);
+                    double dt1, dl1, dt2, dl2, dss, rat;
+                    row_steps(i, sd, v, dv, 0, 0.0, dt1, dl1, dt2, dl2, dss, rat);
                     muaff = fma(fma(a_aff, dl1, lam[sd][i]), fma(a_aff, dt1, t[sd][i]), muaff);
                     if (SOFT && softc(i)) {
                         const int ii = SOFT ? i : 0;
@@ -1030,7 +1036,7 @@ struct SmallSolver {
                 backward<false>(Hs, rt, rb);
                 forward(rb);
             }
-            amax = 1.0;
+            rmax = 1.0;
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 if (term && i < NU) continue;
@@ -1038,18 +1044,12 @@ struct SmallSolver {
 #pragma unroll
                 for (int sd = 0; sd < 2; ++sd) {
                     if (!has(sd, i)) continue;
-                    double dt1, dl1, dt2, dl2, dss;
-                    row_steps(i, sd, v, dv, 1, smu, dt1, dl1, dt2, dl2, dss);
-                    if (dl1 < 0.0) amax = fmin(amax, -lam[sd][i] / dl1);
-                    if (dt1 < 0.0) amax = fmin(amax, -t[sd][i] / dt1);
-                    if (SOFT && softc(i)) {
-                        const int ii = SOFT ? i : 0;
-                        if (dl2 < 0.0) amax = fmin(amax, -lams[sd][ii] / dl2);
-                        if (dt2 < 0.0) amax = fmin(amax, -ts[sd][ii] / dt2);
-                    }
+                    double dt1, dl1, dt2, dl2, dss, rat;
+                    row_steps(i, sd, v, dv, 1, smu, dt1, dl1, dt2, dl2, dss, rat);
+                    rmax = fmax(rmax, rat);
                 }
             }
-            const double alpha = fmin(1.0, IPM_FRAC * seg_min(amax, k, lpi, base));
+            const double alpha = fmin(1.0, IPM_FRAC / seg_max(rmax, k, lpi, base));
             if (qlive) {
                 // rows of (i, sd) only read their own side's state, so they can be advanced in place
 #pragma unroll
@@ -1059,8 +1059,8 @@ struct SmallSolver {
 #pragma unroll
                     for (int sd = 0; sd < 2; ++sd) {
                         if (!has(sd, i)) continue;
-                        double dt1, dl1, dt2, dl2, dss;
-                        row_steps(i, sd, v, dv, 1, smu, dt1, dl1, dt2, dl2, dss);
+                        double dt1, dl1, dt2, dl2, dss, rat;
+                        row_steps(i, sd, v, dv, 1, smu, dt1, dl1, dt2, dl2, dss, rat);
                         lam[sd][i] = fma(alpha, dl1, lam[sd][i]);
                         t[sd][i] = fma(alpha, dt1, t[sd][i]);
                         if (SOFT && softc(i)) {
