@@ -86,6 +86,28 @@ MPCRL_DI double seg_max(double v, int k, int lpi, int base) {
     return __shfl(v, base);
 }
 MPCRL_DI double seg_min(double v, int k, int lpi, int base) { return -seg_max(-v, k, lpi, base); }
+// several reductions in one pass: the cross-lane moves of the different values overlap instead of queueing behind each other
+template <int NMAX, int NSUM>
+MPCRL_DI void seg_reduce(double *mx, double *sm, int k, int lpi, int base) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        double om[NMAX > 0 ? NMAX : 1], os[NSUM > 0 ? NSUM : 1];
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) om[i] = __shfl_down(mx[i], s);
+#pragma unroll
+        for (int i = 0; i < NSUM; ++i) os[i] = __shfl_down(sm[i], s);
+        if (k + s < lpi) {
+#pragma unroll
+            for (int i = 0; i < NMAX; ++i) mx[i] = fmax(mx[i], om[i]);
+#pragma unroll
+            for (int i = 0; i < NSUM; ++i) sm[i] += os[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) mx[i] = __shfl(mx[i], base);
+#pragma unroll
+    for (int i = 0; i < NSUM; ++i) sm[i] = __shfl(sm[i], base);
+}
 
 // Cooperative mode (coop_solve_kernel): a workgroup of COOP_WAVES waves owns COOP_G instances.  The stage-parallel phases stay
 // on the stage lanes; the serial Riccati sweeps of ALL instances of the workgroup run side by side on COOP_G lanes of the last
@@ -951,8 +973,9 @@ struct SmallSolver {
                     }
                 }
             }
-            const double rinf = seg_max(rloc, k, lpi, base);
-            const double mu = n_rows > 0.0 ? seg_sum(muloc, k, lpi, base) / n_rows : 0.0;
+            seg_reduce<1, 1>(&rloc, &muloc, k, lpi, base);
+            const double rinf = rloc;
+            const double mu = n_rows > 0.0 ? muloc / n_rows : 0.0;
             if (qlive) {
                 if (rinf <= IPM_TOL_RES && mu <= IPM_TOL_MU)
                     qlive = false, ok = true;
@@ -976,26 +999,29 @@ struct SmallSolver {
                 okf = backward<true>(Hs, rt, rb);
                 forward(rb);
             }
-            if (seg_max(okf ? 0.0 : 1.0, k, lpi, base) > 0.5) qlive = false;   // non-positive pivot: QP failure
+            double okbad = okf ? 0.0 : 1.0;   // reduced together with the predictor's step length below
             double rmax = 1.0, muaff = 0.0;   // rmax = 1 / (step to the boundary), at least 1
-            double daff[2][NW], dsaff[2][SOFT ? NW : 1];
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 if (term && i < NU) continue;
                 const double v = vc(i) + dvc(dx, du, i), dv = dvc(Dx, Du, i);
 #pragma unroll
                 for (int sd = 0; sd < 2; ++sd) {
-                    daff[sd][i] = 0.0;
-                    if (SOFT) dsaff[sd][SOFT ? i : 0] = 0.0;
                     if (!has(sd, i)) continue;
                     double dt1, dl1, dt2, dl2, dss, rat;
                     row_steps(i, sd, v, dv, 0, 0.0, dt1, dl1, dt2, dl2, dss, rat);
                     rmax = fmax(rmax, rat);
-                    daff[sd][i] = dl1 * dt1;
-                    if (SOFT && softc(i)) dsaff[sd][SOFT ? i : 0] = dl2 * dt2;
+                    aff[sd][i] = dl1 * dt1;   // only read by the corrector (pass = 1)
+                    if (SOFT && softc(i)) affs[sd][SOFT ? i : 0] = dl2 * dt2;
                 }
             }
-            const double a_aff = 1.0 / seg_max(rmax, k, lpi, base);
+            {
+                double two[2] = {rmax, okbad};
+                seg_reduce<2, 0>(two, nullptr, k, lpi, base);
+                rmax = two[0];
+                if (two[1] > 0.5) qlive = false;   // non-positive pivot: QP failure
+            }
+            const double a_aff = 1.0 / rmax;
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 if (term && i < NU) continue;
@@ -1015,13 +1041,6 @@ struct SmallSolver {
             const double mu_aff = n_rows > 0.0 ? seg_sum(muaff, k, lpi, base) / n_rows : 0.0;
             const double ratio = mu > 0.0 ? mu_aff / mu : 0.0;
             const double smu = ratio * ratio * ratio * mu;
-#pragma unroll
-            for (int i = 0; i < NW; ++i)
-#pragma unroll
-                for (int sd = 0; sd < 2; ++sd) {
-                    aff[sd][i] = daff[sd][i];
-                    if (SOFT) affs[sd][SOFT ? i : 0] = dsaff[sd][SOFT ? i : 0];
-                }
             // ---- corrector (same factorisation, vector sweep only)
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
@@ -1243,11 +1262,9 @@ __global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, con
     for (int i = 0; i < NTD; ++i) S.thd[i] = th[M::td_index(i)];
 #pragma unroll
     for (int i = 0; i < NTC; ++i) S.thc[i] = th[M::tc_index(i)];
-    double x0[NX], u0f[NU];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) x0[i] = a.x0[inst * NX + i];
-#pragma unroll
-    for (int i = 0; i < NU; ++i) u0f[i] = S.qmode ? a.u0fix[inst * NU + i] : 0.0;
+    // x0 / u0 are only read by the lane of stage 0, a few times per QP: leave them in memory instead of in registers
+    const double *x0 = a.x0 + inst * NX;
+    const double *u0f = S.qmode ? a.u0fix + inst * NU : a.x0 + inst * NX;
     // ---- iterate: stored (warm) or the reference's cold start (MPC.reset, mpc.py:204-210)
     const size_t nb = (size_t)(N + 1) * NW;
     double *bnd = a.BND + (size_t)inst * 10 * nb + (size_t)k * NW;
@@ -1319,10 +1336,8 @@ __global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, con
         const double cl = S.linearize(xn);
         double rl[4];
         S.nlp_res_local(nun, x0, u0f, rl);
-        const double cost = seg_sum(cl, k, lpi, base);
-        double res[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) res[j] = seg_max(rl[j], k, lpi, base);
+        double res[4] = {rl[0], rl[1], rl[2], rl[3]}, cost = cl;
+        seg_reduce<4, 1>(res, &cost, k, lpi, base);
         const double rmax = fmax(fmax(res[0], res[1]), fmax(res[2], res[3]));
         if (live) {
             Vout = cost, n_sqp = it;
@@ -1434,11 +1449,9 @@ __global__ void __launch_bounds__(64 * COOP_WAVES) coop_solve_kernel(const Small
     for (int i = 0; i < NTD; ++i) S.thd[i] = th[M::td_index(i)];
 #pragma unroll
     for (int i = 0; i < NTC; ++i) S.thc[i] = th[M::tc_index(i)];
-    double x0[NX], u0f[NU];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) x0[i] = a.x0[inst * NX + i];
-#pragma unroll
-    for (int i = 0; i < NU; ++i) u0f[i] = S.qmode ? a.u0fix[inst * NU + i] : 0.0;
+    // x0 / u0 are only read by the lane of stage 0, a few times per QP: leave them in memory instead of in registers
+    const double *x0 = a.x0 + inst * NX;
+    const double *u0f = S.qmode ? a.u0fix + inst * NU : a.x0 + inst * NX;
     // ---- iterate: stored (warm) or the reference's cold start (MPC.reset, mpc.py:204-210)
     const size_t nb = (size_t)(N + 1) * NW;
     double *bnd = a.BND + (size_t)inst * 10 * nb + (size_t)k * NW;
@@ -1511,10 +1524,8 @@ __global__ void __launch_bounds__(64 * COOP_WAVES) coop_solve_kernel(const Small
         S.coop_publish_AB();
         double rl[4];
         S.nlp_res_local(nun, x0, u0f, rl);
-        const double cost = seg_sum(cl, k, lpi, base);
-        double res[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) res[j] = seg_max(rl[j], k, lpi, base);
+        double res[4] = {rl[0], rl[1], rl[2], rl[3]}, cost = cl;
+        seg_reduce<4, 1>(res, &cost, k, lpi, base);
         const double rmax = fmax(fmax(res[0], res[1]), fmax(res[2], res[3]));
         if (live) {
             Vout = cost, n_sqp = it;
