@@ -415,7 +415,7 @@ struct LargeSolver {
     MPCRL_DI double &AFF(int sd, int e) { return aff[sd * (N + 1) * NW + e]; }
     MPCRL_DI double bslack(int sd, int k, int i, double v) const { return sd ? ubv(k, i) - v : v - lbv(k, i); }
 
-    MPCRL_DI bool qp_solve(const double *x0, const double *u0f, int &n_it, double warm_mu) {
+    MPCRL_DI bool qp_solve(const double *x0, const double *u0f, int &n_it, double warm_mu, double tol_res, double tol_mu) {
         const bool warm = warm_mu > 0.0;
         auto Hs = [&](int k, int i, int j) { return ck(k) * M::hess(k == N, i, j, th); };
         const int ne = (N + 1) * NW;
@@ -481,7 +481,7 @@ struct LargeSolver {
             }
             const double rinf = block_max(rloc);
             const double mu = n_rows > 0.0 ? block_sum(muloc) / n_rows : 0.0;
-            if (rinf <= IPM_TOL_RES && mu <= IPM_TOL_MU) {
+            if (rinf <= tol_res && mu <= tol_mu) {
                 ok = true;
                 break;
             }
@@ -620,6 +620,7 @@ __global__ void __launch_bounds__(LARGE_NT) large_solve_kernel(const LargeSpec s
     const int max_iter = rti ? 1 : sp.max_iter;
     int status = 2, n_sqp = 0, n_ipm = 0;
     double cost = 0.0, res[4] = {0, 0, 0, 0};
+    bool last_tight = true;
     double stepn = -1.0;   // perturbation seen by the next QP (< 0: cold)
     if (!(a.flags & 8)) {
         double sl = 0.0;
@@ -639,16 +640,19 @@ __global__ void __launch_bounds__(LARGE_NT) large_solve_kernel(const LargeSpec s
             status = 1;
             break;
         }
-        if (rmax < sp.tol && !(rti && it == 0)) {
+        if (rmax < sp.tol && last_tight && !(rti && it == 0)) {
             status = 0;
             break;
         }
         if (it >= max_iter) {
-            status = 2;
+            status = rmax < sp.tol ? 0 : 2;
             break;
         }
+        const double rr_ = fmin(1.0, rmax), ad_ = rmax < sp.tol ? 0.0 : IPM_ADAPT_C * rr_ * rr_;
+        const double tol_res = fmin(IPM_ADAPT_CAP, fmax(IPM_TOL_RES, ad_)), tol_mu = fmin(0.1 * IPM_ADAPT_CAP, fmax(IPM_TOL_MU, 1e-2 * ad_));
+        last_tight = tol_res <= IPM_TOL_RES && tol_mu <= IPM_TOL_MU;
         const double warm_mu = stepn < 0.0 ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
-        if (!S.qp_solve(x0, u0f, n_ipm, warm_mu)) {
+        if (!S.qp_solve(x0, u0f, n_ipm, warm_mu, tol_res, tol_mu)) {
             status = 4;
             break;
         }

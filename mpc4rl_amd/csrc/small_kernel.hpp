@@ -30,6 +30,9 @@ constexpr double IPM_TOL_RES = 1e-9, IPM_TOL_MU = 1e-11, IPM_T_MIN = 1e-1, IPM_M
 constexpr double NO_BOUND = 1e29;
 // warm start of the interior point method from the previous QP: mu_w = clamp(C * step^2, MIN, MAX)   
 constexpr double IPM_WARM_C = 1e-4, IPM_WARM_MIN = 1e-10, IPM_WARM_MAX = 1e-2;
+// inexact SQP: QP tolerances follow the NLP residual r (tol_res = clamp(C r^2, TOL_RES, CAP), tol_mu = clamp(C r^2 / 100, TOL_MU, CAP / 10));
+// convergence is only declared after a QP solved to the tight tolerances   
+constexpr double IPM_ADAPT_C = 1e-1, IPM_ADAPT_CAP = 1e-6;
 
 struct SmallArgs {
     int B;                 // instances
@@ -875,7 +878,7 @@ struct SmallSolver {
     // ---- Mehrotra predictor-corrector on the QP of the current linearisation -----------------------
     // act: this instance takes part.  Returns true when converged; n_it counts iterations of this instance.
     // warm_mu > 0: start from the rows and multipliers of the previous QP, every complementarity product raised to >= warm_mu.
-    MPCRL_DI bool qp_solve(bool act, const double *x0, const double *u0f, int &n_it, double warm_mu) {
+    MPCRL_DI bool qp_solve(bool act, const double *x0, const double *u0f, int &n_it, double warm_mu, double tol_res, double tol_mu) {
         auto Hs = [&](int i, int j) { return ck * M::hess(term, i, j, sp, thc); };
         const bool warm = warm_mu > 0.0;
         if (act) {
@@ -977,7 +980,7 @@ struct SmallSolver {
             const double rinf = rloc;
             const double mu = n_rows > 0.0 ? muloc / n_rows : 0.0;
             if (qlive) {
-                if (rinf <= IPM_TOL_RES && mu <= IPM_TOL_MU)
+                if (rinf <= tol_res && mu <= tol_mu)
                     qlive = false, ok = true;
                 else if (it >= IPM_MAX_ITER || !(rinf < 1e300))
                     qlive = false;
@@ -1311,7 +1314,7 @@ __global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, con
     // ---- full-step SQP (the reference requests no globalisation; config/cartpole.yaml:8-14)
     const bool rti = (a.flags & 4) != 0;
     const int max_iter = rti ? 1 : sp.max_iter;
-    bool live = valid;
+    bool live = valid, last_tight = true;
     int status = 2, n_sqp = 0, n_ipm = 0;
     // size of the perturbation the next QP sees (< 0: nothing to start from): change of the pinned x0 / u0 for a warm call
     double stepn = -1.0;
@@ -1345,14 +1348,18 @@ __global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, con
             for (int j = 0; j < 4; ++j) res_out[j] = res[j];
             if (!(rmax < 1e300))
                 status = 1, live = false;
-            else if (rmax < sp.tol && !(rti && it == 0))
+            else if (rmax < sp.tol && last_tight && !(rti && it == 0))
                 status = 0, live = false;
             else if (it >= max_iter)
-                status = 2, live = false;
+                status = rmax < sp.tol ? 0 : 2, live = false;
         }
+        // QP tolerances of this iteration (per instance)
+        const double rr_ = fmin(1.0, rmax), ad_ = (rmax < sp.tol || M::DISCRETE) ? 0.0 : IPM_ADAPT_C * rr_ * rr_;   // LQ model: first QP is the answer
+        const double tol_res = fmin(IPM_ADAPT_CAP, fmax(IPM_TOL_RES, ad_)), tol_mu = fmin(0.1 * IPM_ADAPT_CAP, fmax(IPM_TOL_MU, 1e-2 * ad_));
+        if (live) last_tight = tol_res <= IPM_TOL_RES && tol_mu <= IPM_TOL_MU;
         if (!__any(live)) break;
         const double warm_mu = stepn < 0.0 ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
-        const bool ok = S.qp_solve(live, x0, u0f, n_ipm, warm_mu);
+        const bool ok = S.qp_solve(live, x0, u0f, n_ipm, warm_mu, tol_res, tol_mu);
         if (live && !ok) status = 4, live = false;
         {
             double sl = 0.0;
@@ -1498,7 +1505,7 @@ __global__ void __launch_bounds__(64 * COOP_WAVES) coop_solve_kernel(const Small
     // ---- full-step SQP (the reference requests no globalisation; config/cartpole.yaml:8-14)
     const bool rti = (a.flags & 4) != 0;
     const int max_iter = rti ? 1 : sp.max_iter;
-    bool live = valid;
+    bool live = valid, last_tight = true;
     int status = 2, n_sqp = 0, n_ipm = 0;
     // size of the perturbation the next QP sees (< 0: nothing to start from): change of the pinned x0 / u0 for a warm call
     double stepn = -1.0;
@@ -1533,11 +1540,15 @@ __global__ void __launch_bounds__(64 * COOP_WAVES) coop_solve_kernel(const Small
             for (int j = 0; j < 4; ++j) res_out[j] = res[j];
             if (!(rmax < 1e300))
                 status = 1, live = false;
-            else if (rmax < sp.tol && !(rti && it == 0))
+            else if (rmax < sp.tol && last_tight && !(rti && it == 0))
                 status = 0, live = false;
             else if (it >= max_iter)
-                status = 2, live = false;
+                status = rmax < sp.tol ? 0 : 2, live = false;
         }
+        // QP tolerances of this iteration (per instance)
+        const double rr_ = fmin(1.0, rmax), ad_ = (rmax < sp.tol || M::DISCRETE) ? 0.0 : IPM_ADAPT_C * rr_ * rr_;   // LQ model: first QP is the answer
+        const double tol_res = fmin(IPM_ADAPT_CAP, fmax(IPM_TOL_RES, ad_)), tol_mu = fmin(0.1 * IPM_ADAPT_CAP, fmax(IPM_TOL_MU, 1e-2 * ad_));
+        if (live) last_tight = tol_res <= IPM_TOL_RES && tol_mu <= IPM_TOL_MU;
         {   // workgroup-wide any(live)
             const bool w = __any(live);
             if (lane == 0) coop_flags[wave] = w ? 1 : 0;
@@ -1547,7 +1558,7 @@ __global__ void __launch_bounds__(64 * COOP_WAVES) coop_solve_kernel(const Small
             if (!r) break;
         }
         const double warm_mu = stepn < 0.0 ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
-        const bool ok = S.qp_solve(live, x0, u0f, n_ipm, warm_mu);
+        const bool ok = S.qp_solve(live, x0, u0f, n_ipm, warm_mu, tol_res, tol_mu);
         if (live && !ok) status = 4, live = false;
         {
             double sl = 0.0;

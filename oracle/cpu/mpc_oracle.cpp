@@ -318,6 +318,7 @@ struct Solver {
     // ---- Mehrotra predictor-corrector (the iteration of oracle/sqp_dense.py:ipm_dense); returns iterations
     // warm_mu > 0: start from the rows (lam, t, s) and multipliers of the previous QP, re-centred so that every
     // complementarity product is at least warm_mu (the smaller factor of the pair is raised); warm_mu = 0: cold start.
+    double qp_tol_res = IPM_TOL_RES, qp_tol_mu = IPM_TOL_MU;
     int qp_solve(const double *x0, const double *u0fix, bool &ok, double warm_mu) {
         std::fill(dx.begin(), dx.end(), 0.0), std::fill(du.begin(), du.end(), 0.0), std::fill(pi_qp.begin(), pi_qp.end(), 0.0);
         if (warm_mu > 0.0) pi_qp = PI;
@@ -392,7 +393,7 @@ struct Solver {
                     }
             }
             mu /= n_rows;
-            if (rinf <= IPM_TOL_RES && mu <= IPM_TOL_MU) {
+            if (rinf <= qp_tol_res && mu <= qp_tol_mu) {
                 ok = true;
                 break;
             }
@@ -497,6 +498,7 @@ struct Solver {
         n_ipm = 0;
         int status = 2;
         // size of the perturbation the next QP sees: change of the pinned initial state (warm call), then the last step
+        bool last_tight = true;
         double stepn = -1.0;   // < 0: no previous QP to start from
         if (warm) {
             stepn = 0.0;
@@ -509,8 +511,15 @@ struct Solver {
             nlp_residuals(x0, u0fix, res);
             const double rmax = std::max(std::max(res[0], res[1]), std::max(res[2], res[3]));
             if (!std::isfinite(rmax)) return 1;
-            if (rmax < tol) return 0;
-            if (n_sqp == max_iter) return 2;
+            if (rmax < tol && last_tight) return 0;
+            if (n_sqp == max_iter) return rmax < tol ? 0 : 2;
+            {   // QP tolerances for this iteration
+                // (a linear-quadratic OCP is solved by its first QP: no inexactness there)
+                const double rr = std::min(1.0, rmax), a = (rmax < tol || Mdl::DISCRETE) ? 0.0 : IPM_ADAPT_C * rr * rr;
+                qp_tol_res = std::min(IPM_ADAPT_CAP, std::max(IPM_TOL_RES, a));
+                qp_tol_mu = std::min(0.1 * IPM_ADAPT_CAP, std::max(IPM_TOL_MU, 1e-2 * a));
+                last_tight = qp_tol_res <= IPM_TOL_RES && qp_tol_mu <= IPM_TOL_MU;
+            }
             bool ok;
             const double warm_mu = stepn < 0.0 ? 0.0 : std::min(IPM_WARM_MAX, std::max(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
             n_ipm += qp_solve(x0, u0fix, ok, warm_mu);

@@ -183,7 +183,7 @@ def make_linear_system(gamma: float = 0.99, N: int = 40) -> Problem:
         idxbx=np.arange(2), lbx=np.array([0.0, -1.0]), ubx=np.array([1.0, 1.0]),
         idxsbx=np.array([0]), zl=np.array([1e2]), zu=np.array([1e2]),
         gamma=gamma, tol=1e-6, max_iter=100, x0_default=np.array([0.5, 0.5]),
-        extra={"P": P},
+        extra={"P": P, "lq": True},
     )
 
 

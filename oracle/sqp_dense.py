@@ -42,6 +42,9 @@ IPM_FRAC = 0.995        # fraction to the boundary
 # every complementarity product is raised to at least mu_w = clamp(IPM_WARM_C * step^2, MIN, MAX), step = inf-norm of
 # the previous primal step (or of the change of the pinned x0 / u0 for a warm call)
 IPM_WARM_C, IPM_WARM_MIN, IPM_WARM_MAX = 1e-4, 1e-10, 1e-2
+# inexact SQP: the QP tolerances follow the NLP residual r, tol_res = clamp(C r^2, TOL_RES, CAP), tol_mu = clamp(C r^2 / 100, TOL_MU, CAP / 10);
+# convergence is only declared after a QP that was solved to the tight tolerances
+IPM_ADAPT_C, IPM_ADAPT_CAP = 1e-1, 1e-6
 
 
 @dataclass
@@ -176,7 +179,7 @@ class Linearizer:
         return val, g, H
 
 
-def ipm_dense(H, g, G, b, C, d, v0, warm=None, free=None):
+def ipm_dense(H, g, G, b, C, d, v0, warm=None, free=None, tol_res=IPM_TOL_RES, tol_mu=IPM_TOL_MU):
     """Mehrotra predictor-corrector on  min 1/2 v'Hv + g'v  s.t. Gv = b, Cv + t = d, t >= 0.
     warm = (mu_w, lam_prev, t_prev, pi_prev) or None.  free: mask of the variables that are not pinned by an equality
     row of their own (x_0, and u_0 in Q-mode); the stationarity rows of pinned variables only define the multiplier of
@@ -206,7 +209,7 @@ def ipm_dense(H, g, G, b, C, d, v0, warm=None, free=None):
         r_d = C @ v + t - d
         mu = float(lam @ t) / mi
         rinf = max(np.abs(r_g if free is None else r_g[free]).max(), np.abs(r_b).max() if me else 0.0, np.abs(r_d).max())
-        if rinf <= IPM_TOL_RES and mu <= IPM_TOL_MU:
+        if rinf <= tol_res and mu <= tol_mu:
             ok = True
             break
         if it == IPM_MAX_ITER or not np.isfinite(rinf):
@@ -315,6 +318,7 @@ def solve(prob: Problem, x0, p=None, u0fix=None, gamma=None, warm: Optional[Solu
     status, ipm_total = 2, 0
     res = np.full(4, np.inf)
     it = 0
+    last_tight = True
     stepn = -1.0                      # < 0: no previous QP to start from
     piq = None
     if warm is not None:
@@ -332,12 +336,17 @@ def solve(prob: Problem, x0, p=None, u0fix=None, gamma=None, warm: Optional[Solu
         if not np.all(np.isfinite(res)):
             status = 1
             break
-        if res.max() < tol:
+        if res.max() < tol and last_tight:
             status = 0
             break
         if it == max_iter:
-            status = 2
+            status = 0 if res.max() < tol else 2
             break
+        rr = min(1.0, float(res.max()))
+        a_ = 0.0 if (res.max() < tol or P.extra.get("lq", False)) else IPM_ADAPT_C * rr * rr   # an LQ problem is solved by its first QP
+        tol_res = min(IPM_ADAPT_CAP, max(IPM_TOL_RES, a_))
+        tol_mu = min(0.1 * IPM_ADAPT_CAP, max(IPM_TOL_MU, 1e-2 * a_))
+        last_tight = tol_res <= IPM_TOL_RES and tol_mu <= IPM_TOL_MU
         # ---- QP in v = [du; dx; s]
         H = np.zeros((st.nv, st.nv))
         g = np.zeros(st.nv)
@@ -383,7 +392,7 @@ def solve(prob: Problem, x0, p=None, u0fix=None, gamma=None, warm: Optional[Solu
         free[st.ix(0): st.ix(0) + nx] = False
         if u0fix is not None:
             free[:nu] = False
-        v, piq, lam, t, nit, ok = ipm_dense(H, g, G, b, C, d, v0, wrm, free)
+        v, piq, lam, t, nit, ok = ipm_dense(H, g, G, b, C, d, v0, wrm, free, tol_res, tol_mu)
         stepn = float(np.abs(v[: st.nw]).max())
         ipm_total += nit
         if not ok:
