@@ -158,7 +158,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("MPCRL_BENCH_FORCE_DIST"):   # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
@@ -179,7 +179,7 @@ def main():
     def step():
         # cold start every step (MPC.reset semantics) so that every step does the same, full work
         r = mpc.solve(x0, sens_v=sens, sens_pi=sens, cold=not args.rti, rti=args.rti)
-        if world > 1 and sens:
+        if dist is not None and sens:
             # data-parallel RL update: one all-reduce of [sum_i dV_i/dtheta, sum_i V_i, count]
             grad[:N_THETA] = r.dV_dp[:, :N_THETA].sum(0)
             grad[N_THETA] = r.V.sum()
