@@ -160,6 +160,7 @@ struct SmallSolver {
     // Riccati factors of this stage
     double K[NU * NX], Li[NLK], kff[NU], P[NPK], p[NX];
     double rg[NW], rb[NX], rt[NW], Dg[NW];
+    double hscale = 1.0;   // multiplies the Hs accessor of the Riccati stage (c_k for the SQP Hessian, 1 for the exact one)
 
     MPCRL_DI SmallSolver(const SmallSpec &sp_, int k_, int lpi_, int base_)
         : sp(sp_), N(sp_.N), lpi(lpi_), k(k_), base(base_), term(k_ == sp_.N), first(k_ == 0) {}
@@ -183,7 +184,33 @@ struct SmallSolver {
     MPCRL_DI double dvc(const double *ax, const double *au, int i) const {
         return i < NU ? (term ? 0.0 : au[i < NU ? i : 0]) : ax[i >= NU ? i - NU : 0];
     }
-    MPCRL_DI double BA(int m, int j) const { return j < NU ? Bm[m * NU + (j < NU ? j : 0)] : A[m * NX + (j >= NU ? j - NU : 0)]; }
+    // dynamics Jacobians: registers by default; in cooperative mode they live only in the stage's LDS slot (the sweep lane needs
+    // them there anyway), which keeps the stage waves inside their 256-register budget
+    MPCRL_DI double Aget(int i) const {
+        if constexpr (C::ON)
+            return slot(coop.g, k)[oA + i];
+        else
+            return A[i];
+    }
+    MPCRL_DI double Bget(int i) const {
+        if constexpr (C::ON)
+            return slot(coop.g, k)[oB + i];
+        else
+            return Bm[i];
+    }
+    MPCRL_DI void Aset(int i, double v) {
+        if constexpr (C::ON) {
+            if (coop.stage_lane) slot(coop.g, k)[oA + i] = v;
+        } else
+            A[i] = v;
+    }
+    MPCRL_DI void Bset(int i, double v) {
+        if constexpr (C::ON) {
+            if (coop.stage_lane) slot(coop.g, k)[oB + i] = v;
+        } else
+            Bm[i] = v;
+    }
+    MPCRL_DI double BA(int m, int j) const { return j < NU ? Bget(m * NU + (j < NU ? j : 0)) : Aget(m * NX + (j >= NU ? j - NU : 0)); }
     // slack(v) of the bound row on side sd, coordinate i, at value v
     MPCRL_DI double bslack(int sd, int i, double v) const {
         const double sv = SOFT && softc(i) ? s[sd][SOFT ? i : 0] : 0.0;
@@ -205,17 +232,17 @@ struct SmallSolver {
             for (int i = 0; i < NX; ++i) {
                 r[i] = jn[i].v - xnext[i];
 #pragma unroll
-                for (int j = 0; j < NU; ++j) Bm[i * NU + j] = jn[i].d[j];
+                for (int j = 0; j < NU; ++j) Bset(i * NU + j, jn[i].d[j]);
 #pragma unroll
-                for (int j = 0; j < NX; ++j) A[i * NX + j] = jn[i].d[NU + j];
+                for (int j = 0; j < NX; ++j) Aset(i * NX + j, jn[i].d[NU + j]);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NX; ++i) r[i] = 0.0;
 #pragma unroll
-            for (int i = 0; i < NX * NX; ++i) A[i] = 0.0;
+            for (int i = 0; i < NX * NX; ++i) Aset(i, 0.0);
 #pragma unroll
-            for (int i = 0; i < NX * NU; ++i) Bm[i] = 0.0;
+            for (int i = 0; i < NX * NU; ++i) Bset(i, 0.0);
         }
         double val = M::cost_grad(term, k, x, u, sp, thc, q);
 #pragma unroll
@@ -284,7 +311,9 @@ struct SmallSolver {
 
     // ---- one backward Riccati stage: (Pn, pn) of stage k+1  ->  K, Li, kff, P, p of this stage ----
     // FACTOR = false re-uses K, Li and P (vector-only sweep for the corrector / extra right-hand sides).
-    // Hs(i,j): stage Hessian accessor (already scaled), Dg: barrier diagonal, g: modified gradient, bb: dynamics offset.
+    // Hs(i,j): UNSCALED stage Hessian accessor, multiplied by hscale where it is used (keeping the product out of registers:
+    // a per-lane scale times 15-25 kernel-argument constants would otherwise be hoisted and held live across the whole loop);
+    // Dg: barrier diagonal, g: modified gradient, bb: dynamics offset.
     template <bool FACTOR, class HF>
     MPCRL_DI bool riccati_stage(const double *Pn, const double *pn, HF Hs, const double *g, const double *bb) {
         bool ok = true;
@@ -294,7 +323,7 @@ struct SmallSolver {
 #pragma unroll
                 for (int i = 0; i < NX; ++i)
 #pragma unroll
-                    for (int j = 0; j <= i; ++j) P[sym(i, j)] = Hs(NU + i, NU + j) + (i == j ? Dg[NU + i] : 0.0);
+                    for (int j = 0; j <= i; ++j) P[sym(i, j)] = fma(hscale, Hs(NU + i, NU + j), i == j ? Dg[NU + i] : 0.0);
             }
 #pragma unroll
             for (int i = 0; i < NX; ++i) p[i] = g[NU + i];
@@ -332,7 +361,7 @@ struct SmallSolver {
             for (int i = 0; i < NW; ++i)
 #pragma unroll
                 for (int j = 0; j <= i; ++j) {
-                    double a = Hs(i, j) + (i == j ? Dg[i] : 0.0);
+                    double a = fma(hscale, Hs(i, j), i == j ? Dg[i] : 0.0);
 #pragma unroll
                     for (int m = 0; m < NX; ++m) a = fma(BA(m, i), T[m * NW + j], a);
                     Mm[sym(i, j)] = a;
@@ -550,18 +579,8 @@ struct SmallSolver {
     }
     MPCRL_DI double *slot(int g, int kk) const { return coop.lds + (size_t)(g * lpi + kk) * SLOTP; }
 
-    // stage lanes publish the dynamics Jacobians of the current linearisation (once per SQP iteration)
-    MPCRL_DI void coop_publish_AB() {
-        if constexpr (C::ON) {
-            if (coop.stage_lane) {
-                double *sl = slot(coop.g, k);
-#pragma unroll
-                for (int i = 0; i < NX * NX; ++i) sl[oA + i] = A[i];
-#pragma unroll
-                for (int i = 0; i < NX * NU; ++i) sl[oB + i] = Bm[i];
-            }
-        }
-    }
+    // (cooperative mode: linearize() writes A, B straight into the stage's LDS slot)
+    MPCRL_DI void coop_publish_AB() {}
 
     // serial sweeps of one instance on one lane; per-stage data in LDS.  FACTOR: matrix + vector recursion, else vector only.
     template <bool FACTOR>
@@ -879,7 +898,8 @@ struct SmallSolver {
     // act: this instance takes part.  Returns true when converged; n_it counts iterations of this instance.
     // warm_mu > 0: start from the rows and multipliers of the previous QP, every complementarity product raised to >= warm_mu.
     MPCRL_DI bool qp_solve(bool act, const double *x0, const double *u0f, int &n_it, double warm_mu, double tol_res, double tol_mu) {
-        auto Hs = [&](int i, int j) { return ck * M::hess(term, i, j, sp, thc); };
+        auto Hs = [&](int i, int j) { return M::hess(term, i, j, sp, thc); };
+        hscale = ck;
         const bool warm = warm_mu > 0.0;
         if (act) {
 #pragma unroll
@@ -943,9 +963,9 @@ struct SmallSolver {
                 if (!term) {
                     a = r[i] - dxn[i];
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) a = fma(A[i * NX + j], dx[j], a);
+                    for (int j = 0; j < NX; ++j) a = fma(Aget(i * NX + j), dx[j], a);
 #pragma unroll
-                    for (int j = 0; j < NU; ++j) a = fma(Bm[i * NU + j], du[j], a);
+                    for (int j = 0; j < NU; ++j) a = fma(Bget(i * NU + j), du[j], a);
                 }
                 rb[i] = a;
                 rloc = fmax(rloc, fabs(a));
@@ -954,9 +974,10 @@ struct SmallSolver {
             for (int i = 0; i < NW; ++i) {
                 rg[i] = 0.0;
                 if (term && i < NU) continue;
-                double a = q[i] + GTnu(nuqn, nuq, i);
+                double a = q[i] + GTnu(nuqn, nuq, i), hdv = 0.0;
 #pragma unroll
-                for (int j = 0; j < NW; ++j) a = fma(Hs(i, j), dvc(dx, du, j), a);
+                for (int j = 0; j < NW; ++j) hdv = fma(Hs(i, j), dvc(dx, du, j), hdv);
+                a = fma(hscale, hdv, a);
                 if (has(0, i)) a -= lam[0][i];
                 if (has(1, i)) a += lam[1][i];
                 if (fixed(i)) a = 0.0;
@@ -1183,6 +1204,7 @@ struct SmallSolver {
             Dg[i] = d;
         }
         auto Hs = [&](int i, int j) { return Hx[sym(i, j)]; };
+        hscale = 1.0;
         double zero[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) zero[i] = 0.0;
