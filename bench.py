@@ -168,23 +168,20 @@ def main():
     torch.cuda.set_device(dev)
 
     from mpc4rl_amd import MPCBatch, cartpole_ocp
+    from mpc4rl_amd.distributed import allreduce_weighted_grad
     ocp = cartpole_ocp()
     B = args.batch
     sens = not args.no_sens
     mpc = MPCBatch(ocp, B, device=dev)
     x0_np = make_inputs(B, rank)
     x0 = torch.as_tensor(x0_np, device=dev)
-    grad = torch.zeros(N_THETA + 2, dtype=torch.float64, device=dev)
 
     def step():
         # cold start every step (MPC.reset semantics) so that every step does the same, full work
         r = mpc.solve(x0, sens_v=sens, sens_pi=sens, cold=not args.rti, rti=args.rti)
         if dist is not None and sens:
             # data-parallel RL update: one all-reduce of [sum_i dV_i/dtheta, sum_i V_i, count]
-            grad[:N_THETA] = r.dV_dp[:, :N_THETA].sum(0)
-            grad[N_THETA] = r.V.sum()
-            grad[N_THETA + 1] = float(B)
-            dist.all_reduce(grad)
+            allreduce_weighted_grad(r.dV_dp[:, :N_THETA], r.V)   # K5 reduction kernel + one all_reduce of 5 doubles
         return r
 
     if args.rti:

@@ -121,6 +121,12 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
 int mpcrl_get_iterate(mpcrl_handle h, double *x, double *u, double *pi, double *bnd, double *res, void *stream);
 int mpcrl_set_iterate(mpcrl_handle h, const double *x, const double *u, const double *pi, const double *bnd, void *stream);
 
+/* K5, the local half of the one collective on the path: out[j] = sum_i weight[i] * grad[i*ld + j] (j < n), out[n] = sum_i weight[i],
+ * out[n+1] = rows.  Replaces the per-sample Python accumulation of rlmpc/examples/linear_system_mpc_qlearning.py:203
+ * (np.mean(np.vstack([LR * td[i] * dQ_dp[i, :] ...]))); the n+2 doubles are then all-reduced over the ranks (RCCL).
+ * Device pointers on the current device; weight may be NULL (= 1). */
+int mpcrl_weighted_grad_sum(const double *grad, int64_t ld, const double *weight, int rows, int n, double *out, void *stream);
+
 /* Bytes of device memory held by the handle; library version. */
 int64_t mpcrl_workspace_bytes(mpcrl_handle h);
 int mpcrl_version(void);

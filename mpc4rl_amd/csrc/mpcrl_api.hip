@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -12,6 +13,7 @@
 #include <vector>
 
 #include "large_kernel.hpp"
+#include "reduce_kernel.hpp"
 
 using namespace mpcrl;
 
@@ -291,6 +293,22 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
         }
     if (!rc) h->have_iterate = true;
     return rc;
+}
+
+int mpcrl_weighted_grad_sum(const double *grad, int64_t ld, const double *weight, int rows, int n, double *out, void *stream) {
+    if (!grad || !out || rows < 0 || n < 1 || ld < n) return MPCRL_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(hipMemsetAsync(out, 0, (size_t)(n + 2) * sizeof(double), st));
+    if (rows == 0) return 0;
+    if (n <= REDUCE_MAXN_ROWPAR) {
+        const int blocks = std::min(256, (rows + 255) / 256);
+        hipLaunchKernelGGL(grad_reduce_rows_kernel, dim3(blocks), dim3(256), 0, st, grad, (long)ld, weight, rows, n, out);
+    } else {
+        const int ysplit = std::max(1, std::min(64, rows / 64));
+        hipLaunchKernelGGL(grad_reduce_cols_kernel, dim3((n + 255) / 256, ysplit), dim3(256), 0, st, grad, (long)ld, weight, rows, n, out);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
 }
 
 int mpcrl_get_iterate(mpcrl_handle h, double *x, double *u, double *pi, double *bnd, double *res, void *stream) {

@@ -32,9 +32,21 @@ def allreduce_weighted_grad(grad: torch.Tensor, weight: torch.Tensor, group: Opt
     w = weight.to(torch.float64).reshape(-1)
     n_theta = g.shape[1]
     buf = torch.empty(n_theta + 2, dtype=torch.float64, device=g.device)
-    buf[:n_theta] = (w[:, None] * g).sum(0)
-    buf[n_theta] = w.sum()
-    buf[n_theta + 1] = float(g.shape[0])
+    if g.is_cuda and g.stride(1) == 1:
+        # K5 (csrc/reduce_kernel.hpp): one launch instead of a chain of elementwise / reduction kernels
+        import ctypes as C
+        from . import _lib
+        w = w.contiguous()
+        with torch.cuda.device(g.device):
+            rc = _lib.load().mpcrl_weighted_grad_sum(C.c_void_p(g.data_ptr()), int(g.stride(0)), C.c_void_p(w.data_ptr()), int(g.shape[0]),
+                                                     int(n_theta), C.c_void_p(buf.data_ptr()),
+                                                     C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"mpcrl_weighted_grad_sum failed with {rc}")
+    else:   # CPU tensors (gloo tests)
+        buf[:n_theta] = (w[:, None] * g).sum(0)
+        buf[n_theta] = w.sum()
+        buf[n_theta + 1] = float(g.shape[0])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         if deterministic:
             parts = [torch.empty_like(buf) for _ in range(dist.get_world_size(group))]
