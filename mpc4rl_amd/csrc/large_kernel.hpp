@@ -42,7 +42,7 @@ struct LargeArgs {
 template <class M>
 struct LargeLayout {
     static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD;
-    size_t A, B, r, q, dx, du, nuq, Dx, Du, Dnu, rg, rb, rt, Dg, lamw, tw, aff, P, p, K, L, kff, Hex, Fth, term, ynu, total;
+    size_t A, B, r, q, dx, du, nuq, Dx, Du, Dnu, rg, rb, rt, Dg, lamw, tw, aff, P, p, K, L, kff, Hex, term, ynu, total;
     __host__ __device__ explicit LargeLayout(int N) {
         size_t o = 0;
         auto take = [&](size_t n) { size_t s = o; o += n; return s; };
@@ -53,7 +53,7 @@ struct LargeLayout {
         lamw = take((size_t)2 * (N + 1) * NW), tw = take((size_t)2 * (N + 1) * NW), aff = take((size_t)2 * (N + 1) * NW);
         P = take((size_t)(N + 1) * NX * NX), p = take((size_t)(N + 1) * NX), K = take((size_t)N * NU * NX), L = take((size_t)N * NU * NU);
         kff = take((size_t)N * NU);
-        Hex = take((size_t)(N + 1) * NW * NW), Fth = take((size_t)N * NX * NTD), term = take((size_t)N * NTD), ynu = take((size_t)(N + 1) * NX);
+        Hex = take((size_t)(N + 1) * NW * NW), term = take((size_t)N * NTD), ynu = take((size_t)(N + 1) * NX);
         total = (o + 7) & ~(size_t)7;
     }
 };
@@ -717,25 +717,22 @@ __global__ void __launch_bounds__(LARGE_NT) large_sens_kernel(const LargeSpec sp
     const int status = a.status[inst];
     if (!(status == 0 || status == 2)) return;
     const double *th = S.th, *xs = sp.consts, *nu = S.NUv;
-    double *Fth = w + lay.Fth, *Hex = w + lay.Hex, *term = w + lay.term;
-    // ---- dF/dtheta, one (stage, parameter) item per thread
-    for (int it = tid; it < N * NTD; it += NT) {
-        const int k = it / NTD, d = it - k * NTD;
-        Jet1<1> jx[NX], ju[NU], jt[NTD], jn[NX];
-        for (int i = 0; i < NU; ++i) ju[i] = Jet1<1>(S.U[k * NU + i]);
-        for (int i = 0; i < NX; ++i) jx[i] = Jet1<1>(S.X[k * NX + i]);
-        for (int i = 0; i < NTD; ++i) jt[i] = Jet1<1>(th[M::td_index(i)]);
-        jt[d].d[0] = 1.0;
-        disc_map_lean<M, Jet1<1>>(jx, ju, jt, jn, sp.h, sp.rk_steps);
-        for (int m = 0; m < NX; ++m) Fth[((size_t)k * NX + m) * NTD + d] = jn[m].d[0];
+    double *Hex = w + lay.Hex, *term = w + lay.term;
+    // ---- dV/dtheta of the dynamics: sum_k grad_theta (nu_{k+1}' F_k) by one reverse sweep of F per stage
+    for (int k = tid; k < N; k += NT) {
+        double jx[NX], ju[NU], jt[NTD], lm[NX], xb[NX], ub[NU], tb[NTD];
+        for (int i = 0; i < NU; ++i) ju[i] = S.U[k * NU + i];
+        for (int i = 0; i < NX; ++i) jx[i] = S.X[k * NX + i], lm[i] = nu[(k + 1) * NX + i];
+        for (int i = 0; i < NTD; ++i) jt[i] = th[M::td_index(i)];
+        disc_map_adj<M, true, double>(jx, ju, jt, lm, xb, ub, tb, sp.h, sp.rk_steps);
+        for (int d = 0; d < NTD; ++d) term[k * NTD + d] = tb[d];
     }
     __syncthreads();
     if ((a.flags & 1) && a.dV) {
         double *dV = a.dV + (size_t)inst * NP;
         for (int d = tid; d < NTD; d += NT) {
             double acc = 0.0;
-            for (int k = 0; k < N; ++k)
-                for (int m = 0; m < NX; ++m) acc = fma(nu[(k + 1) * NX + m], Fth[((size_t)k * NX + m) * NTD + d], acc);
+            for (int k = 0; k < N; ++k) acc += term[k * NTD + d];
             dV[M::td_index(d)] = acc;
         }
         for (int e = tid; e < NX * NX + NU * NU; e += NT) {   // d/dQ_ij, d/dR_ij of sum_k c_k l_k (ocp_utils.py:276-277)
@@ -753,25 +750,20 @@ __global__ void __launch_bounds__(LARGE_NT) large_sens_kernel(const LargeSpec sp
     }
     if (!((a.flags & 2) && a.dpi) || S.qmode) return;
     double *dpi = a.dpi + (size_t)inst * NU * NP;
-    // ---- exact Lagrangian Hessian blocks: c_k hess l + sum_m nu_{k+1,m} hess F_m, one (stage, i >= j) item per thread
-    constexpr int NPAIR = NW * (NW + 1) / 2;
-    for (int it = tid; it < N * NPAIR; it += NT) {
-        const int k = it / NPAIR, pr = it - k * NPAIR;
-        int i = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
-        while ((i + 1) * (i + 2) / 2 <= pr) ++i;
-        while (i * (i + 1) / 2 > pr) --i;
-        const int j = pr - i * (i + 1) / 2;
-        Jet2<1> jx[NX], ju[NU], jt[NTD], jn[NX];
-        for (int c = 0; c < NU; ++c) ju[c] = Jet2<1>(S.U[k * NU + c]);
-        for (int c = 0; c < NX; ++c) jx[c] = Jet2<1>(S.X[k * NX + c]);
-        for (int c = 0; c < NTD; ++c) jt[c] = Jet2<1>(th[M::td_index(c)]);
-        if (i < NU) ju[i].g[0] = 1.0; else jx[i - NU].g[0] = 1.0;
-        if (j < NU) ju[j].e = 1.0; else jx[j - NU].e = 1.0;
-        disc_map_lean<M, Jet2<1>>(jx, ju, jt, jn, sp.h, sp.rk_steps);
-        double acc = S.ck(k) * M::hess(false, i, j, th);
-        for (int m = 0; m < NX; ++m) acc = fma(nu[(k + 1) * NX + m], jn[m].m[0], acc);
-        Hex[(size_t)k * NW * NW + i * NW + j] = acc;
-        Hex[(size_t)k * NW * NW + j * NW + i] = acc;
+    // ---- exact Lagrangian Hessian blocks c_k hess l + hess (nu_{k+1}' F_k): one (stage, column) item per thread, the column by
+    // forward-over-reverse (tangent e_j through the reverse sweep of F)
+    __syncthreads();   // term is re-used below
+    for (int it = tid; it < N * NW; it += NT) {
+        const int k = it / NW, j = it - k * NW;
+        Jet1<1> jx[NX], ju[NU], jt[NTD], lm[NX], xb[NX], ub[NU];
+        for (int c = 0; c < NU; ++c) ju[c] = Jet1<1>(S.U[k * NU + c]);
+        for (int c = 0; c < NX; ++c) jx[c] = Jet1<1>(S.X[k * NX + c]), lm[c] = Jet1<1>(nu[(k + 1) * NX + c]);
+        for (int c = 0; c < NTD; ++c) jt[c] = Jet1<1>(th[M::td_index(c)]);
+        if (j < NU) ju[j].d[0] = 1.0; else jx[j - NU].d[0] = 1.0;
+        disc_map_adj<M, false, Jet1<1>>(jx, ju, jt, lm, xb, ub, (Jet1<1> *)nullptr, sp.h, sp.rk_steps);
+        const double ckk = S.ck(k);
+        for (int i = 0; i < NW; ++i)
+            Hex[(size_t)k * NW * NW + i * NW + j] = fma(ckk, M::hess(false, i, j, th), i < NU ? ub[i].d[0] : xb[i - NU].d[0]);
     }
     for (int e = tid; e < NW * NW; e += NT) Hex[(size_t)N * NW * NW + e] = S.ck(N) * M::hess(true, e / NW, e % NW, th);
     // barrier diagonal from the final (lam, t) of the bound rows (slacks are constants of the mirror, quirk q1)
@@ -794,19 +786,18 @@ __global__ void __launch_bounds__(LARGE_NT) large_sens_kernel(const LargeSpec sp
         else
             S.template backward<false>(HsEx, S.rt, nullptr);
         S.forward(nullptr);
-        // mixed second-order contraction: y_v' d/dv (nu' dF/dtheta_d) + y_nu' dF/dtheta_d, one (stage, parameter) item per thread
-        for (int it = tid; it < N * NTD; it += NT) {
-            const int k = it / NTD, d = it - k * NTD;
-            Jet2<1> jx[NX], ju[NU], jt[NTD], jn[NX];
-            for (int c = 0; c < NU; ++c) ju[c] = Jet2<1>(S.U[k * NU + c]), ju[c].e = S.Du[k * NU + c];
-            for (int c = 0; c < NX; ++c) jx[c] = Jet2<1>(S.X[k * NX + c]), jx[c].e = S.Dx[k * NX + c];
-            for (int c = 0; c < NTD; ++c) jt[c] = Jet2<1>(th[M::td_index(c)]);
-            jt[d].g[0] = 1.0;
-            disc_map_lean<M, Jet2<1>>(jx, ju, jt, jn, sp.h, sp.rk_steps);
-            double acc = 0.0;
-            for (int m = 0; m < NX; ++m)
-                acc = fma(nu[(k + 1) * NX + m], jn[m].m[0], fma(S.Dnu[(k + 1) * NX + m], Fth[((size_t)k * NX + m) * NTD + d], acc));
-            term[it] = acc;
+        // mixed second-order contraction y_v' d/dv (nu' dF/dtheta) + y_nu' dF/dtheta for all theta at once: the tangent of the
+        // reverse sweep along (y_v, y_nu), one stage per thread
+        for (int k = tid; k < N; k += NT) {
+            Jet1<1> jx[NX], ju[NU], jt[NTD], lm[NX], xb[NX], ub[NU], tb[NTD];
+            for (int c = 0; c < NU; ++c) ju[c] = Jet1<1>(S.U[k * NU + c]), ju[c].d[0] = S.Du[k * NU + c];
+            for (int c = 0; c < NX; ++c) {
+                jx[c] = Jet1<1>(S.X[k * NX + c]), jx[c].d[0] = S.Dx[k * NX + c];
+                lm[c] = Jet1<1>(nu[(k + 1) * NX + c]), lm[c].d[0] = S.Dnu[(k + 1) * NX + c];
+            }
+            for (int c = 0; c < NTD; ++c) jt[c] = Jet1<1>(th[M::td_index(c)]);
+            disc_map_adj<M, true, Jet1<1>>(jx, ju, jt, lm, xb, ub, tb, sp.h, sp.rk_steps);
+            for (int d = 0; d < NTD; ++d) term[k * NTD + d] = tb[d].d[0];
         }
         __syncthreads();
         for (int d = tid; d < NTD; d += NT) {

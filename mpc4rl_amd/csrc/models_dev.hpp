@@ -171,6 +171,55 @@ struct ChainDev {
         for (int i = 0; i < 3 * M; ++i) f[i] = vel[i];
         for (int j = 0; j < 3; ++j) f[3 * M + j] = u[j];
     }
+    // Reverse sweep of ode(): xb += (df/dx)' fb, ub += (df/du)' fb and, with WANT_TH, thb += (df/dth)' fb.
+    // With S = Jet1<1> (tangent seeded on x, u or fb) this is forward-over-reverse: the tangent parts of xb, ub, thb are one
+    // Hessian-vector product of fb' f — what the KKT sensitivities need (nlp.py:1195-1211 builds the same objects symbolically).
+    template <bool WANT_TH, class S>
+    MPCRL_DI static void ode_adj(const S *x, const S *u, const S *th, const S *fb, S *xb, S *ub, S *thb) {
+        const S *pos = x, *vel = x + 3 * (M + 1);
+        const S *m = th, *D = th + NL, *L = th + 4 * NL, *C = th + 7 * NL;
+        S *posb = xb, *velb = xb + 3 * (M + 1);
+        const S *accb = fb + 3 * (M + 1);
+        for (int i = 0; i < 3 * M; ++i) velb[i] = velb[i] + fb[i];
+        for (int j = 0; j < 3; ++j) ub[j] = ub[j] + fb[3 * M + j];
+        if constexpr (WANT_TH)
+            for (int i = 0; i < 3 * M; ++i) thb[10 * NL + i] = thb[10 * NL + i] + accb[i];
+        const S one(1.0);
+        for (int i = 0; i <= M; ++i) {
+            S dist[3], distb[3];
+            for (int j = 0; j < 3; ++j) dist[j] = i ? pos[3 * i + j] - pos[3 * (i - 1) + j] : pos[j];
+            const S inrm = one / jsqrt(dist[0] * dist[0] + dist[1] * dist[1] + dist[2] * dist[2]);
+            const S im = one / m[i];
+            S nrmb(0.0);
+            for (int j = 0; j < 3; ++j) {
+                S Ftb(0.0);   // adjoint of the link force: acc_i -= Ft, acc_{i-1} += Ft
+                if (i < M) Ftb = Ftb - accb[3 * i + j];
+                if (i > 0) Ftb = Ftb + accb[3 * (i - 1) + j];
+                const S a = D[3 * i + j] * im;
+                const S g = 1.0 - L[3 * i + j] * inrm;
+                const S dvb = C[3 * i + j] * Ftb;
+                if (i < M) velb[3 * i + j] = velb[3 * i + j] + dvb; else ub[j] = ub[j] + dvb;
+                if (i > 0) velb[3 * (i - 1) + j] = velb[3 * (i - 1) + j] - dvb;
+                const S gb = Ftb * a * dist[j];
+                if constexpr (WANT_TH) {
+                    const S vr = i < M ? vel[3 * i + j] : u[j];
+                    const S dv = i ? vr - vel[3 * (i - 1) + j] : vr;
+                    const S gd = Ftb * g * dist[j] * im;   // dFs/dD
+                    thb[7 * NL + 3 * i + j] = thb[7 * NL + 3 * i + j] + Ftb * dv;
+                    thb[NL + 3 * i + j] = thb[NL + 3 * i + j] + gd;
+                    thb[i] = thb[i] - gd * a;
+                    thb[4 * NL + 3 * i + j] = thb[4 * NL + 3 * i + j] - gb * inrm;
+                }
+                nrmb = nrmb + gb * L[3 * i + j] * inrm * inrm;
+                distb[j] = Ftb * a * g;
+            }
+            for (int j = 0; j < 3; ++j) {
+                const S db = distb[j] + nrmb * dist[j] * inrm;
+                posb[3 * i + j] = posb[3 * i + j] + db;
+                if (i > 0) posb[3 * (i - 1) + j] = posb[3 * (i - 1) + j] - db;
+            }
+        }
+    }
     // symmetrised cost weights from p (Q, R column-major; ocp_utils.py:267,273)
     MPCRL_DI static double Qs(const double *p, int i, int j) { return 0.5 * (p[OFF_Q + j * NX + i] + p[OFF_Q + i * NX + j]); }
     MPCRL_DI static double Rs(const double *p, int i, int j) { return 0.5 * (p[OFF_R + j * NU + i] + p[OFF_R + i * NU + j]); }
@@ -199,6 +248,39 @@ MPCRL_DI void disc_map_lean(const S *x, const S *u, const S *th, S *xn, double h
         for (int i = 0; i < NX; ++i) xc[i] = xc[i] + (h / 6.0) * (acc[i] + kk[i]);
     }
     for (int i = 0; i < NX; ++i) xn[i] = xc[i];
+}
+
+// Reverse sweep of F = RK4^steps: xb = (dF/dx)' lam, ub = (dF/du)' lam, thb = (dF/dth)' lam (all overwritten).
+// The states at the start of each RK4 step are recomputed rather than stored (steps is 1 or 2 here).
+template <class M, bool WANT_TH, class S>
+MPCRL_DI void disc_map_adj(const S *x, const S *u, const S *th, const S *lam, S *xb, S *ub, S *thb, double h, int steps) {
+    constexpr int NX = M::NX, NU = M::NU, NTD = M::NTD;
+    S lb[NX];
+    for (int i = 0; i < NX; ++i) lb[i] = lam[i];
+    for (int i = 0; i < NU; ++i) ub[i] = S(0.0);
+    if constexpr (WANT_TH)
+        for (int i = 0; i < NTD; ++i) thb[i] = S(0.0);
+    for (int s = steps - 1; s >= 0; --s) {
+        S xc[NX], X2[NX], X3[NX], X4[NX], kk[NX];
+        disc_map_lean<M, S>(x, u, th, xc, h, s);   // state at the start of step s
+        M::template ode<S>(xc, u, th, kk);
+        for (int i = 0; i < NX; ++i) X2[i] = xc[i] + (0.5 * h) * kk[i];
+        M::template ode<S>(X2, u, th, kk);
+        for (int i = 0; i < NX; ++i) X3[i] = xc[i] + (0.5 * h) * kk[i];
+        M::template ode<S>(X3, u, th, kk);
+        for (int i = 0; i < NX; ++i) X4[i] = xc[i] + h * kk[i];
+        S kb[NX], Xb[NX], acc[NX];
+        for (int i = 0; i < NX; ++i) kb[i] = (h / 6.0) * lb[i], Xb[i] = S(0.0), acc[i] = lb[i];
+        M::template ode_adj<WANT_TH, S>(X4, u, th, kb, Xb, ub, thb);
+        for (int i = 0; i < NX; ++i) acc[i] = acc[i] + Xb[i], kb[i] = (h / 3.0) * lb[i] + h * Xb[i], Xb[i] = S(0.0);
+        M::template ode_adj<WANT_TH, S>(X3, u, th, kb, Xb, ub, thb);
+        for (int i = 0; i < NX; ++i) acc[i] = acc[i] + Xb[i], kb[i] = (h / 3.0) * lb[i] + (0.5 * h) * Xb[i], Xb[i] = S(0.0);
+        M::template ode_adj<WANT_TH, S>(X2, u, th, kb, Xb, ub, thb);
+        for (int i = 0; i < NX; ++i) acc[i] = acc[i] + Xb[i], kb[i] = (h / 6.0) * lb[i] + (0.5 * h) * Xb[i], Xb[i] = S(0.0);
+        M::template ode_adj<WANT_TH, S>(xc, u, th, kb, Xb, ub, thb);
+        for (int i = 0; i < NX; ++i) lb[i] = acc[i] + Xb[i];
+    }
+    for (int i = 0; i < NX; ++i) xb[i] = lb[i];
 }
 
 // discrete map F = RK4^steps(ode; h)  (rlmpc/common/integrator.py:6-33)
