@@ -58,6 +58,17 @@ struct LargeLayout {
     }
 };
 
+// Development aid: -DMPCRL_PROFILE_PHASES accumulates wall-clock ticks (100 MHz) per phase of the interior-point loop
+// (read through mpcrl_debug_phases; profiles/microbench/chain_phases.py).  Off in the product build.
+#ifdef MPCRL_PROFILE_PHASES
+__device__ unsigned long long g_phase_ticks[16];
+#define PH_T0() unsigned long long ph_t = wall_clock64()
+#define PH(i) do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long n_ = wall_clock64(); atomicAdd(&g_phase_ticks[i], n_ - ph_t); ph_t = n_; } } while (0)
+#else
+#define PH_T0()
+#define PH(i)
+#endif
+
 MPCRL_DI double wave_sum(double v) {
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
@@ -375,7 +386,7 @@ struct LargeSolver {
     }
 
     // ---- forward sweep: Dx, Du (serial over stages), then Dnu for all stages in parallel
-    MPCRL_DI void forward(const double *bb) {
+    MPCRL_DI void forward(const double *bb, bool want_nu = true) {
         if (tid < NX) scc[tid] = 0.0, Dx[tid] = 0.0;
         __syncthreads();
         for (int k = 0; k < N; ++k) {
@@ -396,7 +407,7 @@ struct LargeSolver {
             if (tid < NX) scc[tid] = xn, Dx[(k + 1) * NX + tid] = xn;
             __syncthreads();
         }
-        for (int e = tid; e < (N + 1) * NX; e += NT) {
+        for (int e = tid; want_nu && e < (N + 1) * NX; e += NT) {
             const int k = e / NX, i = e - k * NX;
             double a = 0.0;
             if (k > 0) {
@@ -447,7 +458,9 @@ struct LargeSolver {
         }
         const double n_rows = block_sum(cnt);
         bool ok = false;
+        PH_T0();
         for (int it = 0;; ++it) {
+            PH(7);
             double rloc = 0.0, muloc = 0.0;
             for (int e = tid; e < N * NX; e += NT) {
                 const int k = e / NX, i = e - k * NX;
@@ -487,6 +500,7 @@ struct LargeSolver {
             }
             if (it >= IPM_MAX_ITER || !(rinf < 1e300)) break;
             ++n_it;
+            PH(0);
             double sigma_mu = 0.0, alpha = 1.0;
             bool fail = false;
             for (int pass = 0; pass < 2; ++pass) {
@@ -509,11 +523,16 @@ struct LargeSolver {
                     rt[e] = rg[e] + er;
                 }
                 __syncthreads();
+                PH(1);
                 if (pass == 0) {
                     if (!backward<true>(Hs, rt, rb)) fail = true;
-                } else
+                    PH(2);
+                } else {
                     backward<false>(Hs, rt, rb);
-                forward(rb);
+                    PH(3);
+                }
+                forward(rb, pass == 1);   // the multiplier step is only needed with the final direction
+                PH(4);
                 double amax = 1.0;
                 for (int e = tid; e < ne; e += NT) {
                     const int k = e / NW, i = e - k * NW;
@@ -553,6 +572,7 @@ struct LargeSolver {
                 } else
                     alpha = fmin(1.0, IPM_FRAC * amax);
             }
+            PH(5);
             if (fail) break;
             for (int e = tid; e < ne; e += NT) {
                 const int k = e / NW, i = e - k * NW;
@@ -582,7 +602,7 @@ struct LargeSolver {
 // solve kernel: one workgroup per instance
 // =====================================================================================================
 template <class M>
-__global__ void __launch_bounds__(LARGE_NT) large_solve_kernel(const LargeSpec sp, const LargeArgs a) {
+__global__ void __launch_bounds__(LARGE_NT, 4) large_solve_kernel(const LargeSpec sp, const LargeArgs a) {
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU;
     __shared__ double sP[NX * NX], sBA[NX * NW], sT[NX * NW], sM[NW * NW];
     __shared__ double sp_[NX], scc[NX], smv[NW], sK[NU * NX + NU], sL[NU * NU], sred[16], sck[64];

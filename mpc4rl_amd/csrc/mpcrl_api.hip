@@ -146,6 +146,18 @@ int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
 
 extern "C" {
 
+#ifdef MPCRL_PROFILE_PHASES
+int mpcrl_debug_phases(unsigned long long *out, int reset) {
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_ticks), sizeof(unsigned long long) * 16));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), z, sizeof(z)));
+    }
+    return 0;
+}
+#endif
+
 int mpcrl_version(void) { return 100; }
 
 int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_handle *out) {
