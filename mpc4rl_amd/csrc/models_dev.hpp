@@ -294,19 +294,21 @@ MPCRL_DI void disc_map(const S *x, const S *u, const S *th, S *xn, double h, int
 #pragma unroll
         for (int i = 0; i < NX; ++i) xc[i] = x[i];
         for (int s = 0; s < steps; ++s) {
-            S k1[NX], k2[NX], k3[NX], k4[NX], xt[NX];
-            M::template ode<S>(xc, u, th, k1);
+            // the weighted sum is accumulated as the stages are produced (same association as k1 + 2 k2 + 2 k3 + k4), so that
+            // only one stage derivative is live at a time: 4 NX fewer jets in registers
+            S acc[NX], kk[NX], xt[NX];
+            M::template ode<S>(xc, u, th, kk);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) xt[i] = xc[i] + (0.5 * h) * k1[i];
-            M::template ode<S>(xt, u, th, k2);
+            for (int i = 0; i < NX; ++i) acc[i] = kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
+            M::template ode<S>(xt, u, th, kk);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) xt[i] = xc[i] + (0.5 * h) * k2[i];
-            M::template ode<S>(xt, u, th, k3);
+            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
+            M::template ode<S>(xt, u, th, kk);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) xt[i] = xc[i] + h * k3[i];
-            M::template ode<S>(xt, u, th, k4);
+            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + h * kk[i];
+            M::template ode<S>(xt, u, th, kk);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) xc[i] = xc[i] + (h / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+            for (int i = 0; i < NX; ++i) xc[i] = xc[i] + (h / 6.0) * (acc[i] + kk[i]);
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) xn[i] = xc[i];
