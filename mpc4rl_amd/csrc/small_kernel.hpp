@@ -460,7 +460,7 @@ struct SmallSolver {
     // product P_{k+1} bb_k is formed beforehand, stage-parallel, by the lane that owns P_{k+1}, so only NX values travel.
     template <bool FACTOR, class HF>
     MPCRL_DI bool backward(HF Hs, const double *g, const double *bb) {
-        // Every lane executes every stage step (full EXEC mask) and only the lane whose turn it is commits the result.
+        // Every lane executes every stage step (full EXEC mask).
         bool ok = true;
         double hb[NX];
         if constexpr (!FACTOR) {
@@ -478,43 +478,23 @@ struct SmallSolver {
 #pragma unroll
             for (int i = 0; i < NX; ++i) hb[i] = 0.0;
         }
+        // No commit/select is needed: a lane whose stage is already final recomputes it from its (final) neighbour and gets the
+        // same bits again; a lane whose turn has not come yet computes throw-away values that its own turn overwrites.
         for (int kk = N; kk >= 0; --kk) {
             double pn[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) pn[i] = lane_dn(p[i] + hb[i]);
-            const bool mine = k == kk;
-            double sK[NU * NX], sLi[NLK], skff[NU], sP[NPK], sp[NX];
-#pragma unroll
-            for (int i = 0; i < NU * NX; ++i) sK[i] = K[i];
-#pragma unroll
-            for (int i = 0; i < NLK; ++i) sLi[i] = Li[i];
-#pragma unroll
-            for (int i = 0; i < NU; ++i) skff[i] = kff[i];
-#pragma unroll
-            for (int i = 0; i < NPK; ++i) sP[i] = P[i];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) sp[i] = p[i];
             double Pn[NPK];
             if constexpr (FACTOR) {
 #pragma unroll
                 for (int i = 0; i < NPK; ++i) Pn[i] = lane_dn(P[i]);
                 const bool okk = riccati_stage<true>(Pn, pn, Hs, g, bb);
-                ok = ok && (okk || !mine);
+                ok = ok && (okk || k != kk);
             } else {
 #pragma unroll
                 for (int i = 0; i < NPK; ++i) Pn[i] = 0.0;
                 riccati_stage<false>(Pn, pn, Hs, g, bb);
             }
-#pragma unroll
-            for (int i = 0; i < NU * NX; ++i) K[i] = mine ? K[i] : sK[i];
-#pragma unroll
-            for (int i = 0; i < NLK; ++i) Li[i] = mine ? Li[i] : sLi[i];
-#pragma unroll
-            for (int i = 0; i < NU; ++i) kff[i] = mine ? kff[i] : skff[i];
-#pragma unroll
-            for (int i = 0; i < NPK; ++i) P[i] = mine ? P[i] : sP[i];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) p[i] = mine ? p[i] : sp[i];
         }
         return ok;
     }
@@ -529,7 +509,6 @@ struct SmallSolver {
 #pragma unroll
         for (int i = 0; i < NX; ++i) xn[i] = 0.0;
         for (int kk = 0; kk < N; ++kk) {
-            const bool mine = k == kk, next = k == kk + 1;
             double tu[NU], tx[NX];
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
@@ -547,13 +526,14 @@ struct SmallSolver {
                 for (int j = 0; j < NU; ++j) a = fma(Bm[i * NU + j], tu[j], a);
                 tx[i] = a;
             }
+            // as in backward(): stages that are already final (k <= kk + 1) are recomputed to the same bits, later ones are provisional
 #pragma unroll
-            for (int i = 0; i < NU; ++i) Du[i] = mine ? tu[i] : Du[i];
+            for (int i = 0; i < NU; ++i) Du[i] = tu[i];
             double xin[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) xin[i] = lane_up(tx[i]);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) Dx[i] = next ? xin[i] : Dx[i];
+            for (int i = 0; i < NX; ++i) Dx[i] = first ? 0.0 : xin[i];
         }
         // multipliers of the arriving dynamics: local to each stage once Dx is known
 #pragma unroll
