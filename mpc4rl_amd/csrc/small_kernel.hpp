@@ -219,6 +219,7 @@ struct SmallSolver {
 
     // ---- linearise the dynamics leaving this stage and the stage cost; returns c_k * l_k ---------
     MPCRL_DI double linearize(const double *xnext) {
+        mx_dyn_dirty = true;
         if (!term) {
             Jet1<NW> jx[NX], ju[NU], jt[NTD], jn[NX];
 #pragma unroll
@@ -453,6 +454,140 @@ struct SmallSolver {
             p[i] = a;
         }
         return ok;
+    }
+
+    // =====================================================================================================================
+    // Factor sweep in MATRIX layout on the matrix cores (NX = 4, NU = 1: v_mfma_f64_4x4x4_4b_f64).
+    // The stage-per-lane layout leaves the serial factor sweep with one useful lane per instance and step (and every 4x4 product
+    // as 64 wave-wide FMAs).  Here the wave switches layout through LDS for the sweep: each stage lane publishes its
+    // linearisation to a slot, then the 64 lanes act as 4 blocks x (4 x 4) matrix elements — block = instance of the wave,
+    // lane = 16 r + 4 blk + c holds element (r, c) — and one MFMA is a 4x4x4 product for all blocks at once.  Measured operand
+    // layout (profiles/microbench/mfma_f64_4x4x4_probe.hip): D(i,j) at lane 16 i + 4 blk + j, B-operand(k,j) at 16 k + 4 blk + j,
+    // A-operand(i,k) at 16 k + 4 blk + i — so a matrix held in the D layout is its own B operand and, as A operand, its
+    // TRANSPOSE:  mfma(X, Y, C) = X' Y + C.  Row r of a block is one quad (4 consecutive lanes): every broadcast the recursion
+    // needs is a quad_perm DPP; nothing crosses DPP rows.  One stage step (P = P_{k+1}, W = [B | bb | 0 | 0], BB = [B B B B]):
+    //   X1 = mfma(P, A)            = P A                      Y  = mfma(P, W, [0 | p | 0 | 0]) = [P B | p + P bb | 0 | 0]
+    //   Q  = mfma(A, X1, Hxx + D)  = A' P A + Hxx + D_x       Zc = mfma(A, Y, [Hxu | g_x])     = [S | mv_x]      (columns)
+    //   Zr = mfma(Y, A, [Hux; 0])  : row 0 = S'               Zb = mfma(BB, Y, [Huu + D_u | g_u]): every row = [R, mv_u]
+    //   K = S / R, kff = mv_u / R, p = mv_x - K mv_u,  P = mfma(-K' (row 0), S' (row 0), Q) = Q - K S'
+    // 7 MFMAs (~18 cycles each) + ~40 VALU per step instead of ~300 VALU instructions.
+    static constexpr bool MX = (NX == 4 && NU == 1 && !C::ON);
+    static constexpr int mxA = 0, mxB = 16, mxbb = 20, mxg = 24, mxH = 29, mxP = 44, mxK = 60, mxkff = 64, mxLi = 65, mxp = 66,
+                         mxFlag = 70, MSLOT = 71;   // odd stride: the 64 stage lanes hit distinct banks
+    double *ms = nullptr;   // LDS, 64 slots of MSLOT doubles (one per stage lane)
+
+    MPCRL_DI static void wave_lds_sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    }
+    template <int CSEL>
+    MPCRL_DI static double quad_bcast(double v) {
+        constexpr int ctrl = CSEL | (CSEL << 2) | (CSEL << 4) | (CSEL << 6);
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xf, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    }
+    MPCRL_DI static double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+
+    // stage lane -> slot: dynamics (only when they changed) and the right-hand side / Hessian + barrier diagonal of this solve
+    template <class HF>
+    MPCRL_DI void mx_publish(HF Hs, const double *g, const double *bb, bool dyn) {
+        double *sl = ms + (threadIdx.x & 63) * MSLOT;
+        if (dyn) {
+#pragma unroll
+            for (int i = 0; i < NX * NX; ++i) sl[mxA + i] = A[i];
+#pragma unroll
+            for (int i = 0; i < NX * NU; ++i) sl[mxB + i] = Bm[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) sl[mxbb + i] = bb[i];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) sl[mxg + i] = g[i];
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) sl[mxH + sym(i, j)] = fma(hscale, Hs(i, j), i == j ? Dg[i] : 0.0);
+    }
+    // the sweep itself, all lanes in matrix layout
+    MPCRL_DI void mx_factor() {
+        const int l = threadIdx.x & 63, r = l >> 4, blk = (l >> 2) & 3, c = l & 3;
+        const int ipw = 64 / lpi;
+        const bool live = blk < ipw;
+        double *S0 = ms + (live ? blk : 0) * lpi * MSLOT;   // an idle block shadows block 0 and never stores
+        const int hi_ = r > c ? r : c, lo_ = r > c ? c : r;
+        const int hxx = mxH + sym(NU + hi_, NU + lo_), hxu_c = mxH + sym(NU + r, 0), hxu_r = mxH + sym(NU + c, 0);
+        double Pm, pcol;
+        {
+            double *sl = S0 + N * MSLOT;
+            Pm = sl[hxx];
+            const double gx = sl[mxg + NU + r];
+            pcol = c == 1 ? gx : 0.0;
+            if (live) {
+                sl[mxP + 4 * r + c] = Pm;
+                if (c == 1) sl[mxp + r] = gx;
+            }
+        }
+        bool ok = true;
+        for (int kk = N - 1; kk >= 0; --kk) {
+            double *sl = S0 + kk * MSLOT;
+            const double Am = sl[mxA + 4 * r + c], Br = sl[mxB + r], bbr = sl[mxbb + r];
+            const double CH = sl[hxx], hxuc = sl[hxu_c], hxur = sl[hxu_r], huu = sl[mxH], gx = sl[mxg + NU + r], gu = sl[mxg];
+            const double Wb = c == 0 ? Br : (c == 1 ? bbr : 0.0);
+            const double CZc = c == 0 ? hxuc : (c == 1 ? gx : 0.0);
+            const double CZr = r == 0 ? hxur : 0.0;
+            const double CB = c == 0 ? huu : (c == 1 ? gu : 0.0);
+            const double X1 = mfma4(Pm, Am, 0.0);
+            const double Y = mfma4(Pm, Wb, pcol);
+            const double Qt = mfma4(Am, X1, CH);
+            const double Zc = mfma4(Am, Y, CZc);
+            const double Zr = mfma4(Y, Am, CZr);
+            const double Zb = mfma4(Br, Y, CB);
+            const double R = quad_bcast<0>(Zb), mvu = quad_bcast<1>(Zb), Sr = quad_bcast<0>(Zc);
+            const bool pin = kk == 0 && qmode;
+            ok = ok && (R > 0.0 || pin);
+            const double Rinv = fast_rcp(R);
+            const double Kr = pin ? 0.0 : Sr * Rinv, kf = pin ? 0.0 : mvu * Rinv;
+            const double pnew = fma(-Kr, mvu, Zc);   // meaningful in column 1
+            pcol = c == 1 ? pnew : 0.0;
+            const double Xb = r == 0 ? Zr : 0.0;
+            const double Xa = pin ? 0.0 : -Xb * Rinv;
+            Pm = mfma4(Xa, Xb, Qt);
+            if (live) {
+                sl[mxP + 4 * r + c] = Pm;
+                if (c == 0) sl[mxK + r] = Kr;
+                if (c == 1) sl[mxp + r] = pnew;
+                if (r == 0 && c == 0) sl[mxkff] = kf, sl[mxLi] = Rinv;
+            }
+        }
+        if (live && r == 0 && c == 0) S0[mxFlag] = ok ? 1.0 : 0.0;
+    }
+    // slot -> stage lane: the factors of this stage
+    MPCRL_DI bool mx_fetch() {
+        const double *sl = ms + (threadIdx.x & 63) * MSLOT;
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) P[sym(i, j)] = sl[mxP + 4 * i + j];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) p[i] = sl[mxp + i];
+        if (!term) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) K[i] = sl[mxK + i];
+            kff[0] = sl[mxkff], Li[0] = sl[mxLi];
+        }
+        return ms[base * MSLOT + mxFlag] != 0.0;
+    }
+    bool mx_dyn_dirty = true;   // A, B changed since they were last published (set by linearize)
+    template <class HF>
+    MPCRL_DI bool mx_backward(HF Hs, const double *g, const double *bb) {
+        mx_publish(Hs, g, bb, mx_dyn_dirty);
+        mx_dyn_dirty = false;
+        wave_lds_sync();
+        mx_factor();
+        wave_lds_sync();
+        return mx_fetch();
     }
 
     // ---- backward sweep over the horizon (serial in k; the lanes of all instances in the wave step together).
@@ -1000,7 +1135,10 @@ struct SmallSolver {
             if constexpr (C::ON)
                 okf = coop_kkt<true>(rt, rb);
             else {
-                okf = backward<true>(Hs, rt, rb);
+                if constexpr (MX)
+                    okf = mx_backward(Hs, rt, rb);
+                else
+                    okf = backward<true>(Hs, rt, rb);
                 forward(rb);
             }
             double okbad = okf ? 0.0 : 1.0;   // reduced together with the predictor's step length below
@@ -1194,7 +1332,11 @@ struct SmallSolver {
 #pragma unroll
             for (int i = 0; i < NW; ++i) rt[i] = (first && i == iu) ? -1.0 : 0.0;
             if (iu == 0) {
-                const bool okf = backward<true>(Hs, rt, zero);
+                bool okf;
+                if constexpr (MX)
+                    okf = mx_backward(Hs, rt, zero);
+                else
+                    okf = backward<true>(Hs, rt, zero);
                 okall = seg_max(okf ? 0.0 : 1.0, k, lpi, base) < 0.5;
             } else
                 backward<false>(Hs, rt, zero);
@@ -1256,6 +1398,8 @@ __global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, con
     if (!valid) inst = a.B - 1;   // dead lanes shadow the last instance and never store
     if (a.perm) inst = a.perm[inst];
     SmallSolver<M> S(sp, k, lpi, base);
+    __shared__ double mx_lds[SmallSolver<M>::MX ? 64 * SmallSolver<M>::MSLOT : 1];
+    S.ms = mx_lds;
     const bool term = S.term, first = S.first;
     S.qmode = a.u0fix != nullptr;
     if (sp.cost_kind == 0)
@@ -1626,6 +1770,8 @@ __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, cons
     if (!valid) inst = a.B - 1;
     if (a.perm) inst = a.perm[inst];
     SmallSolver<M> S(sp, k, lpi, base);
+    __shared__ double mx_lds[SmallSolver<M>::MX ? 64 * SmallSolver<M>::MSLOT : 1];
+    S.ms = mx_lds;
     const bool term = S.term, first = S.first;
     S.qmode = a.u0fix != nullptr;
     if (sp.cost_kind == 0)
