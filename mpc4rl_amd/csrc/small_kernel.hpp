@@ -472,9 +472,16 @@ struct SmallSolver {
     //   K = S / R, kff = mv_u / R, p = mv_x - K mv_u,  P = mfma(-K' (row 0), S' (row 0), Q) = Q - K S'
     // 7 MFMAs (~18 cycles each) + ~40 VALU per step instead of ~300 VALU instructions.
     static constexpr bool MX = (NX == 4 && NU == 1 && !C::ON);
-    static constexpr int mxA = 0, mxB = 16, mxbb = 20, mxg = 24, mxH = 29, mxP = 44, mxK = 60, mxkff = 64, mxLi = 65, mxp = 66,
-                         mxFlag = 70, MSLOT = 71;   // odd stride: the 64 stage lanes hit distinct banks
+    // Slot of one stage (doubles; 16-byte aligned pairs so that one ds_read_b128 brings two operands — LDS instructions, not
+    // bytes, are what the sweep waits for: ~28 cycles each on a lone wavefront):
+    //   [0,32)   (A(r,c), Hxx(r,c) + D_x) pairs at 2 (4 r + c); the sweep overwrites the second member with P_k(r,c)
+    //   [32,48)  per row r: (B[r], Hxu[r]) at 32 + 4 r, (bb[r], g_x[r]) at 34 + 4 r
+    //   [48,56)  per column c: (Huu + D_u | g_u | 0 | 0, Hxu[c]) at 48 + 2 c
+    //   56 K[4], 60 p[4], 64 kff, 65 1/R, 66 ok flag (stage 0's slot), 68/69 write-only dump for lanes with nothing to store
+    static constexpr int mxAH = 0, mxCol = 32, mxRow = 48, mxK = 56, mxp = 60, mxkff = 64, mxLi = 65, mxFlag = 66, mxDump = 68,
+                         MSLOT = 70;   // 64 slots = 35 KB: four single-wave workgroups still fit one CU's LDS
     double *ms = nullptr;   // LDS, 64 slots of MSLOT doubles (one per stage lane)
+    typedef double mx_d2 __attribute__((ext_vector_type(2)));
 
     MPCRL_DI static void wave_lds_sync() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -490,54 +497,60 @@ struct SmallSolver {
         return __hiloint2double(hi, lo);
     }
     MPCRL_DI static double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+    MPCRL_DI static mx_d2 lds_pair(const double *q) { return *(const mx_d2 *)__builtin_assume_aligned(q, 16); }
 
-    // stage lane -> slot: dynamics (only when they changed) and the right-hand side / Hessian + barrier diagonal of this solve
+    // stage lane -> slot: dynamics and cross Hessian (only when they changed), right-hand side and Hessian + barrier diagonal
     template <class HF>
     MPCRL_DI void mx_publish(HF Hs, const double *g, const double *bb, bool dyn) {
         double *sl = ms + (threadIdx.x & 63) * MSLOT;
         if (dyn) {
 #pragma unroll
-            for (int i = 0; i < NX * NX; ++i) sl[mxA + i] = A[i];
+            for (int i = 0; i < NX * NX; ++i) sl[mxAH + 2 * i] = A[i];
 #pragma unroll
-            for (int i = 0; i < NX * NU; ++i) sl[mxB + i] = Bm[i];
+            for (int i = 0; i < NX; ++i) {
+                const double hxu = hscale * Hs(NU + i, 0);
+                sl[mxCol + 4 * i] = Bm[i], sl[mxCol + 4 * i + 1] = hxu, sl[mxRow + 2 * i + 1] = hxu;
+            }
+            sl[mxRow + 4] = 0.0, sl[mxRow + 6] = 0.0;
         }
 #pragma unroll
-        for (int i = 0; i < NX; ++i) sl[mxbb + i] = bb[i];
+        for (int i = 0; i < NX; ++i)
 #pragma unroll
-        for (int i = 0; i < NW; ++i) sl[mxg + i] = g[i];
+            for (int j = 0; j < NX; ++j)
+                sl[mxAH + 2 * (4 * i + j) + 1] = fma(hscale, Hs(NU + (i > j ? i : j), NU + (i > j ? j : i)), i == j ? Dg[NU + i] : 0.0);
 #pragma unroll
-        for (int i = 0; i < NW; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) sl[mxH + sym(i, j)] = fma(hscale, Hs(i, j), i == j ? Dg[i] : 0.0);
+        for (int i = 0; i < NX; ++i) sl[mxCol + 4 * i + 2] = bb[i], sl[mxCol + 4 * i + 3] = g[NU + i];
+        sl[mxRow] = fma(hscale, Hs(0, 0), Dg[0]), sl[mxRow + 2] = g[0];
     }
     // the sweep itself, all lanes in matrix layout
     MPCRL_DI void mx_factor() {
         const int l = threadIdx.x & 63, r = l >> 4, blk = (l >> 2) & 3, c = l & 3;
         const int ipw = 64 / lpi;
         const bool live = blk < ipw;
-        double *S0 = ms + (live ? blk : 0) * lpi * MSLOT;   // an idle block shadows block 0 and never stores
-        const int hi_ = r > c ? r : c, lo_ = r > c ? c : r;
-        const int hxx = mxH + sym(NU + hi_, NU + lo_), hxu_c = mxH + sym(NU + r, 0), hxu_r = mxH + sym(NU + c, 0);
+        double *S0 = ms + (live ? blk : 0) * lpi * MSLOT;   // an idle block shadows block 0 and stores to the dump
+        const int oAH = mxAH + 2 * (4 * r + c), oCol = mxCol + 4 * r + (c == 1 ? 2 : 0), oB = mxCol + 4 * r, oRow = mxRow + 2 * c;
+        const int oPw = live ? oAH + 1 : mxDump;
+        const int oMw = !live ? mxDump + 1 : (c == 0 ? mxK + r : (c == 1 ? mxp + r : (r == 0 ? (c == 2 ? mxkff : mxLi) : mxDump + 1)));
         double Pm, pcol;
         {
-            double *sl = S0 + N * MSLOT;
-            Pm = sl[hxx];
-            const double gx = sl[mxg + NU + r];
-            pcol = c == 1 ? gx : 0.0;
-            if (live) {
-                sl[mxP + 4 * r + c] = Pm;
-                if (c == 1) sl[mxp + r] = gx;
-            }
+            const double *sl = S0 + N * MSLOT;
+            Pm = sl[oAH + 1];
+            pcol = c == 1 ? sl[oCol + 1] : 0.0;   // g_x of the terminal stage
         }
         bool ok = true;
+        // the operands of a stage do not depend on the recursion: those of stage kk - 1 are fetched while stage kk is computed
+        mx_d2 nah, ncp, nrp;
+        double nBr;
+        auto fetch = [&](int kk) {
+            const double *sl = S0 + kk * MSLOT;
+            nah = lds_pair(sl + oAH), ncp = lds_pair(sl + oCol), nrp = lds_pair(sl + oRow), nBr = sl[oB];
+        };
+        fetch(N - 1);
         for (int kk = N - 1; kk >= 0; --kk) {
             double *sl = S0 + kk * MSLOT;
-            const double Am = sl[mxA + 4 * r + c], Br = sl[mxB + r], bbr = sl[mxbb + r];
-            const double CH = sl[hxx], hxuc = sl[hxu_c], hxur = sl[hxu_r], huu = sl[mxH], gx = sl[mxg + NU + r], gu = sl[mxg];
-            const double Wb = c == 0 ? Br : (c == 1 ? bbr : 0.0);
-            const double CZc = c == 0 ? hxuc : (c == 1 ? gx : 0.0);
-            const double CZr = r == 0 ? hxur : 0.0;
-            const double CB = c == 0 ? huu : (c == 1 ? gu : 0.0);
+            const double Am = nah.x, CH = nah.y, Br = nBr;
+            const double Wb = c < 2 ? ncp.x : 0.0, CZc = c < 2 ? ncp.y : 0.0, CB = nrp.x, CZr = r == 0 ? nrp.y : 0.0;
+            fetch(kk > 0 ? kk - 1 : 0);
             const double X1 = mfma4(Pm, Am, 0.0);
             const double Y = mfma4(Pm, Wb, pcol);
             const double Qt = mfma4(Am, X1, CH);
@@ -554,24 +567,20 @@ struct SmallSolver {
             const double Xb = r == 0 ? Zr : 0.0;
             const double Xa = pin ? 0.0 : -Xb * Rinv;
             Pm = mfma4(Xa, Xb, Qt);
-            if (live) {
-                sl[mxP + 4 * r + c] = Pm;
-                if (c == 0) sl[mxK + r] = Kr;
-                if (c == 1) sl[mxp + r] = pnew;
-                if (r == 0 && c == 0) sl[mxkff] = kf, sl[mxLi] = Rinv;
-            }
+            sl[oPw] = Pm;
+            sl[oMw] = c == 0 ? Kr : (c == 1 ? pnew : (c == 2 ? kf : Rinv));
         }
         if (live && r == 0 && c == 0) S0[mxFlag] = ok ? 1.0 : 0.0;
     }
     // slot -> stage lane: the factors of this stage
-    MPCRL_DI bool mx_fetch() {
+    MPCRL_DI bool mx_fetch(const double *g) {
         const double *sl = ms + (threadIdx.x & 63) * MSLOT;
 #pragma unroll
         for (int i = 0; i < NX; ++i)
 #pragma unroll
-            for (int j = 0; j <= i; ++j) P[sym(i, j)] = sl[mxP + 4 * i + j];
+            for (int j = 0; j <= i; ++j) P[sym(i, j)] = sl[mxAH + 2 * (4 * i + j) + 1];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) p[i] = sl[mxp + i];
+        for (int i = 0; i < NX; ++i) p[i] = term ? g[NU + i] : sl[mxp + i];
         if (!term) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) K[i] = sl[mxK + i];
@@ -587,7 +596,7 @@ struct SmallSolver {
         wave_lds_sync();
         mx_factor();
         wave_lds_sync();
-        return mx_fetch();
+        return mx_fetch(g);
     }
 
     // ---- backward sweep over the horizon (serial in k; the lanes of all instances in the wave step together).
@@ -1398,7 +1407,7 @@ __global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, con
     if (!valid) inst = a.B - 1;   // dead lanes shadow the last instance and never store
     if (a.perm) inst = a.perm[inst];
     SmallSolver<M> S(sp, k, lpi, base);
-    __shared__ double mx_lds[SmallSolver<M>::MX ? 64 * SmallSolver<M>::MSLOT : 1];
+    __shared__ __attribute__((aligned(16))) double mx_lds[SmallSolver<M>::MX ? 64 * SmallSolver<M>::MSLOT : 2];
     S.ms = mx_lds;
     const bool term = S.term, first = S.first;
     S.qmode = a.u0fix != nullptr;
@@ -1770,7 +1779,7 @@ __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, cons
     if (!valid) inst = a.B - 1;
     if (a.perm) inst = a.perm[inst];
     SmallSolver<M> S(sp, k, lpi, base);
-    __shared__ double mx_lds[SmallSolver<M>::MX ? 64 * SmallSolver<M>::MSLOT : 1];
+    __shared__ __attribute__((aligned(16))) double mx_lds[SmallSolver<M>::MX ? 64 * SmallSolver<M>::MSLOT : 2];
     S.ms = mx_lds;
     const bool term = S.term, first = S.first;
     S.qmode = a.u0fix != nullptr;
