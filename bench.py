@@ -23,6 +23,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD spec; probe (profiles/microbench/mfma_f64_4x4x4_probe.hip): one v_mfma_f64_4x4x4 (512 flop) per 18 cycles and SIMD
 B_PER_GPU = 4096
 N_THETA = 3             # cartpole model parameters (M, m, l)
 
@@ -214,6 +215,8 @@ def main():
         solves = B * world * args.steps
         bytes_per = algorithmic_bytes_per_solve(ocp.N, ocp.nx, ocp.nu, N_THETA, sens)
         achieved = bytes_per * B / (kern_ms * 1e-3) / 1e9
+        # matrix-core work of the factor sweep: 7 v_mfma_f64_4x4x4 block-products (128 flop each) per stage step and instance
+        mfma_tflops = float(iters[:, 1].sum()) * ocp.N * 7 * 128 / (kern_ms * 1e-3) / 1e12
         out = {
             "metric": "MPC+KKT-sens solves/sec, cartpole N=20 batch=4096" if sens else "MPC solves/sec, cartpole N=20 batch=4096",
             "value": solves / elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -229,7 +232,11 @@ def main():
                 "ipm_iters_max": int(iters[:, 1].max())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B, sens, args.rti),
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_solve": bytes_per},
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_solve": bytes_per,
+                         "mfma_f64": {"achieved": mfma_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": mfma_tflops / FP64_MFMA_PEAK_TFLOPS,
+                                      "note": "the factor sweep is a serial recursion: its MFMAs wait on each other, they do not "
+                                              "fill the pipe (DESIGN.md 4)"}},
         }
         if world == 1 and not args.no_cpu:
             try:
