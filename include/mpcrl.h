@@ -92,6 +92,9 @@ int mpcrl_set_options(mpcrl_handle h, double tol, int max_iter);
 /* Scheduling hint (no effect on results): perm[B] int32 on the device, a permutation of 0..B-1 — slot i of a launch works on
  * instance perm[i], so that instances expected to need similar iteration counts share a wavefront. NULL = identity. */
 int mpcrl_set_order(mpcrl_handle h, const int32_t *perm, void *stream);
+/* Builds that permutation on the device from the initial states themselves (x0: [B, nx] device): the batch ordered along the
+ * coordinate of x0 with the largest spread.  One small kernel; batch <= 8192, else MPCRL_E_ARG (use mpcrl_set_order). */
+int mpcrl_auto_order(mpcrl_handle h, const double *x0, void *stream);
 
 /* Kernel variant (no effect on results).  AUTO = one lane per stage, everything in registers (the default for every model);
  * COOPERATIVE = cartpole N=20 only: a 7-wave workgroup per 16 instances with the Riccati sweeps of all of them on one wave. */

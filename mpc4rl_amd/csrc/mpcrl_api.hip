@@ -14,6 +14,7 @@
 
 #include "large_kernel.hpp"
 #include "reduce_kernel.hpp"
+#include "order_kernel.hpp"
 
 using namespace mpcrl;
 
@@ -257,6 +258,16 @@ int mpcrl_set_order(mpcrl_handle h, const int32_t *perm, void *stream) {
     ON_DEVICE(h->device);
     if (perm) HIP_OK(hipMemcpyAsync(h->perm, perm, (size_t)h->B * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     h->have_perm = perm != nullptr;
+    return 0;
+}
+
+int mpcrl_auto_order(mpcrl_handle h, const double *x0, void *stream) {
+    if (!h || !x0) return MPCRL_E_ARG;
+    if (h->B > ORDER_MAX) return MPCRL_E_ARG;   // larger batches: build the permutation outside and pass it to mpcrl_set_order
+    ON_DEVICE(h->device);
+    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(ORDER_NT), 0, (hipStream_t)stream, x0, h->B, h->nx, h->perm);
+    HIP_OK(hipGetLastError());
+    h->have_perm = true;
     return 0;
 }
 

@@ -253,3 +253,21 @@ def test_cooperative_variant_matches_default(oracle_port):
     r = mpc.solve(x0, sens_v=True, sens_pi=True, cold=True)
     ref = oracle_port.solve(make_cartpole(), x0)
     check(r, ref)
+
+
+def test_auto_order_does_not_change_results():
+    """mpcrl_auto_order (the packing-order kernel) does not change any result: bitwise the same outputs as with the identity order.
+    A wrong permutation (a repeated or missing index) would leave some instance unsolved or solved twice and fail this."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    ocp = cartpole_ocp()
+    B = 1000
+    rng = np.random.default_rng(5)
+    x0 = np.zeros((B, 4))
+    x0[:, 2] = rng.uniform(0.9 * np.pi, 1.1 * np.pi, B)
+    x0[:, 0] = rng.uniform(-0.01, 0.01, B)
+    mpc = MPCBatch(ocp, B)
+    xt = torch.as_tensor(x0, device="cuda")
+    r1 = mpc.solve(xt, sens_v=True, cold=True, reorder=True)
+    mpc.lib.mpcrl_set_order(mpc._h, None, None)
+    r2 = mpc.solve(xt, sens_v=True, cold=True, reorder=False)
+    assert torch.equal(r1.u0, r2.u0) and torch.equal(r1.V, r2.V) and torch.equal(r1.dV_dp, r2.dV_dp)
