@@ -25,6 +25,16 @@
 
 namespace mpcrl {
 
+#ifdef MPCRL_PROFILE_PHASES
+extern __device__ unsigned long long g_phase_ticks[16];
+#define PHW(i) do { unsigned long long n_ = clock64(); phw[i] += n_ - pht; pht = n_; } while (0)
+#define PHW_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_phase_ticks[i_], phw[i_]); } while (0)
+#else
+#define PHW(i)
+#define PHW_FLUSH()
+#endif
+
+
 constexpr int IPM_MAX_ITER = 60;
 constexpr double IPM_TOL_RES = 1e-9, IPM_TOL_MU = 1e-11, IPM_T_MIN = 1e-1, IPM_MU0 = 1.0, IPM_FRAC = 0.995;
 constexpr double NO_BOUND = 1e29;
@@ -160,6 +170,9 @@ struct SmallSolver {
     // Riccati factors of this stage
     double K[NU * NX], Li[NLK], kff[NU], P[NPK], p[NX];
     double rg[NW], rb[NX], rt[NW], Dg[NW];
+#ifdef MPCRL_PROFILE_PHASES
+    unsigned long long phw[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pht = 0;
+#endif
     double hscale = 1.0;   // multiplies the Hs accessor of the Riccati stage (c_k for the SQP Hessian, 1 for the exact one)
 
     MPCRL_DI SmallSolver(const SmallSpec &sp_, int k_, int lpi_, int base_)
@@ -220,7 +233,10 @@ struct SmallSolver {
     // ---- linearise the dynamics leaving this stage and the stage cost; returns c_k * l_k ---------
     MPCRL_DI double linearize(const double *xnext) {
         mx_dyn_dirty = true;
-        if (!term) {
+        {
+            // The terminal lane has no dynamics (A = B = 0, r = 0).  It runs the same code and the results are SELECTED: with an
+            // if/else the optimiser sinks the two branches' stores into one block through pointer phis, which keeps part of A, B,
+            // r in scratch memory for the whole kernel (a global-memory round trip at every use).
             Jet1<NW> jx[NX], ju[NU], jt[NTD], jn[NX];
 #pragma unroll
             for (int i = 0; i < NU; ++i) ju[i] = Jet1<NW>(u[i]), ju[i].d[i] = 1.0;
@@ -231,19 +247,12 @@ struct SmallSolver {
             disc_map<M, Jet1<NW>>(jx, ju, jt, jn, sp.h, sp.rk_steps);
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
-                r[i] = jn[i].v - xnext[i];
+                r[i] = term ? 0.0 : jn[i].v - xnext[i];
 #pragma unroll
-                for (int j = 0; j < NU; ++j) Bset(i * NU + j, jn[i].d[j]);
+                for (int j = 0; j < NU; ++j) Bset(i * NU + j, term ? 0.0 : jn[i].d[j]);
 #pragma unroll
-                for (int j = 0; j < NX; ++j) Aset(i * NX + j, jn[i].d[NU + j]);
+                for (int j = 0; j < NX; ++j) Aset(i * NX + j, term ? 0.0 : jn[i].d[NU + j]);
             }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) r[i] = 0.0;
-#pragma unroll
-            for (int i = 0; i < NX * NX; ++i) Aset(i, 0.0);
-#pragma unroll
-            for (int i = 0; i < NX * NU; ++i) Bset(i, 0.0);
         }
         double val = M::cost_grad(term, k, x, u, sp, thc, q);
 #pragma unroll
@@ -481,6 +490,24 @@ struct SmallSolver {
     static constexpr int mxAH = 0, mxCol = 32, mxRow = 48, mxK = 56, mxp = 60, mxkff = 64, mxLi = 65, mxFlag = 66, mxDump = 68,
                          MSLOT = 70;   // 64 slots = 35 KB: four single-wave workgroups still fit one CU's LDS
     double *ms = nullptr;   // LDS, 64 slots of MSLOT doubles (one per stage lane)
+    // LDS table of the (unscaled) stage-cost Hessian, [non-terminal | terminal] x packed lower triangle.  The Hessian entries are
+    // kernel arguments; which set a lane needs depends on its stage, and a lane-dependent offset into kernel arguments makes the
+    // compiler copy them to scratch and index that (a global-memory round trip per entry and use).  An LDS read is ~10x cheaper.
+    static constexpr int NHT = NW * (NW + 1) / 2;
+    const double *htab = nullptr;
+    MPCRL_DI void fill_htab(double *tab) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) tab[sym(i, j)] = M::hess(false, i, j, sp, thc), tab[NHT + sym(i, j)] = M::hess(true, i, j, sp, thc);
+        htab = tab;
+    }
+    MPCRL_DI double hess_of_stage(int i, int j) const {
+        if constexpr (C::ON)
+            return M::hess(term, i, j, sp, thc);
+        else
+            return htab[(term ? NHT : 0) + (i >= j ? sym(i, j) : sym(j, i))];
+    }
     typedef double mx_d2 __attribute__((ext_vector_type(2)));
 
     MPCRL_DI static void wave_lds_sync() {
@@ -1022,7 +1049,7 @@ struct SmallSolver {
     // act: this instance takes part.  Returns true when converged; n_it counts iterations of this instance.
     // warm_mu > 0: start from the rows and multipliers of the previous QP, every complementarity product raised to >= warm_mu.
     MPCRL_DI bool qp_solve(bool act, const double *x0, const double *u0f, int &n_it, double warm_mu, double tol_res, double tol_mu) {
-        auto Hs = [&](int i, int j) { return M::hess(term, i, j, sp, thc); };
+        auto Hs = [&](int i, int j) { return hess_of_stage(i, j); };
         hscale = ck;
         const bool warm = warm_mu > 0.0;
         if (act) {
@@ -1074,6 +1101,7 @@ struct SmallSolver {
             }
         }
         const double n_rows = seg_sum(cnt, k, lpi, base);
+        PHW(11);
         bool qlive = act, ok = false;
         for (int it = 0;; ++it) {
             // ---- residuals
@@ -1094,6 +1122,7 @@ struct SmallSolver {
                 rb[i] = a;
                 rloc = fmax(rloc, fabs(a));
             }
+            PHW(12);
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 rg[i] = 0.0;
@@ -1121,7 +1150,9 @@ struct SmallSolver {
                     }
                 }
             }
+            PHW(13);
             seg_reduce<1, 1>(&rloc, &muloc, k, lpi, base);
+            PHW(14);
             const double rinf = rloc;
             const double mu = n_rows > 0.0 ? muloc / n_rows : 0.0;
             if (qlive) {
@@ -1132,6 +1163,7 @@ struct SmallSolver {
             }
             if (!any_lane(qlive)) break;
             if (qlive) ++n_it;
+            PHW(0);
             // ---- predictor
             double eaff[NW];
 #pragma unroll
@@ -1141,6 +1173,7 @@ struct SmallSolver {
                 rt[i] = rg[i] + eaff[i];
             }
             bool okf;
+            PHW(1);
             if constexpr (C::ON)
                 okf = coop_kkt<true>(rt, rb);
             else {
@@ -1148,7 +1181,9 @@ struct SmallSolver {
                     okf = mx_backward(Hs, rt, rb);
                 else
                     okf = backward<true>(Hs, rt, rb);
+                PHW(2);
                 forward(rb);
+                PHW(3);
             }
             double okbad = okf ? 0.0 : 1.0;   // reduced together with the predictor's step length below
             double rmax = 1.0, muaff = 0.0;   // rmax = 1 / (step to the boundary), at least 1
@@ -1192,6 +1227,7 @@ struct SmallSolver {
             const double mu_aff = n_rows > 0.0 ? seg_sum(muaff, k, lpi, base) / n_rows : 0.0;
             const double ratio = mu > 0.0 ? mu_aff / mu : 0.0;
             const double smu = ratio * ratio * ratio * mu;
+            PHW(4);
             // ---- corrector (same factorisation, vector sweep only)
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
@@ -1203,8 +1239,11 @@ struct SmallSolver {
             if constexpr (C::ON)
                 coop_kkt<false>(rt, rb);
             else {
+                PHW(5);
                 backward<false>(Hs, rt, rb);
+                PHW(6);
                 forward(rb);
+                PHW(7);
             }
             rmax = 1.0;
 #pragma unroll
@@ -1246,6 +1285,7 @@ struct SmallSolver {
 #pragma unroll
                 for (int i = 0; i < NU; ++i) du[i] = fma(alpha, Du[i], du[i]);
             }
+            PHW(8);
         }
         return ok;
     }
@@ -1296,7 +1336,7 @@ struct SmallSolver {
 #pragma unroll
         for (int i = 0; i < NW; ++i)
 #pragma unroll
-            for (int j = 0; j <= i; ++j) Hx[sym(i, j)] = ck * M::hess(term, i, j, sp, thc);
+            for (int j = 0; j <= i; ++j) Hx[sym(i, j)] = ck * hess_of_stage(i, j);
         if (!term) {
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
@@ -1409,6 +1449,9 @@ __global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, con
     SmallSolver<M> S(sp, k, lpi, base);
     __shared__ __attribute__((aligned(16))) double mx_lds[SmallSolver<M>::MX ? 64 * SmallSolver<M>::MSLOT : 2];
     S.ms = mx_lds;
+    __shared__ double h_lds[2 * SmallSolver<M>::NHT];
+    S.fill_htab(h_lds);
+    SmallSolver<M>::wave_lds_sync();
     const bool term = S.term, first = S.first;
     S.qmode = a.u0fix != nullptr;
     if (sp.cost_kind == 0)
@@ -1491,11 +1534,17 @@ __global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, con
         double xn[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) xn[i] = lane_dn(S.x[i]), nun[i] = lane_dn(S.nu_[i]);
+#ifdef MPCRL_PROFILE_PHASES
+        { unsigned long long n_ = clock64(); if (S.pht) S.phw[10] += n_ - S.pht; S.pht = n_; }
+#endif
         const double cl = S.linearize(xn);
         double rl[4];
         S.nlp_res_local(nun, x0, u0f, rl);
         double res[4] = {rl[0], rl[1], rl[2], rl[3]}, cost = cl;
         seg_reduce<4, 1>(res, &cost, k, lpi, base);
+#ifdef MPCRL_PROFILE_PHASES
+        { unsigned long long n_ = clock64(); S.phw[9] += n_ - S.pht; S.pht = n_; }
+#endif
         const double rmax = fmax(fmax(res[0], res[1]), fmax(res[2], res[3]));
         if (live) {
             Vout = cost, n_sqp = it;
@@ -1533,6 +1582,9 @@ __global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, con
             for (int i = 0; i < NU; ++i) S.u[i] += S.du[i];
         }
     }
+#ifdef MPCRL_PROFILE_PHASES
+    if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_phase_ticks[i_], S.phw[i_]);
+#endif
     // ---- results
     if (valid && first) {
 #pragma unroll
@@ -1781,6 +1833,9 @@ __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, cons
     SmallSolver<M> S(sp, k, lpi, base);
     __shared__ __attribute__((aligned(16))) double mx_lds[SmallSolver<M>::MX ? 64 * SmallSolver<M>::MSLOT : 2];
     S.ms = mx_lds;
+    __shared__ double h_lds[2 * SmallSolver<M>::NHT];
+    S.fill_htab(h_lds);
+    SmallSolver<M>::wave_lds_sync();
     const bool term = S.term, first = S.first;
     S.qmode = a.u0fix != nullptr;
     if (sp.cost_kind == 0)
