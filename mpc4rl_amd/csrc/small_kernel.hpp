@@ -502,11 +502,16 @@ struct SmallSolver {
             for (int j = 0; j <= i; ++j) tab[sym(i, j)] = M::hess(false, i, j, sp, thc), tab[NHT + sym(i, j)] = M::hess(true, i, j, sp, thc);
         htab = tab;
     }
+    double Hc[NHT];   // this lane's set, in registers
     MPCRL_DI double hess_of_stage(int i, int j) const {
         if constexpr (C::ON)
             return M::hess(term, i, j, sp, thc);
         else
-            return htab[(term ? NHT : 0) + (i >= j ? sym(i, j) : sym(j, i))];
+            return Hc[i >= j ? sym(i, j) : sym(j, i)];
+    }
+    MPCRL_DI void load_hc() {
+#pragma unroll
+        for (int e = 0; e < NHT; ++e) Hc[e] = htab[(term ? NHT : 0) + e];
     }
     typedef double mx_d2 __attribute__((ext_vector_type(2)));
 
@@ -1452,6 +1457,7 @@ __global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, con
     __shared__ double h_lds[2 * SmallSolver<M>::NHT];
     S.fill_htab(h_lds);
     SmallSolver<M>::wave_lds_sync();
+    S.load_hc();
     const bool term = S.term, first = S.first;
     S.qmode = a.u0fix != nullptr;
     if (sp.cost_kind == 0)
@@ -1836,6 +1842,7 @@ __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, cons
     __shared__ double h_lds[2 * SmallSolver<M>::NHT];
     S.fill_htab(h_lds);
     SmallSolver<M>::wave_lds_sync();
+    S.load_hc();
     const bool term = S.term, first = S.first;
     S.qmode = a.u0fix != nullptr;
     if (sp.cost_kind == 0)
