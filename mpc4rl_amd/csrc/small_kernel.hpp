@@ -626,9 +626,13 @@ struct SmallSolver {
         mx_publish(Hs, g, bb, mx_dyn_dirty);
         mx_dyn_dirty = false;
         wave_lds_sync();
+        PHW(12);
         mx_factor();
         wave_lds_sync();
-        return mx_fetch(g);
+        PHW(13);
+        const bool okf_ = mx_fetch(g);
+        PHW(14);
+        return okf_;
     }
 
     // ---- backward sweep over the horizon (serial in k; the lanes of all instances in the wave step together).
@@ -1127,7 +1131,6 @@ struct SmallSolver {
                 rb[i] = a;
                 rloc = fmax(rloc, fabs(a));
             }
-            PHW(12);
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 rg[i] = 0.0;
@@ -1155,9 +1158,7 @@ struct SmallSolver {
                     }
                 }
             }
-            PHW(13);
             seg_reduce<1, 1>(&rloc, &muloc, k, lpi, base);
-            PHW(14);
             const double rinf = rloc;
             const double mu = n_rows > 0.0 ? muloc / n_rows : 0.0;
             if (qlive) {
