@@ -1442,7 +1442,7 @@ struct SmallSolver {
 // kernel: floor(64/(N+1)) instances per 64-lane workgroup
 // =====================================================================================================
 template <class M>
-__global__ void __launch_bounds__(64) small_solve_kernel(const SmallSpec sp, const SmallArgs a) {
+__global__ void __launch_bounds__(64, M::DISCRETE ? 2 : 1) small_solve_kernel(const SmallSpec sp, const SmallArgs a) {
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NP = M::NP, NTD = M::NTD, NTC = M::NTC;
     constexpr bool SOFT = M::HAS_SOFT;
     const int lane = threadIdx.x;
