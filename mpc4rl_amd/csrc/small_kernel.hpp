@@ -42,7 +42,7 @@ constexpr double NO_BOUND = 1e29;
 constexpr double IPM_WARM_C = 1e-4, IPM_WARM_MIN = 1e-10, IPM_WARM_MAX = 1e-2;
 // inexact SQP: QP tolerances follow the NLP residual r (tol_res = clamp(C r^2, TOL_RES, CAP), tol_mu = clamp(C r^2 / 100, TOL_MU, CAP / 10));
 // convergence is only declared after a QP solved to the tight tolerances   
-constexpr double IPM_ADAPT_C = 1e-1, IPM_ADAPT_CAP = 1e-6;
+constexpr double IPM_ADAPT_C = 1e1, IPM_ADAPT_CAP = 1e-2;
 
 struct SmallArgs {
     int B;                 // instances

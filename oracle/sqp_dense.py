@@ -44,7 +44,7 @@ IPM_FRAC = 0.995        # fraction to the boundary
 IPM_WARM_C, IPM_WARM_MIN, IPM_WARM_MAX = 1e-4, 1e-10, 1e-2
 # inexact SQP: the QP tolerances follow the NLP residual r, tol_res = clamp(C r^2, TOL_RES, CAP), tol_mu = clamp(C r^2 / 100, TOL_MU, CAP / 10);
 # convergence is only declared after a QP that was solved to the tight tolerances
-IPM_ADAPT_C, IPM_ADAPT_CAP = 1e-1, 1e-6
+IPM_ADAPT_C, IPM_ADAPT_CAP = 1e1, 1e-2
 
 
 @dataclass

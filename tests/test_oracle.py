@@ -92,8 +92,9 @@ def test_dense_python_vs_port_cartpole(oracle_port):
     assert np.abs(mr.R).max() < 1e-6                          # assert_kkt_residual
     r = oracle_port.solve(P, x0)
     assert abs(r.sqp_iter[0] - sol.sqp_iter) <= 1 and abs(r.ipm_iter[0] - sol.ipm_iter) <= 3
-    assert rel(r.X[0], sol.x) < 1e-8 and rel(r.U[0], sol.u) < 1e-8 and rel(r.PI[0], sol.pi) < 1e-8
-    assert rel(r.dV[0], mr.dL_dp[0]) < 1e-10 and rel(r.dpi[0], mr.dpi_dp) < 1e-6
+    # both stop at an NLP residual < 1e-6 after inexactly solved intermediate QPs: the iterates agree to the parity bar (1e-6), not to rounding
+    assert rel(r.X[0], sol.x) < 1e-6 and rel(r.U[0], sol.u) < 1e-6 and rel(r.PI[0], sol.pi) < 1e-6
+    assert rel(r.dV[0], mr.dL_dp[0]) < 1e-6 and rel(r.dpi[0], mr.dpi_dp) < 1e-6
 
 
 def test_value_gradient_vs_finite_differences_linear(oracle_port):
