@@ -1070,9 +1070,9 @@ struct SmallSolver {
         auto recentre = [&](double &l, double &tt) {
             if (l * tt < warm_mu) {
                 if (l >= tt)
-                    tt = warm_mu / l;
+                    tt = warm_mu * fast_rcp(l);
                 else
-                    l = warm_mu / tt;
+                    l = warm_mu * fast_rcp(tt);
             }
         };
         double cnt = 0.0;
@@ -1104,7 +1104,7 @@ struct SmallSolver {
                         lam[sd][i] = l, t[sd][i] = tt;
                     } else {
                         t[sd][i] = fmax(sl, IPM_T_MIN);
-                        lam[sd][i] = IPM_MU0 / t[sd][i];
+                        lam[sd][i] = IPM_MU0 * fast_rcp(t[sd][i]);
                     }
                 }
             }
