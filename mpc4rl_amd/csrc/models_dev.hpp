@@ -54,6 +54,16 @@ struct CartpoleDev {
         f[2] = x[3];
         f[3] = thdd;
     }
+    // Structure of the discrete map: the cart position x0 does not enter the ODE and the cart velocity x1 enters it only through
+    // d(x0)/dt = x1, so for RK4 with any step the columns of A for x0 and x1 are e_0 and [T, 1, 0, 0]' (T = step length) exactly.
+    // Only u, theta, theta_dot are carried as jet directions.
+    static constexpr int NLD = 3;
+    MPCRL_DI static constexpr int lin_coord(int d) { return d == 0 ? 0 : d + 2; }   // stage-vector coordinate (v = [u; x]) of direction d
+    template <class F>
+    MPCRL_DI static void lin_trivial(double T, F set) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) set(i, 0, i == 0 ? 1.0 : 0.0), set(i, 1, i == 0 ? T : (i == 1 ? 1.0 : 0.0));
+    }
     MPCRL_DI static int yi(int i) { return i < NU ? NX + i : i - NU; }   // v index -> y index
     // symmetrised weight between stage-vector coordinates i, j
     MPCRL_DI static double hess(bool term, int i, int j, const SmallSpec &sp, const double *) {
@@ -91,6 +101,10 @@ struct LinearDev {
     static constexpr bool DISCRETE = true, HAS_SOFT = true;
     MPCRL_DI static int td_index(int i) { return i; }
     MPCRL_DI static int tc_index(int i) { return 8 + i; }   // V_0, f_0, f_1, f_2
+    static constexpr int NLD = NX + NU;
+    MPCRL_DI static constexpr int lin_coord(int d) { return d; }
+    template <class F>
+    MPCRL_DI static void lin_trivial(double, F) {}
     // consts: P (2x2 row-major)
     template <class S>
     MPCRL_DI static void ode(const S *x, const S *u, const S *th, S *f) {

@@ -237,21 +237,32 @@ struct SmallSolver {
             // The terminal lane has no dynamics (A = B = 0, r = 0).  It runs the same code and the results are SELECTED: with an
             // if/else the optimiser sinks the two branches' stores into one block through pointer phis, which keeps part of A, B,
             // r in scratch memory for the whole kernel (a global-memory round trip at every use).
-            Jet1<NW> jx[NX], ju[NU], jt[NTD], jn[NX];
+            constexpr int ND = M::NLD;   // jet directions: the coordinates of v = [u; x] whose columns are not known in closed form
+            Jet1<ND> jx[NX], ju[NU], jt[NTD], jn[NX];
 #pragma unroll
-            for (int i = 0; i < NU; ++i) ju[i] = Jet1<NW>(u[i]), ju[i].d[i] = 1.0;
+            for (int i = 0; i < NU; ++i) ju[i] = Jet1<ND>(u[i]);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) jx[i] = Jet1<NW>(x[i]), jx[i].d[NU + i] = 1.0;
+            for (int i = 0; i < NX; ++i) jx[i] = Jet1<ND>(x[i]);
 #pragma unroll
-            for (int i = 0; i < NTD; ++i) jt[i] = Jet1<NW>(thd[i]);
-            disc_map<M, Jet1<NW>>(jx, ju, jt, jn, sp.h, sp.rk_steps);
+            for (int d = 0; d < ND; ++d) {
+                const int c = M::lin_coord(d);
+                if (c < NU) ju[c < NU ? c : 0].d[d] = 1.0; else jx[c >= NU ? c - NU : 0].d[d] = 1.0;
+            }
+#pragma unroll
+            for (int i = 0; i < NTD; ++i) jt[i] = Jet1<ND>(thd[i]);
+            disc_map<M, Jet1<ND>>(jx, ju, jt, jn, sp.h, sp.rk_steps);
+            M::lin_trivial(sp.h * sp.rk_steps, [&](int i, int j, double v) { Aset(i * NX + j, term ? 0.0 : v); });
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 r[i] = term ? 0.0 : jn[i].v - xnext[i];
 #pragma unroll
-                for (int j = 0; j < NU; ++j) Bset(i * NU + j, term ? 0.0 : jn[i].d[j]);
-#pragma unroll
-                for (int j = 0; j < NX; ++j) Aset(i * NX + j, term ? 0.0 : jn[i].d[NU + j]);
+                for (int d = 0; d < ND; ++d) {
+                    const int c = M::lin_coord(d);
+                    if (c < NU)
+                        Bset(i * NU + (c < NU ? c : 0), term ? 0.0 : jn[i].d[d]);
+                    else
+                        Aset(i * NX + (c >= NU ? c - NU : 0), term ? 0.0 : jn[i].d[d]);
+                }
             }
         }
         double val = M::cost_grad(term, k, x, u, sp, thc, q);
