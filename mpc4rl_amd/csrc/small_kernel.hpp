@@ -1355,26 +1355,34 @@ struct SmallSolver {
 #pragma unroll
             for (int j = 0; j <= i; ++j) Hx[sym(i, j)] = ck * hess_of_stage(i, j);
         if (!term) {
+            // second derivatives of F vanish along the coordinates whose Jacobian columns are constant (M::lin_coord lists the others)
+            constexpr int ND = M::NLD;
 #pragma unroll
-            for (int j = 0; j < NW; ++j) {
-                Jet2<NW> jx[NX], ju[NU], jt[NTD], jn[NX];
+            for (int dj = 0; dj < ND; ++dj) {
+                const int cj = M::lin_coord(dj);
+                Jet2<ND> jx[NX], ju[NU], jt[NTD], jn[NX];
 #pragma unroll
-                for (int i = 0; i < NU; ++i) ju[i] = Jet2<NW>(u[i]), ju[i].g[i] = 1.0;
+                for (int i = 0; i < NU; ++i) ju[i] = Jet2<ND>(u[i]);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) jx[i] = Jet2<NW>(x[i]), jx[i].g[NU + i] = 1.0;
+                for (int i = 0; i < NX; ++i) jx[i] = Jet2<ND>(x[i]);
 #pragma unroll
-                for (int i = 0; i < NTD; ++i) jt[i] = Jet2<NW>(thd[i]);
-                if (j < NU)
-                    ju[j < NU ? j : 0].e = 1.0;
+                for (int d = 0; d < ND; ++d) {
+                    const int c = M::lin_coord(d);
+                    if (c < NU) ju[c < NU ? c : 0].g[d] = 1.0; else jx[c >= NU ? c - NU : 0].g[d] = 1.0;
+                }
+#pragma unroll
+                for (int i = 0; i < NTD; ++i) jt[i] = Jet2<ND>(thd[i]);
+                if (cj < NU)
+                    ju[cj < NU ? cj : 0].e = 1.0;
                 else
-                    jx[j >= NU ? j - NU : 0].e = 1.0;
-                disc_map<M, Jet2<NW>>(jx, ju, jt, jn, sp.h, sp.rk_steps);
+                    jx[cj >= NU ? cj - NU : 0].e = 1.0;
+                disc_map<M, Jet2<ND>>(jx, ju, jt, jn, sp.h, sp.rk_steps);
 #pragma unroll
-                for (int i = j; i < NW; ++i) {
+                for (int di = dj; di < ND; ++di) {
                     double a = 0.0;
 #pragma unroll
-                    for (int m = 0; m < NX; ++m) a = fma(nun[m], jn[m].m[i], a);
-                    Hx[sym(i, j)] += a;
+                    for (int m = 0; m < NX; ++m) a = fma(nun[m], jn[m].m[di], a);
+                    Hx[sym(M::lin_coord(di), cj)] += a;
                 }
             }
         }
