@@ -12,14 +12,6 @@
 
 namespace mpcrl {
 
-// 1/x from the hardware seed plus two Newton steps (~1 ulp, no IEEE range/denormal fix-up: ~6 instructions instead of ~30).
-// The model denominators (masses, lengths, norms of link vectors) are normal numbers far from the range limits.
-__device__ __forceinline__ double jet_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return fma(fma(-x, r, 1.0), r, r);
-}
-
 #define MPCRL_DI __device__ __forceinline__
 
 template <int N>
@@ -60,7 +52,7 @@ MPCRL_DI Jet1<N> operator*(const Jet1<N> &a, const Jet1<N> &b) {
 template <int N>
 MPCRL_DI Jet1<N> operator/(const Jet1<N> &a, const Jet1<N> &b) {
     Jet1<N> r;
-    const double inv = jet_rcp(b.v);
+    const double inv = 1.0 / b.v;
     r.v = a.v * inv;
 #pragma unroll
     for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
@@ -154,7 +146,7 @@ MPCRL_DI Jet2<N> operator*(const Jet2<N> &a, const Jet2<N> &b) {
 template <int N>
 MPCRL_DI Jet2<N> jrecip(const Jet2<N> &b) {
     Jet2<N> r;
-    const double i1 = jet_rcp(b.v), i2 = i1 * i1, i3 = 2.0 * i2 * i1;
+    const double i1 = 1.0 / b.v, i2 = i1 * i1, i3 = 2.0 * i2 * i1;
     r.v = i1;
     r.e = -b.e * i2;
 #pragma unroll
