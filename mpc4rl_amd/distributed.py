@@ -22,11 +22,12 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def allreduce_weighted_grad(grad: torch.Tensor, weight: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
-                            deterministic: bool = False) -> Tuple[torch.Tensor, torch.Tensor, int]:
+                            deterministic: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """grad [b, n_theta] (e.g. dQ/dp rows), weight [b] (e.g. lr * td error) of the LOCAL shard.
 
     Returns (sum_i w_i g_i over ALL ranks [n_theta], sum_i w_i, total count) with a single all-reduce of
-    n_theta + 2 doubles.  ``deterministic=True`` uses all-gather + fixed-order summation instead so the result is
+    n_theta + 2 doubles; all three are device tensors (no host synchronisation: the caller's next launches queue up
+    behind the collective instead of waiting for it).  ``deterministic=True`` uses all-gather + fixed-order summation instead so the result is
     bitwise independent of the reduction tree."""
     g = grad.to(torch.float64)
     w = weight.to(torch.float64).reshape(-1)
@@ -54,11 +55,11 @@ def allreduce_weighted_grad(grad: torch.Tensor, weight: torch.Tensor, group: Opt
             buf = torch.stack(parts).sum(0)
         else:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    return buf[:n_theta], buf[n_theta], int(round(float(buf[n_theta + 1].item())))
+    return buf[:n_theta], buf[n_theta], buf[n_theta + 1]
 
 
 def mean_update(grad: torch.Tensor, weight: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
                 deterministic: bool = False) -> torch.Tensor:
     """``mean_i(w_i * g_i)`` over all instances on all ranks — the parameter step of the Q-learning example."""
     s, _, n = allreduce_weighted_grad(grad, weight, group, deterministic)
-    return s / max(n, 1)
+    return s / torch.clamp(n, min=1.0)

@@ -26,7 +26,7 @@ def _worker(rank, world, port, grads, weights, out):
     s, ws, n = allreduce_weighted_grad(g, w)
     s_det, _, _ = allreduce_weighted_grad(g, w, deterministic=True)
     step = mean_update(g, w)
-    out[rank] = (s.numpy().copy(), float(ws), n, s_det.numpy().copy(), step.numpy().copy())
+    out[rank] = (s.numpy().copy(), float(ws), int(round(float(n))), s_det.numpy().copy(), step.numpy().copy())
     dist.barrier()
     dist.destroy_process_group()
 
