@@ -570,7 +570,7 @@ struct LargeSolver {
                     const double ratio = mu > 0.0 ? mu_aff / mu : 0.0;
                     sigma_mu = ratio * ratio * ratio * mu;
                 } else
-                    alpha = fmin(1.0, IPM_FRAC * amax);
+                    alpha = fmin(1.0, fmax(IPM_FRAC, 1.0 - mu) * amax);   // fraction to the boundary -> 1 as mu -> 0
             }
             PH(5);
             if (fail) break;

@@ -1275,7 +1275,7 @@ struct SmallSolver {
                     rmax = fmax(rmax, rat);
                 }
             }
-            const double alpha = fmin(1.0, IPM_FRAC / seg_max(rmax, k, lpi, base));
+            const double alpha = fmin(1.0, (M::DISCRETE ? IPM_FRAC : fmax(IPM_FRAC, 1.0 - mu)) / seg_max(rmax, k, lpi, base));   // fraction to the boundary -> 1 as mu -> 0 (LQ model: fixed)
             if (qlive) {
                 // rows of (i, sd) only read their own side's state, so they can be advanced in place
 #pragma unroll

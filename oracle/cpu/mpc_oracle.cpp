@@ -468,7 +468,7 @@ struct Solver {
                     const double ratio = (sum / n_rows) / mu;
                     sigma = ratio * ratio * ratio;
                 } else
-                    alpha = std::min(1.0, IPM_FRAC * amax);
+                    alpha = std::min(1.0, (Mdl::DISCRETE ? IPM_FRAC : std::max(IPM_FRAC, 1.0 - mu)) * amax);   // fraction to the boundary -> 1 as mu -> 0 (LQ model: fixed)
             }
             for (size_t i = 0; i < dx.size(); ++i) dx[i] += alpha * Dx[i];
             for (size_t i = 0; i < du.size(); ++i) du[i] += alpha * Du[i];

@@ -37,7 +37,7 @@ IPM_TOL_RES = 1e-9      # inf-norm of stationarity / equality / inequality resid
 IPM_TOL_MU = 1e-11      # average complementarity
 IPM_T_MIN = 1e-1        # lower clip of the initial slack
 IPM_MU0 = 1.0           # lambda_0 = mu0 / t_0
-IPM_FRAC = 0.995        # fraction to the boundary
+IPM_FRAC = 0.995        # fraction to the boundary: tau = max(IPM_FRAC, 1 - mu) (nearly full steps once the barrier parameter is small)
 # warm start of QP j >= 1 (and of the first QP of a warm call) from the previous QP's rows and multipliers:
 # every complementarity product is raised to at least mu_w = clamp(IPM_WARM_C * step^2, MIN, MAX), step = inf-norm of
 # the previous primal step (or of the change of the pinned x0 / u0 for a warm call)
@@ -179,7 +179,7 @@ class Linearizer:
         return val, g, H
 
 
-def ipm_dense(H, g, G, b, C, d, v0, warm=None, free=None, tol_res=IPM_TOL_RES, tol_mu=IPM_TOL_MU):
+def ipm_dense(H, g, G, b, C, d, v0, warm=None, free=None, tol_res=IPM_TOL_RES, tol_mu=IPM_TOL_MU, lq=False):
     """Mehrotra predictor-corrector on  min 1/2 v'Hv + g'v  s.t. Gv = b, Cv + t = d, t >= 0.
     warm = (mu_w, lam_prev, t_prev, pi_prev) or None.  free: mask of the variables that are not pinned by an equality
     row of their own (x_0, and u_0 in Q-mode); the stationarity rows of pinned variables only define the multiplier of
@@ -241,7 +241,7 @@ def ipm_dense(H, g, G, b, C, d, v0, warm=None, free=None, tol_res=IPM_TOL_RES, t
         mu_aff = float((lam + a_aff * dlam) @ (t + a_aff * dt)) / mi
         sigma = (mu_aff / mu) ** 3
         dv, dpi, dlam, dt = solve(lam * t + dlam * dt - sigma * mu)
-        a = min(1.0, IPM_FRAC * max_step(dlam, dt))
+        a = min(1.0, (IPM_FRAC if lq else max(IPM_FRAC, 1.0 - mu)) * max_step(dlam, dt))   # fraction to the boundary -> 1 as mu -> 0 (not for LQ problems)
         v = v + a * dv
         pi = pi + a * dpi
         lam = lam + a * dlam
@@ -392,7 +392,7 @@ def solve(prob: Problem, x0, p=None, u0fix=None, gamma=None, warm: Optional[Solu
         free[st.ix(0): st.ix(0) + nx] = False
         if u0fix is not None:
             free[:nu] = False
-        v, piq, lam, t, nit, ok = ipm_dense(H, g, G, b, C, d, v0, wrm, free, tol_res, tol_mu)
+        v, piq, lam, t, nit, ok = ipm_dense(H, g, G, b, C, d, v0, wrm, free, tol_res, tol_mu, lq=bool(P.extra.get("lq", False)))
         stepn = float(np.abs(v[: st.nw]).max())
         ipm_total += nit
         if not ok:
