@@ -39,10 +39,10 @@ constexpr int IPM_MAX_ITER = 60;
 constexpr double IPM_TOL_RES = 1e-9, IPM_TOL_MU = 1e-11, IPM_T_MIN = 1e-1, IPM_MU0 = 1.0, IPM_FRAC = 0.995;
 constexpr double NO_BOUND = 1e29;
 // warm start of the interior point method from the previous QP: mu_w = clamp(C * step^2, MIN, MAX)   
-constexpr double IPM_WARM_C = 1e-4, IPM_WARM_MIN = 1e-10, IPM_WARM_MAX = 1e-2;
+constexpr double IPM_WARM_C = 1e-4, IPM_WARM_MIN = 1e-10, IPM_WARM_MAX = 3e-2;
 // inexact SQP: QP tolerances follow the NLP residual r (tol_res = clamp(C r^2, TOL_RES, CAP), tol_mu = clamp(C r^2 / 100, TOL_MU, CAP / 10));
 // convergence is only declared after a QP solved to the tight tolerances   
-constexpr double IPM_ADAPT_C = 1e1, IPM_ADAPT_CAP = 1e-2;
+constexpr double IPM_ADAPT_C = 1e1, IPM_ADAPT_CAP = 3e-2;
 
 struct SmallArgs {
     int B;                 // instances

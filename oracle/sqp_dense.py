@@ -41,10 +41,10 @@ IPM_FRAC = 0.995        # fraction to the boundary: tau = max(IPM_FRAC, 1 - mu) 
 # warm start of QP j >= 1 (and of the first QP of a warm call) from the previous QP's rows and multipliers:
 # every complementarity product is raised to at least mu_w = clamp(IPM_WARM_C * step^2, MIN, MAX), step = inf-norm of
 # the previous primal step (or of the change of the pinned x0 / u0 for a warm call)
-IPM_WARM_C, IPM_WARM_MIN, IPM_WARM_MAX = 1e-4, 1e-10, 1e-2
+IPM_WARM_C, IPM_WARM_MIN, IPM_WARM_MAX = 1e-4, 1e-10, 3e-2
 # inexact SQP: the QP tolerances follow the NLP residual r, tol_res = clamp(C r^2, TOL_RES, CAP), tol_mu = clamp(C r^2 / 100, TOL_MU, CAP / 10);
 # convergence is only declared after a QP that was solved to the tight tolerances
-IPM_ADAPT_C, IPM_ADAPT_CAP = 1e1, 1e-2
+IPM_ADAPT_C, IPM_ADAPT_CAP = 1e1, 3e-2
 
 
 @dataclass
