@@ -19,7 +19,7 @@
 //   * HBM traffic is the algorithmic minimum: x0 in, iterate in/out, results out.
 //
 // The interior-point iteration (initial point, Mehrotra predictor-corrector, single step length,
-// fraction-to-boundary 0.995, stopping rule) is the one documented in DESIGN.md; its constants are below.
+// fraction to the boundary max(0.995, 1 - mu), stopping rule) is the one documented in DESIGN.md; its constants are below.
 #pragma once
 #include "models_dev.hpp"
 
