@@ -1,7 +1,9 @@
 """bench.py — headline benchmark: MPC + KKT-sensitivity solves per second, cartpole N=20, batch 4096 per GPU.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1 without a launcher: bench.py re-executes itself under
+     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...; under a launcher
+     (WORLD_SIZE set) it is one rank of that job)
 
 One "step" = one pass of the hot path over one batch of synthetic inputs already resident in HBM: 4096
 cartpole OCPs (BASELINE.json config 3: cold-start full SQP to tol 1e-6 + dV/dp + du0*/dp) per GPU, one
@@ -94,6 +96,62 @@ def cpu_baseline(x0_np, sens):
                       f"{float(r.ipm_iter.mean()):.1f}); single thread: 256 instances"}
 
 
+def spawn_command(args, argv, port):
+    """The torchrun line `bench.py --gpus N` re-executes itself under when no launcher set WORLD_SIZE (one rank per GPU)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def maybe_spawn(args, argv):
+    """--gpus N > 1 and not already a rank of a distributed job: become the launcher.  Returns the exit code, or None."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(spawn_command(args, argv, free_port()), env=env)
+
+
+def job_aggregate(elapsed_local, dist_mod, device):
+    """Contract of the driver: the timed region is bracketed by barriers and its length is the MAX over ranks."""
+    if dist_mod is None:
+        return float(elapsed_local)
+    tt = torch.tensor([elapsed_local], dtype=torch.float64, device=device)
+    dist_mod.all_reduce(tt, op=dist_mod.ReduceOp.MAX)
+    return float(tt.item())
+
+
+def dryrun(args):
+    """Launcher / rank plumbing without a GPU (tests/test_bench_ranks.py): gloo rendezvous, barrier-bracketed timed region,
+    MAX over ranks, one JSON line from rank 0.  The step is a no-op, so the line is marked and carries no throughput."""
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3 * (rank + 1))        # uneven ranks: the job time must be the slowest rank's
+    if dist is not None:
+        dist.barrier()
+    elapsed = job_aggregate(time.perf_counter() - t0, dist, torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"metric": "dryrun", "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * elapsed / args.steps, "dryrun": True}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def chain_bench(args):
     """BASELINE config 4: chain_mass n_mass = 5 (nx=21) / 7 (nx=33), N=40, batch 1024, GN-SQP tol 1e-5 + sensitivities.
     x0 = masses on the x axis (examples/chain_mass.py:17-25) + N(0, 1e-2) velocity perturbation, seed 0."""
@@ -152,10 +210,17 @@ def main():
     ap.add_argument("--workload", default="cartpole", choices=["cartpole", "chain5", "chain7"],
                     help="cartpole = the headline metric (default); chain5/chain7 = BASELINE config 4 (not the headline line)")
     args = ap.parse_args()
+    rc = maybe_spawn(args, sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
+    if os.environ.get("MPCRL_BENCH_DRYRUN"):
+        return dryrun(args)
     if args.workload != "cartpole":
         return chain_bench(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus) and not os.environ.get("MPCRL_BENCH_FORCE_DIST"):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -203,10 +268,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = job_aggregate(elapsed, dist, dev)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     status = r.status.cpu().numpy()

@@ -1,0 +1,48 @@
+"""bench.py's launcher and rank plumbing on CPU: `python bench.py --gpus 2` with no launcher in the environment must start
+two ranks itself (torch.distributed.run, 127.0.0.1 rendezvous), time the region as the MAX over ranks and print ONE JSON line
+from rank 0 with n_gpus = the real world size.  The GPU step itself is replaced by a no-op (MPCRL_BENCH_DRYRUN)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(gpus, extra_env=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MPCRL_BENCH_DRYRUN"] = "1"
+    env.update(extra_env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "5", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_2_spawns_two_ranks_and_reports_the_slowest():
+    line = _run(2)
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["dryrun"] is True
+    assert line["ms_per_step"] >= 2.0          # rank 1 sleeps 2 ms per step: MAX over ranks, not rank 0's 1 ms
+
+
+def test_gpus_1_stays_in_process():
+    line = _run(1)
+    assert line["n_gpus"] == 1
+
+
+def test_spawn_command_is_the_drivers_launch_line():
+    sys.path.insert(0, ROOT)
+    import argparse
+    import bench
+    cmd = bench.spawn_command(argparse.Namespace(gpus=4), ["--gpus", "4", "--steps", "3"], 29555)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+
+
+def test_mismatched_launcher_is_refused():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "launcher started 2" in (out.stderr + out.stdout)
