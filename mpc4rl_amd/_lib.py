@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpcrl_hip.so")
+LIB_PATH = os.environ.get("MPCRL_LIB_PATH") or os.path.join(_HERE, "libmpcrl_hip.so")   # the override is for instrumented builds (profiles/microbench)
 
 SENS_V, SENS_PI, RTI, COLD = 1, 2, 4, 8
 MODEL_CARTPOLE, MODEL_LINEAR, MODEL_CHAIN = 0, 1, 2

@@ -1,0 +1,1293 @@
+// chain_kernel.hpp — SQP / Riccati-IPM / adjoint-sensitivity kernels for OCPs whose stage blocks do not fit one lane
+// (chain of masses: nx = 9 / 21 / 33, nu = 3, N = 40; rlmpc/mpc/chain_mass/ocp_utils.py:59-147,195-316).
+//
+// Replaces, for a whole batch at once, what the reference does per instance through
+//   ocp_solver.solve()            rlmpc/mpc/common/mpc.py:42,79,195     (acados SQP + HPIPM, not vendored)
+//   update_nlp(): dL_dp, dpi_dp   rlmpc/mpc/nlp.py:1399-1424            (dense 2385 x 2385 Jacobian + SuperLU, 499 right-hand sides)
+//
+// Mapping on gfx950 (MI355X-first).  The work has two shapes and each gets the launch geometry that suits it:
+//   * DERIVATIVES of the 2-step RK4 map (Jacobians for the SQP, Hessian columns and parameter gradients for the sensitivities)
+//     are independent per (instance, stage, direction): grid-wide kernels with one item per lane, everything in registers
+//     (chain_lin_kernel, chain_sens_ad_kernel, chain_sens_mix_kernel).  They want ~350-500 registers per lane.
+//   * the RICCATI interior-point solve of one QP is a dependency chain over the stages: ONE WAVEFRONT PER OCP INSTANCE, one
+//     wavefront per SIMD (a batch of 1024 instances is exactly one wavefront on each of the chip's 1024 SIMDs).  There is no
+//     workgroup barrier anywhere: lanes of one wavefront exchange data through LDS or through the instance's HBM workspace, and
+//     because the memory operations of a wavefront are performed in order a wavefront-scope fence (a compiler barrier, no
+//     s_waitcnt) is all the ordering needed.  Global stores are fire-and-forget.
+//       - factor sweep: P_{k+1}, [B A]_k, T = P [B A] and M = H + D + [B A]' T of the CURRENT stage live in LDS; the two stage GEMMs
+//         are register-tiled (TI x TJ / TS x TS outputs per lane, operands read as LDS vectors shared by the tile), the operands of
+//         stage k-1 are fetched from HBM while stage k is computed.  Per-stage results (P_k, K_k, L_k and the CLOSED-LOOP matrix
+//         Acl_k = A_k - B_k K_k) stream to HBM: a horizon of factors does not fit on-chip.
+//       - the vector sweeps of the corrector / the extra right-hand sides are pure matrix-vector chains on Acl_k
+//             p_k = (g_x - K' g_u) + Acl_k' (p_{k+1} + P_{k+1} b_k),        dx_{k+1} = Acl_k dx_k + (b_k - B_k kff_k)
+//         with everything that does not sit on the chain (P_{k+1} b_k, kff_k, du_k, the multiplier step) done stage-parallel.
+//   * the SQP loop is a sequence of launches (linearise, QP) x (max_iter + 1); every instance carries an `active` flag in its
+//     workspace and finished instances return at once.  Keeping the two shapes in separate kernels is what keeps both free of
+//     scratch memory: fused, the jets of the derivative code pushed the Riccati loops' operands into scratch, and every scratch
+//     reload is an s_waitcnt vmcnt(0) that also drains the streaming stores.
+// Only hard box bounds are supported here (the chain problem has bounds on u only).
+//
+// The iteration is the one of small_kernel.hpp / DESIGN.md §2 (same constants), so results agree with the oracle to rounding.
+#pragma once
+#include "small_kernel.hpp"
+
+namespace mpcrl {
+
+constexpr int LARGE_MAXNW = 40;
+
+struct LargeSpec {
+    int N, np, cost_kind, rk_steps, max_iter;
+    double dT, gamma, h, tol;
+    double lb0[4], ub0[4];
+    double lb[LARGE_MAXNW], ub[LARGE_MAXNW], lbe[LARGE_MAXNW], ube[LARGE_MAXNW];
+    const double *consts;   // device: x_ss
+};
+
+struct LargeArgs {
+    int B, flags, theta_stride;
+    const int *perm;
+    const double *x0, *u0fix, *theta;
+    double *X, *U, *PI, *BND, *RES;   // iterate (layouts of mpcrl_get_iterate)
+    double *ws;                       // per-instance workspace, ws_stride doubles each
+    size_t ws_stride;
+    double *u0_out, *V, *dV, *dpi;
+    int *status, *iters;
+};
+
+// per-instance workspace layout (doubles)
+template <class M>
+struct LargeLayout {
+    static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD;
+    size_t BA, r, q, dx, du, nuq, Dx, Du, Dnu, rg, rb, rt, Dg, lamw, tw, aff, P, p, K, L, kff, Acl, hb, ccv, cvec, Hex, term, ynu, state, Ydx, Ydu, Ydnu,
+        term2, total;
+    __host__ __device__ explicit LargeLayout(int N) {
+        size_t o = 0;
+        auto take = [&](size_t n) { size_t s = o; o += (n + 1) & ~(size_t)1; return s; };   // every array 16-byte aligned
+        BA = take((size_t)N * NX * NW), r = take((size_t)N * NX), q = take((size_t)(N + 1) * NW);
+        dx = take((size_t)(N + 1) * NX), du = take((size_t)N * NU), nuq = take((size_t)(N + 1) * NX);
+        Dx = take((size_t)(N + 1) * NX), Du = take((size_t)N * NU), Dnu = take((size_t)(N + 1) * NX);
+        rg = take((size_t)(N + 1) * NW), rb = take((size_t)N * NX), rt = take((size_t)(N + 1) * NW), Dg = take((size_t)(N + 1) * NW);
+        lamw = take((size_t)2 * (N + 1) * NW), tw = take((size_t)2 * (N + 1) * NW), aff = take((size_t)2 * (N + 1) * NW);
+        P = take((size_t)(N + 1) * NX * NX), p = take((size_t)(N + 1) * NX), K = take((size_t)N * NU * NX), L = take((size_t)N * NU * NU);
+        kff = take((size_t)N * NU);
+        Acl = take((size_t)N * NX * NX), hb = take((size_t)N * NX), ccv = take((size_t)N * NX), cvec = take((size_t)N * NX);
+        Hex = take((size_t)(N + 1) * NW * NW), term = take((size_t)N * NTD), ynu = take((size_t)(N + 1) * NX);
+        state = take(16);   // ST_* below: the SQP loop's per-instance state between launches
+        Ydx = take((size_t)NU * (N + 1) * NX), Ydu = take((size_t)NU * N * NU), Ydnu = take((size_t)NU * (N + 1) * NX);   // adjoint solutions
+        term2 = take((size_t)NU * N * NTD);
+        total = (o + 7) & ~(size_t)7;
+    }
+};
+
+enum { ST_ACTIVE = 0, ST_IT = 1, ST_NIPM = 2, ST_TIGHT = 3, ST_STEPN = 4, ST_COST = 5, ST_RES = 6, ST_STATUS = 10 };
+
+// An array inside the instance's workspace: one base pointer for all of them (scalar registers) plus a 32-bit offset, so that
+// every access is `global_load/store v, voffset, s[base]` — no 64-bit per-lane address arithmetic to keep live.
+struct WsArr {
+    char *base;
+    unsigned off;   // doubles
+    MPCRL_DI double &operator[](int i) const { return *(double *)(base + ((off + (unsigned)i) << 3)); }
+    MPCRL_DI WsArr operator+(int i) const { return WsArr{base, off + (unsigned)i}; }
+    MPCRL_DI explicit operator bool() const { return base != nullptr; }
+};
+
+// Development aid: -DMPCRL_PROFILE_PHASES accumulates shader-clock ticks of lane 0 per phase, summed over the wavefronts
+// (read through mpcrl_debug_phases; profiles/microbench/chain_phases.py).  Off in the product build.
+#ifdef MPCRL_PROFILE_PHASES
+__device__ unsigned long long g_phase_ticks[16];
+#endif
+
+// Ordering between the lanes of ONE wavefront (LDS and global alike): memory operations of a wavefront are performed in order,
+// so only the compiler has to be kept from moving accesses across this point — no s_waitcnt is emitted.
+MPCRL_DI void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+MPCRL_DI double wave_sum(double v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
+    return v;
+}
+MPCRL_DI double wave_max(double v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = fmax(v, __shfl_xor(v, s));
+    return v;
+}
+
+// tile shapes of the two stage GEMMs: one tile per lane, at most 64 tiles
+template <class M>
+struct ChainCfg {
+    static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU;
+    static constexpr int TI = NX <= 9 ? 2 : (NX <= 21 ? 3 : 4);   // T = P [B A]   : TI x TJ outputs per lane
+    static constexpr int TJ = NX <= 9 ? 3 : (NX <= 21 ? 4 : 6);
+    static constexpr int TS = NX <= 9 ? 2 : (NX <= 21 ? 3 : 4);   // M = [B A]' T  : TS x TS outputs per lane, lower-triangular tile grid
+    static constexpr int NTR = (NX + TI - 1) / TI, NTC = (NW + TJ - 1) / TJ, NMT = (NW + TS - 1) / TS;
+    static constexpr int NTT = NTR * NTC, NMM = NMT * (NMT + 1) / 2;
+    static_assert(NTT <= 64 && NMM <= 64, "one GEMM tile per lane");
+    static_assert(NW % TJ == 0 && NW % TS == 0, "column tiles are full");
+    static constexpr int NBA = (NX * NW + 63) / 64;   // doubles per lane of one [B A] block
+    static constexpr int NAC = (NX * NX + 63) / 64;   // doubles per lane of one nx x nx block
+    // LDS (doubles): P_{k+1} and M share one region (P is dead once T = P [B A] and P b are formed, M once P_k is), [B A], T, vectors
+    static constexpr int oP = 0, oM = 0, oBA = NW * NW, oT = oBA + NX * NW, oVec = oT + NX * NW;
+    static constexpr int oG = oVec, oBB = oG + NW, oDG = oBB + NX + (NX & 1), oPV = oDG + NW, oCC = oPV + NX + (NX & 1), oMV = oCC + NX + (NX & 1),
+                         oK = oMV + NW, oCK = oK + NU * NX + NU + ((NU * NX + NU) & 1), oSV = oCK + 64, oLB = oSV + 2 * (NX + (NX & 1)),
+                         LDS_TOTAL = oLB + 4 * NW + 8;
+    static_assert(LDS_TOTAL * 8 <= 40 * 1024, "four wavefronts per CU");
+    // the vector sweeps stage Acl_k (two buffers) where P / [B A] sit during the factor sweep
+    static constexpr int oA0 = 0, oA1 = NX * NX + (NX & 1);
+    static_assert(2 * (NX * NX + 1) <= oVec, "Acl double buffer fits below the vectors");
+};
+
+// Hessian source of the Riccati factorisation: the SQP uses c_k * (Q, R) from the parameter vector — constant per lane, kept in
+// registers; the sensitivities use the exact Lagrangian Hessian blocks the kernel wrote to the workspace (one tile per stage).
+template <class M>
+struct HessConst {
+    using Cfg = ChainCfg<M>;
+    double h[Cfg::TS][Cfg::TS];     // unscaled, this lane's tile of the [u; x] Hessian
+    const double *th;
+    const double *sck;
+    MPCRL_DI void prefetch(int) {}
+    MPCRL_DI void advance() {}
+    MPCRL_DI double tile(int k, int a, int b) const { return sck[k] * h[a][b]; }
+    MPCRL_DI double term(int N, int i, int j) const { return sck[N] * M::Qs(th, i, j); }
+};
+template <class M>
+struct HessGlobal {
+    using Cfg = ChainCfg<M>;
+    static constexpr int NW = Cfg::NW, NU = Cfg::NU;
+    WsArr Hex;                      // [(N+1), NW, NW]
+    int i0, j0;
+    bool live;
+    double hn[Cfg::TS][Cfg::TS], hc[Cfg::TS][Cfg::TS];
+    MPCRL_DI void prefetch(int k) {
+#pragma unroll
+        for (int a = 0; a < Cfg::TS; ++a)
+#pragma unroll
+            for (int b = 0; b < Cfg::TS; ++b) hn[a][b] = live ? Hex[k * NW * NW + (i0 + a) * NW + j0 + b] : 0.0;
+    }
+    MPCRL_DI void advance() {
+#pragma unroll
+        for (int a = 0; a < Cfg::TS; ++a)
+#pragma unroll
+            for (int b = 0; b < Cfg::TS; ++b) hc[a][b] = hn[a][b];
+    }
+    MPCRL_DI double tile(int, int a, int b) const { return hc[a][b]; }
+    MPCRL_DI double term(int N, int i, int j) const { return Hex[N * NW * NW + (NU + i) * NW + NU + j]; }
+};
+
+template <class M>
+struct ChainSolver {
+    using Cfg = ChainCfg<M>;
+    static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD, NP = M::NP, NT = 64;
+    static constexpr int TI = Cfg::TI, TJ = Cfg::TJ, TS = Cfg::TS;
+    const LargeSpec &sp;
+    const int N, lane;
+    const double *th;   // full parameter vector of this instance
+    bool qmode;
+    // global (per instance)
+    double *X, *U;
+    WsArr NUv;             // NUv[k]: multiplier arriving at stage k, [(N+1)*NX] (index 0 unused)
+    WsArr BA, r, q, dx, du, nuq, Dx, Du, Dnu, rg, rb, rt, Dg, lam, t, aff, P, p, K, L, kff, Acl, hb, ccv, cvec, state;
+    double *lds;
+    // GEMM tiles of this lane
+    int t_i0, t_j0, m_i0, m_j0;
+    bool t_live, m_live, m_diag;
+    // bounded rows: n0 / nm / ne coordinates carry a bound at stage 0 / 1..N-1 / N; coordinate lists in LDS (sidx)
+    int n0, nm, ne, nrows;
+    int *sidx;
+
+    MPCRL_DI ChainSolver(const LargeSpec &s, int lane_) : sp(s), N(s.N), lane(lane_) {}
+
+#ifdef MPCRL_PROFILE_PHASES
+    // per-wavefront tick counters in LDS (no global traffic inside the timed regions), flushed once by ph_flush()
+    unsigned long long ph_t = 0;
+    unsigned long long *ph_lds = nullptr;
+    MPCRL_DI void ph0() { ph_t = clock64(); }
+    MPCRL_DI void ph(int i) {
+        const unsigned long long n_ = clock64();
+        if (lane == 0) ph_lds[i] += n_ - ph_t;
+        ph_t = n_;
+    }
+    MPCRL_DI void ph_init(unsigned long long *b) {
+        ph_lds = b;
+        if (lane < 16) b[lane] = 0;
+        wave_sync();
+    }
+    MPCRL_DI void ph_flush() {
+        wave_sync();
+        if (lane < 16) atomicAdd(&g_phase_ticks[lane], ph_lds[lane]);
+    }
+#else
+    MPCRL_DI void ph0() {}
+    MPCRL_DI void ph(int) {}
+    MPCRL_DI void ph_init(unsigned long long *) {}
+    MPCRL_DI void ph_flush() {}
+#endif
+
+    MPCRL_DI double *sP() const { return lds + Cfg::oP; }
+    MPCRL_DI double *sBA() const { return lds + Cfg::oBA; }
+    MPCRL_DI double *sT() const { return lds + Cfg::oT; }
+    MPCRL_DI double *sM() const { return lds + Cfg::oM; }
+    MPCRL_DI double *sG() const { return lds + Cfg::oG; }
+    MPCRL_DI double *sBB() const { return lds + Cfg::oBB; }
+    MPCRL_DI double *sDG() const { return lds + Cfg::oDG; }
+    MPCRL_DI double *sPV() const { return lds + Cfg::oPV; }
+    MPCRL_DI double *sCC() const { return lds + Cfg::oCC; }
+    MPCRL_DI double *sMV() const { return lds + Cfg::oMV; }
+    MPCRL_DI double *sK() const { return lds + Cfg::oK; }
+    MPCRL_DI double *sCK() const { return lds + Cfg::oCK; }
+    MPCRL_DI double *sSV(int b) const { return lds + Cfg::oSV + b * (NX + (NX & 1)); }
+    MPCRL_DI double *sLB() const { return lds + Cfg::oLB; }          // lb, ub (stages 1..N-1), lbe, ube: NW each; lb0, ub0: 4 each
+    MPCRL_DI double *sA(int b) const { return lds + (b ? Cfg::oA1 : Cfg::oA0); }
+
+    MPCRL_DI double ck(int k) const { return sCK()[k]; }
+    MPCRL_DI double ck_eval(int k) const {
+        if (sp.cost_kind == 0) return k == N ? 1.0 : sp.dT;                                            // nlp.py:1044-1055
+        return k == 0 ? sp.dT : (k == N ? pow(sp.gamma, (double)N) : pow(sp.gamma, (double)k) * sp.dT);   // nlp.py:1083-1091
+    }
+    // bounds out of LDS (a lane-dependent index into kernel arguments would be copied to scratch)
+    MPCRL_DI double lbv(int k, int i) const {
+        if (k == 0) return (i < NU && !qmode) ? sLB()[4 * NW + i] : -1e30;
+        if (k == N) return i >= NU ? sLB()[2 * NW + i] : -1e30;
+        return sLB()[i];
+    }
+    MPCRL_DI double ubv(int k, int i) const {
+        if (k == 0) return (i < NU && !qmode) ? sLB()[4 * NW + 4 + i] : 1e30;
+        if (k == N) return i >= NU ? sLB()[3 * NW + i] : 1e30;
+        return sLB()[NW + i];
+    }
+    MPCRL_DI bool has(int sd, int k, int i) const { return sd ? ubv(k, i) < NO_BOUND : lbv(k, i) > -NO_BOUND; }
+    MPCRL_DI bool fixedc(int k, int i) const { return k == 0 && (i >= NU || qmode); }
+    MPCRL_DI bool skipc(int k, int i) const { return k == N && i < NU; }
+    MPCRL_DI double vc(int k, int i) const { return i < NU ? (k < N ? U[k * NU + i] : 0.0) : X[k * NX + i - NU]; }
+    MPCRL_DI double dvc(const WsArr &ax, const WsArr &au, int k, int i) const {
+        return i < NU ? (k < N ? au[k * NU + i] : 0.0) : ax[k * NX + i - NU];
+    }
+    MPCRL_DI double bslack(int sd, int k, int i, double v) const { return sd ? ubv(k, i) - v : v - lbv(k, i); }
+    // row r of the compact list of bounded coordinates -> (stage, coordinate)
+    MPCRL_DI void row_of(int r_, int &k, int &i) const {
+        if (r_ < n0) {
+            k = 0, i = sidx[r_];
+        } else if (r_ < n0 + (N - 1) * nm) {
+            const int q_ = r_ - n0;
+            const int kk = q_ / nm;
+            k = kk + 1, i = sidx[64 + q_ - kk * nm];
+        } else
+            k = N, i = sidx[128 + r_ - n0 - (N - 1) * nm];
+    }
+    MPCRL_DI double &LAM(int sd, int e) { return lam[sd * (N + 1) * NW + e]; }
+    MPCRL_DI double &TT(int sd, int e) { return t[sd * (N + 1) * NW + e]; }
+    MPCRL_DI double &AFF(int sd, int e) { return aff[sd * (N + 1) * NW + e]; }
+
+    // ---- one-off set-up: constants into LDS, GEMM tile of this lane, list of bounded coordinates
+    MPCRL_DI void setup(double *lds_, int *sidx_) {
+        lds = lds_, sidx = sidx_;
+        if (lane <= N) sCK()[lane] = ck_eval(lane);
+        if (lane == 0) {   // one lane, compile-time indices: the kernel arguments stay scalar operands
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                sLB()[i] = sp.lb[i], sLB()[NW + i] = sp.ub[i];
+                sLB()[2 * NW + i] = i >= NU ? sp.lbe[i >= NU ? i - NU : 0] : -1e30, sLB()[3 * NW + i] = i >= NU ? sp.ube[i >= NU ? i - NU : 0] : 1e30;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sLB()[4 * NW + i] = sp.lb0[i], sLB()[4 * NW + 4 + i] = sp.ub0[i];
+        }
+        {   // T tile: row-major tile index
+            const int tr = lane / Cfg::NTC, tc = lane - tr * Cfg::NTC;
+            t_live = lane < Cfg::NTT;
+            t_i0 = t_live ? tr * TI : 0, t_j0 = t_live ? tc * TJ : 0;
+        }
+        {   // M tile: lower-triangular tile grid, tile index l = ti (ti + 1) / 2 + tj
+            int ti = 0;
+            while ((ti + 1) * (ti + 2) / 2 <= lane) ++ti;
+            const int tj = lane - ti * (ti + 1) / 2;
+            m_live = lane < Cfg::NMM;
+            m_i0 = m_live ? ti * TS : 0, m_j0 = m_live ? tj * TS : 0;
+            m_diag = ti == tj;
+        }
+        wave_sync();
+        if (lane == 0) {
+            int a = 0, b = 0, c = 0;
+            for (int i = 0; i < NW; ++i) {
+                if (i < NU && !qmode && (sLB()[4 * NW + (i < 4 ? i : 0)] > -NO_BOUND || sLB()[4 * NW + 4 + (i < 4 ? i : 0)] < NO_BOUND)) sidx[a++] = i;
+                if (sLB()[i] > -NO_BOUND || sLB()[NW + i] < NO_BOUND) sidx[64 + b++] = i;
+                if (i >= NU && (sLB()[2 * NW + i] > -NO_BOUND || sLB()[3 * NW + i] < NO_BOUND)) sidx[128 + c++] = i;
+            }
+            sidx[192] = a, sidx[193] = b, sidx[194] = c;
+        }
+        wave_sync();
+        n0 = sidx[192], nm = sidx[193], ne = sidx[194];
+        nrows = n0 + (N - 1) * nm + ne;
+    }
+
+    // cost gradient q = c_k grad l_k and local cost value
+    MPCRL_DI double linearize_cost() {
+        const double *xs = sp.consts;
+        double val = 0.0;
+        for (int e = lane; e < (N + 1) * NW; e += NT) {
+            const int k = e / NW, i = e - k * NW;
+            const bool term = k == N;
+            double a = 0.0;
+            if (i < NU) {
+                if (!term)
+                    for (int j = 0; j < NU; ++j) a = fma(M::Rs(th, i, j), U[k * NU + j], a);
+                q[e] = ck(k) * a;
+                if (!term) val += 0.5 * ck(k) * a * U[k * NU + i];
+            } else {
+                for (int j = 0; j < NX; ++j) a = fma(M::Qs(th, i - NU, j), X[k * NX + j] - xs[j], a);
+                q[e] = ck(k) * a;
+                val += 0.5 * ck(k) * a * (X[k * NX + i - NU] - xs[i - NU]);
+            }
+        }
+        return val;
+    }
+    // ([B A]_k' nu_{k+1} - [0; nu_k])_i
+    MPCRL_DI double GTnu(const WsArr &nu, int k, int i) const {
+        double a = 0.0;
+        if (k < N) {
+            const WsArr Bk = BA + (k * NX * NW + i);
+            for (int m = 0; m < NX; ++m) a = fma(Bk[m * NW], nu[(k + 1) * NX + m], a);
+        }
+        if (i >= NU && k > 0) a -= nu[k * NX + i - NU];
+        return a;
+    }
+    MPCRL_DI void nlp_residuals(const double *x0, const double *u0f, double *res) {
+        double rs = 0, re = 0, ri = 0, rc = 0;
+        for (int e = lane; e < (N + 1) * NW; e += NT) {
+            const int k = e / NW, i = e - k * NW;
+            if (skipc(k, i)) continue;
+            if (!fixedc(k, i)) {
+                double g = q[e] + GTnu(NUv, k, i);
+                if (has(0, k, i)) g -= lam[e];
+                if (has(1, k, i)) g += lam[(N + 1) * NW + e];
+                rs = fmax(rs, fabs(g));
+            }
+        }
+        for (int r_ = lane; r_ < nrows; r_ += NT) {
+            int k, i;
+            row_of(r_, k, i);
+            const int e = k * NW + i;
+            const double v = vc(k, i);
+            if (has(0, k, i)) {
+                const double h = lbv(k, i) - v;
+                ri = fmax(ri, h), rc = fmax(rc, fabs(lam[e] * h));
+            }
+            if (has(1, k, i)) {
+                const double h = v - ubv(k, i);
+                ri = fmax(ri, h), rc = fmax(rc, fabs(lam[(N + 1) * NW + e] * h));
+            }
+        }
+        for (int e = lane; e < N * NX; e += NT) re = fmax(re, fabs(r[e]));
+        if (lane < NX) re = fmax(re, fabs(X[lane] - x0[lane]));
+        if (qmode && lane < NU) re = fmax(re, fabs(U[lane] - u0f[lane]));
+        res[0] = wave_max(rs), res[1] = wave_max(re), res[2] = wave_max(ri), res[3] = wave_max(rc);
+    }
+
+    // ---- Riccati factor sweep with the vector recursion of the first right-hand side riding along.
+    // HS: Hessian source; g: modified gradient [(N+1)*NW]; bb: dynamics offsets [N*NX] or null (= 0).
+    // Leaves in the workspace: P_k, p_k, K_k, L_k, kff_k, Acl_k = A_k - B_k K_k, hb_k = P_{k+1} b_k.
+    template <class HS>
+    MPCRL_DI bool factor(HS &hs, const WsArr g, const WsArr bb) {
+        bool ok = true;
+        double *const lP = sP(), *const lBA = sBA(), *const lT = sT(), *const lM = sM();
+        // terminal stage
+        for (int e = lane; e < NX * NX; e += NT) {
+            const int i = e / NX, j = e - i * NX;
+            const double v = hs.term(N, i > j ? i : j, i > j ? j : i) + (i == j ? Dg[N * NW + NU + i] : 0.0);
+            lP[e] = v;
+            P[N * NX * NX + e] = v;
+        }
+        if (lane < NX) {
+            const double v = g[N * NW + NU + lane];
+            sPV()[lane] = v;
+            p[N * NX + lane] = v;
+        }
+        // operands of stage N-1 into registers
+        double nBA[Cfg::NBA], ng = 0.0, nbb = 0.0, nDg = 0.0;
+        auto fetch = [&](int k) {
+            const WsArr src = BA + k * NX * NW;
+#pragma unroll
+            for (int s = 0; s < Cfg::NBA; ++s) {
+                const int e = lane + 64 * s;
+                nBA[s] = e < NX * NW ? src[e] : 0.0;
+            }
+            ng = lane < NW ? g[k * NW + lane] : 0.0;
+            nDg = lane < NW ? Dg[k * NW + lane] : 0.0;
+            nbb = (bb && lane < NX) ? bb[k * NX + lane] : 0.0;
+            hs.prefetch(k);
+        };
+        fetch(N - 1);
+        for (int k = N - 1; k >= 0; --k) {
+            const bool pin = k == 0 && qmode;
+            // ---- publish the stage operands, fetch the next stage's
+#pragma unroll
+            for (int s = 0; s < Cfg::NBA; ++s) {
+                const int e = lane + 64 * s;
+                if (e < NX * NW) lBA[e] = nBA[s];
+            }
+            if (lane < NW) sG()[lane] = ng, sDG()[lane] = nDg;
+            if (lane < NX) sBB()[lane] = nbb;
+            hs.advance();
+            if (k > 0) fetch(k - 1);
+            wave_sync();
+            // ---- T = P [B A]  (TI x TJ tile per lane; P symmetric: row m of P is column m) and cc = p + P b
+            {
+                double acc[TI][TJ];
+#pragma unroll
+                for (int a = 0; a < TI; ++a)
+#pragma unroll
+                    for (int b = 0; b < TJ; ++b) acc[a][b] = 0.0;
+                int ia[TI];
+#pragma unroll
+                for (int a = 0; a < TI; ++a) ia[a] = t_i0 + a < NX ? t_i0 + a : NX - 1;
+#pragma unroll 3
+                for (int m = 0; m < NX; ++m) {
+                    double pa[TI], bv[TJ];
+#pragma unroll
+                    for (int a = 0; a < TI; ++a) pa[a] = lP[m * NX + ia[a]];
+#pragma unroll
+                    for (int b = 0; b < TJ; ++b) bv[b] = lBA[m * NW + t_j0 + b];
+#pragma unroll
+                    for (int a = 0; a < TI; ++a)
+#pragma unroll
+                        for (int b = 0; b < TJ; ++b) acc[a][b] = fma(pa[a], bv[b], acc[a][b]);
+                }
+                if (t_live) {
+#pragma unroll
+                    for (int a = 0; a < TI; ++a)
+                        if (t_i0 + a < NX) {
+#pragma unroll
+                            for (int b = 0; b < TJ; ++b) lT[(t_i0 + a) * NW + t_j0 + b] = acc[a][b];
+                        }
+                }
+                const int li = lane < NX ? lane : 0;
+                double a = 0.0;
+                if (bb)
+                    for (int m = 0; m < NX; ++m) a = fma(lP[li * NX + m], sBB()[m], a);
+                if (lane < NX) {
+                    sCC()[lane] = sPV()[lane] + a;
+                    hb[k * NX + lane] = a;
+                }
+            }
+            wave_sync();
+            ph(10);
+            // ---- M = H + D + [B A]' T (lower-triangular tile grid, mirrored) and mv = g + [B A]' cc
+            {
+                double acc[TS][TS];
+#pragma unroll
+                for (int a = 0; a < TS; ++a)
+#pragma unroll
+                    for (int b = 0; b < TS; ++b) acc[a][b] = hs.tile(k, a, b) + ((m_diag && a == b) ? sDG()[m_i0 + a] : 0.0);
+#pragma unroll 3
+                for (int m = 0; m < NX; ++m) {
+                    double av[TS], tv[TS];
+#pragma unroll
+                    for (int a = 0; a < TS; ++a) av[a] = lBA[m * NW + m_i0 + a];
+#pragma unroll
+                    for (int b = 0; b < TS; ++b) tv[b] = lT[m * NW + m_j0 + b];
+#pragma unroll
+                    for (int a = 0; a < TS; ++a)
+#pragma unroll
+                        for (int b = 0; b < TS; ++b) acc[a][b] = fma(av[a], tv[b], acc[a][b]);
+                }
+                if (m_live) {
+#pragma unroll
+                    for (int a = 0; a < TS; ++a)
+#pragma unroll
+                        for (int b = 0; b < TS; ++b) {
+                            if (m_diag && b > a) continue;   // the diagonal tile keeps its lower triangle, mirrored like the rest
+                            lM[(m_i0 + a) * NW + m_j0 + b] = acc[a][b];
+                            lM[(m_j0 + b) * NW + m_i0 + a] = acc[a][b];
+                        }
+                }
+                const int li = lane < NW ? lane : 0;
+                double a = sG()[li];
+                for (int m = 0; m < NX; ++m) a = fma(lBA[m * NW + li], sCC()[m], a);
+                if (lane < NW) sMV()[lane] = a;
+            }
+            wave_sync();
+            ph(11);
+            // ---- Cholesky of the control block (every lane, redundantly): L lower with inverted diagonal
+            double Lc[NU][NU];
+            {
+                bool okc = true;
+#pragma unroll
+                for (int i = 0; i < NU; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) {
+                        double a = lM[i * NW + j];
+#pragma unroll
+                        for (int m = 0; m < j; ++m) a -= Lc[i][m] * Lc[j][m];
+                        if (i == j) {
+                            okc = okc && (a > 0.0);
+                            Lc[i][i] = 1.0 / sqrt(a);
+                        } else
+                            Lc[i][j] = a * Lc[j][j];
+                    }
+                ok = ok && (okc || pin);
+            }
+            // K columns (lanes j < NX) and the feed-forward (lane NX): solve L L' z = rhs
+            if (lane <= NX) {
+                const int j = lane;
+                double y[NU], z[NU];
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    double a = j < NX ? lM[(NU + j) * NW + i] : sMV()[i];
+#pragma unroll
+                    for (int m = 0; m < i; ++m) a -= Lc[i][m] * y[m];
+                    y[i] = a * Lc[i][i];
+                }
+#pragma unroll
+                for (int i = NU - 1; i >= 0; --i) {
+                    double a = y[i];
+#pragma unroll
+                    for (int m = i + 1; m < NU; ++m) a -= Lc[m][i] * z[m];
+                    z[i] = a * Lc[i][i];
+                }
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    const double v = pin ? 0.0 : z[i];
+                    if (j < NX) {
+                        sK()[i * NX + j] = v;
+                        K[(k * NU + i) * NX + j] = v;
+                    } else {
+                        sK()[NU * NX + i] = v;
+                        kff[k * NU + i] = v;
+                    }
+                }
+            }
+            if (lane < NU * NU) {
+                const int i = lane / NU, j = lane - i * NU;
+                double v = 0.0;
+#pragma unroll
+                for (int a = 0; a < NU; ++a)
+#pragma unroll
+                    for (int b = 0; b <= a; ++b)
+                        if (a == i && b == j) v = Lc[a][b];
+                L[k * NU * NU + lane] = pin ? 0.0 : v;
+            }
+            wave_sync();
+            ph(12);
+            // ---- P_k = Q - S' K (same expression for (i,j) and (j,i): exactly symmetric), p_k = mv_x - K' mv_u, Acl = A - B K
+            {
+                const double *lK = sK();
+                for (int e = lane; e < NX * NX; e += NT) {
+                    const int i0_ = e / NX, j0_ = e - i0_ * NX;
+                    const int i = i0_ > j0_ ? i0_ : j0_, j = i0_ > j0_ ? j0_ : i0_;
+                    double a = lM[(NU + i) * NW + NU + j];
+#pragma unroll
+                    for (int m = 0; m < NU; ++m) a -= lM[(NU + i) * NW + m] * lK[m * NX + j];
+                    double c = lBA[i0_ * NW + NU + j0_];
+#pragma unroll
+                    for (int m = 0; m < NU; ++m) c -= lBA[i0_ * NW + m] * lK[m * NX + j0_];
+                    P[k * NX * NX + e] = a;
+                    Acl[k * NX * NX + e] = c;
+                    lT[e] = a;   // P_k is staged in T (free now) and moved below: lanes still read M here
+                }
+                if (lane < NX) {
+                    double a = sMV()[NU + lane];
+#pragma unroll
+                    for (int m = 0; m < NU; ++m) a -= lK[m * NX + lane] * sMV()[m];
+                    sPV()[lane] = a;
+                    p[k * NX + lane] = a;
+                }
+            }
+            wave_sync();
+            for (int e = lane; e < NX * NX; e += NT) lP[e] = lT[e];
+            wave_sync();
+            ph(13);
+        }
+        return ok;
+    }
+
+    // ---- backward vector sweep for a new right-hand side g on the stored factors (same bb as the factor sweep: hb is re-used).
+    // Produces p_k (workspace), kff_k.
+    MPCRL_DI void backward_vec(const WsArr g) {
+        const int li = lane < NX ? lane : 0;
+        double pcur = g[N * NW + NU + li];
+        if (lane < NX) p[N * NX + lane] = pcur;
+        double nA[Cfg::NAC], ngx = 0.0, nhb = 0.0, ngu[NU], nK[NU];
+        auto fetch = [&](int k) {
+            const WsArr src = Acl + k * NX * NX;
+#pragma unroll
+            for (int s = 0; s < Cfg::NAC; ++s) {
+                const int e = lane + 64 * s;
+                nA[s] = e < NX * NX ? src[e] : 0.0;
+            }
+            ngx = g[k * NW + NU + li], nhb = hb[k * NX + li];
+#pragma unroll
+            for (int m = 0; m < NU; ++m) ngu[m] = g[k * NW + m], nK[m] = K[(k * NU + m) * NX + li];
+        };
+        fetch(N - 1);
+        for (int k = N - 1; k >= 0; --k) {
+            const int buf = k & 1;
+            double *lA = sA(buf), *lv = sSV(buf);
+            const double v = pcur + nhb;
+            if (lane < NX) lv[lane] = v, ccv[k * NX + lane] = v;
+#pragma unroll
+            for (int s = 0; s < Cfg::NAC; ++s) {
+                const int e = lane + 64 * s;
+                if (e < NX * NX) lA[e] = nA[s];
+            }
+            double a = ngx;
+#pragma unroll
+            for (int m = 0; m < NU; ++m) a = fma(-nK[m], ngu[m], a);   // g_x - K' g_u   (K_0 = 0 in Q-mode)
+            if (k > 0) fetch(k - 1);
+            wave_sync();
+            for (int i = 0; i < NX; ++i) a = fma(lA[i * NX + li], lv[i], a);   // column li of Acl_k
+            pcur = a;
+            if (lane < NX) p[k * NX + lane] = a;
+        }
+        wave_sync();
+        // feed-forward kff_k = R_k^{-1} (g_u + B_k' cc_k), one stage per lane
+        for (int k = lane; k < N; k += NT) {
+            const bool pin = k == 0 && qmode;
+            double mv[NU];
+#pragma unroll
+            for (int m = 0; m < NU; ++m) mv[m] = g[k * NW + m];
+            const WsArr Bk = BA + k * NX * NW;
+            for (int i = 0; i < NX; ++i) {
+                const double c = ccv[k * NX + i];
+#pragma unroll
+                for (int m = 0; m < NU; ++m) mv[m] = fma(Bk[i * NW + m], c, mv[m]);
+            }
+            const WsArr Lk = L + k * NU * NU;
+            double y[NU], z[NU];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                double a = mv[i];
+#pragma unroll
+                for (int m = 0; m < i; ++m) a -= Lk[i * NU + m] * y[m];
+                y[i] = a * Lk[i * NU + i];
+            }
+#pragma unroll
+            for (int i = NU - 1; i >= 0; --i) {
+                double a = y[i];
+#pragma unroll
+                for (int m = i + 1; m < NU; ++m) a -= Lk[m * NU + i] * z[m];
+                z[i] = a * Lk[i * NU + i];
+            }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) kff[k * NU + i] = pin ? 0.0 : z[i];
+        }
+        wave_sync();
+    }
+
+    // ---- forward sweep: Dx (serial chain on Acl), then Du and (optionally) Dnu stage-parallel
+    MPCRL_DI void forward(const WsArr bb, bool want_nu) {
+        // c_k = b_k - B_k kff_k
+        for (int e = lane; e < N * NX; e += NT) {
+            const int k = e / NX, i = e - k * NX;
+            double a = bb ? bb[e] : 0.0;
+            const WsArr Bk = BA + (k * NX + i) * NW;
+#pragma unroll
+            for (int m = 0; m < NU; ++m) a = fma(-Bk[m], kff[k * NU + m], a);
+            cvec[e] = a;
+        }
+        wave_sync();
+        const int li = lane < NX ? lane : 0;
+        double xcur = 0.0;
+        if (lane < NX) Dx[lane] = 0.0;
+        double nA[Cfg::NAC], nc = 0.0;
+        auto fetch = [&](int k) {
+            const WsArr src = Acl + k * NX * NX;
+#pragma unroll
+            for (int s = 0; s < Cfg::NAC; ++s) {
+                const int e = lane + 64 * s;
+                nA[s] = e < NX * NX ? src[e] : 0.0;
+            }
+            nc = cvec[k * NX + li];
+        };
+        fetch(0);
+        for (int k = 0; k < N; ++k) {
+            const int buf = k & 1;
+            double *lA = sA(buf), *lv = sSV(buf);
+            if (lane < NX) lv[lane] = xcur;
+#pragma unroll
+            for (int s = 0; s < Cfg::NAC; ++s) {
+                const int e = lane + 64 * s;
+                if (e < NX * NX) lA[e] = nA[s];
+            }
+            double a = nc;
+            if (k + 1 < N) fetch(k + 1);
+            wave_sync();
+            for (int j = 0; j < NX; ++j) a = fma(lA[li * NX + j], lv[j], a);   // row li of Acl_k
+            xcur = a;
+            if (lane < NX) Dx[(k + 1) * NX + lane] = a;
+        }
+        wave_sync();
+        for (int e = lane; e < N * NU; e += NT) {
+            const int k = e / NU;
+            double a = -kff[e];
+            const WsArr Kr = K + e * NX;
+            for (int j = 0; j < NX; ++j) a = fma(-Kr[j], Dx[k * NX + j], a);
+            Du[e] = a;
+        }
+        for (int e = lane; want_nu && e < (N + 1) * NX; e += NT) {
+            const int k = e / NX, i = e - k * NX;
+            double a = 0.0;
+            if (k > 0) {
+                a = p[e];
+                const WsArr Pr = P + (k * NX * NX + i * NX);
+                for (int j = 0; j < NX; ++j) a = fma(Pr[j], Dx[k * NX + j], a);
+            }
+            Dnu[e] = a;
+        }
+        wave_sync();
+    }
+
+    // ---- Mehrotra predictor-corrector on the QP of the current linearisation (hard bounds) --------------------
+    template <class HS>
+    MPCRL_DI bool qp_solve(HS &hs, const double *x0, const double *u0f, int &n_it, double warm_mu, double tol_res, double tol_mu) {
+        const bool warm = warm_mu > 0.0;
+        const int ne = (N + 1) * NW;
+        for (int e = lane; e < (N + 1) * NX; e += NT) dx[e] = e < NX ? x0[e] - X[e] : 0.0, nuq[e] = warm ? NUv[e] : 0.0;
+        for (int e = lane; e < N * NU; e += NT) du[e] = (qmode && e < NU) ? u0f[e] - U[e] : 0.0;
+        wave_sync();
+        double cnt = 0.0;
+        for (int r_ = lane; r_ < nrows; r_ += NT) {
+            int k, i;
+            row_of(r_, k, i);
+            const int e = k * NW + i;
+            const double v = vc(k, i) + dvc(dx, du, k, i);
+            for (int sd = 0; sd < 2; ++sd)
+                if (has(sd, k, i)) {
+                    cnt += 1.0;
+                    if (warm) {
+                        double l = LAM(sd, e), tt = fmax(bslack(sd, k, i, v), TT(sd, e));
+                        if (l * tt < warm_mu) {
+                            if (l >= tt)
+                                tt = warm_mu / l;
+                            else
+                                l = warm_mu / tt;
+                        }
+                        LAM(sd, e) = l, TT(sd, e) = tt;
+                    } else {
+                        const double tt = fmax(bslack(sd, k, i, v), IPM_T_MIN);
+                        TT(sd, e) = tt;
+                        LAM(sd, e) = IPM_MU0 / tt;
+                    }
+                }
+        }
+        const double n_rows = wave_sum(cnt);
+        wave_sync();
+        bool ok = false;
+        for (int it = 0;; ++it) {
+            ph(7);
+            double rloc = 0.0, muloc = 0.0;
+            // equality residual rb = r + [B A] dv - dx+
+            for (int e = lane; e < N * NX; e += NT) {
+                const int k = e / NX, i = e - k * NX;
+                double a = r[e] - dx[(k + 1) * NX + i];
+                const WsArr row = BA + e * NW;
+                for (int j = 0; j < NU; ++j) a = fma(row[j], du[k * NU + j], a);
+                for (int j = 0; j < NX; ++j) a = fma(row[NU + j], dx[k * NX + j], a);
+                rb[e] = a;
+                rloc = fmax(rloc, fabs(a));
+            }
+            // stationarity residual (the stage Hessian of this model is block diagonal: R on u, Q on x)
+            for (int e = lane; e < ne; e += NT) {
+                const int k = e / NW, i = e - k * NW;
+                double a = 0.0;
+                if (!skipc(k, i)) {
+                    a = q[e] + GTnu(nuq, k, i);
+                    double hd = 0.0;
+                    if (i < NU) {
+                        for (int j = 0; j < NU; ++j) hd = fma(M::hess(k == N, i, j, th), du[k * NU + j], hd);
+                    } else {
+                        for (int j = 0; j < NX; ++j) hd = fma(M::Qs(th, i - NU, j), dx[k * NX + j], hd);
+                    }
+                    a = fma(ck(k), hd, a);
+                    if (has(0, k, i)) a -= LAM(0, e);
+                    if (has(1, k, i)) a += LAM(1, e);
+                    if (fixedc(k, i)) a = 0.0;
+                }
+                rg[e] = a;
+                rloc = fmax(rloc, fabs(a));
+            }
+            for (int r_ = lane; r_ < nrows; r_ += NT) {
+                int k, i;
+                row_of(r_, k, i);
+                const int e = k * NW + i;
+                const double v = vc(k, i) + dvc(dx, du, k, i);
+                for (int sd = 0; sd < 2; ++sd)
+                    if (has(sd, k, i)) {
+                        rloc = fmax(rloc, fabs(TT(sd, e) - bslack(sd, k, i, v)));
+                        muloc = fma(LAM(sd, e), TT(sd, e), muloc);
+                    }
+            }
+            const double rinf = wave_max(rloc);
+            const double mu = n_rows > 0.0 ? wave_sum(muloc) / n_rows : 0.0;
+            if (rinf <= tol_res && mu <= tol_mu) {
+                ok = true;
+                break;
+            }
+            if (it >= IPM_MAX_ITER || !(rinf < 1e300)) break;
+            ++n_it;
+            ph(0);
+            double sigma_mu = 0.0, alpha = 1.0;
+            bool fail = false;
+            for (int pass = 0; pass < 2; ++pass) {
+                // barrier diagonal + modified gradient: rt = rg everywhere, corrected on the bounded rows
+                for (int e = lane; e < ne; e += NT) {
+                    rt[e] = rg[e];
+                    if (pass == 0) Dg[e] = 0.0;
+                }
+                wave_sync();
+                for (int r_ = lane; r_ < nrows; r_ += NT) {
+                    int k, i;
+                    row_of(r_, k, i);
+                    const int e = k * NW + i;
+                    double dg = 0.0, er = 0.0;
+                    const double v = vc(k, i) + dvc(dx, du, k, i);
+                    for (int sd = 0; sd < 2; ++sd)
+                        if (has(sd, k, i)) {
+                            const double l1 = LAM(sd, e), t1 = TT(sd, e);
+                            const double rd1 = t1 - bslack(sd, k, i, v);
+                            const double rm = fma(l1, t1, pass ? AFF(sd, e) - sigma_mu : 0.0);
+                            dg += l1 / t1;
+                            er += (sd ? -1.0 : 1.0) * (rm - l1 * rd1) / t1;
+                        }
+                    if (pass == 0) Dg[e] = dg;
+                    rt[e] = rg[e] + er;
+                }
+                wave_sync();
+                ph(1);
+                if (pass == 0) {
+                    if (!factor(hs, rt, rb)) fail = true;
+                    ph(2);
+                } else {
+                    backward_vec(rt);
+                    ph(3);
+                }
+                forward(rb, pass == 1);   // the multiplier step is only needed with the final direction
+                ph(4);
+                double amax = 1.0, muaff = 0.0;
+                for (int r_ = lane; r_ < nrows; r_ += NT) {
+                    int k, i;
+                    row_of(r_, k, i);
+                    const int e = k * NW + i;
+                    const double v = vc(k, i) + dvc(dx, du, k, i), dv = dvc(Dx, Du, k, i);
+                    for (int sd = 0; sd < 2; ++sd)
+                        if (has(sd, k, i)) {
+                            const double l1 = LAM(sd, e), t1 = TT(sd, e);
+                            const double rd1 = t1 - bslack(sd, k, i, v);
+                            const double rm = fma(l1, t1, pass ? AFF(sd, e) - sigma_mu : 0.0);
+                            const double dt1 = -rd1 + (sd ? -dv : dv);
+                            const double dl1 = (-rm - l1 * dt1) / t1;
+                            if (dl1 < 0.0) amax = fmin(amax, -l1 / dl1);
+                            if (dt1 < 0.0) amax = fmin(amax, -t1 / dt1);
+                        }
+                }
+                amax = -wave_max(-amax);
+                if (pass == 0) {
+                    for (int r_ = lane; r_ < nrows; r_ += NT) {
+                        int k, i;
+                        row_of(r_, k, i);
+                        const int e = k * NW + i;
+                        const double v = vc(k, i) + dvc(dx, du, k, i), dv = dvc(Dx, Du, k, i);
+                        for (int sd = 0; sd < 2; ++sd)
+                            if (has(sd, k, i)) {
+                                const double l1 = LAM(sd, e), t1 = TT(sd, e);
+                                const double rd1 = t1 - bslack(sd, k, i, v);
+                                const double dt1 = -rd1 + (sd ? -dv : dv);
+                                const double dl1 = (-l1 * t1 - l1 * dt1) / t1;
+                                muaff = fma(fma(amax, dl1, l1), fma(amax, dt1, t1), muaff);
+                                AFF(sd, e) = dl1 * dt1;
+                            }
+                    }
+                    const double mu_aff = n_rows > 0.0 ? wave_sum(muaff) / n_rows : 0.0;
+                    const double ratio = mu > 0.0 ? mu_aff / mu : 0.0;
+                    sigma_mu = ratio * ratio * ratio * mu;
+                    wave_sync();
+                } else
+                    alpha = fmin(1.0, fmax(IPM_FRAC, 1.0 - mu) * amax);   // fraction to the boundary -> 1 as mu -> 0
+            }
+            ph(5);
+            if (fail) break;
+            for (int r_ = lane; r_ < nrows; r_ += NT) {
+                int k, i;
+                row_of(r_, k, i);
+                const int e = k * NW + i;
+                const double v = vc(k, i) + dvc(dx, du, k, i), dv = dvc(Dx, Du, k, i);
+                for (int sd = 0; sd < 2; ++sd)
+                    if (has(sd, k, i)) {
+                        const double l1 = LAM(sd, e), t1 = TT(sd, e);
+                        const double rd1 = t1 - bslack(sd, k, i, v);
+                        const double rm = fma(l1, t1, AFF(sd, e) - sigma_mu);
+                        const double dt1 = -rd1 + (sd ? -dv : dv);
+                        const double dl1 = (-rm - l1 * dt1) / t1;
+                        LAM(sd, e) = fma(alpha, dl1, l1);
+                        TT(sd, e) = fma(alpha, dt1, t1);
+                    }
+            }
+            wave_sync();
+            for (int e = lane; e < (N + 1) * NX; e += NT) dx[e] = fma(alpha, Dx[e], dx[e]), nuq[e] = fma(alpha, Dnu[e], nuq[e]);
+            for (int e = lane; e < N * NU; e += NT) du[e] = fma(alpha, Du[e], du[e]);
+            wave_sync();
+        }
+        return ok;
+    }
+
+    MPCRL_DI void bind_workspace(double *w, const LargeLayout<M> &lay) {
+        auto at = [&](size_t o) { return WsArr{(char *)w, (unsigned)o}; };
+        BA = at(lay.BA), r = at(lay.r), q = at(lay.q), dx = at(lay.dx), du = at(lay.du), nuq = at(lay.nuq);
+        Dx = at(lay.Dx), Du = at(lay.Du), Dnu = at(lay.Dnu), rg = at(lay.rg), rb = at(lay.rb), rt = at(lay.rt), Dg = at(lay.Dg);
+        lam = at(lay.lamw), t = at(lay.tw), aff = at(lay.aff), P = at(lay.P), p = at(lay.p), K = at(lay.K), L = at(lay.L);
+        kff = at(lay.kff), Acl = at(lay.Acl), hb = at(lay.hb), ccv = at(lay.ccv), cvec = at(lay.cvec), NUv = at(lay.ynu), state = at(lay.state);
+    }
+};
+
+// =====================================================================================================
+// SQP, as a sequence of launches:  init, then (lin, qp) x (max_iter + 1).  Per-instance state lives in ws.state.
+// =====================================================================================================
+
+// ---- iterate set-up: cold start (MPC.reset, mpc.py:204-210) or the stored one.  One wavefront per instance.
+template <class M>
+__global__ void __launch_bounds__(64) chain_init_kernel(const LargeSpec sp, const LargeArgs a) {
+    constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NT = 64;
+    const int lane = threadIdx.x, inst = blockIdx.x, N = sp.N;
+    const LargeLayout<M> lay(N);
+    double *w = a.ws + (size_t)inst * a.ws_stride;
+    double *X = a.X + (size_t)inst * (N + 1) * NX, *U = a.U + (size_t)inst * N * NU;
+    const double *PIg = a.PI + (size_t)inst * N * NX;
+    const size_t nb = (size_t)(N + 1) * NW;
+    const double *bnd = a.BND + (size_t)inst * 10 * nb;
+    const double *x0 = a.x0 + (size_t)inst * NX;
+    const double *u0f = a.u0fix ? a.u0fix + (size_t)inst * NU : nullptr;
+    double *NUv = w + lay.ynu, *lam = w + lay.lamw, *t = w + lay.tw, *aff = w + lay.aff, *st = w + lay.state;
+    const int ne = (N + 1) * NW;
+    double stepn = -1.0;   // perturbation seen by the first QP (< 0: cold)
+    if (a.flags & 8) {
+        for (int e = lane; e < (N + 1) * NX; e += NT) X[e] = x0[e % NX], NUv[e] = 0.0;
+        for (int e = lane; e < N * NU; e += NT) U[e] = 0.0;
+        for (int e = lane; e < 2 * ne; e += NT) lam[e] = 0.0, t[e] = 1.0, aff[e] = 0.0;
+    } else {
+        for (int e = lane; e < (N + 1) * NX; e += NT) NUv[e] = e < NX ? 0.0 : PIg[e - NX];
+        for (int e = lane; e < 2 * ne; e += NT) lam[e] = bnd[e], t[e] = bnd[2 * nb + e], aff[e] = 0.0;
+        double sl = 0.0;
+        if (lane < NX) sl = fabs(x0[lane] - X[lane]);
+        if (u0f && lane < NU) sl = fmax(sl, fabs(u0f[lane] - U[lane]));
+        stepn = wave_max(sl);
+    }
+    if (lane == 0) {
+        st[ST_ACTIVE] = 1.0, st[ST_IT] = 0.0, st[ST_NIPM] = 0.0, st[ST_TIGHT] = 1.0, st[ST_STEPN] = stepn, st[ST_COST] = 0.0;
+        st[ST_STATUS] = 2.0;
+        for (int j = 0; j < 4; ++j) st[ST_RES + j] = 0.0;
+    }
+}
+
+// ---- dynamics linearisation: one (instance, stage, direction) item per lane; fills [B A]_k and r_k = F(x_k, u_k) - x_{k+1}.
+// Forward-mode jet through the 2-step RK4 map, parameters as plain doubles, all state in registers.
+template <class M>
+__global__ void __launch_bounds__(256) chain_lin_kernel(const LargeSpec sp, const LargeArgs a) {
+    constexpr int NX = M::NX, NU = M::NU, NW = NX + NU;
+    const int N = sp.N;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int per = N * NW;
+    const int inst = (int)(gid / per);
+    if (inst >= a.B) return;
+    const LargeLayout<M> lay(N);
+    double *w = a.ws + (size_t)inst * a.ws_stride;
+    if (w[lay.state + ST_ACTIVE] == 0.0) return;
+    const int it = (int)(gid - (long)inst * per), k = it / NW, d = it - k * NW;
+    const double *X = a.X + (size_t)inst * (N + 1) * NX, *U = a.U + (size_t)inst * N * NU;
+    const double *th = a.theta + (size_t)inst * a.theta_stride;
+    Jet1<1> jx[NX], ju[NU], jn[NX];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) ju[i] = Jet1<1>(U[k * NU + i]), ju[i].d[0] = (d == i) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) jx[i] = Jet1<1>(X[k * NX + i]), jx[i].d[0] = (d == NU + i) ? 1.0 : 0.0;
+    disc_map_p<M, Jet1<1>>(jx, ju, th, jn, sp.h, sp.rk_steps);
+    double *BA = w + lay.BA + (size_t)k * NX * NW, *r = w + lay.r + k * NX;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        BA[i * NW + d] = jn[i].d[0];
+        if (d == 0) r[i] = jn[i].v - X[(k + 1) * NX + i];
+    }
+}
+
+// ---- one SQP round of one instance: cost, residuals, stopping test, QP by the Riccati interior-point method, full step.
+template <class M>
+__global__ void __launch_bounds__(64, 1) chain_qp_kernel(const LargeSpec sp, const LargeArgs a) {
+    using Cfg = ChainCfg<M>;
+    constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NT = 64;
+    __shared__ __attribute__((aligned(16))) double lds[Cfg::LDS_TOTAL];
+    __shared__ int sidx[196];
+    const int lane = threadIdx.x, inst = blockIdx.x, N = sp.N;
+    const LargeLayout<M> lay(N);
+    double *w = a.ws + (size_t)inst * a.ws_stride;
+    if (w[lay.state + ST_ACTIVE] == 0.0) return;
+    ChainSolver<M> S(sp, lane);
+    S.th = a.theta + (size_t)inst * a.theta_stride;
+    S.qmode = a.u0fix != nullptr;
+    S.bind_workspace(w, lay);
+    S.setup(lds, sidx);
+    S.X = a.X + (size_t)inst * (N + 1) * NX, S.U = a.U + (size_t)inst * N * NU;
+    const double *x0 = a.x0 + (size_t)inst * NX;
+    const double *u0f = S.qmode ? a.u0fix + (size_t)inst * NU : nullptr;
+    const int ne = (N + 1) * NW;
+    const bool rti = (a.flags & 4) != 0;
+    const int max_iter = rti ? 1 : sp.max_iter;
+    const int it = (int)S.state[ST_IT];
+    int n_ipm = (int)S.state[ST_NIPM];
+    const bool last_tight = S.state[ST_TIGHT] != 0.0;
+    const double stepn = S.state[ST_STEPN];
+#ifdef MPCRL_PROFILE_PHASES
+    __shared__ unsigned long long ph_buf[16];
+    S.ph_init(ph_buf);
+#endif
+    S.ph0();
+    const double cl = S.linearize_cost();
+    wave_sync();
+    const double cost = wave_sum(cl);
+    double res[4];
+    S.nlp_residuals(x0, u0f, res);
+    S.ph(9);
+    const double rmax = fmax(fmax(res[0], res[1]), fmax(res[2], res[3]));
+    int status = -1;   // -1: carry on
+    if (!(rmax < 1e300))
+        status = 1;
+    else if (rmax < sp.tol && last_tight && !(rti && it == 0))
+        status = 0;
+    else if (it >= max_iter)
+        status = rmax < sp.tol ? 0 : 2;
+    if (status < 0) {
+        const double rr_ = fmin(1.0, rmax), ad_ = rmax < sp.tol ? 0.0 : IPM_ADAPT_C * rr_ * rr_;
+        const double tol_res = fmin(IPM_ADAPT_CAP, fmax(IPM_TOL_RES, ad_)), tol_mu = fmin(0.1 * IPM_ADAPT_CAP, fmax(IPM_TOL_MU, 1e-2 * ad_));
+        const bool tight = tol_res <= IPM_TOL_RES && tol_mu <= IPM_TOL_MU;
+        const double warm_mu = stepn < 0.0 ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
+        // the SQP Hessian: this lane's tile of (R, Q) without c_k, in registers
+        HessConst<M> hs;
+        hs.th = S.th, hs.sck = S.sCK();
+#pragma unroll
+        for (int i = 0; i < Cfg::TS; ++i)
+#pragma unroll
+            for (int j = 0; j < Cfg::TS; ++j) hs.h[i][j] = S.m_live ? M::hess(false, S.m_i0 + i, S.m_j0 + j, S.th) : 0.0;
+        if (!S.qp_solve(hs, x0, u0f, n_ipm, warm_mu, tol_res, tol_mu))
+            status = 4;
+        else {
+            double sl = 0.0;
+            for (int e = lane; e < (N + 1) * NX; e += NT) sl = fmax(sl, fabs(S.dx[e]));
+            for (int e = lane; e < N * NU; e += NT) sl = fmax(sl, fabs(S.du[e]));
+            sl = wave_max(sl);
+            for (int e = lane; e < (N + 1) * NX; e += NT) S.X[e] += S.dx[e], S.NUv[e] = S.nuq[e];
+            for (int e = lane; e < N * NU; e += NT) S.U[e] += S.du[e];
+            if (lane == 0) S.state[ST_IT] = it + 1, S.state[ST_NIPM] = n_ipm, S.state[ST_TIGHT] = tight ? 1.0 : 0.0, S.state[ST_STEPN] = sl;
+            S.ph(14);
+            S.ph_flush();
+            return;
+        }
+    }
+    // ---- finished (converged, failed or out of iterations): results + iterate
+    double *PIg = a.PI + (size_t)inst * N * NX;
+    const size_t nb = (size_t)(N + 1) * NW;
+    double *bnd = a.BND + (size_t)inst * 10 * nb;
+    if (lane < NU) a.u0_out[(size_t)inst * NU + lane] = S.U[lane];
+    if (lane == 0) {
+        a.V[inst] = cost;
+        a.status[inst] = status;
+        if (a.iters) a.iters[inst * 2] = it, a.iters[inst * 2 + 1] = n_ipm;
+        for (int j = 0; j < 4; ++j) a.RES[(size_t)inst * 4 + j] = res[j];
+        S.state[ST_ACTIVE] = 0.0, S.state[ST_STATUS] = status;
+    }
+    for (int e = lane; e < N * NX; e += NT) PIg[e] = S.NUv[NX + e];
+    for (int e = lane; e < 2 * ne; e += NT) {
+        const int sd = e / ne, ee = e - sd * ne, k = ee / NW, i = ee - k * NW;
+        const bool h = !S.skipc(k, i) && S.has(sd, k, i);
+        bnd[e] = h ? S.lam[e] : 0.0;
+        bnd[2 * nb + e] = h ? S.t[e] : 1.0;
+    }
+    for (int e = lane; e < 6 * ne; e += NT) bnd[4 * nb + e] = (e >= 4 * ne) ? 1.0 : 0.0;   // no soft rows here
+    S.ph_flush();
+}
+
+// =====================================================================================================
+// sensitivities (dV/dp = dL/dp, nlp.py:1211,1401; du0*/dp by an adjoint Riccati solve, nlp.py:1413-1424), four launches:
+//   sens_ad       grid-wide: per (stage, column) one forward-over-reverse sweep of the RK4 map -> exact Lagrangian Hessian blocks;
+//                 per stage one reverse sweep -> grad_theta (nu_{k+1}' F_k)
+//   sens_riccati  wavefront per instance: dV/dp reductions, factorisation with the exact Hessian + barrier diagonal, nu adjoint solves
+//   sens_mix      grid-wide: per (stage, control) the mixed term y_v' d/dv (nu' dF/dtheta) + y_nu' dF/dtheta for all theta at once
+//                 (the tangent of the reverse sweep along (y_v, y_nu))
+//   sens_out      wavefront per instance: du0*/dp reductions
+// They re-use [B A], lam, t, nu left in the workspace by the last SQP round (its linearisation is at the final iterate).
+// =====================================================================================================
+template <class M>
+__global__ void __launch_bounds__(256) chain_sens_ad_kernel(const LargeSpec sp, const LargeArgs a) {
+    constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD;
+    const int N = sp.N;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int per = N * (NW + 1);
+    const int inst = (int)(gid / per);
+    if (inst >= a.B) return;
+    const int status = a.status[inst];
+    if (!(status == 0 || status == 2)) return;
+    const int it = (int)(gid - (long)inst * per), k = it / (NW + 1), j = it - k * (NW + 1);
+    const bool want_pi = (a.flags & 2) && a.dpi && !a.u0fix;
+    const LargeLayout<M> lay(N);
+    double *w = a.ws + (size_t)inst * a.ws_stride;
+    const double *X = a.X + (size_t)inst * (N + 1) * NX, *U = a.U + (size_t)inst * N * NU;
+    const double *th = a.theta + (size_t)inst * a.theta_stride, *nu = w + lay.ynu;
+    if (j == NW) {   // grad_theta (nu_{k+1}' F_k)
+        double jx[NX], ju[NU], jt[NTD], lm[NX], xb[NX], ub[NU], tb[NTD];
+        for (int i = 0; i < NU; ++i) ju[i] = U[k * NU + i];
+        for (int i = 0; i < NX; ++i) jx[i] = X[k * NX + i], lm[i] = nu[(k + 1) * NX + i];
+        for (int i = 0; i < NTD; ++i) jt[i] = th[M::td_index(i)];
+        disc_map_adj<M, true, double>(jx, ju, jt, lm, xb, ub, tb, sp.h, sp.rk_steps);
+        double *term = w + lay.term + (size_t)k * NTD;
+        for (int d = 0; d < NTD; ++d) term[d] = tb[d];
+        return;
+    }
+    if (!want_pi) return;
+    // column j of c_k hess l + hess (nu_{k+1}' F_k): tangent e_j through the reverse sweep of F
+    Jet1<1> jx[NX], ju[NU], jt[NTD], lm[NX], xb[NX], ub[NU];
+    for (int c = 0; c < NU; ++c) ju[c] = Jet1<1>(U[k * NU + c]);
+    for (int c = 0; c < NX; ++c) jx[c] = Jet1<1>(X[k * NX + c]), lm[c] = Jet1<1>(nu[(k + 1) * NX + c]);
+    for (int c = 0; c < NTD; ++c) jt[c] = Jet1<1>(th[M::td_index(c)]);
+    if (j < NU) ju[j].d[0] = 1.0; else jx[j - NU].d[0] = 1.0;
+    disc_map_adj<M, false, Jet1<1>>(jx, ju, jt, lm, xb, ub, (Jet1<1> *)nullptr, sp.h, sp.rk_steps);
+    const double ckk = sp.cost_kind == 0 ? sp.dT : (k == 0 ? sp.dT : pow(sp.gamma, (double)k) * sp.dT);
+    double *Hex = w + lay.Hex + (size_t)k * NW * NW;
+    for (int i = 0; i < NW; ++i) Hex[i * NW + j] = fma(ckk, M::hess(false, i, j, th), i < NU ? ub[i].d[0] : xb[i - NU].d[0]);
+}
+
+template <class M>
+__global__ void __launch_bounds__(64, 1) chain_sens_riccati_kernel(const LargeSpec sp, const LargeArgs a) {
+    using Cfg = ChainCfg<M>;
+    constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD, NP = M::NP, NT = 64;
+    __shared__ __attribute__((aligned(16))) double lds[Cfg::LDS_TOTAL];
+    __shared__ int sidx[196];
+    const int lane = threadIdx.x, inst = blockIdx.x, N = sp.N;
+    const int status = a.status[inst];
+    if (!(status == 0 || status == 2)) return;
+    ChainSolver<M> S(sp, lane);
+    S.th = a.theta + (size_t)inst * a.theta_stride;
+    S.qmode = a.u0fix != nullptr;
+    const LargeLayout<M> lay(N);
+    double *w = a.ws + (size_t)inst * a.ws_stride;
+    S.bind_workspace(w, lay);
+    S.setup(lds, sidx);
+    S.X = a.X + (size_t)inst * (N + 1) * NX, S.U = a.U + (size_t)inst * N * NU;
+    const int ne = (N + 1) * NW;
+    const double *th = S.th, *xs = sp.consts;
+    const WsArr Hex{(char *)w, (unsigned)lay.Hex}, term{(char *)w, (unsigned)lay.term};
+    if ((a.flags & 1) && a.dV) {
+        double *dV = a.dV + (size_t)inst * NP;
+        for (int d = lane; d < NTD; d += NT) {
+            double acc = 0.0;
+            for (int k = 0; k < N; ++k) acc += term[k * NTD + d];
+            dV[M::td_index(d)] = acc;
+        }
+        for (int e = lane; e < NX * NX + NU * NU; e += NT) {   // d/dQ_ij, d/dR_ij of sum_k c_k l_k (ocp_utils.py:276-277)
+            double acc = 0.0;
+            if (e < NX * NX) {
+                const int j = e / NX, i = e - j * NX;          // column-major position of Q(i, j)
+                for (int k = 0; k <= N; ++k) acc = fma(0.5 * S.ck(k) * (S.X[k * NX + i] - xs[i]), S.X[k * NX + j] - xs[j], acc);
+                dV[M::OFF_Q + e] = acc;
+            } else {
+                const int ee = e - NX * NX, j = ee / NU, i = ee - j * NU;
+                for (int k = 0; k < N; ++k) acc = fma(0.5 * S.ck(k) * S.U[k * NU + i], S.U[k * NU + j], acc);
+                dV[M::OFF_R + ee] = acc;
+            }
+        }
+    }
+    if (!((a.flags & 2) && a.dpi) || S.qmode) return;
+    for (int e = lane; e < NW * NW; e += NT) Hex[N * NW * NW + e] = S.ck(N) * M::hess(true, e / NW, e % NW, th);
+    // barrier diagonal from the final (lam, t) of the bound rows (slacks are constants of the mirror, quirk q1)
+    for (int e = lane; e < ne; e += NT) {
+        const int k = e / NW, i = e - k * NW;
+        double d = 0.0;
+        if (!S.skipc(k, i))
+            for (int sd = 0; sd < 2; ++sd)
+                if (S.has(sd, k, i)) d += S.LAM(sd, e) / S.TT(sd, e);
+        S.Dg[e] = d;
+    }
+    wave_sync();
+    HessGlobal<M> hs;
+    hs.Hex = Hex, hs.i0 = S.m_i0, hs.j0 = S.m_j0, hs.live = S.m_live;
+    const WsArr none{nullptr, 0};
+    const WsArr Ydx{(char *)w, (unsigned)lay.Ydx}, Ydu{(char *)w, (unsigned)lay.Ydu}, Ydnu{(char *)w, (unsigned)lay.Ydnu};
+    bool okall = true;
+    for (int iu = 0; iu < NU; ++iu) {
+        for (int e = lane; e < ne; e += NT) S.rt[e] = e == iu ? -1.0 : 0.0;
+        wave_sync();
+        if (iu == 0)
+            okall = S.factor(hs, S.rt, none);
+        else
+            S.backward_vec(S.rt);
+        S.forward(none, true);
+        for (int e = lane; e < (N + 1) * NX; e += NT) Ydx[iu * (N + 1) * NX + e] = S.Dx[e], Ydnu[iu * (N + 1) * NX + e] = S.Dnu[e];
+        for (int e = lane; e < N * NU; e += NT) Ydu[iu * N * NU + e] = S.Du[e];
+        wave_sync();
+    }
+    if (lane == 0) S.state[ST_STATUS] = okall ? 0.0 : 4.0;   // read by sens_out: NaN sensitivities when the exact-Hessian KKT matrix is not pd
+}
+
+template <class M>
+__global__ void __launch_bounds__(256) chain_sens_mix_kernel(const LargeSpec sp, const LargeArgs a) {
+    constexpr int NX = M::NX, NU = M::NU, NTD = M::NTD;
+    const int N = sp.N;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int per = N * NU;
+    const int inst = (int)(gid / per);
+    if (inst >= a.B) return;
+    const int status = a.status[inst];
+    if (!(status == 0 || status == 2)) return;
+    const int it = (int)(gid - (long)inst * per), iu = it / N, k = it - iu * N;
+    const LargeLayout<M> lay(N);
+    double *w = a.ws + (size_t)inst * a.ws_stride;
+    const double *X = a.X + (size_t)inst * (N + 1) * NX, *U = a.U + (size_t)inst * N * NU;
+    const double *th = a.theta + (size_t)inst * a.theta_stride, *nu = w + lay.ynu;
+    const double *Ydx = w + lay.Ydx + (size_t)iu * (N + 1) * NX, *Ydu = w + lay.Ydu + (size_t)iu * N * NU, *Ydnu = w + lay.Ydnu + (size_t)iu * (N + 1) * NX;
+    Jet1<1> jx[NX], ju[NU], jt[NTD], lm[NX], xb[NX], ub[NU], tb[NTD];
+    for (int c = 0; c < NU; ++c) ju[c] = Jet1<1>(U[k * NU + c]), ju[c].d[0] = Ydu[k * NU + c];
+    for (int c = 0; c < NX; ++c) {
+        jx[c] = Jet1<1>(X[k * NX + c]), jx[c].d[0] = Ydx[k * NX + c];
+        lm[c] = Jet1<1>(nu[(k + 1) * NX + c]), lm[c].d[0] = Ydnu[(k + 1) * NX + c];
+    }
+    for (int c = 0; c < NTD; ++c) jt[c] = Jet1<1>(th[M::td_index(c)]);
+    disc_map_adj<M, true, Jet1<1>>(jx, ju, jt, lm, xb, ub, tb, sp.h, sp.rk_steps);
+    double *term2 = w + lay.term2 + ((size_t)iu * N + k) * NTD;
+    for (int d = 0; d < NTD; ++d) term2[d] = tb[d].d[0];
+}
+
+template <class M>
+__global__ void __launch_bounds__(64) chain_sens_out_kernel(const LargeSpec sp, const LargeArgs a) {
+    constexpr int NX = M::NX, NU = M::NU, NTD = M::NTD, NP = M::NP, NT = 64;
+    const int lane = threadIdx.x, inst = blockIdx.x, N = sp.N;
+    const int status = a.status[inst];
+    if (!(status == 0 || status == 2)) return;
+    const LargeLayout<M> lay(N);
+    double *w = a.ws + (size_t)inst * a.ws_stride;
+    const double *X = a.X + (size_t)inst * (N + 1) * NX, *U = a.U + (size_t)inst * N * NU, *xs = sp.consts;
+    const bool okall = w[lay.state + ST_STATUS] == 0.0;
+    double *dpi = a.dpi + (size_t)inst * NU * NP;
+    auto ck = [&](int k) {
+        if (sp.cost_kind == 0) return k == N ? 1.0 : sp.dT;
+        return k == 0 ? sp.dT : (k == N ? pow(sp.gamma, (double)N) : pow(sp.gamma, (double)k) * sp.dT);
+    };
+    for (int iu = 0; iu < NU; ++iu) {
+        const double *term2 = w + lay.term2 + (size_t)iu * N * NTD;
+        const double *Dx = w + lay.Ydx + (size_t)iu * (N + 1) * NX, *Du = w + lay.Ydu + (size_t)iu * N * NU;
+        for (int d = lane; d < NTD; d += NT) {
+            double acc = 0.0;
+            for (int k = 0; k < N; ++k) acc += term2[k * NTD + d];
+            dpi[(size_t)iu * NP + M::td_index(d)] = okall ? -acc : NAN;
+        }
+        for (int e = lane; e < NX * NX + NU * NU; e += NT) {   // y' d2 l / dv dQ_ij = 1/2 (y_i e_j + y_j e_i)
+            double acc = 0.0;
+            if (e < NX * NX) {
+                const int j = e / NX, i = e - j * NX;
+                for (int k = 0; k <= N; ++k) acc += 0.5 * ck(k) * (Dx[k * NX + i] * (X[k * NX + j] - xs[j]) + Dx[k * NX + j] * (X[k * NX + i] - xs[i]));
+                dpi[(size_t)iu * NP + M::OFF_Q + e] = okall ? -acc : NAN;
+            } else {
+                const int ee = e - NX * NX, j = ee / NU, i = ee - j * NU;
+                for (int k = 0; k < N; ++k) acc += 0.5 * ck(k) * (Du[k * NU + i] * U[k * NU + j] + Du[k * NU + j] * U[k * NU + i]);
+                dpi[(size_t)iu * NP + M::OFF_R + ee] = okall ? -acc : NAN;
+            }
+        }
+    }
+}
+
+}  // namespace mpcrl

@@ -81,6 +81,15 @@ MPCRL_DI Jet1<N> operator-(double s, const Jet1<N> &a) {
     return r;
 }
 template <int N>
+MPCRL_DI Jet1<N> jrecip(const Jet1<N> &b) {
+    Jet1<N> r;
+    r.v = 1.0 / b.v;
+    const double m2 = -r.v * r.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = m2 * b.d[i];
+    return r;
+}
+template <int N>
 MPCRL_DI void jsincos(const Jet1<N> &a, Jet1<N> &s, Jet1<N> &c) {
     double sv, cv;
     sincos(a.v, &sv, &cv);
@@ -217,5 +226,6 @@ MPCRL_DI Jet2<N> jsqrt(const Jet2<N> &a) {
 // plain double overloads so model code can be instantiated for values only
 MPCRL_DI void jsincos(const double &a, double &s, double &c) { sincos(a, &s, &c); }
 MPCRL_DI double jsqrt(double a) { return sqrt(a); }
+MPCRL_DI double jrecip(double a) { return 1.0 / a; }
 
 }  // namespace mpcrl

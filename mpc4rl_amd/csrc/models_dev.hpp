@@ -185,6 +185,38 @@ struct ChainDev {
         for (int i = 0; i < 3 * M; ++i) f[i] = vel[i];
         for (int j = 0; j < 3; ++j) f[3 * M + j] = u[j];
     }
+    // ode() with the parameters as plain doubles read straight from the full parameter vector p (uniform across the lanes of an
+    // instance: scalar loads), fully unrolled so that the state arrays of the caller stay in registers.  Used by the linearisation
+    // of the solve kernel, where only (x, u) carry tangents.
+    template <class S>
+    MPCRL_DI static void ode_p(const S *x, const S *u, const double *p, S *f) {
+        const S *pos = x, *vel = x + 3 * (M + 1);
+        const double *m = p, *D = p + NL, *L = p + 4 * NL, *C = p + 7 * NL, *w = p + OFF_W;
+        S *acc = f + 3 * (M + 1);
+#pragma unroll
+        for (int i = 0; i < 3 * M; ++i) acc[i] = S((i % 3 == 2) ? w[i] + (-9.81) : w[i]);
+#pragma unroll
+        for (int i = 0; i <= M; ++i) {
+            S dist[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dist[j] = i ? pos[3 * i + j] - pos[3 * (i > 0 ? i - 1 : 0) + j] : pos[j];
+            const S inrm = jrecip(jsqrt(dist[0] * dist[0] + dist[1] * dist[1] + dist[2] * dist[2]));
+            const double im = 1.0 / m[i];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const S Fs = (D[3 * i + j] * im) * ((1.0 - L[3 * i + j] * inrm) * dist[j]);
+                const S vr = i < M ? vel[3 * (i < M ? i : 0) + j] : u[j];
+                const S dv = i ? vr - vel[3 * (i > 0 ? i - 1 : 0) + j] : vr;
+                const S Ft = Fs + C[3 * i + j] * dv;
+                if (i < M) acc[3 * (i < M ? i : 0) + j] = acc[3 * (i < M ? i : 0) + j] - Ft;
+                if (i > 0) acc[3 * (i > 0 ? i - 1 : 0) + j] = acc[3 * (i > 0 ? i - 1 : 0) + j] + Ft;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3 * M; ++i) f[i] = vel[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) f[3 * M + j] = u[j];
+    }
     // Reverse sweep of ode(): xb += (df/dx)' fb, ub += (df/du)' fb and, with WANT_TH, thb += (df/dth)' fb.
     // With S = Jet1<1> (tangent seeded on x, u or fb) this is forward-over-reverse: the tangent parts of xb, ub, thb are one
     // Hessian-vector product of fb' f — what the KKT sensitivities need (nlp.py:1195-1211 builds the same objects symbolically).
@@ -261,6 +293,32 @@ MPCRL_DI void disc_map_lean(const S *x, const S *u, const S *th, S *xn, double h
         M::template ode<S>(xt, u, th, kk);
         for (int i = 0; i < NX; ++i) xc[i] = xc[i] + (h / 6.0) * (acc[i] + kk[i]);
     }
+    for (int i = 0; i < NX; ++i) xn[i] = xc[i];
+}
+
+// RK4^steps on M::ode_p (parameters = the full vector p as doubles), everything unrolled: no runtime-indexed arrays.
+template <class M, class S>
+MPCRL_DI void disc_map_p(const S *x, const S *u, const double *p, S *xn, double h, int steps) {
+    constexpr int NX = M::NX;
+    S xc[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xc[i] = x[i];
+    for (int s = 0; s < steps; ++s) {
+        S acc[NX], kk[NX], xt[NX];
+        M::template ode_p<S>(xc, u, p, kk);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) acc[i] = kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
+        M::template ode_p<S>(xt, u, p, kk);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
+        M::template ode_p<S>(xt, u, p, kk);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + h * kk[i];
+        M::template ode_p<S>(xt, u, p, kk);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xc[i] = xc[i] + (h / 6.0) * (acc[i] + kk[i]);
+    }
+#pragma unroll
     for (int i = 0; i < NX; ++i) xn[i] = xc[i];
 }
 

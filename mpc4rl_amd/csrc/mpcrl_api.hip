@@ -12,7 +12,7 @@
 #include <new>
 #include <vector>
 
-#include "large_kernel.hpp"
+#include "chain_kernel.hpp"
 #include "reduce_kernel.hpp"
 #include "order_kernel.hpp"
 
@@ -116,10 +116,24 @@ int fill_large_spec(const MpcrlProblemSpec &s, LargeSpec &d) {
 template <class M>
 int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
     a.ws = h->ws, a.ws_stride = h->ws_stride;
-    hipLaunchKernelGGL(large_solve_kernel<M>, dim3(h->B), dim3(LARGE_NT), 0, st, h->large, a);
+    const int B = h->B, N = h->N, NW = M::NX + M::NU;
+    const int max_iter = (a.flags & MPCRL_RTI) ? 1 : h->large.max_iter;
+    auto blocks = [](long items) { return dim3((unsigned)((items + 255) / 256)); };
+    hipLaunchKernelGGL(chain_init_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
+    // SQP rounds: the instances carry an `active` flag, finished ones return at once (no host synchronisation, the call stays
+    // asynchronous); round r evaluates iterate r and, unless it stops there, takes the full step to iterate r + 1
+    for (int r = 0; r <= max_iter; ++r) {
+        hipLaunchKernelGGL(chain_lin_kernel<M>, blocks((long)B * N * NW), dim3(256), 0, st, h->large, a);
+        hipLaunchKernelGGL(chain_qp_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
+    }
     HIP_OK(hipGetLastError());
     if (a.flags & (MPCRL_SENS_V | MPCRL_SENS_PI)) {
-        hipLaunchKernelGGL(large_sens_kernel<M>, dim3(h->B), dim3(LARGE_NT), 0, st, h->large, a);
+        hipLaunchKernelGGL(chain_sens_ad_kernel<M>, blocks((long)B * N * (NW + 1)), dim3(256), 0, st, h->large, a);
+        hipLaunchKernelGGL(chain_sens_riccati_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
+        if ((a.flags & MPCRL_SENS_PI) && a.dpi && !a.u0fix) {
+            hipLaunchKernelGGL(chain_sens_mix_kernel<M>, blocks((long)B * N * M::NU), dim3(256), 0, st, h->large, a);
+            hipLaunchKernelGGL(chain_sens_out_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
+        }
         HIP_OK(hipGetLastError());
     }
     return 0;
