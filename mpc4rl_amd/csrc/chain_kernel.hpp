@@ -29,6 +29,8 @@
 //
 // The iteration is the one of small_kernel.hpp / DESIGN.md §2 (same constants), so results agree with the oracle to rounding.
 #pragma once
+#include <type_traits>
+
 #include "small_kernel.hpp"
 
 namespace mpcrl {
@@ -54,6 +56,11 @@ struct LargeArgs {
     int *status, *iters;
 };
 
+template <int NX, int NW>
+struct ChainCfgStride {   // stage strides of the streamed blocks (ChainCfg below): whole 16-byte x 64-lane pieces
+    static constexpr int AST = 128 * (((NX * NX + 1) / 2 + 63) / 64), BST = 128 * ((NX * NW / 2 + 63) / 64);
+};
+
 // per-instance workspace layout (doubles)
 template <class M>
 struct LargeLayout {
@@ -68,9 +75,9 @@ struct LargeLayout {
         Dx = take((size_t)(N + 1) * NX), Du = take((size_t)N * NU), Dnu = take((size_t)(N + 1) * NX);
         rg = take((size_t)(N + 1) * NW), rb = take((size_t)N * NX), rt = take((size_t)(N + 1) * NW), Dg = take((size_t)(N + 1) * NW);
         lamw = take((size_t)2 * (N + 1) * NW), tw = take((size_t)2 * (N + 1) * NW), aff = take((size_t)2 * (N + 1) * NW);
-        P = take((size_t)(N + 1) * NX * NX), p = take((size_t)(N + 1) * NX), K = take((size_t)N * NU * NX), L = take((size_t)N * NU * NU);
+        P = take((size_t)(N + 1) * ChainCfgStride<NX, NW>::AST), p = take((size_t)(N + 1) * NX), K = take((size_t)N * NU * NX), L = take((size_t)N * NU * NU);
         kff = take((size_t)N * NU);
-        Acl = take((size_t)N * NX * NX), hb = take((size_t)N * NX), ccv = take((size_t)N * NX), cvec = take((size_t)N * NX);
+        Acl = take((size_t)N * ChainCfgStride<NX, NW>::BST), hb = take((size_t)N * NX), ccv = take((size_t)N * NX), cvec = take((size_t)N * NX);
         Hex = take((size_t)(N + 1) * NW * NW), term = take((size_t)N * NTD), ynu = take((size_t)(N + 1) * NX);
         state = take(16);   // ST_* below: the SQP loop's per-instance state between launches
         Ydx = take((size_t)NU * (N + 1) * NX), Ydu = take((size_t)NU * N * NU), Ydnu = take((size_t)NU * (N + 1) * NX);   // adjoint solutions
@@ -115,6 +122,70 @@ MPCRL_DI double wave_max(double v) {
     return v;
 }
 
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// A lone wavefront per SIMD has nothing to switch to while an LDS read is in flight (~64-130 cycles), and left to itself the
+// scheduler interleaves every read with its use.  The hot loops therefore stage a whole batch of operands into registers,
+// fence the scheduler, and only then start the arithmetic: one exposed LDS latency per batch instead of one per operand.
+#define MPCRL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// Opaque copy of a per-lane value.  Every phase of the solver starts from a laundered lane index: whatever it derives from it
+// (addresses, predicates, tile origins) then cannot be hoisted out of the interior-point loop, where the optimiser would
+// otherwise keep hundreds of such loop invariants live across all phases and spill them (each reload is an s_waitcnt vmcnt(0)).
+MPCRL_DI int launder(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// dot product of NN LDS operands (stride rs) with an LDS vector, in chunks of at most 12 (a double is two registers and only
+// 256 of the 512 are directly usable by the vector ALU: the batches have to stay small); four partial sums
+template <int NN>
+MPCRL_DI double lds_dot(const double *row, int rs, const double *vec, double init) {
+    constexpr int CH = NN <= 12 ? NN : (NN % 12 == 0 ? 12 : (NN % 11 == 0 ? 11 : (NN % 8 == 0 ? 8 : (NN % 7 == 0 ? 7 : 3))));
+    static_assert(NN % CH == 0, "chunking");
+    double acc[4] = {init, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < NN / CH; ++c) {
+        double a[CH], b[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) a[j] = row[(c * CH + j) * rs], b[j] = vec[c * CH + j];
+        MPCRL_SCHED_FENCE();
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[j & 3] = fma(a[j], b[j], acc[j & 3]);
+        MPCRL_SCHED_FENCE();
+    }
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+template <int D, int d = 0, class F>
+MPCRL_DI void static_for(F &&f) {
+    if constexpr (d < D) {
+        f(std::integral_constant<int, d>{});
+        static_for<D, d + 1>(f);
+    }
+}
+// Software pipeline over the stages of a sweep.  The operands of D stages are in flight in registers (slot = compile-time index,
+// so the register arrays are never runtime-indexed); body(idx, slot, refill) consumes slot `slot` for stage number idx (in
+// processing order) and calls refill() once the slot's registers are free, which issues the loads of stage idx + D.  A single
+// wavefront has nobody to switch to while a load is outstanding: the depth is what hides the HBM latency (~1-2 us under load).
+// The steady state is straight-line code: refills past the end re-request the last stage instead of branching, and every block
+// load / LDS store below is unconditional (the arrays are padded), so that s_waitcnt vmcnt(n) can be exact — behind a branch
+// the wait-count analysis falls back to vmcnt(0), which waits for the loads just issued and makes the depth useless.
+template <int D, class Fetch, class Body>
+MPCRL_DI void staged_loop(int n, Fetch &&fetch, Body &&body) {
+    static_for<D>([&](auto s) { fetch(s.value < n ? s.value : n - 1, s); });
+    const int full = n - n % D;
+    for (int base = 0; base < full; base += D)
+        static_for<D>([&](auto s) {
+            const int idx = base + s.value;
+            body(idx, s, [&] { fetch(idx + D < n ? idx + D : n - 1, s); });
+        });
+    static_for<D>([&](auto s) {
+        const int idx = full + s.value;
+        if (idx < n) body(idx, s, [&] {});
+    });
+}
+
 // tile shapes of the two stage GEMMs: one tile per lane, at most 64 tiles
 template <class M>
 struct ChainCfg {
@@ -126,17 +197,33 @@ struct ChainCfg {
     static constexpr int NTT = NTR * NTC, NMM = NMT * (NMT + 1) / 2;
     static_assert(NTT <= 64 && NMM <= 64, "one GEMM tile per lane");
     static_assert(NW % TJ == 0 && NW % TS == 0, "column tiles are full");
-    static constexpr int NBA = (NX * NW + 63) / 64;   // doubles per lane of one [B A] block
-    static constexpr int NAC = (NX * NX + 63) / 64;   // doubles per lane of one nx x nx block
-    // LDS (doubles): P_{k+1} and M share one region (P is dead once T = P [B A] and P b are formed, M once P_k is), [B A], T, vectors
-    static constexpr int oP = 0, oM = 0, oBA = NW * NW, oT = oBA + NX * NW, oVec = oT + NX * NW;
-    static constexpr int oG = oVec, oBB = oG + NW, oDG = oBB + NX + (NX & 1), oPV = oDG + NW, oCC = oPV + NX + (NX & 1), oMV = oCC + NX + (NX & 1),
-                         oK = oMV + NW, oCK = oK + NU * NX + NU + ((NU * NX + NU) & 1), oSV = oCK + 64, oLB = oSV + 2 * (NX + (NX & 1)),
-                         LDS_TOTAL = oLB + 4 * NW + 8;
+    static constexpr int NBA2 = (NX * NW / 2 + 63) / 64;    // 16-byte pieces per lane of one [B A] block
+    static constexpr int NAC2 = ((NX * NX + 1) / 2 + 63) / 64;   // ... of one nx x nx block
+    // stage strides of the streamed blocks in the workspace: whole pieces, so that the block copies need no tail predicate
+    static constexpr int AST = 128 * NAC2;                  // P_k
+    static constexpr int BST = 128 * NBA2;                  // Acl_k (kept in the [B A] block shape)
+#ifndef MPCRL_CHAIN_DEPTH
+#define MPCRL_CHAIN_DEPTH 2
+#endif
+#ifndef MPCRL_CHAIN_FDEPTH
+#define MPCRL_CHAIN_FDEPTH 1
+#endif
+    static constexpr int DEPTH = MPCRL_CHAIN_DEPTH;         // stages in flight in the vector sweeps (<= 63 outstanding memory operations)
+    static constexpr int FDEPTH = MPCRL_CHAIN_FDEPTH;       // ... in the factor sweep (a stage is ~2-6 k cycles of work there)
+    static constexpr int UNR = NX <= 21 ? 3 : 1;            // inner indices per operand group of the stage GEMMs (two groups in registers)
+    // LDS (doubles): the small vectors first (some of them live for the whole kernel), then the big region
+    static constexpr int ev(int n) { return n + (n & 1); }
+    static constexpr int oG = 0, oBB = oG + NW, oDG = oBB + ev(NX), oPV = oDG + NW, oCC = oPV + ev(NX), oMV = oCC + ev(NX), oK = oMV + NW,
+                         oCK = oK + ev(NU * NX + NU), oSV = oCK + 64, oLB = oSV + 2 * ev(NX), oBig = oLB + 4 * NW + 8;
+    // factor sweep: P_{k+1} and M share one region (P is dead once T = P [B A] and P b are formed, M once P_k is), [B A], T
+    static constexpr int oP = oBig, oM = oBig, oBA = oBig + NW * NW, oT = oBA + NX * NW;
+    // vector sweeps: Acl_k where P / M sit, P_k where [B A] sits; residual passes: Q where P / M sit, [B A] in place;
+    // start of an SQP round: Q, then X - x_ss and U of the whole horizon (up to 64 stages)
+    static constexpr int oA = oBig, oPk = oBig + BST, oQ = oBig, oX = oBig + NW * NW, oU = oX + 64 * NX;
+    static constexpr int BIG_F = NW * NW + 2 * NX * NW, BIG_R = NW * NW + 64 * NW;
+    static constexpr int LDS_TOTAL = oBig + (BIG_F > BIG_R ? BIG_F : BIG_R);
+    static_assert(oBig % 2 == 0 && BST + AST <= BIG_F && NX * NX <= NW * NW, "aligned / overlays fit");
     static_assert(LDS_TOTAL * 8 <= 40 * 1024, "four wavefronts per CU");
-    // the vector sweeps stage Acl_k (two buffers) where P / [B A] sit during the factor sweep
-    static constexpr int oA0 = 0, oA1 = NX * NX + (NX & 1);
-    static_assert(2 * (NX * NX + 1) <= oVec, "Acl double buffer fits below the vectors");
 };
 
 // Hessian source of the Riccati factorisation: the SQP uses c_k * (Q, R) from the parameter vector — constant per lane, kept in
@@ -147,8 +234,16 @@ struct HessConst {
     double h[Cfg::TS][Cfg::TS];     // unscaled, this lane's tile of the [u; x] Hessian
     const double *th;
     const double *sck;
+    MPCRL_DI void begin(int i0, int j0, bool live) {
+#pragma unroll
+        for (int a = 0; a < Cfg::TS; ++a)
+#pragma unroll
+            for (int b = 0; b < Cfg::TS; ++b) h[a][b] = live ? M::hess(false, i0 + a, j0 + b, th) : 0.0;
+    }
+    template <class S_>
+    MPCRL_DI void rebind(const S_ &S) { th = S.th, sck = S.sCK(); }
     MPCRL_DI void prefetch(int) {}
-    MPCRL_DI void advance() {}
+    MPCRL_DI void advance(int) {}
     MPCRL_DI double tile(int k, int a, int b) const { return sck[k] * h[a][b]; }
     MPCRL_DI double term(int N, int i, int j) const { return sck[N] * M::Qs(th, i, j); }
 };
@@ -160,17 +255,22 @@ struct HessGlobal {
     int i0, j0;
     bool live;
     double hn[Cfg::TS][Cfg::TS], hc[Cfg::TS][Cfg::TS];
+    MPCRL_DI void begin(int i0_, int j0_, bool live_) { i0 = i0_, j0 = j0_, live = live_; }
+    template <class S_>
+    MPCRL_DI void rebind(const S_ &S) { S.uni(Hex); }
     MPCRL_DI void prefetch(int k) {
 #pragma unroll
         for (int a = 0; a < Cfg::TS; ++a)
 #pragma unroll
             for (int b = 0; b < Cfg::TS; ++b) hn[a][b] = live ? Hex[k * NW * NW + (i0 + a) * NW + j0 + b] : 0.0;
     }
-    MPCRL_DI void advance() {
+    // the tile of stage k becomes current; the tile of stage k - 1 is requested (one stage ahead, independent of the operand ring)
+    MPCRL_DI void advance(int k) {
 #pragma unroll
         for (int a = 0; a < Cfg::TS; ++a)
 #pragma unroll
             for (int b = 0; b < Cfg::TS; ++b) hc[a][b] = hn[a][b];
+        if (k > 0) prefetch(k - 1);
     }
     MPCRL_DI double tile(int, int a, int b) const { return hc[a][b]; }
     MPCRL_DI double term(int N, int i, int j) const { return Hex[N * NW * NW + (NU + i) * NW + NU + j]; }
@@ -181,8 +281,9 @@ struct ChainSolver {
     using Cfg = ChainCfg<M>;
     static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD, NP = M::NP, NT = 64;
     static constexpr int TI = Cfg::TI, TJ = Cfg::TJ, TS = Cfg::TS;
-    const LargeSpec &sp;
-    const int N, lane;
+    const LargeSpec *spp;   // kernel-argument copy of the problem (set-up only)
+    const double *xs;       // x_ss (device)
+    int N, lane;
     const double *th;   // full parameter vector of this instance
     bool qmode;
     // global (per instance)
@@ -197,7 +298,7 @@ struct ChainSolver {
     int n0, nm, ne, nrows;
     int *sidx;
 
-    MPCRL_DI ChainSolver(const LargeSpec &s, int lane_) : sp(s), N(s.N), lane(lane_) {}
+    MPCRL_DI ChainSolver(const LargeSpec &s, int lane_) : spp(&s), xs(s.consts), N(s.N), lane(lane_) {}
 
 #ifdef MPCRL_PROFILE_PHASES
     // per-wavefront tick counters in LDS (no global traffic inside the timed regions), flushed once by ph_flush()
@@ -237,12 +338,14 @@ struct ChainSolver {
     MPCRL_DI double *sMV() const { return lds + Cfg::oMV; }
     MPCRL_DI double *sK() const { return lds + Cfg::oK; }
     MPCRL_DI double *sCK() const { return lds + Cfg::oCK; }
-    MPCRL_DI double *sSV(int b) const { return lds + Cfg::oSV + b * (NX + (NX & 1)); }
+    MPCRL_DI double *sSV(int b) const { return lds + Cfg::oSV + b * Cfg::ev(NX); }
     MPCRL_DI double *sLB() const { return lds + Cfg::oLB; }          // lb, ub (stages 1..N-1), lbe, ube: NW each; lb0, ub0: 4 each
-    MPCRL_DI double *sA(int b) const { return lds + (b ? Cfg::oA1 : Cfg::oA0); }
+    MPCRL_DI double *sA() const { return lds + Cfg::oA; }
+    MPCRL_DI double *sPk() const { return lds + Cfg::oPk; }
 
     MPCRL_DI double ck(int k) const { return sCK()[k]; }
     MPCRL_DI double ck_eval(int k) const {
+        const LargeSpec &sp = *spp;
         if (sp.cost_kind == 0) return k == N ? 1.0 : sp.dT;                                            // nlp.py:1044-1055
         return k == 0 ? sp.dT : (k == N ? pow(sp.gamma, (double)N) : pow(sp.gamma, (double)k) * sp.dT);   // nlp.py:1083-1091
     }
@@ -280,8 +383,29 @@ struct ChainSolver {
     MPCRL_DI double &TT(int sd, int e) { return t[sd * (N + 1) * NW + e]; }
     MPCRL_DI double &AFF(int sd, int e) { return aff[sd * (N + 1) * NW + e]; }
 
+    // 16-byte coalesced moves of one stage block: workspace -> registers -> LDS (n2 = number of 16-byte pieces)
+    template <int NV>
+    MPCRL_DI void blk_load(const WsArr src, int n2, d2_t (&rr)[NV], int lane) const {
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const int e2 = lane + 64 * s;
+            (void)n2;
+            rr[s] = *(const d2_t *)&src[2 * e2];   // past the block: the next array of the workspace (never used)
+        }
+    }
+    template <int NV>
+    MPCRL_DI void blk_to_lds(double *dst, int n2, const d2_t (&rr)[NV], int lane) const {
+#pragma unroll
+        for (int s = 0; s < NV; ++s) {
+            const int e2 = lane + 64 * s;
+            (void)n2;
+            *(d2_t *)(dst + 2 * e2) = rr[s];       // the LDS regions leave room for 128 * NV doubles
+        }
+    }
+
     // ---- one-off set-up: constants into LDS, GEMM tile of this lane, list of bounded coordinates
     MPCRL_DI void setup(double *lds_, int *sidx_) {
+        const LargeSpec &sp = *spp;
         lds = lds_, sidx = sidx_;
         if (lane <= N) sCK()[lane] = ck_eval(lane);
         if (lane == 0) {   // one lane, compile-time indices: the kernel arguments stay scalar operands
@@ -321,27 +445,6 @@ struct ChainSolver {
         nrows = n0 + (N - 1) * nm + ne;
     }
 
-    // cost gradient q = c_k grad l_k and local cost value
-    MPCRL_DI double linearize_cost() {
-        const double *xs = sp.consts;
-        double val = 0.0;
-        for (int e = lane; e < (N + 1) * NW; e += NT) {
-            const int k = e / NW, i = e - k * NW;
-            const bool term = k == N;
-            double a = 0.0;
-            if (i < NU) {
-                if (!term)
-                    for (int j = 0; j < NU; ++j) a = fma(M::Rs(th, i, j), U[k * NU + j], a);
-                q[e] = ck(k) * a;
-                if (!term) val += 0.5 * ck(k) * a * U[k * NU + i];
-            } else {
-                for (int j = 0; j < NX; ++j) a = fma(M::Qs(th, i - NU, j), X[k * NX + j] - xs[j], a);
-                q[e] = ck(k) * a;
-                val += 0.5 * ck(k) * a * (X[k * NX + i - NU] - xs[i - NU]);
-            }
-        }
-        return val;
-    }
     // ([B A]_k' nu_{k+1} - [0; nu_k])_i
     MPCRL_DI double GTnu(const WsArr &nu, int k, int i) const {
         double a = 0.0;
@@ -352,17 +455,74 @@ struct ChainSolver {
         if (i >= NU && k > 0) a -= nu[k * NX + i - NU];
         return a;
     }
-    MPCRL_DI void nlp_residuals(const double *x0, const double *u0f, double *res) {
-        double rs = 0, re = 0, ri = 0, rc = 0;
-        for (int e = lane; e < (N + 1) * NW; e += NT) {
+
+    // ---- start of an SQP round: q = c_k grad l_k, the cost, and the four NLP residual norms (stationarity, equality,
+    // inequality, complementarity).  Q (symmetrised), X - x_ss and U of the whole horizon are staged in LDS; the stationarity
+    // residual q + [B A]' nu_{k+1} - [0; nu_k] -+ lam is a stage-serial pass with [B A]_k staged through LDS (coalesced).
+    MPCRL_DI double round_start(const double *x0, const double *u0f, double *res) {
+        const int ne = (N + 1) * NW;
+        double *lQ = lds + Cfg::oQ, *lX = lds + Cfg::oX, *lU = lds + Cfg::oU;
+        for (int e = lane; e < NX * NX; e += NT) lQ[e] = M::Qs(th, e / NX, e % NX);
+        for (int e = lane; e < (N + 1) * NX; e += NT) lX[e] = X[e] - xs[e % NX];
+        for (int e = lane; e < N * NU; e += NT) lU[e] = U[e];
+        wave_sync();
+        double val = 0.0;
+        for (int e = lane; e < ne; e += NT) {
             const int k = e / NW, i = e - k * NW;
-            if (skipc(k, i)) continue;
-            if (!fixedc(k, i)) {
-                double g = q[e] + GTnu(NUv, k, i);
-                if (has(0, k, i)) g -= lam[e];
-                if (has(1, k, i)) g += lam[(N + 1) * NW + e];
-                rs = fmax(rs, fabs(g));
+            const bool term = k == N;
+            double a = 0.0, v = 0.0;
+            if (i < NU) {
+                if (!term) {
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) a = fma(M::Rs(th, i, j), lU[k * NU + j], a);
+                    v = lU[k * NU + i];
+                }
+            } else {
+                const double *qr = lQ + (i - NU) * NX, *xk = lX + k * NX;
+                a = lds_dot<NX>(qr, 1, xk, 0.0);
+                v = xk[i - NU];
             }
+            const double qe = ck(k) * a;
+            q[e] = qe;
+            val = fma(0.5 * qe, v, val);
+            double g = qe;
+            if (!skipc(k, i)) {
+                if (has(0, k, i)) g -= lam[e];
+                if (has(1, k, i)) g += lam[ne + e];
+            }
+            rg[e] = g;   // q -+ lam: the stage pass below adds the multiplier terms of the dynamics
+        }
+        wave_sync();
+        double rs = 0, re = 0, ri = 0, rc = 0;
+        {
+            d2_t nB[Cfg::DEPTH][Cfg::NBA2];
+            double ng[Cfg::DEPTH], nn[Cfg::DEPTH], no[Cfg::DEPTH];
+            double *lBA = sBA(), *lnu = sBB();
+            const int lj = lane < NW ? lane : 0, lx = lane < NX ? lane : 0;
+            staged_loop<Cfg::DEPTH>(
+                N,
+                [&](int k, auto sl) {
+                    constexpr int d = decltype(sl)::value;
+                    blk_load(BA + k * NX * NW, NX * NW / 2, nB[d], lane);
+                    ng[d] = rg[k * NW + lj], nn[d] = NUv[(k + 1) * NX + lx];
+                    {
+                        const bool c_ = lane >= NU && lane < NW && k > 0;
+                        const double t_ = NUv[c_ ? k * NX + lj - NU : 0];
+                        no[d] = c_ ? t_ : 0.0;
+                    }
+                },
+                [&](int k, auto sl, auto refill) {
+                    constexpr int d = decltype(sl)::value;
+                    blk_to_lds(lBA, NX * NW / 2, nB[d], lane);
+                    if (lane < NX) lnu[lane] = nn[d];
+                    double a = ng[d] - no[d];
+                    refill();
+                    wave_sync();
+                    a = lds_dot<NX>(lBA + lj, NW, lnu, a);
+                    if (lane < NW && !fixedc(k, lane)) rs = fmax(rs, fabs(a));
+                    wave_sync();
+                });
+            if (lane >= NU && lane < NW) rs = fmax(rs, fabs(rg[N * NW + lane] - NUv[N * NX + lane - NU]));
         }
         for (int r_ = lane; r_ < nrows; r_ += NT) {
             int k, i;
@@ -375,271 +535,438 @@ struct ChainSolver {
             }
             if (has(1, k, i)) {
                 const double h = v - ubv(k, i);
-                ri = fmax(ri, h), rc = fmax(rc, fabs(lam[(N + 1) * NW + e] * h));
+                ri = fmax(ri, h), rc = fmax(rc, fabs(lam[ne + e] * h));
             }
         }
         for (int e = lane; e < N * NX; e += NT) re = fmax(re, fabs(r[e]));
         if (lane < NX) re = fmax(re, fabs(X[lane] - x0[lane]));
         if (qmode && lane < NU) re = fmax(re, fabs(U[lane] - u0f[lane]));
         res[0] = wave_max(rs), res[1] = wave_max(re), res[2] = wave_max(ri), res[3] = wave_max(rc);
+        return wave_sum(val);
     }
+
+    // ---- residuals of the QP at (dx, du, nuq, lam): rb = r + [B A] dv - dx+  and  rg = q + H dv + [B A]' nuq+ - [0; nuq] -+ lam.
+    // Same stage pass: [B A]_k through LDS, lane i < NX takes row i (read skewed by i so that the row stride NW does not
+    // collide on LDS banks), lane j < NW takes column j and its row of the stage Hessian.  Returns the inf-norm.
+    MPCRL_DI double qp_residuals() {
+        const int ne = (N + 1) * NW;
+        double *lQ = lds + Cfg::oQ, *lBA = sBA(), *ldv = sG(), *lnu = sBB();
+        for (int e = lane; e < NX * NX; e += NT) lQ[e] = M::Qs(th, e / NX, e % NX);
+        for (int e = lane; e < ne; e += NT) {
+            const int k = e / NW, i = e - k * NW;
+            double g = q[e];
+            if (!skipc(k, i)) {
+                if (has(0, k, i)) g -= lam[e];
+                if (has(1, k, i)) g += lam[ne + e];
+            }
+            rg[e] = g;
+        }
+        double Rrow[NU];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) Rrow[j] = lane < NU ? M::Rs(th, lane < NU ? lane : 0, j) : 0.0;
+        wave_sync();
+        double rloc = 0.0;
+        d2_t nB[Cfg::DEPTH][Cfg::NBA2];
+        double nv[Cfg::DEPTH], nn[Cfg::DEPTH], nxn[Cfg::DEPTH], nr[Cfg::DEPTH], ng[Cfg::DEPTH], no[Cfg::DEPTH];
+        const int lj = lane < NW ? lane : 0, lx = lane < NX ? lane : 0;
+        const double *qr = lQ + (lane >= NU && lane < NW ? lane - NU : 0) * NX;
+        // [B A]_k is published with an odd row stride (NW + 1): lane i reads row i, and NW doubles between rows would put a
+        // whole lane group on four LDS banks
+        constexpr int NWP = NW + 1;
+        int pdst[Cfg::NBA2][2];
+#pragma unroll
+        for (int s_ = 0; s_ < Cfg::NBA2; ++s_)
+#pragma unroll
+            for (int h_ = 0; h_ < 2; ++h_) {
+                const int e = 2 * (lane + 64 * s_) + h_;
+                pdst[s_][h_] = e < NX * NW ? (e / NW) * NWP + e % NW : NX * NWP + (e & 1);   // past the block: a dump slot
+            }
+        staged_loop<Cfg::DEPTH>(
+            N,
+            [&](int k, auto sl) {
+                constexpr int d = decltype(sl)::value;
+                blk_load(BA + k * NX * NW, NX * NW / 2, nB[d], lane);
+                nv[d] = WsArr{dx.base, lane < NU ? du.off + k * NU + lj : dx.off + k * NX + (lane < NW ? lane - NU : 0)}[0];
+                nn[d] = nuq[(k + 1) * NX + lx], nxn[d] = dx[(k + 1) * NX + lx], nr[d] = r[k * NX + lx];
+                ng[d] = rg[k * NW + lj];
+                {
+                    const bool c_ = lane >= NU && lane < NW && k > 0;
+                    const double t_ = nuq[c_ ? k * NX + lj - NU : 0];
+                    no[d] = c_ ? t_ : 0.0;
+                }
+            },
+            [&](int k, auto sl, auto refill) {
+                constexpr int d = decltype(sl)::value;
+#pragma unroll
+                for (int s_ = 0; s_ < Cfg::NBA2; ++s_) {
+                    lBA[pdst[s_][0]] = nB[d][s_].x;
+                    lBA[pdst[s_][1]] = nB[d][s_].y;
+                }
+                if (lane < NW) ldv[lane] = nv[d];
+                if (lane < NX) lnu[lane] = nn[d];
+                double a = nr[d] - nxn[d], g = ng[d] - no[d];
+                refill();
+                wave_sync();
+                a = lds_dot<NW>(lBA + lx * NWP, 1, ldv, a);          // row lx of [B A] times dv
+                g = lds_dot<NX>(lBA + lj, NWP, lnu, g);              // column lj of [B A] times nuq+
+                double hd = lds_dot<NX>(qr, 1, ldv + NU, 0.0);       // row of Q times dx (lanes < NU: overwritten below)
+                if (lane < NU) {
+                    hd = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NU; ++l) hd = fma(Rrow[l], ldv[l], hd);
+                }
+                g = fma(ck(k), hd, g);
+                if (fixedc(k, lane)) g = 0.0;
+                if (lane < NX) rb[k * NX + lane] = a, rloc = fmax(rloc, fabs(a));
+                if (lane < NW) rg[k * NW + lane] = g, rloc = fmax(rloc, fabs(g));
+                wave_sync();
+            });
+        {   // terminal stage: no control, no dynamics leaving it
+            if (lane < NX) ldv[NU + lane] = dx[N * NX + lane];
+            wave_sync();
+            double g = 0.0;
+            if (lane >= NU && lane < NW) {
+                const double hd = lds_dot<NX>(qr, 1, ldv + NU, 0.0);
+                g = fma(ck(N), hd, rg[N * NW + lane] - nuq[N * NX + lane - NU]);
+            }
+            if (lane < NW) rg[N * NW + lane] = g, rloc = fmax(rloc, fabs(g));
+        }
+        wave_sync();
+        return rloc;
+    }
+
 
     // ---- Riccati factor sweep with the vector recursion of the first right-hand side riding along.
     // HS: Hessian source; g: modified gradient [(N+1)*NW]; bb: dynamics offsets [N*NX] or null (= 0).
     // Leaves in the workspace: P_k, p_k, K_k, L_k, kff_k, Acl_k = A_k - B_k K_k, hb_k = P_{k+1} b_k.
     template <class HS>
     MPCRL_DI bool factor(HS &hs, const WsArr g, const WsArr bb) {
+        hs.begin(m_i0, m_j0, m_live);
         bool ok = true;
         double *const lP = sP(), *const lBA = sBA(), *const lT = sT(), *const lM = sM();
+        constexpr int AST = Cfg::AST, FD = Cfg::FDEPTH;
         // terminal stage
         for (int e = lane; e < NX * NX; e += NT) {
             const int i = e / NX, j = e - i * NX;
             const double v = hs.term(N, i > j ? i : j, i > j ? j : i) + (i == j ? Dg[N * NW + NU + i] : 0.0);
             lP[e] = v;
-            P[N * NX * NX + e] = v;
+            P[N * AST + e] = v;
         }
         if (lane < NX) {
             const double v = g[N * NW + NU + lane];
             sPV()[lane] = v;
             p[N * NX + lane] = v;
         }
-        // operands of stage N-1 into registers
-        double nBA[Cfg::NBA], ng = 0.0, nbb = 0.0, nDg = 0.0;
-        auto fetch = [&](int k) {
-            const WsArr src = BA + k * NX * NW;
+        d2_t nB[FD][Cfg::NBA2];
+        double ng[FD], nbb[FD], nDg[FD];
+        const int lj = lane < NW ? lane : 0, lx = lane < NX ? lane : 0;
+        int ia[TI];
 #pragma unroll
-            for (int s = 0; s < Cfg::NBA; ++s) {
-                const int e = lane + 64 * s;
-                nBA[s] = e < NX * NW ? src[e] : 0.0;
-            }
-            ng = lane < NW ? g[k * NW + lane] : 0.0;
-            nDg = lane < NW ? Dg[k * NW + lane] : 0.0;
-            nbb = (bb && lane < NX) ? bb[k * NX + lane] : 0.0;
-            hs.prefetch(k);
-        };
-        fetch(N - 1);
-        for (int k = N - 1; k >= 0; --k) {
-            const bool pin = k == 0 && qmode;
-            // ---- publish the stage operands, fetch the next stage's
-#pragma unroll
-            for (int s = 0; s < Cfg::NBA; ++s) {
-                const int e = lane + 64 * s;
-                if (e < NX * NW) lBA[e] = nBA[s];
-            }
-            if (lane < NW) sG()[lane] = ng, sDG()[lane] = nDg;
-            if (lane < NX) sBB()[lane] = nbb;
-            hs.advance();
-            if (k > 0) fetch(k - 1);
-            wave_sync();
-            // ---- T = P [B A]  (TI x TJ tile per lane; P symmetric: row m of P is column m) and cc = p + P b
-            {
-                double acc[TI][TJ];
-#pragma unroll
-                for (int a = 0; a < TI; ++a)
-#pragma unroll
-                    for (int b = 0; b < TJ; ++b) acc[a][b] = 0.0;
-                int ia[TI];
-#pragma unroll
-                for (int a = 0; a < TI; ++a) ia[a] = t_i0 + a < NX ? t_i0 + a : NX - 1;
-#pragma unroll 3
-                for (int m = 0; m < NX; ++m) {
-                    double pa[TI], bv[TJ];
-#pragma unroll
-                    for (int a = 0; a < TI; ++a) pa[a] = lP[m * NX + ia[a]];
-#pragma unroll
-                    for (int b = 0; b < TJ; ++b) bv[b] = lBA[m * NW + t_j0 + b];
+        for (int a = 0; a < TI; ++a) ia[a] = t_i0 + a < NX ? t_i0 + a : NX - 1;
+        hs.prefetch(N - 1);   // the Hessian source keeps one stage ahead itself (HessGlobal::advance)
+        staged_loop<FD>(
+            N,
+            [&](int idx, auto sl) {
+                constexpr int d = decltype(sl)::value;
+                const int k = N - 1 - idx;
+                blk_load(BA + k * NX * NW, NX * NW / 2, nB[d], lane);
+                ng[d] = g[k * NW + lj], nDg[d] = Dg[k * NW + lj];
+                nbb[d] = bb[k * NX + lx];
+            },
+            [&](int idx, auto sl, auto refill) {
+                constexpr int d = decltype(sl)::value;
+                const int k = N - 1 - idx;
+                const bool pin = k == 0 && qmode;
+                // ---- publish the stage operands, start fetching a later stage's
+                blk_to_lds(lBA, NX * NW / 2, nB[d], lane);
+                if (lane < NW) sG()[lane] = ng[d], sDG()[lane] = nDg[d];
+                if (lane < NX) sBB()[lane] = nbb[d];
+                hs.advance(k);
+                refill();
+                wave_sync();
+                // ---- T = P [B A]  (TI x TJ tile per lane; P symmetric: row m of P is column m) and cc = p + P b
+                {
+                    double acc[TI][TJ];
 #pragma unroll
                     for (int a = 0; a < TI; ++a)
 #pragma unroll
-                        for (int b = 0; b < TJ; ++b) acc[a][b] = fma(pa[a], bv[b], acc[a][b]);
-                }
-                if (t_live) {
+                        for (int b = 0; b < TJ; ++b) acc[a][b] = 0.0;
+                    // groups of UNR inner indices, double-buffered: the operands of the next group are requested before the
+                    // arithmetic of the current one starts (LDS returns in order, so waiting for one group leaves the next in flight)
+                    constexpr int UNR = Cfg::UNR, NG = NX / UNR;
+                    static_assert(NG * UNR == NX, "NX = groups x UNR");
+                    double pa[2][UNR][TI], bv[2][UNR][TJ];
+                    auto ldg = [&](int g_, auto bi) {
+                        constexpr int b_ = decltype(bi)::value;
 #pragma unroll
-                    for (int a = 0; a < TI; ++a)
-                        if (t_i0 + a < NX) {
+                        for (int u = 0; u < UNR; ++u) {
 #pragma unroll
-                            for (int b = 0; b < TJ; ++b) lT[(t_i0 + a) * NW + t_j0 + b] = acc[a][b];
+                            for (int a = 0; a < TI; ++a) pa[b_][u][a] = lP[(g_ * UNR + u) * NX + ia[a]];
+#pragma unroll
+                            for (int b = 0; b < TJ; ++b) bv[b_][u][b] = lBA[(g_ * UNR + u) * NW + t_j0 + b];
                         }
+                    };
+                    auto mac = [&](auto bi) {
+                        constexpr int b_ = decltype(bi)::value;
+                        MPCRL_SCHED_FENCE();
+#pragma unroll
+                        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                            for (int a = 0; a < TI; ++a)
+#pragma unroll
+                                for (int b = 0; b < TJ; ++b) acc[a][b] = fma(pa[b_][u][a], bv[b_][u][b], acc[a][b]);
+                        MPCRL_SCHED_FENCE();
+                    };
+                    const std::integral_constant<int, 0> B0{};
+                    const std::integral_constant<int, 1> B1{};
+                    ldg(0, B0);
+                    for (int g_ = 0; g_ + 1 < NG; g_ += 2) {
+                        ldg(g_ + 1, B1);
+                        mac(B0);
+                        ldg(g_ + 2 < NG ? g_ + 2 : NG - 1, B0);   // past the end: re-request the last group (no branch)
+                        mac(B1);
+                    }
+                    if constexpr (NG % 2 == 1) mac(B0);
+                    const double a = lds_dot<NX>(lP + lx * NX, 1, sBB(), 0.0);
+                    if (t_live) {
+#pragma unroll
+                        for (int a_ = 0; a_ < TI; ++a_)
+                            if (t_i0 + a_ < NX) {
+#pragma unroll
+                                for (int b = 0; b < TJ; ++b) lT[(t_i0 + a_) * NW + t_j0 + b] = acc[a_][b];
+                            }
+                    }
+                    if (lane < NX) {
+                        sCC()[lane] = sPV()[lane] + a;
+                        hb[k * NX + lane] = a;
+                    }
                 }
-                const int li = lane < NX ? lane : 0;
-                double a = 0.0;
-                if (bb)
-                    for (int m = 0; m < NX; ++m) a = fma(lP[li * NX + m], sBB()[m], a);
-                if (lane < NX) {
-                    sCC()[lane] = sPV()[lane] + a;
-                    hb[k * NX + lane] = a;
-                }
-            }
-            wave_sync();
-            ph(10);
-            // ---- M = H + D + [B A]' T (lower-triangular tile grid, mirrored) and mv = g + [B A]' cc
-            {
-                double acc[TS][TS];
-#pragma unroll
-                for (int a = 0; a < TS; ++a)
-#pragma unroll
-                    for (int b = 0; b < TS; ++b) acc[a][b] = hs.tile(k, a, b) + ((m_diag && a == b) ? sDG()[m_i0 + a] : 0.0);
-#pragma unroll 3
-                for (int m = 0; m < NX; ++m) {
-                    double av[TS], tv[TS];
-#pragma unroll
-                    for (int a = 0; a < TS; ++a) av[a] = lBA[m * NW + m_i0 + a];
-#pragma unroll
-                    for (int b = 0; b < TS; ++b) tv[b] = lT[m * NW + m_j0 + b];
+                wave_sync();
+                ph(10);
+                // ---- M = H + D + [B A]' T (lower-triangular tile grid, mirrored) and mv = g + [B A]' cc
+                {
+                    double acc[TS][TS];
 #pragma unroll
                     for (int a = 0; a < TS; ++a)
 #pragma unroll
-                        for (int b = 0; b < TS; ++b) acc[a][b] = fma(av[a], tv[b], acc[a][b]);
-                }
-                if (m_live) {
+                        for (int b = 0; b < TS; ++b) acc[a][b] = hs.tile(k, a, b) + ((m_diag && a == b) ? sDG()[m_i0 + a] : 0.0);
+                    constexpr int UNR = Cfg::UNR, NG = NX / UNR;
+                    double av[2][UNR][TS], tv[2][UNR][TS];
+                    auto ldg = [&](int g_, auto bi) {
+                        constexpr int b_ = decltype(bi)::value;
 #pragma unroll
-                    for (int a = 0; a < TS; ++a)
+                        for (int u = 0; u < UNR; ++u) {
 #pragma unroll
-                        for (int b = 0; b < TS; ++b) {
-                            if (m_diag && b > a) continue;   // the diagonal tile keeps its lower triangle, mirrored like the rest
-                            lM[(m_i0 + a) * NW + m_j0 + b] = acc[a][b];
-                            lM[(m_j0 + b) * NW + m_i0 + a] = acc[a][b];
+                            for (int a = 0; a < TS; ++a) av[b_][u][a] = lBA[(g_ * UNR + u) * NW + m_i0 + a];
+#pragma unroll
+                            for (int b = 0; b < TS; ++b) tv[b_][u][b] = lT[(g_ * UNR + u) * NW + m_j0 + b];
                         }
-                }
-                const int li = lane < NW ? lane : 0;
-                double a = sG()[li];
-                for (int m = 0; m < NX; ++m) a = fma(lBA[m * NW + li], sCC()[m], a);
-                if (lane < NW) sMV()[lane] = a;
-            }
-            wave_sync();
-            ph(11);
-            // ---- Cholesky of the control block (every lane, redundantly): L lower with inverted diagonal
-            double Lc[NU][NU];
-            {
-                bool okc = true;
+                    };
+                    auto mac = [&](auto bi) {
+                        constexpr int b_ = decltype(bi)::value;
+                        MPCRL_SCHED_FENCE();
 #pragma unroll
-                for (int i = 0; i < NU; ++i)
+                        for (int u = 0; u < UNR; ++u)
 #pragma unroll
-                    for (int j = 0; j <= i; ++j) {
-                        double a = lM[i * NW + j];
+                            for (int a = 0; a < TS; ++a)
 #pragma unroll
-                        for (int m = 0; m < j; ++m) a -= Lc[i][m] * Lc[j][m];
-                        if (i == j) {
-                            okc = okc && (a > 0.0);
-                            Lc[i][i] = 1.0 / sqrt(a);
-                        } else
-                            Lc[i][j] = a * Lc[j][j];
+                                for (int b = 0; b < TS; ++b) acc[a][b] = fma(av[b_][u][a], tv[b_][u][b], acc[a][b]);
+                        MPCRL_SCHED_FENCE();
+                    };
+                    const std::integral_constant<int, 0> B0{};
+                    const std::integral_constant<int, 1> B1{};
+                    ldg(0, B0);
+                    for (int g_ = 0; g_ + 1 < NG; g_ += 2) {
+                        ldg(g_ + 1, B1);
+                        mac(B0);
+                        ldg(g_ + 2 < NG ? g_ + 2 : NG - 1, B0);   // past the end: re-request the last group (no branch)
+                        mac(B1);
                     }
-                ok = ok && (okc || pin);
-            }
-            // K columns (lanes j < NX) and the feed-forward (lane NX): solve L L' z = rhs
-            if (lane <= NX) {
-                const int j = lane;
-                double y[NU], z[NU];
+                    if constexpr (NG % 2 == 1) mac(B0);
+                    const double a = lds_dot<NX>(lBA + lj, NW, sCC(), sG()[lj]);
+                    // M overwrites P_{k+1} (same LDS region): every lane is past its reads of P here (T and cc are complete)
+                    wave_sync();
+                    if (m_live) {
 #pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    double a = j < NX ? lM[(NU + j) * NW + i] : sMV()[i];
+                        for (int a_ = 0; a_ < TS; ++a_)
 #pragma unroll
-                    for (int m = 0; m < i; ++m) a -= Lc[i][m] * y[m];
-                    y[i] = a * Lc[i][i];
+                            for (int b = 0; b < TS; ++b) {
+                                if (m_diag && b > a_) continue;   // the diagonal tile keeps its lower triangle, mirrored like the rest
+                                lM[(m_i0 + a_) * NW + m_j0 + b] = acc[a_][b];
+                                lM[(m_j0 + b) * NW + m_i0 + a_] = acc[a_][b];
+                            }
+                    }
+                    if (lane < NW) sMV()[lane] = a;
                 }
+                wave_sync();
+                ph(11);
+                // ---- Cholesky of the control block (every lane, redundantly): L lower with inverted diagonal
+                double Lc[NU][NU];
+                {
+                    bool okc = true;
 #pragma unroll
-                for (int i = NU - 1; i >= 0; --i) {
-                    double a = y[i];
+                    for (int i = 0; i < NU; ++i)
 #pragma unroll
-                    for (int m = i + 1; m < NU; ++m) a -= Lc[m][i] * z[m];
-                    z[i] = a * Lc[i][i];
+                        for (int j = 0; j <= i; ++j) {
+                            double a = lM[i * NW + j];
+#pragma unroll
+                            for (int m = 0; m < j; ++m) a -= Lc[i][m] * Lc[j][m];
+                            if (i == j) {
+                                okc = okc && (a > 0.0);
+                                Lc[i][i] = 1.0 / sqrt(a);
+                            } else
+                                Lc[i][j] = a * Lc[j][j];
+                        }
+                    ok = ok && (okc || pin);
                 }
+                // K columns (lanes j < NX) and the feed-forward (lane NX): solve L L' z = rhs
+                if (lane <= NX) {
+                    const int j = lane;
+                    double y[NU], z[NU];
 #pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    const double v = pin ? 0.0 : z[i];
-                    if (j < NX) {
-                        sK()[i * NX + j] = v;
-                        K[(k * NU + i) * NX + j] = v;
-                    } else {
-                        sK()[NU * NX + i] = v;
-                        kff[k * NU + i] = v;
+                    for (int i = 0; i < NU; ++i) {
+                        double a = j < NX ? lM[(NU + j) * NW + i] : sMV()[i];
+#pragma unroll
+                        for (int m = 0; m < i; ++m) a -= Lc[i][m] * y[m];
+                        y[i] = a * Lc[i][i];
+                    }
+#pragma unroll
+                    for (int i = NU - 1; i >= 0; --i) {
+                        double a = y[i];
+#pragma unroll
+                        for (int m = i + 1; m < NU; ++m) a -= Lc[m][i] * z[m];
+                        z[i] = a * Lc[i][i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) {
+                        const double v = pin ? 0.0 : z[i];
+                        if (j < NX) {
+                            sK()[i * NX + j] = v;
+                            K[(k * NU + i) * NX + j] = v;
+                        } else {
+                            sK()[NU * NX + i] = v;
+                            kff[k * NU + i] = v;
+                        }
                     }
                 }
-            }
-            if (lane < NU * NU) {
-                const int i = lane / NU, j = lane - i * NU;
-                double v = 0.0;
+                if (lane < NU * NU) {
+                    const int i = lane / NU, j = lane - i * NU;
+                    double v = 0.0;
 #pragma unroll
-                for (int a = 0; a < NU; ++a)
+                    for (int a = 0; a < NU; ++a)
 #pragma unroll
-                    for (int b = 0; b <= a; ++b)
-                        if (a == i && b == j) v = Lc[a][b];
-                L[k * NU * NU + lane] = pin ? 0.0 : v;
-            }
-            wave_sync();
-            ph(12);
-            // ---- P_k = Q - S' K (same expression for (i,j) and (j,i): exactly symmetric), p_k = mv_x - K' mv_u, Acl = A - B K
-            {
-                const double *lK = sK();
-                for (int e = lane; e < NX * NX; e += NT) {
-                    const int i0_ = e / NX, j0_ = e - i0_ * NX;
-                    const int i = i0_ > j0_ ? i0_ : j0_, j = i0_ > j0_ ? j0_ : i0_;
-                    double a = lM[(NU + i) * NW + NU + j];
-#pragma unroll
-                    for (int m = 0; m < NU; ++m) a -= lM[(NU + i) * NW + m] * lK[m * NX + j];
-                    double c = lBA[i0_ * NW + NU + j0_];
-#pragma unroll
-                    for (int m = 0; m < NU; ++m) c -= lBA[i0_ * NW + m] * lK[m * NX + j0_];
-                    P[k * NX * NX + e] = a;
-                    Acl[k * NX * NX + e] = c;
-                    lT[e] = a;   // P_k is staged in T (free now) and moved below: lanes still read M here
+                        for (int b = 0; b <= a; ++b)
+                            if (a == i && b == j) v = Lc[a][b];
+                    L[k * NU * NU + lane] = pin ? 0.0 : v;
                 }
-                if (lane < NX) {
-                    double a = sMV()[NU + lane];
+                wave_sync();
+                ph(12);
+                // ---- P_k = Q - S' K, p_k = mv_x - K' mv_u, Acl = A - B K: lane i takes row i (own-row base + immediate offsets, no
+                // per-element address arithmetic to keep live).  P_k is written lower + mirrored into T (exactly symmetric), Acl
+                // replaces A in this lane's own row of [B A]; both blocks then leave for HBM as 16-byte coalesced copies.
+                {
+                    const double *lK = sK();
+                    const double *mrow = lM + (NU + lx) * NW, *brow = lBA + lx * NW;
+                    double Si[NU], Bi[NU];
 #pragma unroll
-                    for (int m = 0; m < NU; ++m) a -= lK[m * NX + lane] * sMV()[m];
-                    sPV()[lane] = a;
-                    p[k * NX + lane] = a;
+                    for (int m = 0; m < NU; ++m) Si[m] = mrow[m], Bi[m] = brow[m];
+                    constexpr int JC = NX % 7 == 0 ? 7 : 3;
+                    static_assert(NX % JC == 0, "column chunks");
+                    for (int j0 = 0; j0 < NX; j0 += JC) {
+                        double mv_[JC], av_[JC], kk[NU][JC];
+#pragma unroll
+                        for (int jj = 0; jj < JC; ++jj) {
+                            mv_[jj] = mrow[NU + j0 + jj], av_[jj] = brow[NU + j0 + jj];
+#pragma unroll
+                            for (int m = 0; m < NU; ++m) kk[m][jj] = lK[m * NX + j0 + jj];
+                        }
+                        MPCRL_SCHED_FENCE();
+#pragma unroll
+                        for (int jj = 0; jj < JC; ++jj) {
+                            double a = mv_[jj], c = av_[jj];
+#pragma unroll
+                            for (int m = 0; m < NU; ++m) a -= Si[m] * kk[m][jj], c -= Bi[m] * kk[m][jj];
+                            const int j = j0 + jj;
+                            if (lane < NX) {
+                                if (j <= lane) lT[lane * NX + j] = a, lT[j * NX + lane] = a;
+                                lBA[lane * NW + NU + j] = c;
+                            }
+                        }
+                    }
+                    double pk = 0.0;
+                    if (lane < NX) {
+                        pk = sMV()[NU + lane];
+#pragma unroll
+                        for (int m = 0; m < NU; ++m) pk -= lK[m * NX + lane] * sMV()[m];
+                        p[k * NX + lane] = pk;
+                        sPV()[lane] = pk;
+                    }
+                    wave_sync();
+                    d2_t cp[Cfg::NAC2], ca[Cfg::NBA2];
+#pragma unroll
+                    for (int s_ = 0; s_ < Cfg::NAC2; ++s_) {
+                        const int e2 = lane + 64 * s_;
+                        cp[s_] = *(const d2_t *)(lT + 2 * e2);
+                    }
+#pragma unroll
+                    for (int s_ = 0; s_ < Cfg::NBA2; ++s_) {
+                        const int e2 = lane + 64 * s_;
+                        ca[s_] = *(const d2_t *)(lBA + 2 * e2);
+                    }
+#pragma unroll
+                    for (int s_ = 0; s_ < Cfg::NAC2; ++s_) {
+                        const int e2 = lane + 64 * s_;
+                        *(d2_t *)&P[k * AST + 2 * e2] = cp[s_];
+                        if (s_ + 1 < Cfg::NAC2 || 2 * e2 < NW * NW - 1) *(d2_t *)(lP + 2 * e2) = cp[s_];   // M is dead: every lane is past its reads (sync above)
+                    }
+#pragma unroll
+                    for (int s_ = 0; s_ < Cfg::NBA2; ++s_) {
+                        const int e2 = lane + 64 * s_;
+                        *(d2_t *)&Acl[k * Cfg::BST + 2 * e2] = ca[s_];
+                    }
                 }
-            }
-            wave_sync();
-            for (int e = lane; e < NX * NX; e += NT) lP[e] = lT[e];
-            wave_sync();
-            ph(13);
-        }
+                wave_sync();
+                ph(13);
+            });
         return ok;
     }
 
     // ---- backward vector sweep for a new right-hand side g on the stored factors (same bb as the factor sweep: hb is re-used).
     // Produces p_k (workspace), kff_k.
     MPCRL_DI void backward_vec(const WsArr g) {
+        constexpr int AST = Cfg::AST, D = Cfg::DEPTH;
         const int li = lane < NX ? lane : 0;
         double pcur = g[N * NW + NU + li];
         if (lane < NX) p[N * NX + lane] = pcur;
-        double nA[Cfg::NAC], ngx = 0.0, nhb = 0.0, ngu[NU], nK[NU];
-        auto fetch = [&](int k) {
-            const WsArr src = Acl + k * NX * NX;
+        d2_t nA[D][Cfg::NBA2];
+        double ngx[D], nhb[D], ngu[D][NU], nK[D][NU];
+        double *lA = sA(), *lv = sSV(0);
+        staged_loop<D>(
+            N,
+            [&](int idx, auto sl) {
+                constexpr int d = decltype(sl)::value;
+                const int k = N - 1 - idx;
+                blk_load(Acl + k * Cfg::BST, NX * NW / 2, nA[d], lane);
+                ngx[d] = g[k * NW + NU + li], nhb[d] = hb[k * NX + li];
 #pragma unroll
-            for (int s = 0; s < Cfg::NAC; ++s) {
-                const int e = lane + 64 * s;
-                nA[s] = e < NX * NX ? src[e] : 0.0;
-            }
-            ngx = g[k * NW + NU + li], nhb = hb[k * NX + li];
+                for (int m = 0; m < NU; ++m) ngu[d][m] = g[k * NW + m], nK[d][m] = K[(k * NU + m) * NX + li];
+            },
+            [&](int idx, auto sl, auto refill) {
+                constexpr int d = decltype(sl)::value;
+                const int k = N - 1 - idx;
+                const double v = pcur + nhb[d];
+                if (lane < NX) lv[lane] = v, ccv[k * NX + lane] = v;
+                blk_to_lds(lA, NX * NW / 2, nA[d], lane);
+                double a = ngx[d];
 #pragma unroll
-            for (int m = 0; m < NU; ++m) ngu[m] = g[k * NW + m], nK[m] = K[(k * NU + m) * NX + li];
-        };
-        fetch(N - 1);
-        for (int k = N - 1; k >= 0; --k) {
-            const int buf = k & 1;
-            double *lA = sA(buf), *lv = sSV(buf);
-            const double v = pcur + nhb;
-            if (lane < NX) lv[lane] = v, ccv[k * NX + lane] = v;
-#pragma unroll
-            for (int s = 0; s < Cfg::NAC; ++s) {
-                const int e = lane + 64 * s;
-                if (e < NX * NX) lA[e] = nA[s];
-            }
-            double a = ngx;
-#pragma unroll
-            for (int m = 0; m < NU; ++m) a = fma(-nK[m], ngu[m], a);   // g_x - K' g_u   (K_0 = 0 in Q-mode)
-            if (k > 0) fetch(k - 1);
-            wave_sync();
-            for (int i = 0; i < NX; ++i) a = fma(lA[i * NX + li], lv[i], a);   // column li of Acl_k
-            pcur = a;
-            if (lane < NX) p[k * NX + lane] = a;
-        }
-        wave_sync();
+                for (int m = 0; m < NU; ++m) a = fma(-nK[d][m], ngu[d][m], a);   // g_x - K' g_u   (K_0 = 0 in Q-mode)
+                refill();
+                wave_sync();
+                a = lds_dot<NX>(lA + NU + li, NW, lv, a);   // column li of Acl_k (stored where A_k sits in the [B A] block)
+                pcur = a;
+                if (lane < NX) p[k * NX + lane] = a;
+                wave_sync();
+            });
         // feed-forward kff_k = R_k^{-1} (g_u + B_k' cc_k), one stage per lane
         for (int k = lane; k < N; k += NT) {
             const bool pin = k == 0 && qmode;
@@ -647,6 +974,7 @@ struct ChainSolver {
 #pragma unroll
             for (int m = 0; m < NU; ++m) mv[m] = g[k * NW + m];
             const WsArr Bk = BA + k * NX * NW;
+#pragma unroll 3
             for (int i = 0; i < NX; ++i) {
                 const double c = ccv[k * NX + i];
 #pragma unroll
@@ -675,64 +1003,71 @@ struct ChainSolver {
     }
 
     // ---- forward sweep: Dx (serial chain on Acl), then Du and (optionally) Dnu stage-parallel
-    MPCRL_DI void forward(const WsArr bb, bool want_nu) {
-        // c_k = b_k - B_k kff_k
-        for (int e = lane; e < N * NX; e += NT) {
-            const int k = e / NX, i = e - k * NX;
-            double a = bb ? bb[e] : 0.0;
-            const WsArr Bk = BA + (k * NX + i) * NW;
-#pragma unroll
-            for (int m = 0; m < NU; ++m) a = fma(-Bk[m], kff[k * NU + m], a);
-            cvec[e] = a;
-        }
-        wave_sync();
+    template <bool want_nu>
+    MPCRL_DI void forward(const WsArr bb) {
+        constexpr int AST = Cfg::AST, D = Cfg::DEPTH;
         const int li = lane < NX ? lane : 0;
         double xcur = 0.0;
-        if (lane < NX) Dx[lane] = 0.0;
-        double nA[Cfg::NAC], nc = 0.0;
-        auto fetch = [&](int k) {
-            const WsArr src = Acl + k * NX * NX;
+        if (lane < NX) Dx[lane] = 0.0, Dnu[lane] = 0.0;
+        d2_t nA[D][Cfg::NBA2], nP[D][Cfg::NAC2];
+        double nbb[D], npv[D], nkf[D][NU];
+        double *lA = sA(), *lPk = sPk(), *lv = sSV(0);
+        // stage k: dx_{k+1} = Acl_k dx_k + (b_k - B_k kff_k)  (B_k sits beside Acl_k in the staged block);
+        // with want_nu also the multiplier step of stage k, Dnu_k = p_k + P_k dx_k (k >= 1)
+        staged_loop<D>(
+            N,
+            [&](int k, auto sl) {
+                constexpr int d = decltype(sl)::value;
+                blk_load(Acl + k * Cfg::BST, NX * NW / 2, nA[d], lane);
+                nbb[d] = bb[k * NX + li];
 #pragma unroll
-            for (int s = 0; s < Cfg::NAC; ++s) {
-                const int e = lane + 64 * s;
-                nA[s] = e < NX * NX ? src[e] : 0.0;
-            }
-            nc = cvec[k * NX + li];
-        };
-        fetch(0);
-        for (int k = 0; k < N; ++k) {
-            const int buf = k & 1;
-            double *lA = sA(buf), *lv = sSV(buf);
+                for (int m = 0; m < NU; ++m) nkf[d][m] = kff[k * NU + m];
+                if (want_nu) {
+                    blk_load(P + k * AST, AST / 2, nP[d], lane);
+                    npv[d] = p[k * NX + li];
+                }
+            },
+            [&](int k, auto sl, auto refill) {
+                constexpr int d = decltype(sl)::value;
+                if (lane < NX) lv[lane] = xcur;
+                blk_to_lds(lA, NX * NW / 2, nA[d], lane);
+                if (want_nu) blk_to_lds(lPk, AST / 2, nP[d], lane);
+                double a = nbb[d], b = want_nu ? npv[d] : 0.0;
+                double kf[NU];
+#pragma unroll
+                for (int m = 0; m < NU; ++m) kf[m] = nkf[d][m];
+                refill();
+                wave_sync();
+                const double *row = lA + li * NW;
+#pragma unroll
+                for (int m = 0; m < NU; ++m) a = fma(-row[m], kf[m], a);
+                a = lds_dot<NX>(row + NU, 1, lv, a);   // row li of Acl_k
+                if (want_nu && k > 0) {
+                    b = lds_dot<NX>(lPk + li * NX, 1, lv, b);
+                    if (lane < NX) Dnu[k * NX + lane] = b;
+                }
+                xcur = a;
+                if (lane < NX) Dx[(k + 1) * NX + lane] = a;
+                wave_sync();
+            });
+        if (want_nu) {   // terminal multiplier step
+            d2_t tP[Cfg::NAC2];
+            blk_load(P + N * AST, AST / 2, tP, lane);
+            double b = p[N * NX + li];
             if (lane < NX) lv[lane] = xcur;
-#pragma unroll
-            for (int s = 0; s < Cfg::NAC; ++s) {
-                const int e = lane + 64 * s;
-                if (e < NX * NX) lA[e] = nA[s];
-            }
-            double a = nc;
-            if (k + 1 < N) fetch(k + 1);
+            blk_to_lds(lPk, AST / 2, tP, lane);
             wave_sync();
-            for (int j = 0; j < NX; ++j) a = fma(lA[li * NX + j], lv[j], a);   // row li of Acl_k
-            xcur = a;
-            if (lane < NX) Dx[(k + 1) * NX + lane] = a;
+            b = lds_dot<NX>(lPk + li * NX, 1, lv, b);
+            if (lane < NX) Dnu[N * NX + lane] = b;
         }
         wave_sync();
         for (int e = lane; e < N * NU; e += NT) {
             const int k = e / NU;
             double a = -kff[e];
             const WsArr Kr = K + e * NX;
+#pragma unroll 3
             for (int j = 0; j < NX; ++j) a = fma(-Kr[j], Dx[k * NX + j], a);
             Du[e] = a;
-        }
-        for (int e = lane; want_nu && e < (N + 1) * NX; e += NT) {
-            const int k = e / NX, i = e - k * NX;
-            double a = 0.0;
-            if (k > 0) {
-                a = p[e];
-                const WsArr Pr = P + (k * NX * NX + i * NX);
-                for (int j = 0; j < NX; ++j) a = fma(Pr[j], Dx[k * NX + j], a);
-            }
-            Dnu[e] = a;
         }
         wave_sync();
     }
@@ -775,37 +1110,7 @@ struct ChainSolver {
         bool ok = false;
         for (int it = 0;; ++it) {
             ph(7);
-            double rloc = 0.0, muloc = 0.0;
-            // equality residual rb = r + [B A] dv - dx+
-            for (int e = lane; e < N * NX; e += NT) {
-                const int k = e / NX, i = e - k * NX;
-                double a = r[e] - dx[(k + 1) * NX + i];
-                const WsArr row = BA + e * NW;
-                for (int j = 0; j < NU; ++j) a = fma(row[j], du[k * NU + j], a);
-                for (int j = 0; j < NX; ++j) a = fma(row[NU + j], dx[k * NX + j], a);
-                rb[e] = a;
-                rloc = fmax(rloc, fabs(a));
-            }
-            // stationarity residual (the stage Hessian of this model is block diagonal: R on u, Q on x)
-            for (int e = lane; e < ne; e += NT) {
-                const int k = e / NW, i = e - k * NW;
-                double a = 0.0;
-                if (!skipc(k, i)) {
-                    a = q[e] + GTnu(nuq, k, i);
-                    double hd = 0.0;
-                    if (i < NU) {
-                        for (int j = 0; j < NU; ++j) hd = fma(M::hess(k == N, i, j, th), du[k * NU + j], hd);
-                    } else {
-                        for (int j = 0; j < NX; ++j) hd = fma(M::Qs(th, i - NU, j), dx[k * NX + j], hd);
-                    }
-                    a = fma(ck(k), hd, a);
-                    if (has(0, k, i)) a -= LAM(0, e);
-                    if (has(1, k, i)) a += LAM(1, e);
-                    if (fixedc(k, i)) a = 0.0;
-                }
-                rg[e] = a;
-                rloc = fmax(rloc, fabs(a));
-            }
+            double rloc = qp_residuals_call(*this), muloc = 0.0;
             for (int r_ = lane; r_ < nrows; r_ += NT) {
                 int k, i;
                 row_of(r_, k, i);
@@ -855,13 +1160,16 @@ struct ChainSolver {
                 wave_sync();
                 ph(1);
                 if (pass == 0) {
-                    if (!factor(hs, rt, rb)) fail = true;
+                    if (!factor_call(*this, hs, rt, rb)) fail = true;
                     ph(2);
                 } else {
-                    backward_vec(rt);
+                    backward_vec_call(*this, rt);
                     ph(3);
                 }
-                forward(rb, pass == 1);   // the multiplier step is only needed with the final direction
+                if (pass == 1)   // the multiplier step is only needed with the final direction
+                    forward_call<true>(*this, rb);
+                else
+                    forward_call<false>(*this, rb);
                 ph(4);
                 double amax = 1.0, muaff = 0.0;
                 for (int r_ = lane; r_ < nrows; r_ += NT) {
@@ -928,6 +1236,72 @@ struct ChainSolver {
             wave_sync();
         }
         return ok;
+    }
+
+    // ---- phase calls.  The big phases are real (non-inlined) functions: each gets a register allocation of its own, so the
+    // operands of one phase are never spilled on behalf of another (inlined into one body, the interior-point loop carried
+    // hundreds of hoisted loop invariants through every phase, and each reload from scratch is an s_waitcnt vmcnt(0) that also
+    // drains the streaming stores).  The solver travels by value; on entry the wave-uniform fields are made provably uniform
+    // again (scalar registers, scalar-base addressing) and the pointers get their address spaces back.
+    MPCRL_DI static unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+    template <class T>
+    MPCRL_DI static T *uni_global(T *ptr) {
+        const unsigned long long v = (unsigned long long)ptr;
+        const unsigned lo = rfl((unsigned)v), hi = rfl((unsigned)(v >> 32));
+        typedef __attribute__((address_space(1))) T GT;
+        return (T *)(GT *)(((unsigned long long)hi << 32) | lo);
+    }
+    template <class T>
+    MPCRL_DI static T *uni_lds(T *ptr) {
+        typedef __attribute__((address_space(3))) T LT;
+        return (T *)(LT *)(unsigned long)rfl((unsigned)(unsigned long long)ptr);
+    }
+    MPCRL_DI void uni(WsArr &a_) const { a_.base = a_.base ? BA.base : nullptr, a_.off = rfl(a_.off); }
+    MPCRL_DI void uniformize() {
+        N = (int)rfl((unsigned)N), qmode = rfl(qmode ? 1u : 0u) != 0;
+        n0 = (int)rfl((unsigned)n0), nm = (int)rfl((unsigned)nm), ne = (int)rfl((unsigned)ne), nrows = (int)rfl((unsigned)nrows);
+        lane = threadIdx.x;
+        BA.base = uni_global(BA.base);
+        for (WsArr *a_ : {&BA, &r, &q, &dx, &du, &nuq, &Dx, &Du, &Dnu, &rg, &rb, &rt, &Dg, &lam, &t, &aff, &P, &p, &K, &L, &kff, &Acl, &hb, &ccv,
+                          &cvec, &state, &NUv})
+            uni(*a_);
+        X = uni_global(X), U = uni_global(U), th = uni_global(th), xs = uni_global(xs);
+        lds = uni_lds(lds), sidx = uni_lds(sidx);
+#ifdef MPCRL_PROFILE_PHASES
+        ph_lds = uni_lds(ph_lds);
+#endif
+    }
+    struct RoundStart {
+        double cost, res[4];
+    };
+    __device__ __attribute__((noinline)) static RoundStart round_start_call(ChainSolver S, const double *x0, const double *u0f) {
+        S.uniformize();
+        x0 = uni_global(x0), u0f = u0f ? uni_global(u0f) : nullptr;
+        RoundStart o;
+        o.cost = S.round_start(x0, u0f, o.res);
+        return o;
+    }
+    __device__ __attribute__((noinline)) static double qp_residuals_call(ChainSolver S) {
+        S.uniformize();
+        return S.qp_residuals();
+    }
+    template <class HS>
+    __device__ __attribute__((noinline)) static bool factor_call(ChainSolver S, HS hs, WsArr g, WsArr bb) {
+        S.uniformize();
+        S.uni(g), S.uni(bb);
+        hs.rebind(S);
+        return S.factor(hs, g, bb);
+    }
+    __device__ __attribute__((noinline)) static void backward_vec_call(ChainSolver S, WsArr g) {
+        S.uniformize();
+        S.uni(g);
+        S.backward_vec(g);
+    }
+    template <bool want_nu>
+    __device__ __attribute__((noinline)) static void forward_call(ChainSolver S, WsArr bb) {
+        S.uniformize();
+        S.uni(bb);
+        S.template forward<want_nu>(bb);
     }
 
     MPCRL_DI void bind_workspace(double *w, const LargeLayout<M> &lay) {
@@ -1039,11 +1413,9 @@ __global__ void __launch_bounds__(64, 1) chain_qp_kernel(const LargeSpec sp, con
     S.ph_init(ph_buf);
 #endif
     S.ph0();
-    const double cl = S.linearize_cost();
-    wave_sync();
-    const double cost = wave_sum(cl);
-    double res[4];
-    S.nlp_residuals(x0, u0f, res);
+    const auto rs0 = ChainSolver<M>::round_start_call(S, x0, u0f);
+    const double cost = rs0.cost;
+    const double res[4] = {rs0.res[0], rs0.res[1], rs0.res[2], rs0.res[3]};
     S.ph(9);
     const double rmax = fmax(fmax(res[0], res[1]), fmax(res[2], res[3]));
     int status = -1;   // -1: carry on
@@ -1061,10 +1433,6 @@ __global__ void __launch_bounds__(64, 1) chain_qp_kernel(const LargeSpec sp, con
         // the SQP Hessian: this lane's tile of (R, Q) without c_k, in registers
         HessConst<M> hs;
         hs.th = S.th, hs.sck = S.sCK();
-#pragma unroll
-        for (int i = 0; i < Cfg::TS; ++i)
-#pragma unroll
-            for (int j = 0; j < Cfg::TS; ++j) hs.h[i][j] = S.m_live ? M::hess(false, S.m_i0 + i, S.m_j0 + j, S.th) : 0.0;
         if (!S.qp_solve(hs, x0, u0f, n_ipm, warm_mu, tol_res, tol_mu))
             status = 4;
         else {
@@ -1205,18 +1573,18 @@ __global__ void __launch_bounds__(64, 1) chain_sens_riccati_kernel(const LargeSp
     }
     wave_sync();
     HessGlobal<M> hs;
-    hs.Hex = Hex, hs.i0 = S.m_i0, hs.j0 = S.m_j0, hs.live = S.m_live;
-    const WsArr none{nullptr, 0};
+    hs.Hex = Hex;
+    for (int e = lane; e < N * NX; e += NT) S.rb[e] = 0.0;   // no dynamics offset in the adjoint systems
     const WsArr Ydx{(char *)w, (unsigned)lay.Ydx}, Ydu{(char *)w, (unsigned)lay.Ydu}, Ydnu{(char *)w, (unsigned)lay.Ydnu};
     bool okall = true;
     for (int iu = 0; iu < NU; ++iu) {
         for (int e = lane; e < ne; e += NT) S.rt[e] = e == iu ? -1.0 : 0.0;
         wave_sync();
         if (iu == 0)
-            okall = S.factor(hs, S.rt, none);
+            okall = ChainSolver<M>::factor_call(S, hs, S.rt, S.rb);
         else
-            S.backward_vec(S.rt);
-        S.forward(none, true);
+            ChainSolver<M>::backward_vec_call(S, S.rt);
+        ChainSolver<M>::template forward_call<true>(S, S.rb);
         for (int e = lane; e < (N + 1) * NX; e += NT) Ydx[iu * (N + 1) * NX + e] = S.Dx[e], Ydnu[iu * (N + 1) * NX + e] = S.Dnu[e];
         for (int e = lane; e < N * NU; e += NT) Ydu[iu * N * NU + e] = S.Du[e];
         wave_sync();
