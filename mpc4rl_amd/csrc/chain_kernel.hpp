@@ -1539,27 +1539,7 @@ __global__ void __launch_bounds__(64, 1) chain_sens_riccati_kernel(const LargeSp
     S.X = a.X + (size_t)inst * (N + 1) * NX, S.U = a.U + (size_t)inst * N * NU;
     const int ne = (N + 1) * NW;
     const double *th = S.th, *xs = sp.consts;
-    const WsArr Hex{(char *)w, (unsigned)lay.Hex}, term{(char *)w, (unsigned)lay.term};
-    if ((a.flags & 1) && a.dV) {
-        double *dV = a.dV + (size_t)inst * NP;
-        for (int d = lane; d < NTD; d += NT) {
-            double acc = 0.0;
-            for (int k = 0; k < N; ++k) acc += term[k * NTD + d];
-            dV[M::td_index(d)] = acc;
-        }
-        for (int e = lane; e < NX * NX + NU * NU; e += NT) {   // d/dQ_ij, d/dR_ij of sum_k c_k l_k (ocp_utils.py:276-277)
-            double acc = 0.0;
-            if (e < NX * NX) {
-                const int j = e / NX, i = e - j * NX;          // column-major position of Q(i, j)
-                for (int k = 0; k <= N; ++k) acc = fma(0.5 * S.ck(k) * (S.X[k * NX + i] - xs[i]), S.X[k * NX + j] - xs[j], acc);
-                dV[M::OFF_Q + e] = acc;
-            } else {
-                const int ee = e - NX * NX, j = ee / NU, i = ee - j * NU;
-                for (int k = 0; k < N; ++k) acc = fma(0.5 * S.ck(k) * S.U[k * NU + i], S.U[k * NU + j], acc);
-                dV[M::OFF_R + ee] = acc;
-            }
-        }
-    }
+    const WsArr Hex{(char *)w, (unsigned)lay.Hex};
     if (!((a.flags & 2) && a.dpi) || S.qmode) return;
     for (int e = lane; e < NW * NW; e += NT) Hex[N * NW * NW + e] = S.ck(N) * M::hess(true, e / NW, e % NW, th);
     // barrier diagonal from the final (lam, t) of the bound rows (slacks are constants of the mirror, quirk q1)
@@ -1620,42 +1600,58 @@ __global__ void __launch_bounds__(256) chain_sens_mix_kernel(const LargeSpec sp,
     for (int d = 0; d < NTD; ++d) term2[d] = tb[d].d[0];
 }
 
+// One output element per lane: slot 0 = dV/dp (with MPCRL_SENS_V), slots 1..NU = rows of du0*/dp (with MPCRL_SENS_PI).
+// Each element is a sum over the stages of per-stage terms left in the workspace, or of closed forms in (X, U, adjoint solution).
 template <class M>
-__global__ void __launch_bounds__(64) chain_sens_out_kernel(const LargeSpec sp, const LargeArgs a) {
-    constexpr int NX = M::NX, NU = M::NU, NTD = M::NTD, NP = M::NP, NT = 64;
-    const int lane = threadIdx.x, inst = blockIdx.x, N = sp.N;
+__global__ void __launch_bounds__(256) chain_sens_out_kernel(const LargeSpec sp, const LargeArgs a) {
+    constexpr int NX = M::NX, NU = M::NU, NTD = M::NTD, NP = M::NP;
+    constexpr int NE = NTD + NX * NX + NU * NU;   // elements per slot: dynamics parameters, Q (column-major), R
+    const int N = sp.N;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int per = (NU + 1) * NE;
+    const int inst = (int)(gid / per);
+    if (inst >= a.B) return;
     const int status = a.status[inst];
     if (!(status == 0 || status == 2)) return;
+    const int rem = (int)(gid - (long)inst * per), slot = rem / NE, e0 = rem - slot * NE;
+    const bool want_v = (a.flags & 1) && a.dV, want_pi = (a.flags & 2) && a.dpi && !a.u0fix;
+    if (slot == 0 ? !want_v : !want_pi) return;
     const LargeLayout<M> lay(N);
-    double *w = a.ws + (size_t)inst * a.ws_stride;
+    const double *w = a.ws + (size_t)inst * a.ws_stride;
     const double *X = a.X + (size_t)inst * (N + 1) * NX, *U = a.U + (size_t)inst * N * NU, *xs = sp.consts;
-    const bool okall = w[lay.state + ST_STATUS] == 0.0;
-    double *dpi = a.dpi + (size_t)inst * NU * NP;
     auto ck = [&](int k) {
         if (sp.cost_kind == 0) return k == N ? 1.0 : sp.dT;
         return k == 0 ? sp.dT : (k == N ? pow(sp.gamma, (double)N) : pow(sp.gamma, (double)k) * sp.dT);
     };
-    for (int iu = 0; iu < NU; ++iu) {
-        const double *term2 = w + lay.term2 + (size_t)iu * N * NTD;
-        const double *Dx = w + lay.Ydx + (size_t)iu * (N + 1) * NX, *Du = w + lay.Ydu + (size_t)iu * N * NU;
-        for (int d = lane; d < NTD; d += NT) {
-            double acc = 0.0;
-            for (int k = 0; k < N; ++k) acc += term2[k * NTD + d];
-            dpi[(size_t)iu * NP + M::td_index(d)] = okall ? -acc : NAN;
+    const int iu = slot - 1;
+    const double *tm = slot == 0 ? w + lay.term : w + lay.term2 + (size_t)iu * N * NTD;
+    const double *Dx = w + lay.Ydx + (size_t)(iu < 0 ? 0 : iu) * (N + 1) * NX, *Du = w + lay.Ydu + (size_t)(iu < 0 ? 0 : iu) * N * NU;
+    double acc = 0.0;
+    int pidx;
+    if (e0 < NTD) {
+        for (int k = 0; k < N; ++k) acc += tm[k * NTD + e0];
+        pidx = M::td_index(e0);
+    } else if (e0 < NTD + NX * NX) {
+        const int e = e0 - NTD, j = e / NX, i = e - j * NX;   // column-major position of Q(i, j)
+        if (slot == 0) {   // d/dQ_ij of sum_k c_k l_k (ocp_utils.py:276-277)
+            for (int k = 0; k <= N; ++k) acc = fma(0.5 * ck(k) * (X[k * NX + i] - xs[i]), X[k * NX + j] - xs[j], acc);
+        } else {           // y' d2 l / dv dQ_ij = 1/2 (y_i e_j + y_j e_i)
+            for (int k = 0; k <= N; ++k) acc += 0.5 * ck(k) * (Dx[k * NX + i] * (X[k * NX + j] - xs[j]) + Dx[k * NX + j] * (X[k * NX + i] - xs[i]));
         }
-        for (int e = lane; e < NX * NX + NU * NU; e += NT) {   // y' d2 l / dv dQ_ij = 1/2 (y_i e_j + y_j e_i)
-            double acc = 0.0;
-            if (e < NX * NX) {
-                const int j = e / NX, i = e - j * NX;
-                for (int k = 0; k <= N; ++k) acc += 0.5 * ck(k) * (Dx[k * NX + i] * (X[k * NX + j] - xs[j]) + Dx[k * NX + j] * (X[k * NX + i] - xs[i]));
-                dpi[(size_t)iu * NP + M::OFF_Q + e] = okall ? -acc : NAN;
-            } else {
-                const int ee = e - NX * NX, j = ee / NU, i = ee - j * NU;
-                for (int k = 0; k < N; ++k) acc += 0.5 * ck(k) * (Du[k * NU + i] * U[k * NU + j] + Du[k * NU + j] * U[k * NU + i]);
-                dpi[(size_t)iu * NP + M::OFF_R + ee] = okall ? -acc : NAN;
-            }
+        pidx = M::OFF_Q + e;
+    } else {
+        const int ee = e0 - NTD - NX * NX, j = ee / NU, i = ee - j * NU;
+        if (slot == 0) {
+            for (int k = 0; k < N; ++k) acc = fma(0.5 * ck(k) * U[k * NU + i], U[k * NU + j], acc);
+        } else {
+            for (int k = 0; k < N; ++k) acc += 0.5 * ck(k) * (Du[k * NU + i] * U[k * NU + j] + Du[k * NU + j] * U[k * NU + i]);
         }
+        pidx = M::OFF_R + ee;
     }
+    if (slot == 0)
+        a.dV[(size_t)inst * NP + pidx] = acc;
+    else
+        a.dpi[((size_t)inst * NU + iu) * NP + pidx] = (w[lay.state + ST_STATUS] == 0.0) ? -acc : NAN;
 }
 
 }  // namespace mpcrl

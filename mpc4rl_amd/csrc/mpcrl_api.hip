@@ -129,11 +129,13 @@ int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
     HIP_OK(hipGetLastError());
     if (a.flags & (MPCRL_SENS_V | MPCRL_SENS_PI)) {
         hipLaunchKernelGGL(chain_sens_ad_kernel<M>, blocks((long)B * N * (NW + 1)), dim3(256), 0, st, h->large, a);
-        hipLaunchKernelGGL(chain_sens_riccati_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
-        if ((a.flags & MPCRL_SENS_PI) && a.dpi && !a.u0fix) {
+        const bool want_pi = (a.flags & MPCRL_SENS_PI) && a.dpi && !a.u0fix;
+        if (want_pi) {
+            hipLaunchKernelGGL(chain_sens_riccati_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
             hipLaunchKernelGGL(chain_sens_mix_kernel<M>, blocks((long)B * N * M::NU), dim3(256), 0, st, h->large, a);
-            hipLaunchKernelGGL(chain_sens_out_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
         }
+        hipLaunchKernelGGL(chain_sens_out_kernel<M>, blocks((long)B * (M::NU + 1) * (M::NTD + M::NX * M::NX + M::NU * M::NU)), dim3(256), 0, st,
+                           h->large, a);
         HIP_OK(hipGetLastError());
     }
     return 0;

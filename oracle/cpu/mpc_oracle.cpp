@@ -319,6 +319,7 @@ struct Solver {
     // warm_mu > 0: start from the rows (lam, t, s) and multipliers of the previous QP, re-centred so that every
     // complementarity product is at least warm_mu (the smaller factor of the pair is raised); warm_mu = 0: cold start.
     double qp_tol_res = IPM_TOL_RES, qp_tol_mu = IPM_TOL_MU;
+    bool exact = false;   // ORACLE_EXACT: tight QPs, cold interior-point starts, fixed fraction to the boundary
     int qp_solve(const double *x0, const double *u0fix, bool &ok, double warm_mu) {
         std::fill(dx.begin(), dx.end(), 0.0), std::fill(du.begin(), du.end(), 0.0), std::fill(pi_qp.begin(), pi_qp.end(), 0.0);
         if (warm_mu > 0.0) pi_qp = PI;
@@ -468,7 +469,7 @@ struct Solver {
                     const double ratio = (sum / n_rows) / mu;
                     sigma = ratio * ratio * ratio;
                 } else
-                    alpha = std::min(1.0, (Mdl::DISCRETE ? IPM_FRAC : std::max(IPM_FRAC, 1.0 - mu)) * amax);   // fraction to the boundary -> 1 as mu -> 0 (LQ model: fixed)
+                    alpha = std::min(1.0, ((Mdl::DISCRETE || exact) ? IPM_FRAC : std::max(IPM_FRAC, 1.0 - mu)) * amax);   // fraction to the boundary -> 1 as mu -> 0 (LQ model: fixed)
             }
             for (size_t i = 0; i < dx.size(); ++i) dx[i] += alpha * Dx[i];
             for (size_t i = 0; i < du.size(); ++i) du[i] += alpha * Du[i];
@@ -486,7 +487,8 @@ struct Solver {
 
     // ---- full-step SQP (oracle/sqp_dense.py:solve)
     int sqp(const double *x0, const double *u0fix, bool warm, int max_iter, double tol, double *res, int &n_sqp, int &n_ipm,
-            double &cost) {
+            double &cost, bool rti = false) {
+        if (rti) max_iter = 1;
         setup_bounds(u0fix != nullptr);
         if (!warm) {
             for (int k = 0; k <= N; ++k)
@@ -511,17 +513,17 @@ struct Solver {
             nlp_residuals(x0, u0fix, res);
             const double rmax = std::max(std::max(res[0], res[1]), std::max(res[2], res[3]));
             if (!std::isfinite(rmax)) return 1;
-            if (rmax < tol && last_tight) return 0;
+            if (rmax < tol && last_tight && !(rti && n_sqp == 0)) return 0;
             if (n_sqp == max_iter) return rmax < tol ? 0 : 2;
             {   // QP tolerances for this iteration
                 // (a linear-quadratic OCP is solved by its first QP: no inexactness there)
-                const double rr = std::min(1.0, rmax), a = (rmax < tol || Mdl::DISCRETE) ? 0.0 : IPM_ADAPT_C * rr * rr;
+                const double rr = std::min(1.0, rmax), a = (rmax < tol || Mdl::DISCRETE || exact) ? 0.0 : IPM_ADAPT_C * rr * rr;
                 qp_tol_res = std::min(IPM_ADAPT_CAP, std::max(IPM_TOL_RES, a));
                 qp_tol_mu = std::min(0.1 * IPM_ADAPT_CAP, std::max(IPM_TOL_MU, 1e-2 * a));
                 last_tight = qp_tol_res <= IPM_TOL_RES && qp_tol_mu <= IPM_TOL_MU;
             }
             bool ok;
-            const double warm_mu = stepn < 0.0 ? 0.0 : std::min(IPM_WARM_MAX, std::max(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
+            const double warm_mu = (stepn < 0.0 || exact) ? 0.0 : std::min(IPM_WARM_MAX, std::max(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
             n_ipm += qp_solve(x0, u0fix, ok, warm_mu);
             if (!ok) return 4;
             stepn = 0.0;
@@ -660,7 +662,9 @@ int run(const OracleSpec *sp, int Bn, const double *x0, const double *u0fix, con
         }
         double r4[4], cost = 0;
         int ns = 0, ni = 0;
-        const int st = S.sqp(x0 + (size_t)b * NX, u0fix ? u0fix + (size_t)b * NU : nullptr, warm, sp->max_iter, sp->tol, r4, ns, ni, cost);
+        S.exact = (flags & ORACLE_EXACT) != 0;
+        const int st = S.sqp(x0 + (size_t)b * NX, u0fix ? u0fix + (size_t)b * NU : nullptr, warm, sp->max_iter, sp->tol, r4, ns, ni, cost,
+                             (flags & ORACLE_RTI) != 0);
         if (status) status[b] = st;
         if (sqp_iter) sqp_iter[b] = ns;
         if (ipm_iter) ipm_iter[b] = ni;

@@ -9,7 +9,17 @@ extern "C" {
 
 enum { ORACLE_MODEL_CARTPOLE = 0, ORACLE_MODEL_LINEAR = 1, ORACLE_MODEL_CHAIN = 2 };
 enum { ORACLE_COST_NLS = 0, ORACLE_COST_EXTERNAL = 1 };
-enum { ORACLE_SENS_V = 1, ORACLE_SENS_PI = 2, ORACLE_WARM = 4 };
+enum {
+    ORACLE_SENS_V = 1,
+    ORACLE_SENS_PI = 2,
+    ORACLE_WARM = 4,
+    /* EXACT-QP mode (frozen; what acados + HPIPM do with the reference's options, config/cartpole.yaml:8-14): every QP is
+     * solved to the tight tolerances from a cold interior-point start with the fixed fraction to the boundary 0.995 — no
+     * inexact-SQP forcing term, no interior-point warm start, no adaptive step rule.  The product is tuned against THIS mode
+     * (tests/test_exact_vs_inexact.py); its constants are not to be touched when the product's iteration is tuned. */
+    ORACLE_EXACT = 8,
+    ORACLE_RTI = 16 /* one SQP iteration from the given iterate (the product's MPCRL_RTI; not a reference mode) */
+};
 
 typedef struct {
     int model;          /* ORACLE_MODEL_* */

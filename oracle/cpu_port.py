@@ -14,7 +14,7 @@ from .problems import Problem
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libmpc_oracle.so")
 
-SENS_V, SENS_PI, WARM = 1, 2, 4
+SENS_V, SENS_PI, WARM, EXACT, RTI = 1, 2, 4, 8, 16
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 
@@ -94,7 +94,8 @@ class PortResult:
 
 
 def solve(P: Problem, x0, p=None, u0fix=None, gamma=None, flags=SENS_V | SENS_PI, warm: Optional[PortResult] = None,
-          max_iter=None, tol=None, nthreads=0, want_bnd=True) -> PortResult:
+          max_iter=None, tol=None, nthreads=0, want_bnd=True, exact=False, rti=False) -> PortResult:
+    """exact=True: the frozen exact-QP mode (ORACLE_EXACT, oracle/cpu/mpc_oracle.h); rti=True: one SQP iteration from ``warm``."""
     x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, float)))
     B = x0.shape[0]
     nw = P.nu + P.nx
@@ -115,6 +116,7 @@ def solve(P: Problem, x0, p=None, u0fix=None, gamma=None, flags=SENS_V | SENS_PI
         max_iter=P.max_iter if max_iter is None else max_iter,
         lb0=dptr(lb0), ub0=dptr(ub0), lb=dptr(lb), ub=dptr(ub), lbe=dptr(lbe), ube=dptr(ube), soft=soft.ctypes.data_as(_ip),
         zl=dptr(zl), zu=dptr(zu), consts=dptr(consts), n_consts=len(consts))
+    flags |= (EXACT if exact else 0) | (RTI if rti else 0)
     if warm is not None:
         flags |= WARM
         X, U, PI, BND = warm.X.copy(), warm.U.copy(), warm.PI.copy(), warm.BND.copy()

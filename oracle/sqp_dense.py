@@ -281,9 +281,17 @@ def nlp_residuals(prob: Problem, st: Structure, X, U, S, pi0, pi, lam, A, B, Fv,
 
 
 def solve(prob: Problem, x0, p=None, u0fix=None, gamma=None, warm: Optional[Solution] = None,
-          max_iter=None, tol=None, verbose=False) -> Solution:
+          max_iter=None, tol=None, verbose=False, exact: bool = False, rti: bool = False) -> Solution:
     """Full-step SQP from the reference's cold start (MPC.reset, mpc.py:204-210: x_k = x0, u_k = 0)
-    or from ``warm``.  ``u0fix`` reproduces q_update (mpc.py:52-96: lbu_0 = ubu_0 = u0)."""
+    or from ``warm``.  ``u0fix`` reproduces q_update (mpc.py:52-96: lbu_0 = ubu_0 = u0).
+
+    ``exact=True`` is the FROZEN exact-QP mode — what acados + HPIPM do with the reference's options (config/cartpole.yaml:8-14):
+    every QP to the tight tolerances (1e-9, 1e-11) from a cold interior-point start, fixed fraction to the boundary 0.995; no
+    forcing term, no warm start, no adaptive step rule.  The tuned (inexact) iteration is tested against it
+    (tests/test_exact_vs_inexact.py); its constants must not change when the product is tuned.
+    ``rti=True``: exactly one SQP iteration from ``warm`` (the product's MPCRL_RTI; not a reference mode)."""
+    if rti:
+        max_iter = 1
     P = prob
     N, nx, nu = P.N, P.nx, P.nu
     p = P.p0 if p is None else np.asarray(p, float)
@@ -336,14 +344,14 @@ def solve(prob: Problem, x0, p=None, u0fix=None, gamma=None, warm: Optional[Solu
         if not np.all(np.isfinite(res)):
             status = 1
             break
-        if res.max() < tol and last_tight:
+        if res.max() < tol and last_tight and not (rti and it == 0):
             status = 0
             break
         if it == max_iter:
             status = 0 if res.max() < tol else 2
             break
         rr = min(1.0, float(res.max()))
-        a_ = 0.0 if (res.max() < tol or P.extra.get("lq", False)) else IPM_ADAPT_C * rr * rr   # an LQ problem is solved by its first QP
+        a_ = 0.0 if (res.max() < tol or P.extra.get("lq", False) or exact) else IPM_ADAPT_C * rr * rr   # an LQ problem is solved by its first QP
         tol_res = min(IPM_ADAPT_CAP, max(IPM_TOL_RES, a_))
         tol_mu = min(0.1 * IPM_ADAPT_CAP, max(IPM_TOL_MU, 1e-2 * a_))
         last_tight = tol_res <= IPM_TOL_RES and tol_mu <= IPM_TOL_MU
@@ -385,14 +393,14 @@ def solve(prob: Problem, x0, p=None, u0fix=None, gamma=None, warm: Optional[Solu
         if u0fix is not None:
             v0[:nu] = u0fix - U[0]
         wrm = None
-        if stepn >= 0.0:
+        if stepn >= 0.0 and not exact:
             v0[st.nw:] = S
             wrm = (min(IPM_WARM_MAX, max(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn)), lam, t, piq)
         free = np.ones(st.nv, bool)
         free[st.ix(0): st.ix(0) + nx] = False
         if u0fix is not None:
             free[:nu] = False
-        v, piq, lam, t, nit, ok = ipm_dense(H, g, G, b, C, d, v0, wrm, free, tol_res, tol_mu, lq=bool(P.extra.get("lq", False)))
+        v, piq, lam, t, nit, ok = ipm_dense(H, g, G, b, C, d, v0, wrm, free, tol_res, tol_mu, lq=bool(P.extra.get("lq", False)) or exact)
         stepn = float(np.abs(v[: st.nw]).max())
         ipm_total += nit
         if not ok:
