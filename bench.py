@@ -44,15 +44,26 @@ def make_inputs(B, rank):
     return x0
 
 
-def measured_traffic(B, sens, rti):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in
-    separate rocprofv3 runs of this command); only valid for the default workload, else null."""
+TRAFFIC_FILE = os.path.join("profiles", "r02_hbm_traffic.json")
+
+
+def measured_traffic(workload, B, sens, rti):
+    """(HBM bytes per step, source) from the committed PMC passes: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3
+    --pmc runs of this very command (profiles/microbench/pmc.sh), summed over the kernels of one step and corrected as
+    MI355X_MICROARCH.md prescribes.  A counter pass cannot run inside a timed bench run, so the figure is read from the file
+    that pass wrote; it is only valid for the default batch of each workload and is regenerated whenever the kernels change."""
     try:
-        if B != B_PER_GPU or not sens or rti:
-            return None
-        return float(json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))["traffic_bytes_per_step"])
+        d = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))[workload]
+        if B != d["batch"] or not sens or rti:
+            return None, None
+        return float(d["traffic_bytes_per_step"]), TRAFFIC_FILE
     except Exception:
-        return None
+        return None, None
+
+
+def riccati_sweep_flops(N, nx, nu):
+    """SURVEY.md §8d (Frison-Jorgensen count): flops of one Riccati sweep (factorisation + solve) of an N-stage problem."""
+    return N * (7.0 / 3.0 * nx ** 3 + 4.0 * nx ** 2 * nu + 2.0 * nx * nu ** 2 + nu ** 3 / 3.0) + N * (8.0 * nx ** 2 + 8.0 * nx * nu + 2.0 * nu ** 2)
 
 
 def usable_cores():
@@ -186,6 +197,8 @@ def chain_bench(args):
     b_sweep = 2 * 8 * N * ((nx + nu) ** 2 + (nx + nu))
     sweeps = float(it[:, 1].mean()) + (1 + nu if sens else 0)
     achieved = (b_alg + sweeps * b_sweep) * B / (kern_ms * 1e-3) / 1e9
+    fp64 = sweeps * riccati_sweep_flops(N, nx, nu) * B / (kern_ms * 1e-3) / 1e12
+    traffic, traffic_src = measured_traffic(args.workload, B, sens, False)
     out = {"metric": f"MPC+KKT-sens solves/sec, chain_mass n_mass={n_mass} N=40 batch={B}", "value": B * args.steps / elapsed,
            "unit": "solves/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -194,7 +207,10 @@ def chain_bench(args):
                       "converged_fraction": float((r.status == 0).float().mean().item()), "sqp_iters_mean": float(it[:, 0].mean()),
                       "ipm_iters_mean": float(it[:, 1].mean())},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": None, "kernel_ms": kern_ms, "algorithmic_bytes_per_solve": b_alg + sweeps * b_sweep}}
+                        "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms,
+                        "algorithmic_bytes_per_solve": b_alg + sweeps * b_sweep, "sweeps_per_solve": sweeps,
+                        "fp64": {"achieved": fp64, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp64 / FP64_MFMA_PEAK_TFLOPS,
+                                 "note": "SURVEY.md 8d: sweeps/s x F_sweep, sweeps = interior-point iterations + 1 + nu"}}}
     print(json.dumps(out), flush=True)
 
 
@@ -279,6 +295,11 @@ def main():
         achieved = bytes_per * B / (kern_ms * 1e-3) / 1e9
         # matrix-core work of the factor sweep: 7 v_mfma_f64_4x4x4 block-products (128 flop each) per stage step and instance
         mfma_tflops = float(iters[:, 1].sum()) * ocp.N * 7 * 128 / (kern_ms * 1e-3) / 1e12
+        # algorithmic flops = Riccati sweeps x F_sweep, sweeps per solve = interior-point iterations (+ 1 sensitivity
+        # factorisation + nu adjoint solves)
+        sweeps = float(iters[:, 1].mean()) + (1 + ocp.nu if sens else 0)
+        fp64_tflops = sweeps * riccati_sweep_flops(ocp.N, ocp.nx, ocp.nu) * B / (kern_ms * 1e-3) / 1e12
+        traffic, traffic_src = measured_traffic("cartpole", B, sens, args.rti)
         out = {
             "metric": "MPC+KKT-sens solves/sec, cartpole N=20 batch=4096" if sens else "MPC solves/sec, cartpole N=20 batch=4096",
             "value": solves / elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -293,12 +314,16 @@ def main():
                 "sqp_iters_max": int(iters[:, 0].max()), "ipm_iters_mean": float(iters[:, 1].mean()),
                 "ipm_iters_max": int(iters[:, 1].max())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B, sens, args.rti),
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_solve": bytes_per,
-                         "mfma_f64": {"achieved": mfma_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_solve": bytes_per, "sweeps_per_solve": sweeps,
+                         "fp64": {"achieved": fp64_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": fp64_tflops / FP64_MFMA_PEAK_TFLOPS,
+                                  "note": "SURVEY.md 8d: sweeps/s x F_sweep (7 673 flop per sweep), sweeps = interior-point "
+                                          "iterations + 1 + nu; the path is a serial dependency chain, not flop-bound"},
+                         "mfma_f64_hw": {"achieved": mfma_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": mfma_tflops / FP64_MFMA_PEAK_TFLOPS,
-                                      "note": "the factor sweep is a serial recursion: its MFMAs wait on each other, they do not "
-                                              "fill the pipe (DESIGN.md 4)"}},
+                                         "note": "hardware flops of the 7 v_mfma_f64_4x4x4 per factor-sweep stage step (padded 4x4x4 "
+                                                 "products; vector sweeps excluded): the MFMAs of the recursion wait on each other"}},
         }
         if world == 1 and not args.no_cpu:
             try:

@@ -8,8 +8,12 @@
  *     rlmpc/mpc/cartpole/acados.py:192-203,
  *     rlmpc/mpc/linear_system/acados.py:20-22,126-129,
  *     rlmpc/mpc/chain_mass/acados.py:27-29,45
- *   ocp_solver.set(stage,"p",..) / cost_set(..)                mpcrl_set_theta
- *     rlmpc/mpc/common/mpc.py:137-154,212-257
+ *   ocp_solver.set(stage,"p",..) / cost_set(stage,"W"|"yref")  mpcrl_set_theta   (the cartpole cost block W_0, W, W_e,
+ *     rlmpc/mpc/common/mpc.py:137-154,212-257                    yref_0, yref, yref_e of p is what the solve uses)
+ *   ocp_solver.constraints_set(stage,"lbu"|"ubu"|"lbx"|"ubx")  mpcrl_set_bounds
+ *     rlmpc/mpc/common/mpc.py:72-73,87-88
+ *   float(nlp.L.val)  (MPC.get_L)                              mpcrl_get_lagrangian
+ *     rlmpc/mpc/common/mpc.py:325-332
  *   shared_lib.ocp_nlp_cost_model_set(.., "scaling", gamma^k)  mpcrl_set_gamma
  *     rlmpc/mpc/common/mpc.py:259-285  (the reference's one raw C call)
  *   ocp_solver.reset(); set(stage,"x",x0)                      mpcrl_reset
@@ -26,7 +30,8 @@
  *   - plain C, no torch types.  Every array argument of mpcrl_solve / *_iterate / mpcrl_reset /
  *     mpcrl_set_theta is a DEVICE pointer (HIP), double precision, row-major, owned by the caller.
  *   - the handle owns the warm-start iterate and all workspace; mpcrl_solve allocates nothing and is
- *     asynchronous on the given HIP stream.
+ *     asynchronous on the given HIP stream.  A new handle holds the cold iterate (x = 0, u = 0, multipliers 0,
+ *     slacks 1); mpcrl_reset(h, x0) restores it with x_k = x0.
  *   - return value: 0 ok, < 0 API misuse (MPCRL_E_*).  Per-instance solver status goes to status[B]
  *     with acados' numbering: 0 success, 1 NaN, 2 max-iter, 4 QP failure (reference: solve() returns
  *     int status, update/q_update raise on != 0, rlmpc/mpc/common/mpc.py:81-83,197-198).
@@ -50,7 +55,10 @@ enum {
     MPCRL_SENS_V = 1,  /* dV/dp (or dQ/dp with u0_fixed)  = dL/dp   nlp.py:1211,1401 */
     MPCRL_SENS_PI = 2, /* du0* / dp                        nlp.py:1413-1424 */
     MPCRL_RTI = 4,     /* one SQP iteration from the stored iterate (build-side mode; the reference always runs full SQP) */
-    MPCRL_COLD = 8     /* ignore the stored iterate: x_k = x0, u = 0, multipliers 0 (MPC.reset, mpc.py:204-210) */
+    MPCRL_COLD = 8,    /* ignore the stored iterate: x_k = x0, u = 0, multipliers 0 (MPC.reset, mpc.py:204-210) */
+    MPCRL_COLD_DUAL = 16 /* start from the stored x, u, pi but ignore the stored bound multipliers / slacks (the interior point
+                            starts from its default point).  Implied for the first solve after mpcrl_set_iterate(bnd = NULL):
+                            the reference's `for stage: ocp_solver.set(stage, "x", x0)` initial guess (mpc.py:208-210) */
 };
 enum { MPCRL_E_ARG = -1, MPCRL_E_MODEL = -2, MPCRL_E_HIP = -3, MPCRL_E_NOMEM = -4 };
 
@@ -96,13 +104,21 @@ int mpcrl_set_order(mpcrl_handle h, const int32_t *perm, void *stream);
  * coordinate of x0 with the largest spread.  One small kernel; batch <= 8192, else MPCRL_E_ARG (use mpcrl_set_order). */
 int mpcrl_auto_order(mpcrl_handle h, const double *x0, void *stream);
 
-/* Kernel variant (no effect on results).  AUTO = one lane per stage, everything in registers (the default for every model);
- * COOPERATIVE = cartpole N=20 only: a 7-wave workgroup per 16 instances with the Riccati sweeps of all of them on one wave. */
-enum { MPCRL_VARIANT_AUTO = 0, MPCRL_VARIANT_COOPERATIVE = 1 };
-int mpcrl_set_variant(mpcrl_handle h, int variant);
+/* Box bounds after creation — ocp_solver.constraints_set(stage, "lbu"|"ubu"|"lbx"|"ubx", v) (rlmpc/mpc/common/mpc.py:72-73,87-88).
+ * HOST pointers, stage-vector order v = [u; x]; |bound| >= 1e29 = absent.  which: U0 = controls of stage 0 (nu values),
+ * STAGE = stages 1..N-1 (nu + nx; a coordinate created as a soft bound must keep both sides), TERMINAL = stage N (nx).
+ * The pin lbu_0 = ubu_0 = u0 of Q(s,a) is the u0_fixed argument of mpcrl_solve (per instance), not this call. */
+enum { MPCRL_BOUNDS_U0 = 0, MPCRL_BOUNDS_STAGE = 1, MPCRL_BOUNDS_TERMINAL = 2 };
+int mpcrl_set_bounds(mpcrl_handle h, int which, const double *lb, const double *ub);
 
-/* Cold iterate: x_k := x0 for all k, u := 0, all multipliers 0. x0: [B, nx] device. */
+/* Cold iterate: x_k := x0 for all k (x0: [B, nx] device, or NULL: 0), u := 0, all multipliers 0, slacks 1; the next solve
+ * starts cold (interior point from its default point). */
 int mpcrl_reset(mpcrl_handle h, const double *x0, void *stream);
+
+/* Per-instance MPCRL_COLD for the NEXT mpcrl_solve only: mask [B] int32 on the device, non-zero = that instance ignores its stored
+ * iterate and starts from x_k = x0, u = 0, multipliers 0 (the reference's per-environment `mpc.reset(obs)` when an episode ends,
+ * scripts/cartpole_mpc_as_td3_agent_closed_loop.py:62-64, for a batch in which only some environments ended).  NULL clears it. */
+int mpcrl_set_cold_mask(mpcrl_handle h, const int32_t *mask, void *stream);
 
 /* Solves all instances.
  *   x0        [B, nx]            initial states
@@ -123,6 +139,9 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
  *   res [B, 4]: stationarity, equality, inequality, complementarity residual of the last solve */
 int mpcrl_get_iterate(mpcrl_handle h, double *x, double *u, double *pi, double *bnd, double *res, void *stream);
 int mpcrl_set_iterate(mpcrl_handle h, const double *x, const double *u, const double *pi, const double *bnd, void *stream);
+/* L [B] device: the Lagrangian of the mirror NLP at the iterate the last solve returned, L = cost + pi'g + lam'h
+ * (nlp.L, rlmpc/mpc/nlp.py:1180,1390; MPC.get_L, rlmpc/mpc/common/mpc.py:325-332). */
+int mpcrl_get_lagrangian(mpcrl_handle h, double *L, void *stream);
 
 /* K5, the local half of the one collective on the path: out[j] = sum_i weight[i] * grad[i*ld + j] (j < n), out[n] = sum_i weight[i],
  * out[n+1] = rows.  Replaces the per-sample Python accumulation of rlmpc/examples/linear_system_mpc_qlearning.py:203

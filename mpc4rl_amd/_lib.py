@@ -11,6 +11,7 @@ SENS_V, SENS_PI, RTI, COLD = 1, 2, 4, 8
 MODEL_CARTPOLE, MODEL_LINEAR, MODEL_CHAIN = 0, 1, 2
 COST_NLS, COST_EXTERNAL = 0, 1
 NO_BOUND = 1e30
+BOUNDS_U0, BOUNDS_STAGE, BOUNDS_TERMINAL = 0, 1, 2
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -27,8 +28,8 @@ class ProblemSpec(C.Structure):
     ]
 
 
-EXPORTS = ["mpcrl_create", "mpcrl_destroy", "mpcrl_set_theta", "mpcrl_set_gamma", "mpcrl_set_options", "mpcrl_set_order", "mpcrl_set_variant", "mpcrl_reset",
-           "mpcrl_solve", "mpcrl_get_iterate", "mpcrl_set_iterate", "mpcrl_weighted_grad_sum", "mpcrl_auto_order", "mpcrl_workspace_bytes", "mpcrl_version"]
+EXPORTS = ["mpcrl_create", "mpcrl_destroy", "mpcrl_set_theta", "mpcrl_set_gamma", "mpcrl_set_options", "mpcrl_set_order", "mpcrl_set_bounds", "mpcrl_set_cold_mask", "mpcrl_reset",
+           "mpcrl_solve", "mpcrl_get_iterate", "mpcrl_set_iterate", "mpcrl_get_lagrangian", "mpcrl_weighted_grad_sum", "mpcrl_auto_order", "mpcrl_workspace_bytes", "mpcrl_version"]
 
 _lib = None
 
@@ -50,11 +51,13 @@ def load():
     lib.mpcrl_set_gamma.argtypes = [vp, C.c_double]
     lib.mpcrl_set_options.argtypes = [vp, C.c_double, C.c_int]
     lib.mpcrl_set_order.argtypes = [vp, vp, vp]
-    lib.mpcrl_set_variant.argtypes = [vp, C.c_int]
+    lib.mpcrl_set_bounds.argtypes = [vp, C.c_int, _dp, _dp]
+    lib.mpcrl_set_cold_mask.argtypes = [vp, vp, vp]
     lib.mpcrl_reset.argtypes = [vp, vp, vp]
     lib.mpcrl_solve.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     lib.mpcrl_get_iterate.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.mpcrl_set_iterate.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.mpcrl_get_lagrangian.argtypes = [vp, vp, vp]
     lib.mpcrl_auto_order.argtypes = [vp, vp, vp]
     lib.mpcrl_weighted_grad_sum.argtypes = [vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp]
     lib.mpcrl_workspace_bytes.argtypes = [vp]

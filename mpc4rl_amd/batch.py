@@ -43,15 +43,19 @@ class MPCBatch:
         self.ocp = ocp
         self.B = int(batch)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:      # "cuda" = the current device, not GPU 0
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.nx, self.nu, self.N, self.n_p = ocp.nx, ocp.nu, ocp.N, ocp.n_p
         spec, keep = ocp.c_spec()
         h = C.c_void_p()
-        rc = self.lib.mpcrl_create(C.byref(spec), self.B, self.device.index or 0, C.byref(h))
+        rc = self.lib.mpcrl_create(C.byref(spec), self.B, self.device.index, C.byref(h))
         del keep
         if rc != 0:
             raise RuntimeError(f"mpcrl_create failed with {rc}")
         self._h = h
         self._theta = None
+        self.has_iterate = False       # a stored iterate exists (after a solve / set_iterate; cleared by reset)
+        self.duals_valid = False       # ... and its bound multipliers / slacks come from a solve (not the cold placeholders)
         self.set_theta(torch.as_tensor(ocp.p0, dtype=torch.float64))
         self.gamma = ocp.gamma
 
@@ -94,13 +98,24 @@ class MPCBatch:
     def set_options(self, tol: float = -1.0, max_iter: int = -1) -> None:
         self._check(self.lib.mpcrl_set_options(self._h, float(tol), int(max_iter)), "mpcrl_set_options")
 
-    def set_variant(self, variant: int) -> None:
-        """0 = default (lane per stage), 1 = cooperative sweeps (cartpole N=20 only; experiment)."""
-        self._check(self.lib.mpcrl_set_variant(self._h, int(variant)), "mpcrl_set_variant")
+    def set_bounds(self, which: int, lb, ub) -> None:
+        """ocp_solver.constraints_set (mpc.py:72-73,87-88): which = _lib.BOUNDS_U0 (stage-0 controls, nu values), BOUNDS_STAGE
+        (stages 1..N-1, v = [u; x], nu + nx values), BOUNDS_TERMINAL (stage N, nx values); |bound| >= 1e29 = absent."""
+        lb = np.ascontiguousarray(np.asarray(lb, float).reshape(-1))
+        ub = np.ascontiguousarray(np.asarray(ub, float).reshape(-1))
+        n = {_lib.BOUNDS_U0: self.nu, _lib.BOUNDS_STAGE: self.nu + self.nx, _lib.BOUNDS_TERMINAL: self.nx}[which]
+        if lb.shape[0] != n or ub.shape[0] != n:
+            raise ValueError(f"bounds of kind {which} have {n} entries")
+        dp = C.POINTER(C.c_double)
+        self._check(self.lib.mpcrl_set_bounds(self._h, int(which), lb.ctypes.data_as(dp), ub.ctypes.data_as(dp)), "mpcrl_set_bounds")
 
     def reset(self, x0=None) -> None:
-        """MPC.reset (mpc.py:204-210): the next solve starts from x_k = x0, u = 0, multipliers 0."""
-        self._check(self.lib.mpcrl_reset(self._h, None, self._stream()), "mpcrl_reset")
+        """MPC.reset (mpc.py:204-210): the next solve starts from x_k = x0, u = 0, multipliers 0.  With x0 ([B, nx]) the stored
+        iterate is set to that cold iterate as well (what get_iterate returns until the next solve)."""
+        x0t = None if x0 is None else self._dev(x0, (self.B, self.nx))
+        with torch.cuda.device(self.device):
+            self._check(self.lib.mpcrl_reset(self._h, _ptr(x0t), self._stream()), "mpcrl_reset")
+        self.has_iterate = self.duals_valid = False
 
     # ------------------------------------------------------------------ the hot path
     def _pack_order(self, x0: torch.Tensor) -> None:
@@ -116,8 +131,13 @@ class MPCBatch:
         self._check(self.lib.mpcrl_set_order(self._h, _ptr(perm), self._stream()), "mpcrl_set_order")
 
     def solve(self, x0, u0=None, sens_v: bool = False, sens_pi: bool = False, rti: bool = False, cold: bool = False,
-              reorder: bool = True) -> SolveResult:
+              reorder: bool = True, cold_mask: Optional[torch.Tensor] = None) -> SolveResult:
+        """cold_mask [B] (bool / int): these instances ignore their stored iterate (per-environment ``mpc.reset`` at an episode end)."""
         x0 = self._dev(x0, (self.B, self.nx))
+        if cold_mask is not None:
+            cm = cold_mask.to(device=self.device, dtype=torch.int32).reshape(self.B).contiguous()
+            with torch.cuda.device(self.device):
+                self._check(self.lib.mpcrl_set_cold_mask(self._h, _ptr(cm), self._stream()), "mpcrl_set_cold_mask")
         u0f = None if u0 is None else self._dev(u0, (self.B, self.nu))
         if reorder:
             with torch.cuda.device(self.device):
@@ -135,6 +155,7 @@ class MPCBatch:
             rc = self.lib.mpcrl_solve(self._h, _ptr(x0), _ptr(u0f), flags, _ptr(u0_out), _ptr(V), _ptr(dV), _ptr(dpi),
                                       _ptr(status), _ptr(iters), self._stream())
         self._check(rc, "mpcrl_solve")
+        self.has_iterate = self.duals_valid = True
         return SolveResult(u0_out, V, status, iters, dV, dpi)
 
     def get_action(self, x0) -> torch.Tensor:
@@ -157,6 +178,8 @@ class MPCBatch:
         return x, u, pi, bnd, res
 
     def set_iterate(self, x, u, pi, bnd=None) -> None:
+        """bnd = None: the bound multipliers / slacks are reset to the cold state and the next solve starts its interior point from
+        the default point (MPCRL_COLD_DUAL) — an initial guess for x, u, pi, not a warm start."""
         nw = self.nx + self.nu
         x = self._dev(x, (self.B, self.N + 1, self.nx))
         u = self._dev(u, (self.B, self.N, self.nu))
@@ -165,6 +188,14 @@ class MPCBatch:
         with torch.cuda.device(self.device):
             self._check(self.lib.mpcrl_set_iterate(self._h, _ptr(x), _ptr(u), _ptr(pi), _ptr(bnd), self._stream()),
                         "mpcrl_set_iterate")
+        self.has_iterate, self.duals_valid = True, bnd is not None
+
+    def get_lagrangian(self) -> torch.Tensor:
+        """[B] Lagrangian of the mirror NLP at the iterate of the last solve (nlp.L, nlp.py:1180,1390)."""
+        L = torch.empty((self.B,), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.mpcrl_get_lagrangian(self._h, _ptr(L), self._stream()), "mpcrl_get_lagrangian")
+        return L
 
     def workspace_bytes(self) -> int:
         return int(self.lib.mpcrl_workspace_bytes(self._h))

@@ -48,8 +48,10 @@ struct LargeSpec {
 struct LargeArgs {
     int B, flags, theta_stride;
     const int *perm;
+    const int *cold;                  // [B] or null: per-instance MPCRL_COLD
     const double *x0, *u0fix, *theta;
     double *X, *U, *PI, *BND, *RES;   // iterate (layouts of mpcrl_get_iterate)
+    double *LAG;                      // [B] Lagrangian of the mirror at the returned iterate (mpcrl_get_lagrangian)
     double *ws;                       // per-instance workspace, ws_stride doubles each
     size_t ws_stride;
     double *u0_out, *V, *dV, *dpi;
@@ -1333,7 +1335,7 @@ __global__ void __launch_bounds__(64) chain_init_kernel(const LargeSpec sp, cons
     double *NUv = w + lay.ynu, *lam = w + lay.lamw, *t = w + lay.tw, *aff = w + lay.aff, *st = w + lay.state;
     const int ne = (N + 1) * NW;
     double stepn = -1.0;   // perturbation seen by the first QP (< 0: cold)
-    if (a.flags & 8) {
+    if ((a.flags & 8) || (a.cold && a.cold[inst])) {
         for (int e = lane; e < (N + 1) * NX; e += NT) X[e] = x0[e % NX], NUv[e] = 0.0;
         for (int e = lane; e < N * NU; e += NT) U[e] = 0.0;
         for (int e = lane; e < 2 * ne; e += NT) lam[e] = 0.0, t[e] = 1.0, aff[e] = 0.0;
@@ -1343,7 +1345,7 @@ __global__ void __launch_bounds__(64) chain_init_kernel(const LargeSpec sp, cons
         double sl = 0.0;
         if (lane < NX) sl = fabs(x0[lane] - X[lane]);
         if (u0f && lane < NU) sl = fmax(sl, fabs(u0f[lane] - U[lane]));
-        stepn = wave_max(sl);
+        stepn = (a.flags & 16) ? -1.0 : wave_max(sl);   // MPCRL_COLD_DUAL: the interior point starts from its default point
     }
     if (lane == 0) {
         st[ST_ACTIVE] = 1.0, st[ST_IT] = 0.0, st[ST_NIPM] = 0.0, st[ST_TIGHT] = 1.0, st[ST_STEPN] = stepn, st[ST_COST] = 0.0;
@@ -1460,13 +1462,23 @@ __global__ void __launch_bounds__(64, 1) chain_qp_kernel(const LargeSpec sp, con
         for (int j = 0; j < 4; ++j) a.RES[(size_t)inst * 4 + j] = res[j];
         S.state[ST_ACTIVE] = 0.0, S.state[ST_STATUS] = status;
     }
-    for (int e = lane; e < N * NX; e += NT) PIg[e] = S.NUv[NX + e];
+    // Lagrangian of the mirror, L = cost + pi' g + lam' h (nlp.py:1180; MPC.get_L, mpc.py:325-332): g_k = F(x_k, u_k) - x_{k+1}
+    // is the r of this round's linearisation, h = -(slack of the bound row)
+    double lag = 0.0;
+    for (int e = lane; e < N * NX; e += NT) {
+        const double pi_e = S.NUv[NX + e];
+        PIg[e] = pi_e;
+        lag = fma(pi_e, S.r[e], lag);
+    }
     for (int e = lane; e < 2 * ne; e += NT) {
         const int sd = e / ne, ee = e - sd * ne, k = ee / NW, i = ee - k * NW;
         const bool h = !S.skipc(k, i) && S.has(sd, k, i);
         bnd[e] = h ? S.lam[e] : 0.0;
         bnd[2 * nb + e] = h ? S.t[e] : 1.0;
+        if (h) lag = fma(-S.lam[e], S.bslack(sd, k, i, S.vc(k, i)), lag);
     }
+    lag = wave_sum(lag);
+    if (lane == 0 && a.LAG) a.LAG[inst] = cost + lag;
     for (int e = lane; e < 6 * ne; e += NT) bnd[4 * nb + e] = (e >= 4 * ne) ? 1.0 : 0.0;   // no soft rows here
     S.ph_flush();
 }
@@ -1498,23 +1510,21 @@ __global__ void __launch_bounds__(256) chain_sens_ad_kernel(const LargeSpec sp, 
     const double *X = a.X + (size_t)inst * (N + 1) * NX, *U = a.U + (size_t)inst * N * NU;
     const double *th = a.theta + (size_t)inst * a.theta_stride, *nu = w + lay.ynu;
     if (j == NW) {   // grad_theta (nu_{k+1}' F_k)
-        double jx[NX], ju[NU], jt[NTD], lm[NX], xb[NX], ub[NU], tb[NTD];
+        double jx[NX], ju[NU], lm[NX], xb[NX], ub[NU], tb[NTD];
         for (int i = 0; i < NU; ++i) ju[i] = U[k * NU + i];
         for (int i = 0; i < NX; ++i) jx[i] = X[k * NX + i], lm[i] = nu[(k + 1) * NX + i];
-        for (int i = 0; i < NTD; ++i) jt[i] = th[M::td_index(i)];
-        disc_map_adj<M, true, double>(jx, ju, jt, lm, xb, ub, tb, sp.h, sp.rk_steps);
+        disc_map_adj_p<M, true, double>(jx, ju, th, lm, xb, ub, tb, sp.h, sp.rk_steps);
         double *term = w + lay.term + (size_t)k * NTD;
         for (int d = 0; d < NTD; ++d) term[d] = tb[d];
         return;
     }
     if (!want_pi) return;
     // column j of c_k hess l + hess (nu_{k+1}' F_k): tangent e_j through the reverse sweep of F
-    Jet1<1> jx[NX], ju[NU], jt[NTD], lm[NX], xb[NX], ub[NU];
+    Jet1<1> jx[NX], ju[NU], lm[NX], xb[NX], ub[NU];
     for (int c = 0; c < NU; ++c) ju[c] = Jet1<1>(U[k * NU + c]);
     for (int c = 0; c < NX; ++c) jx[c] = Jet1<1>(X[k * NX + c]), lm[c] = Jet1<1>(nu[(k + 1) * NX + c]);
-    for (int c = 0; c < NTD; ++c) jt[c] = Jet1<1>(th[M::td_index(c)]);
     if (j < NU) ju[j].d[0] = 1.0; else jx[j - NU].d[0] = 1.0;
-    disc_map_adj<M, false, Jet1<1>>(jx, ju, jt, lm, xb, ub, (Jet1<1> *)nullptr, sp.h, sp.rk_steps);
+    disc_map_adj_p<M, false, Jet1<1>>(jx, ju, th, lm, xb, ub, (Jet1<1> *)nullptr, sp.h, sp.rk_steps);
     const double ckk = sp.cost_kind == 0 ? sp.dT : (k == 0 ? sp.dT : pow(sp.gamma, (double)k) * sp.dT);
     double *Hex = w + lay.Hex + (size_t)k * NW * NW;
     for (int i = 0; i < NW; ++i) Hex[i * NW + j] = fma(ckk, M::hess(false, i, j, th), i < NU ? ub[i].d[0] : xb[i - NU].d[0]);
@@ -1588,14 +1598,13 @@ __global__ void __launch_bounds__(256) chain_sens_mix_kernel(const LargeSpec sp,
     const double *X = a.X + (size_t)inst * (N + 1) * NX, *U = a.U + (size_t)inst * N * NU;
     const double *th = a.theta + (size_t)inst * a.theta_stride, *nu = w + lay.ynu;
     const double *Ydx = w + lay.Ydx + (size_t)iu * (N + 1) * NX, *Ydu = w + lay.Ydu + (size_t)iu * N * NU, *Ydnu = w + lay.Ydnu + (size_t)iu * (N + 1) * NX;
-    Jet1<1> jx[NX], ju[NU], jt[NTD], lm[NX], xb[NX], ub[NU], tb[NTD];
+    Jet1<1> jx[NX], ju[NU], lm[NX], xb[NX], ub[NU], tb[NTD];
     for (int c = 0; c < NU; ++c) ju[c] = Jet1<1>(U[k * NU + c]), ju[c].d[0] = Ydu[k * NU + c];
     for (int c = 0; c < NX; ++c) {
         jx[c] = Jet1<1>(X[k * NX + c]), jx[c].d[0] = Ydx[k * NX + c];
         lm[c] = Jet1<1>(nu[(k + 1) * NX + c]), lm[c].d[0] = Ydnu[(k + 1) * NX + c];
     }
-    for (int c = 0; c < NTD; ++c) jt[c] = Jet1<1>(th[M::td_index(c)]);
-    disc_map_adj<M, true, Jet1<1>>(jx, ju, jt, lm, xb, ub, tb, sp.h, sp.rk_steps);
+    disc_map_adj_p<M, true, Jet1<1>>(jx, ju, th, lm, xb, ub, tb, sp.h, sp.rk_steps);
     double *term2 = w + lay.term2 + ((size_t)iu * N + k) * NTD;
     for (int d = 0; d < NTD; ++d) term2[d] = tb[d].d[0];
 }

@@ -36,10 +36,13 @@ struct SmallSpec {
 struct CartpoleDev {
     static constexpr int NX = 4, NU = 1, NW = 5, NP = 83, NTD = 3, NTC = 0;
     static constexpr bool DISCRETE = false, HAS_SOFT = false;
+    static constexpr int MAX_IPW = 4;   // instances per wavefront: the matrix-core factor sweep has four 4x4 blocks
     MPCRL_DI static int td_index(int i) { return i; }
     MPCRL_DI static int tc_index(int) { return 0; }
-    // consts: W (5x5 row-major, y = [x;u] order), yref(5), W_e (4x4), yref_e(4)
-    static constexpr int C_W = 0, C_YREF = 25, C_WE = 30, C_YREFE = 46;
+    // cost block of the parameter vector (nlp.py:969-989, each field column-major): W_0 (5x5), W (5x5), W_e (4x4), yref_0 (5),
+    // yref (5), yref_e (4) in y = [x; u] order.  The solve uses whatever set_parameter / cost_set wrote there (mpc.py:233-257);
+    // the mirror's cost is not parameterised by them (nlp.py:1039-1055): cost_dp / cost_mixed contribute nothing.
+    static constexpr int P_W0 = 3, P_W = 28, P_WE = 53, P_YREF0 = 69, P_YREF = 74, P_YREFE = 79;
 
     template <class S>
     MPCRL_DI static void ode(const S *x, const S *u, const S *th, S *f) {
@@ -64,34 +67,39 @@ struct CartpoleDev {
 #pragma unroll
         for (int i = 0; i < NX; ++i) set(i, 0, i == 0 ? 1.0 : 0.0), set(i, 1, i == 0 ? T : (i == 1 ? 1.0 : 0.0));
     }
-    MPCRL_DI static int yi(int i) { return i < NU ? NX + i : i - NU; }   // v index -> y index
-    // symmetrised weight between stage-vector coordinates i, j
-    MPCRL_DI static double hess(bool term, int i, int j, const SmallSpec &sp, const double *) {
-        if (term) {
+    MPCRL_DI static constexpr int yi(int i) { return i < NU ? NX + i : i - NU; }   // v index -> y index
+    // symmetrised weight between stage-vector coordinates i, j for stage kind 0 (stage 0) / 1 (interior) / 2 (terminal);
+    // p = the instance's full parameter vector (global memory; read once per launch into the LDS cost table)
+    MPCRL_DI static double hess(int kind, int i, int j, const SmallSpec &, const double *p) {
+        if (kind == 2) {
             if (i < NU || j < NU) return 0.0;
-            return 0.5 * (sp.consts[C_WE + (i - NU) * 4 + (j - NU)] + sp.consts[C_WE + (j - NU) * 4 + (i - NU)]);
+            return 0.5 * (p[P_WE + (j - NU) * 4 + (i - NU)] + p[P_WE + (i - NU) * 4 + (j - NU)]);
         }
-        return 0.5 * (sp.consts[C_W + yi(i) * 5 + yi(j)] + sp.consts[C_W + yi(j) * 5 + yi(i)]);
+        const double *W = p + (kind == 0 ? P_W0 : P_W);
+        return 0.5 * (W[yi(j) * 5 + yi(i)] + W[yi(i) * 5 + yi(j)]);
     }
-    MPCRL_DI static double resid(bool term, int i, const double *x, const double *u, const SmallSpec &sp) {
-        if (term) return i < NU ? 0.0 : x[i - NU] - sp.consts[C_YREFE + i - NU];
-        return (i < NU ? u[i] : x[i - NU]) - sp.consts[C_YREF + yi(i)];
+    // reference point of the residual, stage-vector order
+    MPCRL_DI static double yref(int kind, int i, const double *p) {
+        if (kind == 2) return i < NU ? 0.0 : p[P_YREFE + i - NU];
+        return p[(kind == 0 ? P_YREF0 : P_YREF) + yi(i)];
     }
-    // gradient (stage-vector order) and value of the unscaled stage cost
-    MPCRL_DI static double cost_grad(bool term, int, const double *x, const double *u, const SmallSpec &sp, const double *tc,
-                                     double *g) {
-        double val = 0.0;
+    // gradient (stage-vector order) and value of the unscaled stage cost 1/2 r' H r, r = v - yref; H / yr: this stage's set of the
+    // cost table (packed lower triangle / reference point)
+    MPCRL_DI static double cost_grad(bool, int, const double *x, const double *u, const SmallSpec &, const double *, const double *H,
+                                     const double *yr, double *g) {
+        double r[NW], val = 0.0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) r[i] = (i < NU ? u[i < NU ? i : 0] : x[i >= NU ? i - NU : 0]) - yr[i];
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             double a = 0.0;
 #pragma unroll
-            for (int j = 0; j < NW; ++j) a = fma(hess(term, i, j, sp, tc), resid(term, j, x, u, sp), a);
+            for (int j = 0; j < NW; ++j) a = fma(H[i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i], r[j], a);
             g[i] = a;
-            val = fma(0.5 * a, resid(term, i, x, u, sp), val);
+            val = fma(0.5 * a, r[i], val);
         }
         return val;
     }
-    // non-parameterised NLS mirror: the cost does not depend on p (nlp.py:1039-1055)
     MPCRL_DI static void cost_dp(bool, int, const double *, const double *, double, double *) {}
     MPCRL_DI static void cost_mixed(bool, const double *, double, double *) {}
 };
@@ -99,6 +107,7 @@ struct CartpoleDev {
 struct LinearDev {
     static constexpr int NX = 2, NU = 1, NW = 3, NP = 12, NTD = 8, NTC = 4;
     static constexpr bool DISCRETE = true, HAS_SOFT = true;
+    static constexpr int MAX_IPW = 21;   // N >= 2
     MPCRL_DI static int td_index(int i) { return i; }
     MPCRL_DI static int tc_index(int i) { return 8 + i; }   // V_0, f_0, f_1, f_2
     static constexpr int NLD = NX + NU;
@@ -112,13 +121,14 @@ struct LinearDev {
         f[0] = th[0] * x[0] + th[2] * x[1] + th[4] * u[0] + th[6];
         f[1] = th[1] * x[0] + th[3] * x[1] + th[5] * u[0] + th[7];
     }
-    MPCRL_DI static double hess(bool term, int i, int j, const SmallSpec &sp, const double *) {
-        if (!term) return i == j ? 1.0 : 0.0;
+    MPCRL_DI static double hess(int kind, int i, int j, const SmallSpec &sp, const double *) {
+        if (kind != 2) return i == j ? 1.0 : 0.0;
         if (i < NU || j < NU) return 0.0;
         return 0.5 * (sp.consts[(i - NU) * 2 + (j - NU)] + sp.consts[(j - NU) * 2 + (i - NU)]);
     }
+    MPCRL_DI static double yref(int, int, const double *) { return 0.0; }
     MPCRL_DI static double cost_grad(bool term, int k, const double *x, const double *u, const SmallSpec &sp, const double *tc,
-                                     double *g) {
+                                     const double *, const double *, double *g) {
         if (!term) {   // l = 1/2 y'y + f'y (+ V_0 at k = 0), y = [x; u], f = tc[1..3]
             g[0] = u[0] + tc[3];
             g[1] = x[0] + tc[1];
@@ -266,6 +276,56 @@ struct ChainDev {
             }
         }
     }
+    // ode_adj() with the parameters as plain doubles read from the full parameter vector p (as ode_p): the parameters are never a
+    // differentiation direction of the jets (their derivatives come out of the reverse sweep, thb), so carrying them as jets only
+    // costs registers — 2 x NTD of them in the forward-over-reverse kernels.  thb is indexed like the dynamics parameters
+    // (m, D, L, C, w), i.e. by td position.
+    template <bool WANT_TH, class S>
+    MPCRL_DI static void ode_adj_p(const S *x, const S *u, const double *p, const S *fb, S *xb, S *ub, S *thb) {
+        const S *pos = x, *vel = x + 3 * (M + 1);
+        const double *m = p, *D = p + NL, *L = p + 4 * NL, *C = p + 7 * NL;
+        S *posb = xb, *velb = xb + 3 * (M + 1);
+        const S *accb = fb + 3 * (M + 1);
+        for (int i = 0; i < 3 * M; ++i) velb[i] = velb[i] + fb[i];
+        for (int j = 0; j < 3; ++j) ub[j] = ub[j] + fb[3 * M + j];
+        if constexpr (WANT_TH)
+            for (int i = 0; i < 3 * M; ++i) thb[10 * NL + i] = thb[10 * NL + i] + accb[i];
+        for (int i = 0; i <= M; ++i) {
+            S dist[3], distb[3];
+            for (int j = 0; j < 3; ++j) dist[j] = i ? pos[3 * i + j] - pos[3 * (i - 1) + j] : pos[j];
+            const S inrm = jrecip(jsqrt(dist[0] * dist[0] + dist[1] * dist[1] + dist[2] * dist[2]));
+            const double im = 1.0 / m[i];
+            S nrmb(0.0);
+            for (int j = 0; j < 3; ++j) {
+                S Ftb(0.0);   // adjoint of the link force: acc_i -= Ft, acc_{i-1} += Ft
+                if (i < M) Ftb = Ftb - accb[3 * i + j];
+                if (i > 0) Ftb = Ftb + accb[3 * (i - 1) + j];
+                const double a = D[3 * i + j] * im;
+                const S g = 1.0 - L[3 * i + j] * inrm;
+                const S dvb = C[3 * i + j] * Ftb;
+                if (i < M) velb[3 * i + j] = velb[3 * i + j] + dvb; else ub[j] = ub[j] + dvb;
+                if (i > 0) velb[3 * (i - 1) + j] = velb[3 * (i - 1) + j] - dvb;
+                const S fd = Ftb * dist[j];
+                const S gb = a * fd;
+                if constexpr (WANT_TH) {
+                    const S vr = i < M ? vel[3 * i + j] : u[j];
+                    const S dv = i ? vr - vel[3 * (i - 1) + j] : vr;
+                    const S gd = im * (fd * g);   // dFs/dD
+                    thb[7 * NL + 3 * i + j] = thb[7 * NL + 3 * i + j] + Ftb * dv;
+                    thb[NL + 3 * i + j] = thb[NL + 3 * i + j] + gd;
+                    thb[i] = thb[i] - a * gd;
+                    thb[4 * NL + 3 * i + j] = thb[4 * NL + 3 * i + j] - gb * inrm;
+                }
+                nrmb = nrmb + L[3 * i + j] * (gb * inrm * inrm);
+                distb[j] = a * (Ftb * g);
+            }
+            for (int j = 0; j < 3; ++j) {
+                const S db = distb[j] + nrmb * dist[j] * inrm;
+                posb[3 * i + j] = posb[3 * i + j] + db;
+                if (i > 0) posb[3 * (i - 1) + j] = posb[3 * (i - 1) + j] - db;
+            }
+        }
+    }
     // symmetrised cost weights from p (Q, R column-major; ocp_utils.py:267,273)
     MPCRL_DI static double Qs(const double *p, int i, int j) { return 0.5 * (p[OFF_Q + j * NX + i] + p[OFF_Q + i * NX + j]); }
     MPCRL_DI static double Rs(const double *p, int i, int j) { return 0.5 * (p[OFF_R + j * NU + i] + p[OFF_R + i * NU + j]); }
@@ -350,6 +410,38 @@ MPCRL_DI void disc_map_adj(const S *x, const S *u, const S *th, const S *lam, S 
         M::template ode_adj<WANT_TH, S>(X2, u, th, kb, Xb, ub, thb);
         for (int i = 0; i < NX; ++i) acc[i] = acc[i] + Xb[i], kb[i] = (h / 6.0) * lb[i] + (0.5 * h) * Xb[i], Xb[i] = S(0.0);
         M::template ode_adj<WANT_TH, S>(xc, u, th, kb, Xb, ub, thb);
+        for (int i = 0; i < NX; ++i) lb[i] = acc[i] + Xb[i];
+    }
+    for (int i = 0; i < NX; ++i) xb[i] = lb[i];
+}
+
+// disc_map_adj() on M::ode_p / M::ode_adj_p: parameters as plain doubles out of the full vector p (thb in td order).
+template <class M, bool WANT_TH, class S>
+MPCRL_DI void disc_map_adj_p(const S *x, const S *u, const double *p, const S *lam, S *xb, S *ub, S *thb, double h, int steps) {
+    constexpr int NX = M::NX, NU = M::NU, NTD = M::NTD;
+    S lb[NX];
+    for (int i = 0; i < NX; ++i) lb[i] = lam[i];
+    for (int i = 0; i < NU; ++i) ub[i] = S(0.0);
+    if constexpr (WANT_TH)
+        for (int i = 0; i < NTD; ++i) thb[i] = S(0.0);
+    for (int s = steps - 1; s >= 0; --s) {
+        S xc[NX], X2[NX], X3[NX], X4[NX], kk[NX];
+        disc_map_p<M, S>(x, u, p, xc, h, s);   // state at the start of step s
+        M::template ode_p<S>(xc, u, p, kk);
+        for (int i = 0; i < NX; ++i) X2[i] = xc[i] + (0.5 * h) * kk[i];
+        M::template ode_p<S>(X2, u, p, kk);
+        for (int i = 0; i < NX; ++i) X3[i] = xc[i] + (0.5 * h) * kk[i];
+        M::template ode_p<S>(X3, u, p, kk);
+        for (int i = 0; i < NX; ++i) X4[i] = xc[i] + h * kk[i];
+        S kb[NX], Xb[NX], acc[NX];
+        for (int i = 0; i < NX; ++i) kb[i] = (h / 6.0) * lb[i], Xb[i] = S(0.0), acc[i] = lb[i];
+        M::template ode_adj_p<WANT_TH, S>(X4, u, p, kb, Xb, ub, thb);
+        for (int i = 0; i < NX; ++i) acc[i] = acc[i] + Xb[i], kb[i] = (h / 3.0) * lb[i] + h * Xb[i], Xb[i] = S(0.0);
+        M::template ode_adj_p<WANT_TH, S>(X3, u, p, kb, Xb, ub, thb);
+        for (int i = 0; i < NX; ++i) acc[i] = acc[i] + Xb[i], kb[i] = (h / 3.0) * lb[i] + (0.5 * h) * Xb[i], Xb[i] = S(0.0);
+        M::template ode_adj_p<WANT_TH, S>(X2, u, p, kb, Xb, ub, thb);
+        for (int i = 0; i < NX; ++i) acc[i] = acc[i] + Xb[i], kb[i] = (h / 6.0) * lb[i] + (0.5 * h) * Xb[i], Xb[i] = S(0.0);
+        M::template ode_adj_p<WANT_TH, S>(xc, u, p, kb, Xb, ub, thb);
         for (int i = 0; i < NX; ++i) lb[i] = acc[i] + Xb[i];
     }
     for (int i = 0; i < NX; ++i) xb[i] = lb[i];

@@ -10,11 +10,11 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
-#include <vector>
 
 #include "chain_kernel.hpp"
 #include "reduce_kernel.hpp"
 #include "order_kernel.hpp"
+#include "iterate_kernel.hpp"
 
 using namespace mpcrl;
 
@@ -25,15 +25,15 @@ struct MpcrlSolver {
     bool is_large = false;
     int n_mass = 0;
     double *ws = nullptr, *consts_dev = nullptr;
-    int *perm = nullptr;
-    bool have_perm = false;
-    int variant = MPCRL_VARIANT_AUTO;
+    int *perm = nullptr, *cold_mask = nullptr;
+    bool have_perm = false, have_cold_mask = false;
     size_t ws_stride = 0;
     double *theta = nullptr;   // [np] or [B, np]
     int theta_stride = 0;
-    double *X = nullptr, *U = nullptr, *PI = nullptr, *BND = nullptr, *RES = nullptr;
+    double *X = nullptr, *U = nullptr, *PI = nullptr, *BND = nullptr, *RES = nullptr, *LAG = nullptr;
     int64_t bytes = 0;
     bool have_iterate = false;
+    bool dual_cold = false;   // the stored bound multipliers are placeholders (set_iterate without bnd): next solve = MPCRL_COLD_DUAL
 };
 
 #define HIP_OK(expr)                                                                          \
@@ -78,7 +78,7 @@ void copy_or_fill(double *dst, const double *src, int n, int cap, double fill) {
 
 int fill_small_spec(const MpcrlProblemSpec &s, SmallSpec &d) {
     const int nw = s.nx + s.nu;
-    if (nw > SMALL_MAXNW || s.n_consts > SMALL_MAXC || s.N + 1 > 64 || s.N < 1) return MPCRL_E_ARG;
+    if (nw > SMALL_MAXNW || s.n_consts > SMALL_MAXC || s.N + 1 > 64 || s.N < 2) return MPCRL_E_ARG;
     std::memset(&d, 0, sizeof(d));
     d.N = s.N, d.np = s.np, d.cost_kind = s.cost_kind, d.rk_steps = s.rk_steps, d.max_iter = s.max_iter;
     d.dT = s.dT, d.gamma = s.gamma, d.h = s.h, d.tol = s.tol;
@@ -143,19 +143,23 @@ int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
 
 template <class M>
 int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
-    const int ipw = 64 / (h->N + 1);
+    const int ipw = std::min(64 / (h->N + 1), M::MAX_IPW);
     const int blocks = (h->B + ipw - 1) / ipw;
-    // cooperative sweeps pay off once the batch needs more than one round of wavefronts (1024 SIMDs x 1 wave)
-    // MPCRL_VARIANT_COOPERATIVE is an experiment: 3.8x fewer VALU instructions, but slower end to end
-    if (M::NU == 1 && M::NX == 4 && h->N == 20 && h->variant == MPCRL_VARIANT_COOPERATIVE) {
-        hipLaunchKernelGGL(coop_solve_kernel<M>, dim3((h->B + COOP_G - 1) / COOP_G), dim3(64 * COOP_WAVES), 0, st, h->small, a);
-    } else
-        hipLaunchKernelGGL(small_solve_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
+    hipLaunchKernelGGL(small_solve_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
     HIP_OK(hipGetLastError());
     if (a.flags & (MPCRL_SENS_V | MPCRL_SENS_PI)) {
         hipLaunchKernelGGL(small_sens_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
         HIP_OK(hipGetLastError());
     }
+    return 0;
+}
+
+// writes the cold iterate (MPC.reset) into the stored-iterate arrays; x0 may be null (x_k = 0)
+int fill_cold_iterate(MpcrlSolver *h, const double *x0, bool primal, hipStream_t st) {
+    const long n = (long)h->B * 10 * (h->N + 1) * (h->nx + h->nu);
+    hipLaunchKernelGGL(cold_iterate_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, st, x0, h->B, h->N, h->nx, h->nu,
+                       primal ? h->X : nullptr, primal ? h->U : nullptr, primal ? h->PI : nullptr, h->BND);
+    HIP_OK(hipGetLastError());
     return 0;
 }
 
@@ -214,23 +218,31 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
     if (!rc) rc = dev_alloc(&h->PI, B * N * nx, h->bytes);
     if (!rc) rc = dev_alloc(&h->BND, B * 10 * (N + 1) * nw, h->bytes);
     if (!rc) rc = dev_alloc(&h->RES, B * 4, h->bytes);
+    if (!rc) rc = dev_alloc(&h->LAG, B, h->bytes);
     if (!rc) rc = dev_alloc(&h->theta, B * (size_t)spec->np, h->bytes);
     if (!rc) rc = dev_alloc(&h->perm, B, h->bytes);
+    if (!rc) rc = dev_alloc(&h->cold_mask, B, h->bytes);
     if (!rc && h->is_large) {
         h->ws_stride = h->n_mass == 3 ? LargeLayout<ChainDev<3>>(spec->N).total
                                       : (h->n_mass == 5 ? LargeLayout<ChainDev<5>>(spec->N).total : LargeLayout<ChainDev<7>>(spec->N).total);
         rc = dev_alloc(&h->ws, B * h->ws_stride, h->bytes);
         if (!rc) rc = dev_alloc(&h->consts_dev, (size_t)spec->n_consts, h->bytes);
         if (!rc) {
-            HIP_OK(hipMemcpy(h->consts_dev, spec->consts, spec->n_consts * sizeof(double), hipMemcpyHostToDevice));
+            if (hipMemcpy(h->consts_dev, spec->consts, spec->n_consts * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = MPCRL_E_HIP;
             h->large.consts = h->consts_dev;
         }
     }
+    // parameters 0, residuals 0, and the stored iterate = the cold iterate with x_k = 0: nothing the handle owns is ever read
+    // uninitialised (get_iterate / set_iterate before the first solve)
+    if (!rc && hipMemset(h->theta, 0, B * (size_t)spec->np * sizeof(double)) != hipSuccess) rc = MPCRL_E_HIP;
+    if (!rc && hipMemset(h->RES, 0, B * 4 * sizeof(double)) != hipSuccess) rc = MPCRL_E_HIP;
+    if (!rc && hipMemset(h->LAG, 0, B * sizeof(double)) != hipSuccess) rc = MPCRL_E_HIP;
+    if (!rc) rc = fill_cold_iterate(h, nullptr, true, nullptr);
+    if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) rc = MPCRL_E_HIP;
     if (rc) {
         mpcrl_destroy(h);
         return rc;
     }
-    HIP_OK(hipMemset(h->theta, 0, B * (size_t)spec->np * sizeof(double)));
     *out = h;
     return 0;
 }
@@ -238,9 +250,10 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
 int mpcrl_destroy(mpcrl_handle h) {
     if (!h) return MPCRL_E_ARG;
     DeviceGuard guard_(h->device);
-    for (double *p : {h->X, h->U, h->PI, h->BND, h->RES, h->theta, h->ws, h->consts_dev})
+    for (double *p : {h->X, h->U, h->PI, h->BND, h->RES, h->LAG, h->theta, h->ws, h->consts_dev})
         if (p) hipFree(p);
     if (h->perm) hipFree(h->perm);
+    if (h->cold_mask) hipFree(h->cold_mask);
     delete h;
     return 0;
 }
@@ -277,6 +290,14 @@ int mpcrl_set_order(mpcrl_handle h, const int32_t *perm, void *stream) {
     return 0;
 }
 
+int mpcrl_set_cold_mask(mpcrl_handle h, const int32_t *mask, void *stream) {
+    if (!h) return MPCRL_E_ARG;
+    ON_DEVICE(h->device);
+    if (mask) HIP_OK(hipMemcpyAsync(h->cold_mask, mask, (size_t)h->B * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    h->have_cold_mask = mask != nullptr;
+    return 0;
+}
+
 int mpcrl_auto_order(mpcrl_handle h, const double *x0, void *stream) {
     if (!h || !x0) return MPCRL_E_ARG;
     if (h->B > ORDER_MAX) return MPCRL_E_ARG;   // larger batches: build the permutation outside and pass it to mpcrl_set_order
@@ -287,17 +308,34 @@ int mpcrl_auto_order(mpcrl_handle h, const double *x0, void *stream) {
     return 0;
 }
 
-int mpcrl_set_variant(mpcrl_handle h, int variant) {
-    if (!h || variant < MPCRL_VARIANT_AUTO || variant > MPCRL_VARIANT_COOPERATIVE) return MPCRL_E_ARG;
-    h->variant = variant;
+int mpcrl_set_bounds(mpcrl_handle h, int which, const double *lb, const double *ub) {
+    if (!h || !lb || !ub || which < MPCRL_BOUNDS_U0 || which > MPCRL_BOUNDS_TERMINAL) return MPCRL_E_ARG;
+    const int nw = h->nx + h->nu;
+    const int n = which == MPCRL_BOUNDS_U0 ? h->nu : (which == MPCRL_BOUNDS_STAGE ? nw : h->nx);
+    for (int i = 0; i < n; ++i)
+        if (!(lb[i] <= ub[i])) return MPCRL_E_ARG;
+    double *dl, *du;
+    if (h->is_large)
+        dl = which == MPCRL_BOUNDS_U0 ? h->large.lb0 : (which == MPCRL_BOUNDS_STAGE ? h->large.lb : h->large.lbe),
+        du = which == MPCRL_BOUNDS_U0 ? h->large.ub0 : (which == MPCRL_BOUNDS_STAGE ? h->large.ub : h->large.ube);
+    else
+        dl = which == MPCRL_BOUNDS_U0 ? h->small.lb0 : (which == MPCRL_BOUNDS_STAGE ? h->small.lb : h->small.lbe),
+        du = which == MPCRL_BOUNDS_U0 ? h->small.ub0 : (which == MPCRL_BOUNDS_STAGE ? h->small.ub : h->small.ube);
+    if (which == MPCRL_BOUNDS_STAGE && !h->is_large)   // a soft bound must stay a two-sided bound (its slack rows exist for both sides)
+        for (int i = 0; i < n; ++i)
+            if (h->small.soft[i] && (lb[i] <= -MPCRL_NO_BOUND * 0.1 || ub[i] >= MPCRL_NO_BOUND * 0.1)) return MPCRL_E_ARG;
+    for (int i = 0; i < n; ++i) dl[i] = lb[i], du[i] = ub[i];
     return 0;
 }
 
 int mpcrl_reset(mpcrl_handle h, const double *x0, void *stream) {
     if (!h) return MPCRL_E_ARG;
-    (void)x0, (void)stream;
-    h->have_iterate = false;   // the next solve builds the cold iterate x_k = x0, u = 0 itself
-    return 0;
+    ON_DEVICE(h->device);
+    // the next solve builds the cold iterate itself from ITS x0 (MPCRL_COLD); the stored arrays are set to the same state so
+    // that get_iterate / set_iterate after a reset see the cold iterate and not the previous solution
+    int rc = fill_cold_iterate(h, x0, true, (hipStream_t)stream);
+    h->have_iterate = false, h->dual_cold = false;
+    return rc;
 }
 
 int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int flags, double *u0_out, double *V, double *dV_dp,
@@ -308,10 +346,13 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
     ON_DEVICE(h->device);
     hipStream_t st = (hipStream_t)stream;
     if (!h->have_iterate) flags |= MPCRL_COLD;
+    if (h->dual_cold) flags |= MPCRL_COLD_DUAL;
     SmallArgs a;
     a.B = h->B, a.flags = flags, a.theta_stride = h->theta_stride, a.perm = h->have_perm ? h->perm : nullptr;
+    a.cold = (h->have_cold_mask && h->have_iterate) ? h->cold_mask : nullptr;   // one-shot: consumed by this solve
+    h->have_cold_mask = false;
     a.x0 = x0, a.u0fix = u0_fixed, a.theta = h->theta;
-    a.X = h->X, a.U = h->U, a.PI = h->PI, a.BND = h->BND, a.RES = h->RES;
+    a.X = h->X, a.U = h->U, a.PI = h->PI, a.BND = h->BND, a.RES = h->RES, a.LAG = h->LAG;
     a.u0_out = u0_out, a.V = V, a.dV = (flags & MPCRL_SENS_V) ? dV_dp : nullptr, a.dpi = (flags & MPCRL_SENS_PI) ? dpi_dp : nullptr;
     a.status = status, a.iters = iters;
     if (a.dV) HIP_OK(hipMemsetAsync(dV_dp, 0, (size_t)h->B * h->np * sizeof(double), st));
@@ -319,8 +360,8 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
     int rc;
     if (h->is_large) {
         LargeArgs la;
-        la.B = a.B, la.flags = a.flags, la.theta_stride = a.theta_stride, la.perm = a.perm, la.x0 = a.x0, la.u0fix = a.u0fix, la.theta = a.theta;
-        la.X = a.X, la.U = a.U, la.PI = a.PI, la.BND = a.BND, la.RES = a.RES, la.ws = nullptr, la.ws_stride = 0;
+        la.B = a.B, la.flags = a.flags, la.theta_stride = a.theta_stride, la.perm = a.perm, la.cold = a.cold, la.x0 = a.x0, la.u0fix = a.u0fix, la.theta = a.theta;
+        la.X = a.X, la.U = a.U, la.PI = a.PI, la.BND = a.BND, la.RES = a.RES, la.LAG = a.LAG, la.ws = nullptr, la.ws_stride = 0;
         la.u0_out = a.u0_out, la.V = a.V, la.dV = a.dV, la.dpi = a.dpi, la.status = a.status, la.iters = a.iters;
         rc = h->n_mass == 3 ? launch_large<ChainDev<3>>(h, la, st)
                             : (h->n_mass == 5 ? launch_large<ChainDev<5>>(h, la, st) : launch_large<ChainDev<7>>(h, la, st));
@@ -330,7 +371,7 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
             case MPCRL_MODEL_LINEAR: rc = launch_small<LinearDev>(h, a, st); break;
             default: rc = MPCRL_E_MODEL;
         }
-    if (!rc) h->have_iterate = true;
+    if (!rc) h->have_iterate = true, h->dual_cold = false;
     return rc;
 }
 
@@ -363,6 +404,13 @@ int mpcrl_get_iterate(mpcrl_handle h, double *x, double *u, double *pi, double *
     return 0;
 }
 
+int mpcrl_get_lagrangian(mpcrl_handle h, double *L, void *stream) {
+    if (!h || !L) return MPCRL_E_ARG;
+    ON_DEVICE(h->device);
+    HIP_OK(hipMemcpyAsync(L, h->LAG, (size_t)h->B * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
 int mpcrl_set_iterate(mpcrl_handle h, const double *x, const double *u, const double *pi, const double *bnd, void *stream) {
     if (!h || !x || !u || !pi) return MPCRL_E_ARG;
     ON_DEVICE(h->device);
@@ -373,16 +421,11 @@ int mpcrl_set_iterate(mpcrl_handle h, const double *x, const double *u, const do
     HIP_OK(hipMemcpyAsync(h->PI, pi, B * N * nx * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (bnd)
         HIP_OK(hipMemcpyAsync(h->BND, bnd, B * 10 * (N + 1) * nw * sizeof(double), hipMemcpyDeviceToDevice, st));
-    else {
-        // multipliers 0, slacks t = 1: the state MPCRL_COLD would build
-        std::vector<double> hb(10 * (N + 1) * nw, 0.0);
-        for (size_t j : {2, 3, 8, 9})
-            for (size_t i = 0; i < (N + 1) * nw; ++i) hb[j * (N + 1) * nw + i] = 1.0;
-        for (size_t b = 0; b < B; ++b)
-            HIP_OK(hipMemcpyAsync(h->BND + b * hb.size(), hb.data(), hb.size() * sizeof(double), hipMemcpyHostToDevice, st));
-        HIP_OK(hipStreamSynchronize(st));
+    else {   // multipliers 0, slacks t = 1: the state MPCRL_COLD would build
+        int rc = fill_cold_iterate(h, nullptr, false, st);
+        if (rc) return rc;
     }
-    h->have_iterate = true;
+    h->have_iterate = true, h->dual_cold = bnd == nullptr;
     return 0;
 }
 

@@ -49,10 +49,12 @@ struct SmallArgs {
     int flags;             // MPCRL_* solve flags
     int theta_stride;      // 0 = shared theta, np = per instance
     const int *perm;       // packing order: slot i of the launch works on instance perm[i] (null = identity)
+    const int *cold;       // [B] or null: non-zero = this instance ignores its stored iterate (per-instance MPCRL_COLD)
     const double *x0;      // [B, nx]
     const double *u0fix;   // [B, nu] or null
     const double *theta;   // [np] or [B, np]
     double *X, *U, *PI, *BND, *RES;   // iterate workspace (in/out), layouts of mpcrl_get_iterate
+    double *LAG;           // [B] Lagrangian of the mirror at the returned iterate (mpcrl_get_lagrangian)
     double *u0_out, *V, *dV, *dpi;
     int *status, *iters;
 };
@@ -122,32 +124,9 @@ MPCRL_DI void seg_reduce(double *mx, double *sm, int k, int lpi, int base) {
     for (int i = 0; i < NSUM; ++i) sm[i] = __shfl(sm[i], base);
 }
 
-// Cooperative mode (coop_solve_kernel): a workgroup of COOP_WAVES waves owns COOP_G instances.  The stage-parallel phases stay
-// on the stage lanes; the serial Riccati sweeps of ALL instances of the workgroup run side by side on COOP_G lanes of the last
-// wave, exchanging per-stage data through LDS (one slot of SLOTP doubles per (instance, stage)).
-struct NoCoop {
-    static constexpr bool ON = false;
-};
-struct CoopCtx {
-    static constexpr bool ON = true;
-    double *lds;        // slots
-    double *okbuf;      // [COOP_G] factorisation-ok flags (1.0 / 0.0)
-    int *flags_ipm;     // [COOP_WAVES] workgroup-any scratch
-    int g;              // instance index inside the workgroup (stage lanes)
-    bool stage_lane;    // this lane owns a (g, k) stage slot
-    bool sweep_lane;    // this lane runs the sweeps of instance gs
-    int gs, wave, nwave;
-};
-constexpr int COOP_G = 16, COOP_STAGE_WAVES = 6, COOP_WAVES = 7;   // 6 waves of stage lanes (3 instances each, the last one 1) + 1 sweep wave
-
-template <class M, class C = NoCoop>
+template <class M>
 struct SmallSolver {
     static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD, NTC = M::NTC, NP = M::NP;
-    C coop;
-    // LDS slot layout of one (instance, stage) in cooperative mode
-    static constexpr int oA = 0, oB = oA + NX * NX, oDg = oB + NX * NU, oRt = oDg + NW, oRb = oRt + NW, oK = oRb + NX,
-                         oKff = oK + NU * NX, oLi = oKff + NU, oP = oLi + NU * (NU + 1) / 2, oPv = oP + NX * (NX + 1) / 2,
-                         SLOT = oPv + NX, SLOTP = SLOT | 1;
     static constexpr int NPK = NX * (NX + 1) / 2, NLK = NU * (NU + 1) / 2;
     static constexpr bool SOFT = M::HAS_SOFT;
     MPCRL_DI static constexpr int sym(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
@@ -197,32 +176,10 @@ struct SmallSolver {
     MPCRL_DI double dvc(const double *ax, const double *au, int i) const {
         return i < NU ? (term ? 0.0 : au[i < NU ? i : 0]) : ax[i >= NU ? i - NU : 0];
     }
-    // dynamics Jacobians: registers by default; in cooperative mode they live only in the stage's LDS slot (the sweep lane needs
-    // them there anyway), which keeps the stage waves inside their 256-register budget
-    MPCRL_DI double Aget(int i) const {
-        if constexpr (C::ON)
-            return slot(coop.g, k)[oA + i];
-        else
-            return A[i];
-    }
-    MPCRL_DI double Bget(int i) const {
-        if constexpr (C::ON)
-            return slot(coop.g, k)[oB + i];
-        else
-            return Bm[i];
-    }
-    MPCRL_DI void Aset(int i, double v) {
-        if constexpr (C::ON) {
-            if (coop.stage_lane) slot(coop.g, k)[oA + i] = v;
-        } else
-            A[i] = v;
-    }
-    MPCRL_DI void Bset(int i, double v) {
-        if constexpr (C::ON) {
-            if (coop.stage_lane) slot(coop.g, k)[oB + i] = v;
-        } else
-            Bm[i] = v;
-    }
+    MPCRL_DI double Aget(int i) const { return A[i]; }
+    MPCRL_DI double Bget(int i) const { return Bm[i]; }
+    MPCRL_DI void Aset(int i, double v) { A[i] = v; }
+    MPCRL_DI void Bset(int i, double v) { Bm[i] = v; }
     MPCRL_DI double BA(int m, int j) const { return j < NU ? Bget(m * NU + (j < NU ? j : 0)) : Aget(m * NX + (j >= NU ? j - NU : 0)); }
     // slack(v) of the bound row on side sd, coordinate i, at value v
     MPCRL_DI double bslack(int sd, int i, double v) const {
@@ -265,7 +222,7 @@ struct SmallSolver {
                 }
             }
         }
-        double val = M::cost_grad(term, k, x, u, sp, thc, q);
+        double val = M::cost_grad(term, k, x, u, sp, thc, Hc, ctab + NHT, q);
 #pragma unroll
         for (int i = 0; i < NW; ++i) q[i] *= ck;
         val *= ck;
@@ -491,7 +448,7 @@ struct SmallSolver {
     //   Zr = mfma(Y, A, [Hux; 0])  : row 0 = S'               Zb = mfma(BB, Y, [Huu + D_u | g_u]): every row = [R, mv_u]
     //   K = S / R, kff = mv_u / R, p = mv_x - K mv_u,  P = mfma(-K' (row 0), S' (row 0), Q) = Q - K S'
     // 7 MFMAs (~18 cycles each) + ~40 VALU per step instead of ~300 VALU instructions.
-    static constexpr bool MX = (NX == 4 && NU == 1 && !C::ON);
+    static constexpr bool MX = (NX == 4 && NU == 1);
     // Slot of one stage (doubles; 16-byte aligned pairs so that one ds_read_b128 brings two operands — LDS instructions, not
     // bytes, are what the sweep waits for: ~28 cycles each on a lone wavefront):
     //   [0,32)   (A(r,c), Hxx(r,c) + D_x) pairs at 2 (4 r + c); the sweep overwrites the second member with P_k(r,c)
@@ -501,28 +458,35 @@ struct SmallSolver {
     static constexpr int mxAH = 0, mxCol = 32, mxRow = 48, mxK = 56, mxp = 60, mxkff = 64, mxLi = 65, mxFlag = 66, mxDump = 68,
                          MSLOT = 70;   // 64 slots = 35 KB: four single-wave workgroups still fit one CU's LDS
     double *ms = nullptr;   // LDS, 64 slots of MSLOT doubles (one per stage lane)
-    // LDS table of the (unscaled) stage-cost Hessian, [non-terminal | terminal] x packed lower triangle.  The Hessian entries are
-    // kernel arguments; which set a lane needs depends on its stage, and a lane-dependent offset into kernel arguments makes the
-    // compiler copy them to scratch and index that (a global-memory round trip per entry and use).  An LDS read is ~10x cheaper.
-    static constexpr int NHT = NW * (NW + 1) / 2;
-    const double *htab = nullptr;
-    MPCRL_DI void fill_htab(double *tab) {
+    // LDS cost table, one per instance of the wavefront: for each stage kind (0 = stage 0, 1 = interior, 2 = terminal) the packed
+    // lower triangle of the UNSCALED stage-cost Hessian and the reference point of the residual (cartpole: W_0 / W / W_e and
+    // yref_0 / yref / yref_e out of the instance's parameter vector, so that set_parameter / cost_set reach the solve as they do
+    // in the reference, mpc.py:233-257).  A lane keeps its own stage's Hessian set in registers (Hc); a lane-dependent offset into
+    // kernel arguments instead would make the compiler copy them to scratch and index that (a global-memory round trip per use).
+    static constexpr int NHT = NW * (NW + 1) / 2, CSET = NHT + NW, CTAB = 3 * CSET;
+    const double *ctab = nullptr;   // this lane's set: [NHT Hessian | NW reference point]
+    MPCRL_DI int stage_kind() const { return first ? 0 : (term ? 2 : 1); }
+    // tab: LDS, CTAB doubles per instance slot of the wavefront; th: the instance's full parameter vector
+    MPCRL_DI void fill_cost_table(double *tab, int slot_, bool owner, const double *th) {
+        double *mine = tab + slot_ * CTAB;
+        if (first && owner) {   // lanes past the last instance slot of the wavefront shadow slot 0 and must not write its table
+            for (int kind = 0; kind < 3; ++kind) {
+                double *set = mine + kind * CSET;
 #pragma unroll
-        for (int i = 0; i < NW; ++i)
+                for (int i = 0; i < NW; ++i) {
 #pragma unroll
-            for (int j = 0; j <= i; ++j) tab[sym(i, j)] = M::hess(false, i, j, sp, thc), tab[NHT + sym(i, j)] = M::hess(true, i, j, sp, thc);
-        htab = tab;
+                    for (int j = 0; j <= i; ++j) set[sym(i, j)] = M::hess(kind, i, j, sp, th);
+                    set[NHT + i] = M::yref(kind, i, th);
+                }
+            }
+        }
+        ctab = mine + stage_kind() * CSET;
     }
-    double Hc[NHT];   // this lane's set, in registers
-    MPCRL_DI double hess_of_stage(int i, int j) const {
-        if constexpr (C::ON)
-            return M::hess(term, i, j, sp, thc);
-        else
-            return Hc[i >= j ? sym(i, j) : sym(j, i)];
-    }
+    double Hc[NHT];   // this lane's Hessian set, in registers
+    MPCRL_DI double hess_of_stage(int i, int j) const { return Hc[i >= j ? sym(i, j) : sym(j, i)]; }
     MPCRL_DI void load_hc() {
 #pragma unroll
-        for (int e = 0; e < NHT; ++e) Hc[e] = htab[(term ? NHT : 0) + e];
+        for (int e = 0; e < NHT; ++e) Hc[e] = ctab[e];
     }
     typedef double mx_d2 __attribute__((ext_vector_type(2)));
 
@@ -568,7 +532,7 @@ struct SmallSolver {
     // the sweep itself, all lanes in matrix layout
     MPCRL_DI void mx_factor() {
         const int l = threadIdx.x & 63, r = l >> 4, blk = (l >> 2) & 3, c = l & 3;
-        const int ipw = 64 / lpi;
+        const int ipw = min(64 / lpi, M::MAX_IPW);
         const bool live = blk < ipw;
         double *S0 = ms + (live ? blk : 0) * lpi * MSLOT;   // an idle block shadows block 0 and stores to the dump
         const int oAH = mxAH + 2 * (4 * r + c), oCol = mxCol + 4 * r + (c == 1 ? 2 : 0), oB = mxCol + 4 * r, oRow = mxRow + 2 * c;
@@ -734,278 +698,6 @@ struct SmallSolver {
             for (int j = 0; j < NX; ++j) a = fma(P[sym(i, j)], Dx[j], a);
             Dnu[i] = first ? 0.0 : a;
         }
-    }
-
-    // ---- workgroup-wide "any" (cooperative mode) / wave-wide (default) ---------------------------------
-    MPCRL_DI bool any_lane(bool v) {
-        if constexpr (C::ON) {
-            const bool w = __any(v);
-            if ((threadIdx.x & 63) == 0) coop.flags_ipm[coop.wave] = w ? 1 : 0;
-            __syncthreads();
-            int r = 0;
-            for (int i = 0; i < coop.nwave; ++i) r |= coop.flags_ipm[i];
-            return r != 0;
-        } else
-            return __any(v);
-    }
-    MPCRL_DI double *slot(int g, int kk) const { return coop.lds + (size_t)(g * lpi + kk) * SLOTP; }
-
-    // (cooperative mode: linearize() writes A, B straight into the stage's LDS slot)
-    MPCRL_DI void coop_publish_AB() {}
-
-    // serial sweeps of one instance on one lane; per-stage data in LDS.  FACTOR: matrix + vector recursion, else vector only.
-    template <bool FACTOR>
-    MPCRL_DI bool coop_sweep(int gs) {
-        bool ok = true;
-        double Pc[NPK], pc[NX];
-        {   // terminal stage
-            double *sl = slot(gs, N);
-            const double ckN = sp.cost_kind == 0 ? 1.0 : pow(sp.gamma, (double)N);
-            if constexpr (FACTOR) {
-#pragma unroll
-                for (int i = 0; i < NX; ++i)
-#pragma unroll
-                    for (int j = 0; j <= i; ++j) {
-                        Pc[sym(i, j)] = ckN * M::hess(true, NU + i, NU + j, sp, thc) + (i == j ? sl[oDg + NU + i] : 0.0);
-                        sl[oP + sym(i, j)] = Pc[sym(i, j)];
-                    }
-            } else {
-#pragma unroll
-                for (int i = 0; i < NPK; ++i) Pc[i] = sl[oP + i];
-            }
-#pragma unroll
-            for (int i = 0; i < NX; ++i) pc[i] = sl[oRt + NU + i], sl[oPv + i] = pc[i];
-        }
-        double ckk_next = sp.cost_kind == 0 ? sp.dT : pow(sp.gamma, (double)N) * sp.dT;   // gamma^(k+1) dT, updated as k decreases
-        for (int kk = N - 1; kk >= 0; --kk) {
-            double *sl = slot(gs, kk);
-            const double ckk = sp.cost_kind == 0 ? sp.dT : (kk == 0 ? sp.dT : ckk_next / sp.gamma);
-            ckk_next = kk == 0 ? ckk_next : ckk;
-            const bool pin = kk == 0 && qmode;
-            double BAv[NX * NW], g[NW], bb[NX], cc[NX], mv[NW];
-#pragma unroll
-            for (int m = 0; m < NX; ++m) {
-#pragma unroll
-                for (int j = 0; j < NU; ++j) BAv[m * NW + j] = sl[oB + m * NU + j];
-#pragma unroll
-                for (int j = 0; j < NX; ++j) BAv[m * NW + NU + j] = sl[oA + m * NX + j];
-            }
-#pragma unroll
-            for (int i = 0; i < NW; ++i) g[i] = sl[oRt + i];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) bb[i] = sl[oRb + i];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                double a = pc[i];
-#pragma unroll
-                for (int j = 0; j < NX; ++j) a = fma(Pc[sym(i, j)], bb[j], a);
-                cc[i] = a;
-            }
-#pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                double a = g[i];
-#pragma unroll
-                for (int m = 0; m < NX; ++m) a = fma(BAv[m * NW + i], cc[m], a);
-                mv[i] = a;
-            }
-            double Kc[NU * NX], Lc[NLK], kf[NU];
-            if constexpr (FACTOR) {
-                double T[NX * NW], Mm[NW * (NW + 1) / 2];
-#pragma unroll
-                for (int i = 0; i < NX; ++i)
-#pragma unroll
-                    for (int j = 0; j < NW; ++j) {
-                        double a = 0.0;
-#pragma unroll
-                        for (int m = 0; m < NX; ++m) a = fma(Pc[sym(i, m)], BAv[m * NW + j], a);
-                        T[i * NW + j] = a;
-                    }
-#pragma unroll
-                for (int i = 0; i < NW; ++i)
-#pragma unroll
-                    for (int j = 0; j <= i; ++j) {
-                        double a = ckk * M::hess(false, i, j, sp, thc) + (i == j ? sl[oDg + i] : 0.0);
-#pragma unroll
-                        for (int m = 0; m < NX; ++m) a = fma(BAv[m * NW + i], T[m * NW + j], a);
-                        Mm[sym(i, j)] = a;
-                    }
-#pragma unroll
-                for (int i = 0; i < NU; ++i)
-#pragma unroll
-                    for (int j = 0; j <= i; ++j) {
-                        double a = Mm[sym(i, j)];
-#pragma unroll
-                        for (int m = 0; m < j; ++m) a -= Lc[sym(i, m)] * Lc[sym(j, m)];
-                        if (i == j) {
-                            ok = ok && (a > 0.0 || pin);
-                            Lc[sym(i, i)] = 1.0 / sqrt(a);
-                        } else
-                            Lc[sym(i, j)] = a * Lc[sym(j, j)];
-                    }
-#pragma unroll
-                for (int j = 0; j < NX; ++j) {
-                    double y[NU];
-#pragma unroll
-                    for (int i = 0; i < NU; ++i) {
-                        double a = Mm[sym(NU + j, i)];
-#pragma unroll
-                        for (int m = 0; m < i; ++m) a -= Lc[sym(i, m)] * y[m];
-                        y[i] = a * Lc[sym(i, i)];
-                    }
-#pragma unroll
-                    for (int i = NU - 1; i >= 0; --i) {
-                        double a = y[i];
-#pragma unroll
-                        for (int m = i + 1; m < NU; ++m) a -= Lc[sym(m, i)] * Kc[m * NX + j];
-                        Kc[i * NX + j] = pin ? 0.0 : a * Lc[sym(i, i)];
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < NX; ++i)
-#pragma unroll
-                    for (int j = 0; j <= i; ++j) {
-                        double a = Mm[sym(NU + i, NU + j)];
-#pragma unroll
-                        for (int m = 0; m < NU; ++m) a -= Mm[sym(NU + i, m)] * Kc[m * NX + j];
-                        Pc[sym(i, j)] = a;
-                    }
-#pragma unroll
-                for (int i = 0; i < NU * NX; ++i) sl[oK + i] = Kc[i];
-#pragma unroll
-                for (int i = 0; i < NLK; ++i) sl[oLi + i] = Lc[i];
-#pragma unroll
-                for (int i = 0; i < NPK; ++i) sl[oP + i] = Pc[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < NU * NX; ++i) Kc[i] = sl[oK + i];
-#pragma unroll
-                for (int i = 0; i < NLK; ++i) Lc[i] = sl[oLi + i];
-#pragma unroll
-                for (int i = 0; i < NPK; ++i) Pc[i] = sl[oP + i];
-            }
-            {
-                double y[NU];
-#pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    double a = mv[i];
-#pragma unroll
-                    for (int m = 0; m < i; ++m) a -= Lc[sym(i, m)] * y[m];
-                    y[i] = a * Lc[sym(i, i)];
-                }
-#pragma unroll
-                for (int i = NU - 1; i >= 0; --i) {
-                    double a = y[i];
-#pragma unroll
-                    for (int m = i + 1; m < NU; ++m) a -= Lc[sym(m, i)] * kf[m];
-                    kf[i] = pin ? 0.0 : a * Lc[sym(i, i)];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                double a = mv[NU + i];
-#pragma unroll
-                for (int m = 0; m < NU; ++m) a -= Kc[m * NX + i] * mv[m];
-                pc[i] = a;
-            }
-#pragma unroll
-            for (int i = 0; i < NU; ++i) sl[oKff + i] = kf[i];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) sl[oPv + i] = pc[i];
-        }
-        // forward sweep; Du, Dx overwrite the (consumed) gradient slots
-        double dxc[NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) dxc[i] = 0.0;
-        for (int kk = 0; kk < N; ++kk) {
-            double *sl = slot(gs, kk);
-            double duc[NU], xn[NX];
-#pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                double a = -sl[oKff + i];
-#pragma unroll
-                for (int j = 0; j < NX; ++j) a = fma(-sl[oK + i * NX + j], dxc[j], a);
-                duc[i] = a;
-            }
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                double a = sl[oRb + i];
-#pragma unroll
-                for (int j = 0; j < NX; ++j) a = fma(sl[oA + i * NX + j], dxc[j], a);
-#pragma unroll
-                for (int j = 0; j < NU; ++j) a = fma(sl[oB + i * NU + j], duc[j], a);
-                xn[i] = a;
-            }
-#pragma unroll
-            for (int i = 0; i < NU; ++i) sl[oRt + i] = duc[i];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) sl[oRt + NU + i] = dxc[i], dxc[i] = xn[i];
-        }
-        {
-            double *sl = slot(gs, N);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) sl[oRt + NU + i] = dxc[i];
-        }
-        return ok;
-    }
-
-    // program of the sweep wave: mirrors the barrier sequence of the stage waves (SQP loop / IPM loop / two KKT solves)
-    MPCRL_DI void coop_sweep_program(const int *flags_sqp) {
-        for (;;) {
-            __syncthreads();   // (a) SQP-level any(live)
-            int r = 0;
-            for (int i = 0; i < coop.nwave; ++i) r |= flags_sqp[i];
-            if (!r) break;
-            for (;;) {
-                __syncthreads();   // (b) IPM-level any(qlive)
-                int q = 0;
-                for (int i = 0; i < coop.nwave; ++i) q |= coop.flags_ipm[i];
-                if (!q) break;
-                __syncthreads();
-                if (coop.sweep_lane) {
-                    const bool ok = coop_sweep<true>(coop.gs);
-                    coop.okbuf[coop.gs] = ok ? 1.0 : 0.0;
-                }
-                __syncthreads();
-                __syncthreads();
-                if (coop.sweep_lane) coop_sweep<false>(coop.gs);
-                __syncthreads();
-            }
-        }
-    }
-
-    // stage-lane side of one KKT solve: publish, let the sweep lanes work, collect the Newton step
-    template <bool FACTOR>
-    MPCRL_DI bool coop_kkt(const double *g, const double *bb) {
-        if (coop.stage_lane) {
-            double *sl = slot(coop.g, k);
-            if constexpr (FACTOR) {
-#pragma unroll
-                for (int i = 0; i < NW; ++i) sl[oDg + i] = Dg[i];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) sl[oRb + i] = bb[i];
-            }
-#pragma unroll
-            for (int i = 0; i < NW; ++i) sl[oRt + i] = g[i];
-        }
-        __syncthreads();   // inputs published -> the sweep wave (coop_sweep_program) works between these two barriers
-        __syncthreads();
-        bool okr = true;
-        if (coop.stage_lane) {
-            const double *sl = slot(coop.g, k);
-#pragma unroll
-            for (int i = 0; i < NU; ++i) Du[i] = term ? 0.0 : sl[oRt + i];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) Dx[i] = sl[oRt + NU + i];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                double a = sl[oPv + i];
-#pragma unroll
-                for (int j = 0; j < NX; ++j) a = fma(sl[oP + sym(i, j)], Dx[j], a);
-                Dnu[i] = first ? 0.0 : a;
-            }
-            okr = coop.okbuf[coop.g] > 0.5;
-        }
-        return okr;
     }
 
     // ---- interior point: per-row Newton quantities ------------------------------------------------
@@ -1178,7 +870,7 @@ struct SmallSolver {
                 else if (it >= IPM_MAX_ITER || !(rinf < 1e300))
                     qlive = false;
             }
-            if (!any_lane(qlive)) break;
+            if (!__any(qlive)) break;
             if (qlive) ++n_it;
             PHW(0);
             // ---- predictor
@@ -1191,17 +883,13 @@ struct SmallSolver {
             }
             bool okf;
             PHW(1);
-            if constexpr (C::ON)
-                okf = coop_kkt<true>(rt, rb);
-            else {
-                if constexpr (MX)
-                    okf = mx_backward(Hs, rt, rb);
-                else
-                    okf = backward<true>(Hs, rt, rb);
-                PHW(2);
-                forward(rb);
-                PHW(3);
-            }
+            if constexpr (MX)
+                okf = mx_backward(Hs, rt, rb);
+            else
+                okf = backward<true>(Hs, rt, rb);
+            PHW(2);
+            forward(rb);
+            PHW(3);
             double okbad = okf ? 0.0 : 1.0;   // reduced together with the predictor's step length below
             double rmax = 1.0, muaff = 0.0;   // rmax = 1 / (step to the boundary), at least 1
 #pragma unroll
@@ -1253,15 +941,11 @@ struct SmallSolver {
                 barrier_terms(i, v, 1, smu, dgi, ec);
                 rt[i] = rg[i] + ec;
             }
-            if constexpr (C::ON)
-                coop_kkt<false>(rt, rb);
-            else {
-                PHW(5);
-                backward<false>(Hs, rt, rb);
-                PHW(6);
-                forward(rb);
-                PHW(7);
-            }
+            PHW(5);
+            backward<false>(Hs, rt, rb);
+            PHW(6);
+            forward(rb);
+            PHW(7);
             rmax = 1.0;
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
@@ -1465,7 +1149,7 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? 2 : 1) small_solve_kernel(co
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NP = M::NP, NTD = M::NTD, NTC = M::NTC;
     constexpr bool SOFT = M::HAS_SOFT;
     const int lane = threadIdx.x;
-    const int N = sp.N, lpi = N + 1, ipw = 64 / lpi;
+    const int N = sp.N, lpi = N + 1, ipw = min(64 / lpi, M::MAX_IPW);
     const int slot = lane / lpi, k = lane - slot * lpi, base = slot * lpi;
     long inst = (long)blockIdx.x * ipw + slot;
     const bool valid = slot < ipw && inst < a.B;
@@ -1474,10 +1158,6 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? 2 : 1) small_solve_kernel(co
     SmallSolver<M> S(sp, k, lpi, base);
     __shared__ __attribute__((aligned(16))) double mx_lds[SmallSolver<M>::MX ? 64 * SmallSolver<M>::MSLOT : 2];
     S.ms = mx_lds;
-    __shared__ double h_lds[2 * SmallSolver<M>::NHT];
-    S.fill_htab(h_lds);
-    SmallSolver<M>::wave_lds_sync();
-    S.load_hc();
     const bool term = S.term, first = S.first;
     S.qmode = a.u0fix != nullptr;
     if (sp.cost_kind == 0)
@@ -1485,6 +1165,10 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? 2 : 1) small_solve_kernel(co
     else
         S.ck = first ? sp.dT : (term ? pow(sp.gamma, (double)N) : pow(sp.gamma, (double)k) * sp.dT);   // nlp.py:1083-1091
     const double *th = a.theta + (size_t)inst * a.theta_stride;
+    __shared__ double c_lds[M::MAX_IPW * SmallSolver<M>::CTAB];
+    S.fill_cost_table(c_lds, slot < ipw ? slot : 0, slot < ipw, th);
+    SmallSolver<M>::wave_lds_sync();
+    S.load_hc();
 #pragma unroll
     for (int i = 0; i < NTD; ++i) S.thd[i] = th[M::td_index(i)];
 #pragma unroll
@@ -1495,6 +1179,9 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? 2 : 1) small_solve_kernel(co
     // ---- iterate: stored (warm) or the reference's cold start (MPC.reset, mpc.py:204-210)
     const size_t nb = (size_t)(N + 1) * NW;
     double *bnd = a.BND + (size_t)inst * 10 * nb + (size_t)k * NW;
+    // the whole-batch flag is wave-uniform (a scalar branch); the per-instance mask is applied with selects inside the warm path —
+    // a lane-divergent if/else around these stores makes the optimiser merge them through pointer phis and park state in scratch
+    const bool cold = (a.flags & 8) || (a.cold && a.cold[inst]);
     if (a.flags & 8) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) S.x[i] = x0[i], S.nu_[i] = 0.0;
@@ -1509,18 +1196,25 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? 2 : 1) small_solve_kernel(co
     } else {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            S.x[i] = a.X[(inst * (N + 1) + k) * NX + i];
-            S.nu_[i] = first ? 0.0 : a.PI[(inst * N + k - 1) * NX + i];
+            const double xs = a.X[(inst * (N + 1) + k) * NX + i], ns = a.PI[(inst * N + (first ? 0 : k - 1)) * NX + i];
+            S.x[i] = cold ? x0[i] : xs;
+            S.nu_[i] = (first || cold) ? 0.0 : ns;
         }
 #pragma unroll
-        for (int i = 0; i < NU; ++i) S.u[i] = term ? 0.0 : a.U[(inst * N + k) * NU + i];
+        for (int i = 0; i < NU; ++i) {
+            const double us = a.U[(inst * N + (term ? 0 : k)) * NU + i];
+            S.u[i] = (term || cold) ? 0.0 : us;
+        }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            S.lam[0][i] = bnd[0 * nb + i], S.lam[1][i] = bnd[1 * nb + i], S.t[0][i] = bnd[2 * nb + i], S.t[1][i] = bnd[3 * nb + i];
+            const double l0 = bnd[0 * nb + i], l1 = bnd[1 * nb + i], t0 = bnd[2 * nb + i], t1 = bnd[3 * nb + i];
+            S.lam[0][i] = cold ? 0.0 : l0, S.lam[1][i] = cold ? 0.0 : l1, S.t[0][i] = cold ? 1.0 : t0, S.t[1][i] = cold ? 1.0 : t1;
             S.aff[0][i] = S.aff[1][i] = 0.0;
             if constexpr (SOFT) {
-                S.s[0][i] = bnd[4 * nb + i], S.s[1][i] = bnd[5 * nb + i], S.lams[0][i] = bnd[6 * nb + i], S.lams[1][i] = bnd[7 * nb + i];
-                S.ts[0][i] = bnd[8 * nb + i], S.ts[1][i] = bnd[9 * nb + i], S.affs[0][i] = S.affs[1][i] = 0.0;
+                const double s0 = bnd[4 * nb + i], s1 = bnd[5 * nb + i], m0 = bnd[6 * nb + i], m1 = bnd[7 * nb + i], u0_ = bnd[8 * nb + i],
+                             u1_ = bnd[9 * nb + i];
+                S.s[0][i] = cold ? 0.0 : s0, S.s[1][i] = cold ? 0.0 : s1, S.lams[0][i] = cold ? 0.0 : m0, S.lams[1][i] = cold ? 0.0 : m1;
+                S.ts[0][i] = cold ? 1.0 : u0_, S.ts[1][i] = cold ? 1.0 : u1_, S.affs[0][i] = S.affs[1][i] = 0.0;
             }
         }
     }
@@ -1542,7 +1236,8 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? 2 : 1) small_solve_kernel(co
     int status = 2, n_sqp = 0, n_ipm = 0;
     // size of the perturbation the next QP sees (< 0: nothing to start from): change of the pinned x0 / u0 for a warm call
     double stepn = -1.0;
-    if (!(a.flags & 8)) {
+    if (!(a.flags & (8 | 16))) {   // MPCRL_COLD_DUAL: stored primal iterate, interior point from its default point
+        // (instances of the cold mask take part in the reduction and discard its result below)
         double sl = 0.0;
         if (first) {
 #pragma unroll
@@ -1553,6 +1248,7 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? 2 : 1) small_solve_kernel(co
             }
         }
         stepn = seg_max(sl, k, lpi, base);
+        if (cold) stepn = -1.0;
     }
     double Vout = 0.0, res_out[4] = {0, 0, 0, 0};
     double nun[NX];
@@ -1612,206 +1308,30 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? 2 : 1) small_solve_kernel(co
     if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_phase_ticks[i_], S.phw[i_]);
 #endif
     // ---- results
-    if (valid && first) {
-#pragma unroll
-        for (int i = 0; i < NU; ++i) a.u0_out[inst * NU + i] = S.u[i];
-        a.V[inst] = Vout;
-        a.status[inst] = status;
-        if (a.iters) a.iters[inst * 2] = n_sqp, a.iters[inst * 2 + 1] = n_ipm;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a.RES[inst * 4 + j] = res_out[j];
-    }
-    if (valid) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            a.X[(inst * (N + 1) + k) * NX + i] = S.x[i];
-            if (!first) a.PI[(inst * N + k - 1) * NX + i] = S.nu_[i];
-        }
+    // Lagrangian of the mirror, L = cost + pi' g + lam' h (nlp.py:1180; MPC.get_L, mpc.py:325-332): g_k = F(x_k, u_k) - x_{k+1} is the
+    // r of the last linearisation, h = -(slack of the bound row); slack rows -s <= 0 carry lams
+    double lag = 0.0;
+    if (a.LAG) {
         if (!term) {
 #pragma unroll
-            for (int i = 0; i < NU; ++i) a.U[(inst * N + k) * NU + i] = S.u[i];
+            for (int m = 0; m < NX; ++m) lag = fma(nun[m], S.r[m], lag);
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            bnd[0 * nb + i] = S.has(0, i) ? S.lam[0][i] : 0.0, bnd[1 * nb + i] = S.has(1, i) ? S.lam[1][i] : 0.0;
-            bnd[2 * nb + i] = S.has(0, i) ? S.t[0][i] : 1.0, bnd[3 * nb + i] = S.has(1, i) ? S.t[1][i] : 1.0;
-            if constexpr (SOFT) {
-                bnd[4 * nb + i] = S.s[0][i], bnd[5 * nb + i] = S.s[1][i], bnd[6 * nb + i] = S.lams[0][i], bnd[7 * nb + i] = S.lams[1][i];
-                bnd[8 * nb + i] = S.ts[0][i], bnd[9 * nb + i] = S.ts[1][i];
-            }
+            if (term && i < NU) continue;
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd)
+                if (S.has(sd, i)) {
+                    lag = fma(-S.lam[sd][i], S.bslack(sd, i, S.vc(i)), lag);
+                    if constexpr (SOFT) {
+                        if (S.softc(i)) lag = fma(-S.lams[sd][i], S.s[sd][i], lag);
+                    }
+                }
         }
+        lag = seg_sum(lag, k, lpi, base);
     }
-}
-
-// =====================================================================================================
-// cooperative kernel: COOP_G instances per workgroup of COOP_WAVES waves; sweeps of all instances on 16 lanes of the last wave.
-// Needs N + 1 = 21 stage lanes per instance (3 per wave) — the cartpole benchmark horizon; other horizons use small_solve_kernel.
-// =====================================================================================================
-template <class M>
-__global__ void __launch_bounds__(64 * COOP_WAVES) coop_solve_kernel(const SmallSpec sp, const SmallArgs a) {
-    constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NP = M::NP, NTD = M::NTD, NTC = M::NTC;
-    constexpr bool SOFT = M::HAS_SOFT;
-    using Solver = SmallSolver<M, CoopCtx>;
-    __shared__ double coop_lds[COOP_G * 21 * Solver::SLOTP];
-    __shared__ double coop_ok[COOP_G];
-    __shared__ int coop_flags[2 * COOP_WAVES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int N = sp.N, lpi = N + 1, ipw = 64 / lpi;
-    const int slot = lane / lpi, k = lane - slot * lpi, base = slot * lpi;
-    const int g = wave * ipw + slot;
-    const bool stage_lane = slot < ipw && g < COOP_G && wave < COOP_STAGE_WAVES;
-    long inst = (long)blockIdx.x * COOP_G + g;
-    const bool valid = stage_lane && inst < a.B;
-    if (!valid) inst = a.B - 1;   // dead lanes shadow the last instance and never store
-    if (a.perm) inst = a.perm[inst];
-    Solver S(sp, k, lpi, base);
-    S.coop.lds = coop_lds, S.coop.okbuf = coop_ok, S.coop.flags_ipm = coop_flags + COOP_WAVES, S.coop.g = stage_lane ? g : 0;
-    S.coop.stage_lane = stage_lane && wave < COOP_STAGE_WAVES, S.coop.wave = wave, S.coop.nwave = COOP_WAVES;
-    S.coop.gs = lane;
-    S.coop.sweep_lane = wave == COOP_WAVES - 1 && lane < COOP_G && (long)blockIdx.x * COOP_G + lane < a.B;
-    if (threadIdx.x < 2 * COOP_WAVES) coop_flags[threadIdx.x] = 0;
-    __syncthreads();
-    if (wave == COOP_WAVES - 1) {   // warp-specialised: this wave only runs the serial sweeps of the workgroup's instances
-        S.qmode = a.u0fix != nullptr;
-#pragma unroll
-        for (int i = 0; i < M::NTC; ++i) S.thc[i] = 0.0;
-        S.coop_sweep_program(coop_flags);
-        return;
-    }
-    const bool term = S.term, first = S.first;
-    S.qmode = a.u0fix != nullptr;
-    if (sp.cost_kind == 0)
-        S.ck = term ? 1.0 : sp.dT;                                                        // nlp.py:1044-1055
-    else
-        S.ck = first ? sp.dT : (term ? pow(sp.gamma, (double)N) : pow(sp.gamma, (double)k) * sp.dT);   // nlp.py:1083-1091
-    const double *th = a.theta + (size_t)inst * a.theta_stride;
-#pragma unroll
-    for (int i = 0; i < NTD; ++i) S.thd[i] = th[M::td_index(i)];
-#pragma unroll
-    for (int i = 0; i < NTC; ++i) S.thc[i] = th[M::tc_index(i)];
-    // x0 / u0 are only read by the lane of stage 0, a few times per QP: leave them in memory instead of in registers
-    const double *x0 = a.x0 + inst * NX;
-    const double *u0f = S.qmode ? a.u0fix + inst * NU : a.x0 + inst * NX;
-    // ---- iterate: stored (warm) or the reference's cold start (MPC.reset, mpc.py:204-210)
-    const size_t nb = (size_t)(N + 1) * NW;
-    double *bnd = a.BND + (size_t)inst * 10 * nb + (size_t)k * NW;
-    if (a.flags & 8) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) S.x[i] = x0[i], S.nu_[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < NU; ++i) S.u[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            S.lam[0][i] = S.lam[1][i] = 0.0, S.t[0][i] = S.t[1][i] = 1.0, S.aff[0][i] = S.aff[1][i] = 0.0;
-            if constexpr (SOFT) S.s[0][i] = S.s[1][i] = 0.0, S.lams[0][i] = S.lams[1][i] = 0.0, S.ts[0][i] = S.ts[1][i] = 1.0,
-                                S.affs[0][i] = S.affs[1][i] = 0.0;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            S.x[i] = a.X[(inst * (N + 1) + k) * NX + i];
-            S.nu_[i] = first ? 0.0 : a.PI[(inst * N + k - 1) * NX + i];
-        }
-#pragma unroll
-        for (int i = 0; i < NU; ++i) S.u[i] = term ? 0.0 : a.U[(inst * N + k) * NU + i];
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            S.lam[0][i] = bnd[0 * nb + i], S.lam[1][i] = bnd[1 * nb + i], S.t[0][i] = bnd[2 * nb + i], S.t[1][i] = bnd[3 * nb + i];
-            S.aff[0][i] = S.aff[1][i] = 0.0;
-            if constexpr (SOFT) {
-                S.s[0][i] = bnd[4 * nb + i], S.s[1][i] = bnd[5 * nb + i], S.lams[0][i] = bnd[6 * nb + i], S.lams[1][i] = bnd[7 * nb + i];
-                S.ts[0][i] = bnd[8 * nb + i], S.ts[1][i] = bnd[9 * nb + i], S.affs[0][i] = S.affs[1][i] = 0.0;
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < S.NPK; ++i) S.P[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) S.p[i] = 0.0, S.dx[i] = 0.0, S.nuq[i] = 0.0, S.Dx[i] = 0.0, S.Dnu[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < NU; ++i) S.du[i] = 0.0, S.Du[i] = 0.0, S.kff[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < NU * NX; ++i) S.K[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < S.NLK; ++i) S.Li[i] = 0.0;
-
-    // ---- full-step SQP (the reference requests no globalisation; config/cartpole.yaml:8-14)
-    const bool rti = (a.flags & 4) != 0;
-    const int max_iter = rti ? 1 : sp.max_iter;
-    bool live = valid, last_tight = true;
-    int status = 2, n_sqp = 0, n_ipm = 0;
-    // size of the perturbation the next QP sees (< 0: nothing to start from): change of the pinned x0 / u0 for a warm call
-    double stepn = -1.0;
-    if (!(a.flags & 8)) {
-        double sl = 0.0;
-        if (first) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) sl = fmax(sl, fabs(x0[i] - S.x[i]));
-            if (S.qmode) {
-#pragma unroll
-                for (int i = 0; i < NU; ++i) sl = fmax(sl, fabs(u0f[i] - S.u[i]));
-            }
-        }
-        stepn = seg_max(sl, k, lpi, base);
-    }
-    double Vout = 0.0, res_out[4] = {0, 0, 0, 0};
-    double nun[NX];
-    for (int it = 0;; ++it) {
-        double xn[NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) xn[i] = lane_dn(S.x[i]), nun[i] = lane_dn(S.nu_[i]);
-        const double cl = S.linearize(xn);
-        S.coop_publish_AB();
-        double rl[4];
-        S.nlp_res_local(nun, x0, u0f, rl);
-        double res[4] = {rl[0], rl[1], rl[2], rl[3]}, cost = cl;
-        seg_reduce<4, 1>(res, &cost, k, lpi, base);
-        const double rmax = fmax(fmax(res[0], res[1]), fmax(res[2], res[3]));
-        if (live) {
-            Vout = cost, n_sqp = it;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) res_out[j] = res[j];
-            if (!(rmax < 1e300))
-                status = 1, live = false;
-            else if (rmax < sp.tol && last_tight && !(rti && it == 0))
-                status = 0, live = false;
-            else if (it >= max_iter)
-                status = rmax < sp.tol ? 0 : 2, live = false;
-        }
-        // QP tolerances of this iteration (per instance)
-        const double rr_ = fmin(1.0, rmax), ad_ = (rmax < sp.tol || M::DISCRETE) ? 0.0 : IPM_ADAPT_C * rr_ * rr_;   // LQ model: first QP is the answer
-        const double tol_res = fmin(IPM_ADAPT_CAP, fmax(IPM_TOL_RES, ad_)), tol_mu = fmin(0.1 * IPM_ADAPT_CAP, fmax(IPM_TOL_MU, 1e-2 * ad_));
-        if (live) last_tight = tol_res <= IPM_TOL_RES && tol_mu <= IPM_TOL_MU;
-        {   // workgroup-wide any(live)
-            const bool w = __any(live);
-            if (lane == 0) coop_flags[wave] = w ? 1 : 0;
-            __syncthreads();
-            int r = 0;
-            for (int i = 0; i < COOP_WAVES; ++i) r |= coop_flags[i];
-            if (!r) break;
-        }
-        const double warm_mu = stepn < 0.0 ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
-        const bool ok = S.qp_solve(live, x0, u0f, n_ipm, warm_mu, tol_res, tol_mu);
-        if (live && !ok) status = 4, live = false;
-        {
-            double sl = 0.0;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) sl = fmax(sl, fabs(S.dx[i]));
-            if (!term) {
-#pragma unroll
-                for (int i = 0; i < NU; ++i) sl = fmax(sl, fabs(S.du[i]));
-            }
-            stepn = seg_max(sl, k, lpi, base);
-        }
-        if (live) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) S.x[i] += S.dx[i], S.nu_[i] = S.nuq[i];
-#pragma unroll
-            for (int i = 0; i < NU; ++i) S.u[i] += S.du[i];
-        }
-    }
-    // ---- results
     if (valid && first) {
+        if (a.LAG) a.LAG[inst] = Vout + lag;
 #pragma unroll
         for (int i = 0; i < NU; ++i) a.u0_out[inst * NU + i] = S.u[i];
         a.V[inst] = Vout;
@@ -1850,7 +1370,7 @@ template <class M>
 __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, const SmallArgs a) {
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NP = M::NP, NTD = M::NTD, NTC = M::NTC;
     const int lane = threadIdx.x;
-    const int N = sp.N, lpi = N + 1, ipw = 64 / lpi;
+    const int N = sp.N, lpi = N + 1, ipw = min(64 / lpi, M::MAX_IPW);
     const int slot = lane / lpi, k = lane - slot * lpi, base = slot * lpi;
     long inst = (long)blockIdx.x * ipw + slot;
     const bool valid = slot < ipw && inst < a.B;
@@ -1859,10 +1379,6 @@ __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, cons
     SmallSolver<M> S(sp, k, lpi, base);
     __shared__ __attribute__((aligned(16))) double mx_lds[SmallSolver<M>::MX ? 64 * SmallSolver<M>::MSLOT : 2];
     S.ms = mx_lds;
-    __shared__ double h_lds[2 * SmallSolver<M>::NHT];
-    S.fill_htab(h_lds);
-    SmallSolver<M>::wave_lds_sync();
-    S.load_hc();
     const bool term = S.term, first = S.first;
     S.qmode = a.u0fix != nullptr;
     if (sp.cost_kind == 0)
@@ -1870,6 +1386,10 @@ __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, cons
     else
         S.ck = first ? sp.dT : (term ? pow(sp.gamma, (double)N) : pow(sp.gamma, (double)k) * sp.dT);
     const double *th = a.theta + (size_t)inst * a.theta_stride;
+    __shared__ double c_lds[M::MAX_IPW * SmallSolver<M>::CTAB];
+    S.fill_cost_table(c_lds, slot < ipw ? slot : 0, slot < ipw, th);
+    SmallSolver<M>::wave_lds_sync();
+    S.load_hc();
 #pragma unroll
     for (int i = 0; i < NTD; ++i) S.thd[i] = th[M::td_index(i)];
 #pragma unroll

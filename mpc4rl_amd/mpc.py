@@ -20,24 +20,109 @@ from .batch import MPCBatch
 from .problems import OcpDescription, cartpole_ocp, chain_mass_ocp, linear_system_ocp
 
 
+class _DM(np.ndarray):
+    """ndarray with the two CasADi ``DM`` methods the reference's call sites use (``.full()``, ``float()``)."""
+
+    def __new__(cls, a):
+        return np.asarray(a, float).view(cls)
+
+    def full(self) -> np.ndarray:
+        return np.array(self, dtype=float).reshape(self.shape if self.ndim == 2 else (-1, 1))
+
+
+class _PStruct:
+    """``nlp.p.sym(value)`` / ``nlp.p.val`` look-alike: the full parameter vector viewed as the struct of nlp.py:969-989
+    (``model`` block, then W_0, W, W_e, yref_0, yref, yref_e — each column-major)."""
+
+    def __init__(self, ocp: OcpDescription, vec):
+        self._ocp = ocp
+        self._v = np.asarray(vec, float).reshape(-1).copy()
+        if self._v.shape[0] != ocp.n_p:
+            raise ValueError(f"parameter vector has {self._v.shape[0]} entries, expected {ocp.n_p}")
+
+    def _span(self, key):
+        if key == "model":
+            return 0, (self._ocp.n_model_p,)
+        return self._ocp.cost_fields[key]
+
+    def keys(self):
+        return ["model"] + list(self._ocp.cost_fields.keys())
+
+    def __getitem__(self, key) -> _DM:
+        off, shape = self._span(key)
+        return _DM(self._v[off: off + int(np.prod(shape))].reshape(shape, order="F"))
+
+    def __setitem__(self, key, value):
+        off, shape = self._span(key)
+        self._v[off: off + int(np.prod(shape))] = np.asarray(value, float).flatten("F")
+
+    @property
+    def cat(self) -> _DM:
+        return _DM(self._v.reshape(-1, 1))
+
+
 class _ParamView:
-    """``mpc.nlp.p`` look-alike: ``.val.cat.full()`` -> (n_p, 1) array (mpc.py:160)."""
+    """``mpc.nlp.p``: ``.val.cat.full()`` -> (n_p, 1) (mpc.py:160), ``.val[key]``, ``.sym(value)`` (mpc.py:214,234)."""
 
     def __init__(self, owner):
         self._o = owner
 
     @property
-    def val(self):
+    def val(self) -> _PStruct:
+        return _PStruct(self._o.ocp, self._o._p)
+
+    def sym(self, value) -> _PStruct:
+        return _PStruct(self._o.ocp, value)
+
+
+class _VarsVal:
+    """``mpc.nlp.vars.val`` look-alike (nlp.py:903-964,1137-1166): item access to the primal iterate, the per-stage bound
+    parameters, ``dT`` and ``gamma`` — reads come from the engine, writes are routed to it."""
+
+    _BOUND = ("lbu", "ubu", "lbx", "ubx")
+
+    def __init__(self, owner):
+        self._o = owner
+
+    @staticmethod
+    def _split(key):
+        if isinstance(key, tuple):
+            return key[0], int(key[1])
+        name, _, stage = key.rpartition("_")
+        if name in _VarsVal._BOUND and stage.isdigit():
+            return name, int(stage)
+        return key, None
+
+    def __getitem__(self, key):
         o = self._o
-        return SimpleNamespace(cat=SimpleNamespace(full=lambda: o._p.copy().reshape(-1, 1)))
+        f, k = self._split(key)
+        if f in ("x", "u"):
+            return _DM(o.get(k, f))
+        if f == "dT":
+            return o.ocp.dT
+        if f == "gamma":
+            return o.discount_factor
+        if f == "p":
+            return _DM(o.get_p())
+        if f in self._BOUND:
+            return _DM(o._bound_value(k, f))
+        raise KeyError(key)
+
+    def __setitem__(self, key, value):
+        f, k = self._split(key)
+        if f == "gamma":
+            self._o.set_discount_factor(float(value))
+        else:
+            self._o.nlp.set(k, f, value)
 
 
 class _NlpShim:
-    """The handful of ``mpc.nlp`` members the reference's scripts touch."""
+    """The ``mpc.nlp`` members the reference's MPC class and scripts touch."""
 
     def __init__(self, owner):
         self._o = owner
         self.p = _ParamView(owner)
+        self.vars = SimpleNamespace(val=_VarsVal(owner))
 
     @property
     def dL_dp(self):
@@ -51,16 +136,35 @@ class _NlpShim:
     def cost(self):
         return SimpleNamespace(val=self._o.get_V())
 
-    def get_parameter(self, field_):
-        off, shape = self._o.ocp.cost_fields[field_]
-        n = int(np.prod(shape))
-        return self._o._p[off: off + n].reshape(shape, order="F")
+    @property
+    def L(self):
+        return SimpleNamespace(val=self._o.get_L())
 
-    def set_parameter(self, field_, value_):
-        off, shape = self._o.ocp.cost_fields[field_]
-        p = self._o._p.copy()
-        p[off: off + int(np.prod(shape))] = np.asarray(value_, float).flatten("F")
-        self._o._set_p_internal(p)
+    def get_parameter(self, field_) -> _DM:          # nlp.py:317-318
+        return _PStruct(self._o.ocp, self._o._p)[field_]
+
+    def set_parameter(self, field_, value_):          # nlp.py:314-315
+        ps = _PStruct(self._o.ocp, self._o._p)
+        ps[field_] = value_
+        self._o._set_p_internal(ps._v)
+
+    def set(self, stage_, field_, value_):            # nlp.py:285-312
+        value_ = np.asarray(value_, float).reshape(-1)
+        if len(value_) == 0:
+            return
+        o = self._o
+        if field_ in ("x", "u", "pi"):
+            o.set(stage_, field_, value_)
+        elif field_ == "p":
+            o.set(stage_, "p", value_)
+        elif field_ == "dT":
+            if abs(float(value_[0]) - o.ocp.dT) > 1e-15:
+                raise NotImplementedError("dT is fixed by the OcpDescription (tf / N)")
+        elif field_ in _VarsVal._BOUND:
+            o._set_bound(stage_, field_, value_)
+        else:
+            raise Exception(f"Field {field_} not supported.")
+        return 0
 
     def assert_kkt_residual(self, tol: float = 1e-6) -> bool:
         """nlp.py:1295-1299: all four KKT residual norms below tol."""
@@ -103,18 +207,25 @@ class _SolverShim:
         return self._o._batch.get_iterate()[4][0].cpu().numpy()
 
     def solve(self) -> int:
-        return self._o._solve(self._o._x0, None, sens=False)
+        """Solve with the x0 / stage-0 input bounds last written through ``constraints_set`` / ``set`` (lbu_0 = ubu_0 pins u_0)."""
+        return self._o._solve(self._o._x0, self._o._u0_pin(), sens=False)
 
     def reset(self):
         self._o._batch.reset()
 
     def cost_set(self, stage, field, value, api="new"):
+        """cost_set(stage, "W" | "yref", value) (mpc.py:236-252).  The reference writes stage 0 from W_0 / yref_0, EVERY stage
+        1..N-1 from W / yref and never touches the terminal stage; the engine keeps one W / yref for all interior stages, so a
+        call for any of them updates that one."""
         key = {"W": "W_0" if stage == 0 else ("W_e" if stage == self._o.ocp.N else "W"),
                "yref": "yref_0" if stage == 0 else ("yref_e" if stage == self._o.ocp.N else "yref")}[field]
+        if key not in self._o.ocp.cost_fields:
+            raise Exception(f"this OCP has no cost field {key}")
         self._o.nlp.set_parameter(key, value)
 
     def constraints_set(self, stage, field, value):
-        raise NotImplementedError("bounds are part of the OcpDescription; use q_update(x0, u0) to pin u_0")
+        """constraints_set(stage, "lbu" | "ubu" | "lbx" | "ubx", value) (mpc.py:72-73,87-88)."""
+        self._o._set_bound(stage, field, np.asarray(value, float).reshape(-1))
 
 
 class MPC:
@@ -132,6 +243,10 @@ class MPC:
         self._u0 = None
         self._last = None
         self._sens_fresh = False
+        # box bounds as the solver currently has them (stage-vector order v = [u; x]); constraints_set / nlp.set edit them
+        lb, ub, lbe, ube, _, _, _ = ocp.stage_bounds()
+        self._lb0, self._ub0 = lb[: ocp.nu].copy(), ub[: ocp.nu].copy()
+        self._lb, self._ub, self._lbe, self._ube = lb, ub, lbe, ube
         self.ocp_solver = _SolverShim(self)
         self.nlp = _NlpShim(self)
 
@@ -149,6 +264,53 @@ class MPC:
     def _set_p_internal(self, p):
         self._p = np.asarray(p, float).reshape(-1).copy()
         self._batch.set_theta(torch.as_tensor(self._p))
+        self._sens_fresh = False
+
+    def _u0_pin(self):
+        """lbu_0 == ubu_0 written through constraints_set is the reference's way of pinning u_0 (Q(s, a), mpc.py:71-76)."""
+        return self._lb0.copy() if np.array_equal(self._lb0, self._ub0) else None
+
+    def _bound_value(self, stage, field):
+        ocp, nu = self.ocp, self.ocp.nu
+        lo = field.startswith("l")
+        if field in ("lbu", "ubu"):
+            return (self._lb0 if lo else self._ub0).copy() if stage == 0 else (self._lb if lo else self._ub)[:nu].copy()
+        if stage == 0:
+            return None if self._x0 is None else self._x0.copy()          # lbx_0 = ubx_0 = x0 (mpc.py:38-39)
+        if stage == ocp.N:
+            return (self._lbe if lo else self._ube)[ocp.idxbx_e].copy()
+        return (self._lb if lo else self._ub)[nu + ocp.idxbx].copy()
+
+    def _set_bound(self, stage, field, value):
+        """One bound vector of one stage.  Stage 0: lbu/ubu are the stage-0 input bounds (equal = u_0 pinned), lbx/ubx are x0.
+        Stages 1..N-1 share one set of bounds (as ocp.constraints.lbx/ubx/lbu/ubu do in the reference), stage N has its own."""
+        from . import _lib
+        ocp, nu = self.ocp, self.ocp.nu
+        value = np.asarray(value, float).reshape(-1)
+        lo = field.startswith("l")
+        if field in ("lbx", "ubx") and stage == 0:
+            self._x0 = value.copy()
+            return
+        if field in ("lbu", "ubu"):
+            if stage == 0:
+                (self._lb0 if lo else self._ub0)[:] = value
+                if np.all(self._lb0 < self._ub0):      # a pin (lb == ub) is passed per solve as u0_fixed instead
+                    self._batch.set_bounds(_lib.BOUNDS_U0, self._lb0, self._ub0)
+                return
+            if stage >= ocp.N:
+                raise Exception("no input at the terminal stage")
+            (self._lb if lo else self._ub)[:nu] = value
+        elif field in ("lbx", "ubx"):
+            if stage == ocp.N:
+                (self._lbe if lo else self._ube)[ocp.idxbx_e] = value
+                if np.all(self._lbe <= self._ube):
+                    self._batch.set_bounds(_lib.BOUNDS_TERMINAL, self._lbe, self._ube)
+                return
+            (self._lb if lo else self._ub)[nu + ocp.idxbx] = value
+        else:
+            raise Exception(f"Field {field} not supported.")
+        if np.all(self._lb <= self._ub):
+            self._batch.set_bounds(_lib.BOUNDS_STAGE, self._lb, self._ub)
         self._sens_fresh = False
 
     # ---------------------------------------------------------------- reference surface
@@ -204,9 +366,9 @@ class MPC:
         return status
 
     def reset(self, x0: np.ndarray):                  # mpc.py:204-210
-        self._batch.reset()
-        self._batch.set_discount_factor(self.discount_factor)
         self._x0 = np.asarray(x0, float).reshape(-1).copy()
+        self._batch.reset(self._x0.reshape(1, -1))
+        self._batch.set_discount_factor(self.discount_factor)
 
     def set(self, stage, field, value, finite_differences: bool = False):   # mpc.py:212-231
         if field == "p":
@@ -218,12 +380,17 @@ class MPC:
                 p[: self.ocp.n_model_p] = v
                 self._set_p_internal(p)
             return
-        x, u, pi, bnd, _ = self._batch.get_iterate()
-        tgt = {"x": x, "u": u, "pi": pi}.get(field)
-        if tgt is None:
+        if field not in ("x", "u", "pi"):
             raise Exception(f"Field {field} not supported.")
+        # Before the first solve and after reset() the handle holds the cold iterate (x_k = x0 or 0, u = 0, multipliers 0,
+        # slacks 1); the edited stage goes on top of it and the bound multipliers stay cold (bnd = None), so that the
+        # reference's initialisation pattern `for stage: ocp_solver.set(stage, "x", x0)` (mpc.py:208-210) is a cold start
+        # from that guess — never a warm start from stale multipliers.
+        duals = self._batch.duals_valid
+        x, u, pi, bnd, _ = self._batch.get_iterate()
+        tgt = {"x": x, "u": u, "pi": pi}[field]
         tgt[0, stage] = torch.as_tensor(np.asarray(value, float).reshape(-1), device=tgt.device)
-        self._batch.set_iterate(x, u, pi, bnd)
+        self._batch.set_iterate(x, u, pi, bnd if duals else None)
 
     def set_parameter(self, value_, api="new"):       # mpc.py:233-257
         self._set_p_internal(value_)
@@ -270,6 +437,9 @@ class MPC:
         if not self._sens_fresh:
             self.update_nlp()
         return self._last.dV_dp.cpu().numpy().reshape(1, -1)
+
+    def get_L(self) -> float:                         # mpc.py:325-332 (float(nlp.L.val), nlp.py:1180,1390)
+        return float(self._batch.get_lagrangian()[0].item())
 
     def get_V(self) -> float:                         # mpc.py:334-343
         return float(self._last.V[0].item())

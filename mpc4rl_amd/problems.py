@@ -91,7 +91,8 @@ class OcpDescription:
 
 
 def cartpole_ocp(N: int = 20, tf: float = 2.0, M: float = 1.0, m: float = 0.1, l: float = 0.5,
-                 W=None, W_e=None, yref=None, yref_e=None, max_iter: int = 500, tol: float = 1e-6) -> OcpDescription:
+                 W=None, W_e=None, yref=None, yref_e=None, W_0=None, yref_0=None, max_iter: int = 500,
+                 tol: float = 1e-6) -> OcpDescription:
     """Cartpole swing-up OCP.  Defaults: config/cartpole.yaml with the horizon of BASELINE.json (N=20 at the
     reference's dt = tf/N = 0.1; the yaml itself has N=30, tf=3.0).  One RK4 step of h = tf/N/4 per stage
     (rlmpc/mpc/cartpole/acados.py:86-92)."""
@@ -99,7 +100,10 @@ def cartpole_ocp(N: int = 20, tf: float = 2.0, M: float = 1.0, m: float = 0.1, l
     W_e = np.diag([10.0, 0.1, 10.0, 0.1]) if W_e is None else np.asarray(W_e, float)
     yref = np.zeros(5) if yref is None else np.asarray(yref, float)
     yref_e = np.zeros(4) if yref_e is None else np.asarray(yref_e, float)
-    p0 = np.concatenate([[M, m, l], W.flatten("F"), W.flatten("F"), W_e.flatten("F"), yref, yref, yref_e])
+    W_0 = W if W_0 is None else np.asarray(W_0, float)                 # yaml: W_0 = W, yref_0 = yref
+    yref_0 = yref if yref_0 is None else np.asarray(yref_0, float)
+    # the cost block of p is what the kernels use (csrc/models_dev.hpp CartpoleDev): set_parameter / cost_set reach the solve
+    p0 = np.concatenate([[M, m, l], W_0.flatten("F"), W.flatten("F"), W_e.flatten("F"), yref_0, yref, yref_e])
     labels = ["M", "m", "l"] + [f"W_0_{i}" for i in range(25)] + [f"W_{i}" for i in range(25)] + \
         [f"W_e_{i}" for i in range(16)] + [f"yref_0_{i}" for i in range(5)] + [f"yref_{i}" for i in range(5)] + \
         [f"yref_e_{i}" for i in range(4)]
@@ -110,8 +114,7 @@ def cartpole_ocp(N: int = 20, tf: float = 2.0, M: float = 1.0, m: float = 0.1, l
         name="cartpole", model=_lib.MODEL_CARTPOLE, N=N, nx=4, nu=1, dT=tf / N, cost_kind=_lib.COST_NLS, h=tf / N / 4,
         rk_steps=1, p0=p0, p_labels=labels, x_labels=["x", "x_dot", "theta", "theta_dot"], u_labels=["F"],
         lbu=np.array([-30.0]), ubu=np.array([30.0]), idxbx=np.arange(4), lbx=-xb, ubx=xb, idxbx_e=np.arange(4),
-        lbx_e=-xb, ubx_e=xb, consts=np.concatenate([W.reshape(-1), yref, W_e.reshape(-1), yref_e]),
-        tol=tol, max_iter=max_iter, x0=np.array([0.0, 0.0, 3.14, 0.0]), n_model_p=3, cost_fields=fields)
+        lbx_e=-xb, ubx_e=xb, tol=tol, max_iter=max_iter, x0=np.array([0.0, 0.0, 3.14, 0.0]), n_model_p=3, cost_fields=fields)
 
 
 def linear_system_ocp(param: Optional[dict] = None, discount_factor: float = 0.99, N: int = 40) -> OcpDescription:

@@ -48,6 +48,7 @@ class BatchedQLearning:
         self.scale_action = scale_action or (lambda u: u)
         self.unscale_action = unscale_action or (lambda a: a)
         self.group = group
+        self.last_episode = None
 
     def run_episode(self) -> EpisodeStats:
         dev = self.rollout_mpc.device
@@ -61,6 +62,7 @@ class BatchedQLearning:
             S.append(obs), A.append(u), C.append(cost.to(dev))
             obs = nxt.to(dev)
         S, A, C = torch.stack(S), torch.stack(A), torch.stack(C)      # [T, E, .]
+        self.last_episode = (S, A, C)                                 # the replay buffer of the reference loop (168-172)
         n = self.T - 1                                                # replay_buffer.size() - 1 samples (172)
         s = S[:n].reshape(n * self.E, -1)
         a = A[:n].reshape(n * self.E, -1)

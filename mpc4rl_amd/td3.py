@@ -74,3 +74,170 @@ class MPCActor:
         self.theta = self.theta + step
         self.mpc.set_theta(self.theta)
         return step
+
+
+class DeviceReplayBuffer:
+    """Ring buffer of transitions on the device, filled E environments at a time (stable_baselines3's ReplayBuffer as
+    scripts/cartpole_mpc_as_td3_agent_closed_loop.py:47-58 uses it: obs, next_obs, action, reward, done)."""
+
+    def __init__(self, capacity_steps: int, num_envs: int, obs_dim: int, act_dim: int, device, dtype=torch.float32):
+        kw = dict(dtype=dtype, device=device)
+        self.cap, self.E = capacity_steps, num_envs
+        self.obs = torch.zeros(capacity_steps, num_envs, obs_dim, **kw)
+        self.next_obs = torch.zeros(capacity_steps, num_envs, obs_dim, **kw)
+        self.act = torch.zeros(capacity_steps, num_envs, act_dim, **kw)
+        self.rew = torch.zeros(capacity_steps, num_envs, **kw)
+        self.done = torch.zeros(capacity_steps, num_envs, **kw)
+        self.pos, self.full = 0, False
+
+    def add(self, obs, next_obs, act, rew, done) -> None:
+        i = self.pos
+        self.obs[i], self.next_obs[i], self.act[i] = obs.to(self.obs.dtype), next_obs.to(self.obs.dtype), act.to(self.obs.dtype)
+        self.rew[i], self.done[i] = rew.to(self.obs.dtype), done.to(self.obs.dtype)
+        self.pos = (i + 1) % self.cap
+        self.full = self.full or self.pos == 0
+
+    def size(self) -> int:
+        return (self.cap if self.full else self.pos) * self.E
+
+    def sample(self, n: int, gen: Optional[torch.Generator] = None):
+        steps = self.cap if self.full else self.pos
+        idx = torch.randint(0, steps * self.E, (n,), device=self.obs.device, generator=gen)
+        f = lambda t: t[:steps].reshape(steps * self.E, *t.shape[2:])[idx]
+        return f(self.obs), f(self.next_obs), f(self.act), f(self.rew), f(self.done)
+
+
+class BatchedTD3:
+    """TD3 with the MPC as the actor, closed loop over E batched environments per rank (BASELINE config 5).
+
+    What stable_baselines3's ``TD3`` does with ``MPCTD3Policy`` (rlmpc/td3/policies.py:225-361, driven by
+    scripts/cartpole_mpc_as_td3_agent_closed_loop.py:40-67), with every per-observation loop turned into one batched solve:
+
+      collect   a_t = clip(actor(s_t) + N(0, action_noise), -1, 1); env.step; replay.add; environments that ended are reset and their
+                OCP instances start cold in the next solve (``mpc.reset(obs)``, script lines 62-64)
+      train     sample B transitions; target action = clip(actor_target(s') + clip(N(0, target_noise), +-noise_clip), -1, 1) — the
+                target actor is the same MPC with Polyak-averaged parameters theta'; y = r + gamma (1 - done) min_i Q_i'(s', a');
+                critic loss = sum_i mse(Q_i(s, a), y); every ``policy_delay`` updates the deterministic policy gradient
+                theta += lr_actor * mean_i (dpi/dtheta_i' grad_a Q_1(s_i, pi(s_i)))   (the step the reference leaves as a stub,
+                "NOTE: The actor optimizer is not being used", policies.py:332), then Polyak updates of both targets.
+      ranks     every rank owns its environments, its replay buffer and its solver handles; per update the critic gradients and the
+                theta-gradient sums travel in ONE all-reduce (RCCL over xGMI with backend "nccl"), so all ranks hold identical
+                critics and identical theta.
+    The reference env's ``reward`` is the quadratic x^2 + theta^2 (continuous_cartpole/environment.py:193-194) — a cost; the default
+    ``reward_scale = -1`` makes TD3 maximise its negative."""
+
+    def __init__(self, ocp, env, batch_size: int = 256, buffer_steps: int = 64, gamma: float = 0.99, tau: float = 0.005,
+                 policy_delay: int = 2, action_noise: float = 0.1, target_noise: float = 0.2, noise_clip: float = 0.5,
+                 lr_critic: float = 1e-3, lr_actor: float = 1e-4, reward_scale: float = -1.0, net_arch=(64, 64), device=None,
+                 group=None, seed: int = 0, learn_mask: Optional[torch.Tensor] = None, actor_factory=None):
+        """actor_factory(batch) -> an MPCActor-like object (default: MPCActor on the GPU).  The CPU tests of the loop's plumbing
+        (replay, critic update, the single all-reduce) pass a closed-form stand-in policy; the product path never does."""
+        self.env, self.E, self.B = env, env.num_envs, batch_size
+        make = actor_factory or (lambda batch: MPCActor(ocp, batch, device))
+        self.actor = make(self.E)                               # roll-out: keeps one warm-start iterate per environment
+        dev = self.actor.mpc.device
+        self.device = dev
+        self.pi_mpc = make(batch_size)                          # pi(s_i) + dpi/dtheta_i on replay samples
+        self.target_mpc = make(batch_size)                      # actor_target(s'_i): parameters theta'
+        self.theta = self.actor.theta.clone()
+        self.theta_target = self.theta.clone()
+        # which entries of theta the policy gradient may move (default: the model block; W / yref have zero du0/dp anyway)
+        self.learn_mask = torch.zeros_like(self.theta) if learn_mask is None else learn_mask.to(self.theta)
+        if learn_mask is None:
+            self.learn_mask[: ocp.n_model_p] = 1.0
+        torch.manual_seed(seed)                                 # identical critic initialisation on every rank
+        self.critic = ContinuousCritic(ocp.nx, ocp.nu, net_arch).to(dev)
+        self.critic_target = ContinuousCritic(ocp.nx, ocp.nu, net_arch).to(dev)
+        self.critic_target.load_state_dict(self.critic.state_dict())
+        self.critic_opt = torch.optim.Adam(self.critic.parameters(), lr=lr_critic)
+        self.buffer = DeviceReplayBuffer(buffer_steps, self.E, ocp.nx, ocp.nu, dev)
+        self.gamma, self.tau, self.policy_delay = gamma, tau, policy_delay
+        self.action_noise, self.target_noise, self.noise_clip = action_noise, target_noise, noise_clip
+        self.lr_actor, self.reward_scale, self.group = lr_actor, reward_scale, group
+        rank = torch.distributed.get_rank(group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+        self.gen = torch.Generator(device=dev).manual_seed(seed + 1000 * rank)     # exploration / sampling differ per rank
+        self.n_updates = 0
+        self.obs = self.env.reset().to(dev)
+        self._ended = None
+        self.n_crit = sum(p.numel() for p in self.critic.parameters())
+
+    # ------------------------------------------------------------------ roll-out
+    def collect(self, n_steps: int) -> dict:
+        """n_steps closed-loop steps of all E environments; returns roll-out statistics (device tensors -> python floats once)."""
+        rew_sum = torch.zeros((), dtype=torch.float64, device=self.device)
+        conv = torch.zeros((), dtype=torch.float64, device=self.device)
+        ended_total = torch.zeros((), dtype=torch.float64, device=self.device)
+        for _ in range(n_steps):
+            r = self.actor.mpc.solve(self.obs.to(torch.float64), cold_mask=self._ended)   # ONE launch for E policies
+            a = self.actor.scale_action(r.u0).to(torch.float32)
+            a = (a + self.action_noise * torch.randn(a.shape, device=self.device, generator=self.gen)).clamp(-1.0, 1.0)
+            nxt, rew, term, trunc = self.env.step(a.to(self.env.device))
+            nxt, rew = nxt.to(self.device), rew.to(self.device)
+            done = (term | trunc).to(self.device)
+            self.buffer.add(self.obs, nxt, a, self.reward_scale * rew, term.to(self.device))
+            rew_sum += rew.sum()
+            conv += (r.status == 0).sum()
+            ended_total += done.sum()
+            any_done = bool(done.any())      # the one host synchronisation of a step (an episode end changes the control flow)
+            self.obs = self.env.reset(done.to(self.env.device)).to(self.device) if any_done else nxt
+            self._ended = done if any_done else None
+        n = n_steps * self.E
+        return {"mean_reward": float(rew_sum.item()) / n, "converged_fraction": float(conv.item()) / n, "episodes_ended": int(ended_total.item())}
+
+    # ------------------------------------------------------------------ learning
+    def _allreduce(self, flat: torch.Tensor) -> torch.Tensor:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return flat
+
+    def train(self, n_updates: int) -> dict:
+        loss, step = None, None
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        n_theta = self.theta.numel()
+        for _ in range(n_updates):
+            self.n_updates += 1
+            obs, nxt, act, rew, done = self.buffer.sample(self.B, self.gen)
+            with torch.no_grad():
+                noise = (self.target_noise * torch.randn(act.shape, device=self.device, generator=self.gen)).clamp(-self.noise_clip, self.noise_clip)
+                rt = self.target_mpc.mpc.solve(nxt.to(torch.float64), cold=True)               # actor_target(s'), one launch
+                a_next = (self.target_mpc.scale_action(rt.u0).to(torch.float32) + noise).clamp(-1.0, 1.0)
+                q_next = torch.min(*self.critic_target(nxt, a_next)).squeeze(1)
+                ok_t = (rt.status == 0).to(torch.float32)
+                y = rew + self.gamma * (1.0 - done) * q_next
+            qs = self.critic(obs, act)
+            loss = sum((((q.squeeze(1) - y) ** 2) * ok_t).sum() for q in qs) / ok_t.sum().clamp(min=1.0)
+            self.critic_opt.zero_grad(set_to_none=True)
+            loss.backward()
+            do_policy = self.n_updates % self.policy_delay == 0
+            # one flat message: critic gradients (already the local mean) | theta-gradient sum | sample count
+            flat = torch.zeros(self.n_crit + n_theta + 1, dtype=torch.float64, device=self.device)
+            flat[: self.n_crit] = torch.cat([p.grad.reshape(-1) for p in self.critic.parameters()]).to(torch.float64) / world
+            if do_policy:
+                rp = self.pi_mpc.mpc.solve(obs.to(torch.float64), sens_pi=True, cold=True)   # pi(s_i), dpi/dtheta_i: one launch
+                a_pi = self.pi_mpc.scale_action(rp.u0).to(torch.float32).detach().requires_grad_(True)
+                (dq_da,) = torch.autograd.grad(self.critic.q1_forward(obs, a_pi).sum(), a_pi)
+                chain = (2.0 / (self.pi_mpc.high - self.pi_mpc.low)) if self.pi_mpc.scale else torch.ones_like(self.pi_mpc.low)
+                okp = (rp.status == 0).to(torch.float64)
+                g = torch.einsum("bu,bup->bp", dq_da.to(torch.float64) * chain * okp[:, None], torch.nan_to_num(rp.dpi_dp))
+                flat[self.n_crit: self.n_crit + n_theta] = g.sum(0)
+                flat[-1] = okp.sum()
+            flat = self._allreduce(flat)
+            off = 0
+            for p in self.critic.parameters():
+                p.grad.copy_(flat[off: off + p.numel()].reshape(p.shape).to(p.dtype))
+                off += p.numel()
+            self.critic_opt.step()
+            if do_policy:
+                step = self.lr_actor * self.learn_mask * flat[self.n_crit: self.n_crit + n_theta] / flat[-1].clamp(min=1.0)
+                self.theta = self.theta + step
+                self.theta_target = (1.0 - self.tau) * self.theta_target + self.tau * self.theta
+                for m, th in ((self.actor, self.theta), (self.pi_mpc, self.theta), (self.target_mpc, self.theta_target)):
+                    m.theta = th
+                    m.mpc.set_theta(th)
+                with torch.no_grad():
+                    for p, pt in zip(self.critic.parameters(), self.critic_target.parameters()):
+                        pt.mul_(1.0 - self.tau).add_(self.tau * p)
+        return {"critic_loss": float(loss.item()) if loss is not None else 0.0,
+                "theta_step_norm": float(step.norm().item()) if step is not None else 0.0}

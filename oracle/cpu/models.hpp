@@ -107,7 +107,12 @@ struct Cartpole {
     static constexpr int NX = 4, NU = 1, NP = 83, NTD = 3;
     static constexpr bool DISCRETE = false;
     static int td_index(int i) { return i; }
-    // consts: W (5x5 row-major, y = [x;u] order), yref(5), W_e (4x4), yref_e(4)
+    // cost block of the full parameter vector p (nlp.py:969-989, column-major): W_0 (5x5) at 3, W at 28, W_e (4x4) at 53, yref_0 at 69,
+    // yref at 74, yref_e at 79.  The solver sees whatever set_parameter / cost_set wrote there (mpc.py:233-257); the mirror's cost
+    // is NOT parameterised by them (nlp.py:1039-1055), so their gradient entries stay zero (cost_dp / cost_mixed below).
+    static constexpr int P_W0 = 3, P_W = 28, P_WE = 53, P_YREF0 = 69, P_YREF = 74, P_YREFE = 79;
+    static const double *Wof(int k, const double *p) { return p + (k == 0 ? P_W0 : P_W); }
+    static const double *yrof(int k, const double *p) { return p + (k == 0 ? P_YREF0 : P_YREF); }
     template <class S>
     static void ode(const S *x, const S *u, const S *th, S *f, const OracleSpec &) {
         const double g = 9.8;
@@ -122,27 +127,27 @@ struct Cartpole {
     }
     // y index of stage-vector coordinate i (v = [u; x] -> y = [x; u])
     static int yi(int i) { return i < NU ? NX + i : i - NU; }
-    static double cost_val(int k, int N, const double *x, const double *u, const double *, const OracleSpec &sp) {
-        const double *W = sp.consts, *yr = sp.consts + 25, *We = sp.consts + 30, *yre = sp.consts + 46;
+    static double cost_val(int k, int N, const double *x, const double *u, const double *p, const OracleSpec &) {
+        const double *W = Wof(k, p), *yr = yrof(k, p), *We = p + P_WE, *yre = p + P_YREFE;
         double v = 0;
         if (k < N) {
             double y[5] = {x[0] - yr[0], x[1] - yr[1], x[2] - yr[2], x[3] - yr[3], u[0] - yr[4]};
             for (int i = 0; i < 5; ++i)
-                for (int j = 0; j < 5; ++j) v += 0.5 * y[i] * W[i * 5 + j] * y[j];
+                for (int j = 0; j < 5; ++j) v += 0.5 * y[i] * W[j * 5 + i] * y[j];
         } else {
             double y[4] = {x[0] - yre[0], x[1] - yre[1], x[2] - yre[2], x[3] - yre[3]};
             for (int i = 0; i < 4; ++i)
-                for (int j = 0; j < 4; ++j) v += 0.5 * y[i] * We[i * 4 + j] * y[j];
+                for (int j = 0; j < 4; ++j) v += 0.5 * y[i] * We[j * 4 + i] * y[j];
         }
         return v;
     }
-    static void cost_grad(int k, int N, const double *x, const double *u, const double *, const OracleSpec &sp, double *g) {
-        const double *W = sp.consts, *yr = sp.consts + 25, *We = sp.consts + 30, *yre = sp.consts + 46;
+    static void cost_grad(int k, int N, const double *x, const double *u, const double *p, const OracleSpec &, double *g) {
+        const double *W = Wof(k, p), *yr = yrof(k, p), *We = p + P_WE, *yre = p + P_YREFE;
         if (k < N) {
             double y[5] = {x[0] - yr[0], x[1] - yr[1], x[2] - yr[2], x[3] - yr[3], u[0] - yr[4]};
             for (int i = 0; i < 5; ++i) {
                 double a = 0;
-                for (int j = 0; j < 5; ++j) a += 0.5 * (W[yi(i) * 5 + j] + W[j * 5 + yi(i)]) * y[j];
+                for (int j = 0; j < 5; ++j) a += 0.5 * (W[j * 5 + yi(i)] + W[yi(i) * 5 + j]) * y[j];
                 g[i] = a;
             }
         } else {
@@ -150,21 +155,21 @@ struct Cartpole {
             g[0] = 0;
             for (int i = 0; i < 4; ++i) {
                 double a = 0;
-                for (int j = 0; j < 4; ++j) a += 0.5 * (We[i * 4 + j] + We[j * 4 + i]) * y[j];
+                for (int j = 0; j < 4; ++j) a += 0.5 * (We[j * 4 + i] + We[i * 4 + j]) * y[j];
                 g[NU + i] = a;
             }
         }
     }
-    static void cost_hess(int k, int N, const double *, const double *, const double *, const OracleSpec &sp, double *H) {
-        const double *W = sp.consts, *We = sp.consts + 30;
+    static void cost_hess(int k, int N, const double *, const double *, const double *p, const OracleSpec &, double *H) {
+        const double *W = Wof(k, p), *We = p + P_WE;
         constexpr int NW = NX + NU;
         for (int i = 0; i < NW * NW; ++i) H[i] = 0;
         if (k < N) {
             for (int i = 0; i < NW; ++i)
-                for (int j = 0; j < NW; ++j) H[i * NW + j] = 0.5 * (W[yi(i) * 5 + yi(j)] + W[yi(j) * 5 + yi(i)]);
+                for (int j = 0; j < NW; ++j) H[i * NW + j] = 0.5 * (W[yi(j) * 5 + yi(i)] + W[yi(i) * 5 + yi(j)]);
         } else {
             for (int i = 0; i < NX; ++i)
-                for (int j = 0; j < NX; ++j) H[(NU + i) * NW + NU + j] = 0.5 * (We[i * 4 + j] + We[j * 4 + i]);
+                for (int j = 0; j < NX; ++j) H[(NU + i) * NW + NU + j] = 0.5 * (We[j * 4 + i] + We[i * 4 + j]);
         }
     }
     // non-parameterised NLS mirror: the cost does not depend on p (nlp.py:1039-1055)

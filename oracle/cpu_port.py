@@ -68,8 +68,7 @@ def stage_bounds(P: Problem):
 def model_consts(P: Problem) -> tuple:
     """(model id, h, rk_steps, consts) — the per-model constant blob read by mpc_oracle.cpp."""
     if P.name == "cartpole":
-        W, We = P.extra["W"], P.extra["W_e"]
-        return 0, P.extra["h"], 1, np.concatenate([W.reshape(-1), np.zeros(5), We.reshape(-1), np.zeros(4)])
+        return 0, P.extra["h"], 1, np.zeros(1)     # the cost block is read from p (models.hpp Cartpole)
     if P.name == "linear_system":
         return 1, 0.0, 0, P.extra["P"].reshape(-1).copy()
     if P.name.startswith("chain_mass"):

@@ -125,18 +125,22 @@ def make_cartpole(N: int = 20, tf: float = 2.0) -> Problem:
     labels = ["M", "m", "l"] + [f"W_0_{i}" for i in range(25)] + [f"W_{i}" for i in range(25)] + \
         [f"W_e_{i}" for i in range(16)] + [f"yref_0_{i}" for i in range(5)] + [f"yref_{i}" for i in range(5)] + \
         [f"yref_e_{i}" for i in range(4)]
-    Wt, Wet = torch.tensor(W), torch.tensor(W_e)
 
     def F(x, u, p):
         return rk4(cartpole_ode, x, u, p, h, 1)
 
     def stage_cost(k, x, u, p):
-        # non-parameterised NLS mirror: numeric W, yref baked in (nlp.py:517-534)
-        y = torch.cat([x, u])
-        return 0.5 * y @ (Wt @ y)
+        # non-parameterised NLS mirror (nlp.py:517-534,1039-1055): W, yref enter as NUMBERS — the values set_parameter / cost_set
+        # put into the cost block of p (mpc.py:233-257), detached so that no derivative with respect to them exists
+        pd = p.detach()
+        Wk = (pd[3:28] if k == 0 else pd[28:53]).reshape(5, 5).T          # column-major blocks W_0 / W
+        y = torch.cat([x, u]) - (pd[69:74] if k == 0 else pd[74:79])
+        return 0.5 * y @ (Wk @ y)
 
     def terminal_cost(x, p):
-        return 0.5 * x @ (Wet @ x)
+        pd = p.detach()
+        y = x - pd[79:83]
+        return 0.5 * y @ (pd[53:69].reshape(4, 4).T @ y)
 
     xb = np.array([2.4, 10.0, 6.28, 10.0])             # yaml:86-91
     return Problem(

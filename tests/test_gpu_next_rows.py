@@ -19,17 +19,25 @@ def test_batched_qlearning_linear_system_two_episodes(oracle_port):
     assert st.converged_fraction == 1.0 and np.isfinite(st.total_cost) and np.isfinite(st.td_error_mean)
     assert torch.allclose(ql.theta, theta0 + st.step) and float(st.step.abs().max()) > 0.0
     assert torch.equal(ql.rollout_mpc.get_theta(), ql.theta)
-    # oracle check of one Q / V / dQ evaluation on fresh samples with the updated parameters
+    # the parameter step recomputed independently: Q(s_i, a_i), dQ/dp_i and V(s_i) of every recorded sample from the CPU oracle
+    # port at the parameters the episode was run with, then the formula of linear_system_mpc_qlearning.py:193-205
     P = make_linear_system(gamma=0.9)
-    s = np.array([[0.5, 0.5], [0.3, -0.2]])
-    a = np.array([[-0.3], [0.4]])
-    th = ql.theta.cpu().numpy()
-    from mpc4rl_amd import MPCBatch
-    m = MPCBatch(ocp, 2)
-    m.set_theta(ql.theta)
-    rq = m.solve(s, u0=a, sens_v=True, cold=True)
-    ref = oracle_port.solve(P, s, p=th, u0fix=a, gamma=0.9)
-    assert np.allclose(rq.V.cpu().numpy(), ref.V, rtol=1e-9) and np.allclose(rq.dV_dp.cpu().numpy(), ref.dV, rtol=1e-7, atol=1e-9)
+    S, A, C = [t.cpu().numpy() for t in ql.last_episode]            # [T, E, .]
+    T, E = S.shape[:2]
+    n = T - 1
+    s, a = S[:n].reshape(n * E, -1), A[:n].reshape(n * E, -1)
+    th0 = theta0.cpu().numpy()
+    oq = oracle_port.solve(P, s, p=th0, u0fix=a, gamma=0.9)
+    ov = oracle_port.solve(P, s, p=th0, gamma=0.9)
+    assert np.all(oq.status == 0) and np.all(ov.status == 0)
+    q, v, dq = oq.V.reshape(n, E), ov.V.reshape(n, E), oq.dV.reshape(n, E, -1)
+    td = C[: n - 1] + 0.9 * v[1:] - q[:-1]
+    step_ref = np.mean((1e-4 * td)[..., None] * dq[: n - 1], axis=(0, 1))
+    assert np.allclose(st.step.cpu().numpy(), step_ref, rtol=1e-6, atol=1e-12)
+    assert abs(st.td_error_mean - td.mean()) < 1e-8 * max(1.0, abs(td.mean()))
+    # the rollout itself: a_t = u0*(s_t) of the oracle for the recorded states (warm-started full SQP lands on the same optimum)
+    oa = oracle_port.solve(P, S[:, 0], p=th0, gamma=0.9, flags=0)
+    assert np.allclose(A[:, 0], oa.u0, rtol=1e-6, atol=1e-6)      # two interior-point runs of one QP (complementarity 1e-11): ~3e-7
     st2 = ql.run_episode()
     assert np.isfinite(st2.td_error_mean)
 
@@ -96,3 +104,156 @@ def test_weighted_grad_sum_kernel():
         s, ws, cnt = allreduce_weighted_grad(g, w)
         ref = (w[:, None] * g).sum(0)
         assert cnt == B and torch.allclose(s, ref, rtol=1e-12, atol=1e-12) and abs(float(ws) - float(w.sum())) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["cartpole", "linear", "chain"])
+def test_rti_step_vs_oracle(oracle_port, name):
+    """MPCRL_RTI = exactly one QP from the stored iterate: the same step as the oracle's RTI mode (oracle/cpu
+    ORACLE_RTI) from the same converged iterate and the same perturbed initial state, to 1e-6."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp, chain_mass_ocp, linear_system_ocp
+    from oracle.problems import make_cartpole, make_chain_mass, make_linear_system
+    rng = np.random.default_rng(3)
+    if name == "cartpole":
+        ocp, P, B = cartpole_ocp(), make_cartpole(), 48
+        x0 = rng.uniform(-1, 1, (B, 4)) * np.array([0.5, 1.0, 0.3, 1.0])
+        x0[: B // 2] = 0.0
+        x0[: B // 2, 2] = rng.uniform(0.9 * np.pi, 1.1 * np.pi, B // 2)
+        x1 = x0 + rng.normal(0, 1, (B, 4)) * np.array([0.01, 0.05, 0.02, 0.05])
+    elif name == "linear":
+        ocp, P, B = linear_system_ocp(discount_factor=0.99), make_linear_system(gamma=0.99), 16
+        x0 = np.column_stack([rng.uniform(0.2, 0.8, B), rng.uniform(-0.4, 0.4, B)])
+        x1 = x0 + rng.normal(0, 0.02, (B, 2))
+    else:
+        ocp, P, B = chain_mass_ocp(), make_chain_mass(), 6
+        x0 = np.tile(ocp.x0, (B, 1))
+        x0[:, 12:] += rng.normal(0, 1e-2, (B, 9))
+        x1 = x0.copy()
+        x1[:, 9:12] += rng.normal(0, 5e-3, (B, 3))
+        x1[:, 12:] += rng.normal(0, 5e-3, (B, 9))
+    mpc = MPCBatch(ocp, B)
+    r0 = mpc.solve(x0, cold=True)
+    full = oracle_port.solve(P, x0)
+    assert bool((r0.status == 0).all()) and np.all(full.status == 0)
+    r = mpc.solve(x1, rti=True, sens_v=True)
+    ref = oracle_port.solve(P, x1, warm=full, rti=True)
+    it = r.iters.cpu().numpy()
+    assert np.all(it[:, 0] == 1) and np.all(ref.sqp_iter == 1)
+    assert np.array_equal(r.status.cpu().numpy(), ref.status)
+    rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - b) / np.maximum(np.abs(b), 1.0)))
+    x, u, pi, _, _ = [t.cpu().numpy() for t in mpc.get_iterate()]
+    assert rel(r.u0.cpu().numpy(), ref.u0) < 1e-6 and rel(r.V.cpu().numpy(), ref.V) < 1e-6
+    assert rel(x, ref.X) < 1e-6 and rel(u, ref.U) < 1e-6 and rel(pi, ref.PI) < 1e-6
+    assert rel(r.dV_dp.cpu().numpy(), ref.dV) < 1e-6
+    assert np.abs(it[:, 1] - ref.ipm_iter).max() <= 1
+
+
+def test_device_envs_vs_reference_formulas():
+    """The batched envs on the GPU against the reference's step written out in numpy: cartpole swing-up (Euler, tau = 0.02,
+    continuous_cartpole/environment.py:105-134,178-194) and the linear system (linear_system/environment.py:28-58)."""
+    import math
+    from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedLinearSystemEnv
+    B = 4096
+    env = BatchedCartPoleSwingUpEnv(B, device="cuda", seed=3)
+    obs = env.reset()
+    s = obs.cpu().numpy().copy()
+    assert np.all(s[:, [0, 1, 3]] == 0.0) and s[:, 2].min() >= 0.9 * math.pi and s[:, 2].max() <= 1.1 * math.pi
+    rng = np.random.default_rng(0)
+    g, mc, mp_, l, fm, tau = 9.8, 1.0, 0.1, 0.5, 30.0, 0.02
+    for _ in range(25):
+        a = rng.uniform(-1, 1, (B, 1))
+        obs, rew, term, trunc = env.step(torch.as_tensor(a, device="cuda"))
+        x, xd, th, thd = s.T
+        force = fm * a[:, 0]
+        c, sn = np.cos(th), np.sin(th)
+        temp = (force + mp_ * l * thd ** 2 * sn) / (mp_ + mc)
+        thacc = (g * sn - c * temp) / (l * (4.0 / 3.0 - mp_ * c ** 2 / (mp_ + mc)))
+        xacc = temp - mp_ * l * thacc * c / (mp_ + mc)
+        s = np.stack([x + tau * xd, xd + tau * xacc, th + tau * thd, thd + tau * thacc], 1)     # Euler, environment.py:123-127
+        assert np.allclose(obs.cpu().numpy(), s, rtol=1e-12, atol=1e-12)
+        assert np.allclose(rew.cpu().numpy(), s[:, 0] ** 2 + s[:, 2] ** 2, rtol=1e-12)
+        t_ref = (np.abs(s[:, 0]) < 0.1) & (np.abs(s[:, 1]) < 0.1) & (np.abs(s[:, 2]) < math.radians(2.0)) & (np.abs(s[:, 3]) < 0.1)
+        assert np.array_equal(term.cpu().numpy(), t_ref) and not bool(trunc.any())
+    lin = BatchedLinearSystemEnv(B, device="cuda", lb_noise=-0.1, ub_noise=0.0, seed=1)
+    o = lin.reset()
+    assert bool((o == torch.tensor([0.5, 0.5], device="cuda", dtype=o.dtype)).all())
+    A, Bm = np.array([[0.9, 0.35], [0.0, 1.1]]), np.array([[0.0813], [0.2]])
+    prev = o.cpu().numpy()
+    a = rng.uniform(-1, 1, (B, 1))
+    o2, cost, _, _ = lin.step(torch.as_tensor(a, device="cuda"))
+    o2 = o2.cpu().numpy()
+    noise = o2 - prev @ A.T - a @ Bm.T
+    assert np.all(noise[:, 0] >= -0.1 - 1e-12) and np.all(noise[:, 0] <= 1e-12) and np.abs(noise[:, 1]).max() < 1e-12
+    viol_lo = ((np.array([0.0, -1.0]) - o2) > 0).any(1) * 1e2
+    viol_hi = ((o2 - np.array([1.0, 1.0])) > 0).any(1) * 1e2
+    assert np.allclose(cost.cpu().numpy(), 0.5 * (o2 ** 2).sum(1) + 0.5 * (a ** 2).sum(1) + viol_lo + viol_hi, rtol=1e-12)
+
+
+def test_td3_closed_loop_on_gpu(oracle_port):
+    """BASELINE config 5, one rank: 4096 batched cartpole environments -> MPC actor (one launch per step, warm-started, cold only
+    where an episode ended) -> replay -> critic TD update -> deterministic policy gradient through du0*/dtheta.  Checks the hot-path
+    pieces against the oracle on recorded samples and the loop's invariants."""
+    from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedTD3, cartpole_ocp
+    from oracle.problems import make_cartpole
+    E = 4096
+    ocp = cartpole_ocp()
+    env = BatchedCartPoleSwingUpEnv(E, device="cuda", seed=0, max_episode_steps=3)      # every environment is truncated at step 3
+    agent = BatchedTD3(ocp, env, batch_size=512, buffer_steps=8, policy_delay=2, lr_actor=1e-6, seed=1)
+    # the swing-up start saturates the input (u0* = -30, du0*/dtheta = 0): put the upper half of the environments near the upright
+    # position so that the policy gradient has something to work with
+    g = torch.Generator(device="cuda").manual_seed(7)
+    near = (torch.rand(E // 2, 4, generator=g, device="cuda", dtype=env.state.dtype) * 2 - 1) * torch.tensor([0.5, 1.0, 0.3, 1.0], device="cuda", dtype=env.state.dtype)
+    env.state[E // 2:] = near
+    agent.obs = env.state.clone()
+    obs0 = agent.obs.clone()
+    theta0 = agent.theta.clone()
+    st = agent.collect(5)
+    assert st["converged_fraction"] == 1.0 and E <= st["episodes_ended"] <= E + 8 and agent.buffer.size() == 5 * E   # (+ the odd terminated one)
+    # step 0 of the roll-out: the stored action is the MPC policy (scaled, plus exploration noise of sigma 0.1, clipped)
+    ref = oracle_port.solve(make_cartpole(), obs0[:64].double().cpu().numpy(), flags=0)
+    a_ref = 2.0 * (ref.u0 + 30.0) / 60.0 - 1.0
+    a0 = agent.buffer.act[0, :64].cpu().numpy()
+    dev = a0 - np.clip(a_ref, -1, 1)          # N(0, 0.1) exploration noise, clipped into [-1, 1] (the swing-up start saturates at -1)
+    assert np.abs(dev).max() < 0.6 and 0.0 < np.abs(dev).mean() < 0.15 and a0.min() >= -1.0 and a0.max() <= 1.0
+    # the environments that ended were re-drawn from the reset distribution and their next solve started cold (it converged)
+    o3 = agent.buffer.obs[3]
+    fresh = (o3[:, [0, 1, 3]].abs().max(1).values == 0.0) & (o3[:, 2] >= 0.9 * np.pi - 1e-6) & (o3[:, 2] <= 1.1 * np.pi + 1e-6)
+    assert int(fresh.sum()) >= E - 8
+    tr = agent.train(4)
+    assert np.isfinite(tr["critic_loss"]) and agent.n_updates == 4
+    step = (agent.theta - theta0).cpu().numpy()
+    assert np.abs(step[:3]).max() > 0.0 and np.all(step[3:] == 0.0) and np.all(np.isfinite(step))
+    assert torch.equal(agent.actor.mpc.get_theta(), agent.theta) and torch.equal(agent.target_mpc.mpc.get_theta(), agent.theta_target)
+    # the policy-gradient ingredients on a recorded batch against the oracle: u0*(s_i) and du0*/dtheta_i
+    obs = agent.buffer.obs[1, :48].double()
+    rp = agent.pi_mpc.mpc
+    from mpc4rl_amd import MPCBatch
+    m = MPCBatch(ocp, 48)
+    m.set_theta(theta0)
+    r = m.solve(obs, sens_pi=True, cold=True)
+    o = oracle_port.solve(make_cartpole(), obs.cpu().numpy(), p=np.tile(theta0.cpu().numpy(), (48, 1)))
+    assert np.allclose(r.u0.cpu().numpy(), o.u0, rtol=1e-6, atol=1e-8) and np.allclose(r.dpi_dp.cpu().numpy(), o.dpi, rtol=1e-5, atol=1e-7)
+
+
+def test_per_instance_cold_mask(oracle_port):
+    """mpcrl_set_cold_mask: the masked instances of a warm call restart from the cold iterate (bitwise what a cold call gives them),
+    the others continue from their stored iterate."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    B = 90
+    rng = np.random.default_rng(2)
+    x0 = np.zeros((B, 4))
+    x0[:, 2] = rng.uniform(0.9 * np.pi, 1.1 * np.pi, B)
+    x1 = x0 + rng.normal(0, 0.01, (B, 4))
+    mask = torch.as_tensor(rng.uniform(size=B) < 0.4, device="cuda")
+    a = MPCBatch(cartpole_ocp(), B)
+    a.solve(x0, cold=True, reorder=False)
+    ra = a.solve(x1, cold_mask=mask, reorder=False)
+    cold = MPCBatch(cartpole_ocp(), B).solve(x1, cold=True, reorder=False)
+    warm = MPCBatch(cartpole_ocp(), B)
+    warm.solve(x0, cold=True, reorder=False)
+    rw = warm.solve(x1, reorder=False)
+    m = mask.cpu().numpy()
+    assert torch.equal(ra.u0[mask], cold.u0[mask]) and torch.equal(ra.iters[mask], cold.iters[mask]) and torch.equal(ra.V[mask], cold.V[mask])
+    assert torch.equal(ra.u0[~mask], rw.u0[~mask]) and torch.equal(ra.iters[~mask], rw.iters[~mask])
+    assert int(ra.iters[~mask][:, 0].max()) < int(ra.iters[mask][:, 0].min())        # warm starts need far fewer SQP iterations
+    rb = a.solve(x1, reorder=False)                                                   # the mask was one-shot
+    assert int(rb.iters[:, 0].max()) == 0

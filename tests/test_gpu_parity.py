@@ -3,6 +3,8 @@
 Tolerances: the engine and the oracle run the same iteration in fp64, so iterates agree to ~1e-10; the bar
 from BASELINE.json's north_star is 1e-6 relative on u0*, V, dV/dp, du0*/dp and that is what is asserted
 (tighter values are printed)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -151,36 +153,76 @@ def test_chain_mass_sweep_vs_oracle(oracle_port):
     assert np.abs(fd[1:-1] - dpi[1:-1, :, p_idx]).max() < 5e-3 * max(1.0, np.abs(dpi[:, :, p_idx]).max())
 
 
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
 def test_chain_mass_vs_golden():
+    """G4 (all ten sweep points, n_mass = 5) and G5 (n_mass = 7, nx = 33): the tuned HIP path against vectors the dense oracle
+    produced in its frozen exact-QP mode (tests/golden/make_golden.py)."""
     from mpc4rl_amd import MPCBatch, chain_mass_ocp
-    import os
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g4_chain5.npz"))
+    g = np.load(os.path.join(GOLD, "g4_chain5.npz"))
     ocp = chain_mass_ocp()
+    assert len(g["p_vals"]) == 10
     theta = np.tile(ocp.p0, (len(g["p_vals"]), 1))
     theta[:, int(g["p_idx"])] = g["p_vals"]
-    mpc = MPCBatch(ocp, len(theta))
-    mpc.set_theta(torch.as_tensor(theta))
-    r = mpc.solve(g["x0"], sens_v=True, sens_pi=True, cold=True)
-    assert np.all(r.status.cpu().numpy() == 0)
-    assert rel_err(r.u0.cpu().numpy(), g["u0"]) < RTOL and rel_err(r.V.cpu().numpy(), g["V"]) < RTOL
-    assert rel_err(r.dV_dp.cpu().numpy(), g["dV"]) < RTOL
-    assert rel_err(r.dpi_dp.cpu().numpy(), g["dpi"], floor=np.abs(g["dpi"]).max()) < RTOL
+    # at the golden's NLP tolerance (1e-8) the north_star bar 1e-6; at the chain's default tolerance 1e-5 (ocp_utils.py:311-312) a run
+    # is itself only within ~1e-5 x conditioning of the KKT point (tests/test_oracle.py::test_port_vs_golden_chain)
+    for tol, bar in ((1e-8, RTOL), (None, 2e-5)):
+        mpc = MPCBatch(chain_mass_ocp() if tol is None else chain_mass_ocp(tol=tol), len(theta))
+        mpc.set_theta(torch.as_tensor(theta))
+        r = mpc.solve(g["x0"], sens_v=True, sens_pi=True, cold=True)
+        assert np.all(r.status.cpu().numpy() == 0)
+        assert rel_err(r.u0.cpu().numpy(), g["u0"]) < bar and rel_err(r.V.cpu().numpy(), g["V"]) < RTOL
+        assert rel_err(r.dV_dp.cpu().numpy(), g["dV"]) < bar
+        assert rel_err(r.dpi_dp.cpu().numpy(), g["dpi"], floor=np.abs(g["dpi"]).max()) < bar
+        assert float((mpc.get_lagrangian() - r.V).abs().max()) < 1e-5   # lam'h + pi'g vanish at a KKT point up to the barrier parameter
+    g = np.load(os.path.join(GOLD, "g5_chain7.npz"))
+    for tol, bar in ((1e-8, RTOL), (None, 2e-5)):
+        mpc = MPCBatch(chain_mass_ocp(n_mass=7) if tol is None else chain_mass_ocp(n_mass=7, tol=tol), len(g["x0"]))
+        r = mpc.solve(g["x0"], sens_v=True, sens_pi=True, cold=True)
+        assert np.all(r.status.cpu().numpy() == 0)
+        assert rel_err(r.u0.cpu().numpy(), g["u0"]) < bar and rel_err(r.V.cpu().numpy(), g["V"]) < RTOL
+        assert rel_err(r.dV_dp.cpu().numpy(), g["dV"]) < bar
+        assert rel_err(r.dpi_dp.cpu().numpy(), g["dpi"], floor=np.abs(g["dpi"]).max()) < bar
 
 
 def test_golden_cartpole_and_linear_on_gpu():
-    """HIP path against the committed golden vectors (dense Python oracle + autograd mirror)."""
-    import os
+    """HIP path (tuned inexact SQP) against the committed golden vectors (dense Python oracle in its frozen exact-QP mode +
+    autograd mirror): G3 = 64 reset-distribution states + 64 near-upright states, each at theta x {1, 0.9, 1.1}."""
     from mpc4rl_amd import MPCBatch, cartpole_ocp, linear_system_ocp
-    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    g = np.load(os.path.join(gold, "g3_cartpole.npz"))
-    mpc = MPCBatch(cartpole_ocp(), len(g["x0"]))
-    mpc.set_theta(torch.as_tensor(g["theta"]))
-    r = mpc.solve(g["x0"], sens_v=True, sens_pi=True, cold=True)
-    assert np.all(r.status.cpu().numpy() == 0)
-    for k, a in (("u0", r.u0), ("V", r.V), ("dV", r.dV_dp), ("dpi", r.dpi_dp)):
-        assert rel_err(a.cpu().numpy(), g[k]) < RTOL, k
+    g = np.load(os.path.join(GOLD, "g3_cartpole.npz"))
+    ocp = cartpole_ocp()
+    B = len(g["x0"])
+    assert B == 384
+    theta = np.tile(ocp.p0, (B, 1))
+    theta[:, :3] = g["theta_model"]
+    strict = g["sc"] >= 1e-3          # strict-complementarity filter of SURVEY.md §8c (see tests/test_oracle.py::check_against_kkt_golden)
+
+    def per_instance(a, b):
+        a, b = np.asarray(a, float).reshape(B, -1), np.asarray(b, float).reshape(B, -1)
+        return (np.abs(a - b) / np.maximum(np.abs(b).max(1, keepdims=True), 1.0)).max(1)
+
+    for tol in (1e-8, None):          # the golden's own NLP tolerance, then the solver default 1e-6 (the reference's setting)
+        mpc = MPCBatch(cartpole_ocp() if tol is None else cartpole_ocp(tol=tol), B)
+        mpc.set_theta(torch.as_tensor(theta))
+        r = mpc.solve(g["x0"], sens_v=True, sens_pi=True, cold=True)
+        assert np.all(r.status.cpu().numpy() == 0)
+        e = {k: per_instance(a.cpu().numpy(), g[k]) for k, a in (("u0", r.u0), ("V", r.V), ("dV", r.dV_dp), ("dpi", r.dpi_dp))}
+        print("tol", tol, {k: (float(v.max()), float((v < RTOL).mean())) for k, v in e.items()})
+        assert e["V"].max() < RTOL and e["dV"].max() < RTOL and e["dpi"].max() < 2e-5
+        if tol is not None:           # both at the KKT point: the north_star bar on every instance
+            assert e["u0"].max() < RTOL and e["dpi"][strict].max() < RTOL
+        else:                         # a run stopped at 1e-6 is itself only within ~1e-6 x conditioning of the KKT point
+            assert e["u0"].max() < 1e-5 and (e["u0"] < RTOL).mean() >= 0.99 and (e["dpi"][strict] < RTOL).mean() >= 0.99
+        assert rel_err(mpc.get_lagrangian().cpu().numpy(), g["L"]) < RTOL
+        x, u, pi, _, _ = mpc.get_iterate()
+        assert rel_err(x[:12].cpu().numpy(), g["X"]) < 1e-5 and rel_err(u[:12].cpu().numpy(), g["U"]) < 1e-5
+        assert rel_err(pi[:12].cpu().numpy(), g["PI"]) < 1e-5
+    mq = MPCBatch(ocp, 1)
+    rq = mq.solve(g["q_x0"], g["q_u0fix"], sens_v=True, sens_pi=True, cold=True)   # scripts/cartpole_mpc_sensitivities.py:80-81
+    assert int(rq.status[0]) == 0 and rel_err(rq.V.cpu().numpy(), g["q_V"]) < RTOL and rel_err(rq.dV_dp.cpu().numpy(), g["q_dV"]) < RTOL
     for tag in ("g099", "g09"):
-        g = np.load(os.path.join(gold, f"g2_linear_{tag}.npz"))
+        g = np.load(os.path.join(GOLD, f"g2_linear_{tag}.npz"))
         mpc = MPCBatch(linear_system_ocp(discount_factor=float(g["gamma"])), len(g["x0"]))
         r = mpc.solve(g["x0"], sens_v=True, sens_pi=True, cold=True)
         assert np.all(r.status.cpu().numpy() == 0)
@@ -188,6 +230,74 @@ def test_golden_cartpole_and_linear_on_gpu():
         for k, a in (("u0", r.u0), ("V", r.V), ("dV", r.dV_dp)):
             assert rel_err(a.cpu().numpy(), g[k]) < RTOL, k
         assert rel_err(r.dpi_dp.cpu().numpy()[strict], g["dpi"][strict]) < RTOL
+
+
+def test_chain_mass_n7_vs_oracle_and_full_size_properties(oracle_port):
+    """BASELINE config 4 at its perf dimension (n_mass = 7, nx = 33, N = 40): parity with the oracle port on 8 instances, then the
+    full batch of 1024 through size-independent properties (all converge, KKT residuals below tol, bounds respected, a second
+    call from the stored iterate needs no iteration and reproduces the outputs, results independent of the batch order)."""
+    from mpc4rl_amd import MPCBatch, chain_mass_ocp
+    from oracle.problems import make_chain_mass
+    ocp, P = chain_mass_ocp(n_mass=7), make_chain_mass(n_mass=7)
+    assert ocp.nx == 33 and ocp.n_p == P.n_p
+    rng = np.random.default_rng(0)
+
+    def inputs(B):
+        x0 = np.tile(ocp.x0, (B, 1))
+        x0[:, 3 * 6:] += rng.normal(0.0, 1e-2, (B, 15))      # SURVEY.md §8d config 4: N(0, 1e-2) velocity perturbation
+        return x0
+
+    x0 = inputs(8)
+    _, r, ref = run_both(ocp, P, oracle_port, x0)
+    st = r.status.cpu().numpy()
+    assert np.all(st == 0) and np.array_equal(st, ref.status)
+    assert np.abs(r.iters.cpu().numpy()[:, 0] - ref.sqp_iter).max() <= 1
+    assert rel_err(r.u0.cpu().numpy(), ref.u0) < RTOL and rel_err(r.V.cpu().numpy(), ref.V) < RTOL
+    assert rel_err(r.dV_dp.cpu().numpy(), ref.dV) < RTOL
+    assert rel_err(r.dpi_dp.cpu().numpy(), ref.dpi, floor=np.abs(ref.dpi).max()) < RTOL
+    B = 1024
+    x0 = inputs(B)
+    mpc = MPCBatch(ocp, B)
+    r = mpc.solve(x0, sens_v=True, sens_pi=True, cold=True)
+    assert bool((r.status == 0).all())
+    assert float(mpc.get_iterate()[4].max()) < 1e-5 and float(r.u0.abs().max()) <= 1.0 + 1e-9
+    assert bool(torch.isfinite(r.dV_dp).all()) and bool(torch.isfinite(r.dpi_dp).all())
+    r2 = mpc.solve(x0, sens_v=True, sens_pi=True)
+    assert int(r2.iters[:, 0].max()) == 0 and torch.allclose(r2.V, r.V, rtol=1e-13) and torch.allclose(r2.dV_dp, r.dV_dp, rtol=1e-10, atol=1e-12)
+    perm = rng.permutation(B)
+    rp = MPCBatch(ocp, B).solve(x0[perm], sens_v=True, cold=True)
+    idx = torch.as_tensor(perm, device=r.V.device)
+    assert torch.equal(rp.V, r.V[idx]) and torch.equal(rp.dV_dp, r.dV_dp[idx])
+    ref8 = oracle_port.solve(P, x0[:8])
+    assert rel_err(r.u0.cpu().numpy()[:8], ref8.u0) < RTOL and rel_err(r.dV_dp.cpu().numpy()[:8], ref8.dV) < RTOL
+
+
+def test_cartpole_cost_parameters_reach_the_kernel(oracle_port):
+    """W_0, W, W_e, yref_0, yref, yref_e are part of p and the solve uses them (set_parameter / cost_set, mpc.py:233-257), per
+    instance; their gradient entries stay zero (non-parameterised NLS mirror, nlp.py:1039-1055)."""
+    from mpc4rl_amd import cartpole_ocp
+    from oracle.problems import make_cartpole
+    B = 48
+    P = make_cartpole()
+    rng = np.random.default_rng(4)
+    theta = np.tile(P.p0, (B, 1))
+    theta[:, :3] *= rng.uniform(0.95, 1.05, (B, 3))
+    for b in range(B):
+        d0, d, de = rng.uniform(0.5, 2.0, 5), rng.uniform(0.5, 2.0, 5), rng.uniform(0.5, 2.0, 4)
+        W0, W, We = np.diag(P.p0[3:28].reshape(5, 5).diagonal() * d0), np.diag(P.p0[28:53].reshape(5, 5).diagonal() * d), \
+            np.diag(P.p0[53:69].reshape(4, 4).diagonal() * de)
+        W[0, 2] = W[2, 0] = 0.3 * rng.uniform(-1, 1)              # off-diagonal weight, symmetric
+        W[1, 4] = 0.004                                           # and an unsymmetric entry: only (W + W')/2 matters
+        theta[b, 3:28], theta[b, 28:53], theta[b, 53:69] = W0.flatten("F"), W.flatten("F"), We.flatten("F")
+        theta[b, 69:74] = rng.uniform(-0.1, 0.1, 5)
+        theta[b, 74:79] = rng.uniform(-0.1, 0.1, 5)
+        theta[b, 79:83] = rng.uniform(-0.05, 0.05, 4)
+    x0 = cartpole_x0(B, 4)
+    _, r, ref = run_both(cartpole_ocp(), P, oracle_port, x0, theta=theta)
+    check(r, ref)
+    nominal = oracle_port.solve(P, x0)
+    assert np.abs(ref.u0 - nominal.u0).max() > 0.5                # the cost block matters
+    assert bool((r.dV_dp[:, 3:] == 0).all()) and bool((r.dpi_dp[:, :, 3:] == 0).all())
 
 
 @pytest.mark.parametrize("B", [1, 2, 4, 100, 4097])
@@ -240,19 +350,6 @@ def test_full_size_properties_cartpole():
     perm = rng.permutation(B)
     rp = MPCBatch(cartpole_ocp(), B).solve(x0[perm], cold=True)
     assert torch.equal(rp.V, r.V[torch.as_tensor(perm, device=r.V.device)])
-
-
-def test_cooperative_variant_matches_default(oracle_port):
-    """The experimental cooperative kernel (16 instances per 7-wave workgroup, sweeps on one wave) must agree with the oracle."""
-    from mpc4rl_amd import MPCBatch, cartpole_ocp
-    from oracle.problems import make_cartpole
-    B = 100
-    x0 = cartpole_x0(B, seed=11)
-    mpc = MPCBatch(cartpole_ocp(), B)
-    mpc.set_variant(1)
-    r = mpc.solve(x0, sens_v=True, sens_pi=True, cold=True)
-    ref = oracle_port.solve(make_cartpole(), x0)
-    check(r, ref)
 
 
 def test_auto_order_does_not_change_results():

@@ -34,50 +34,129 @@ def test_g1_lqr_dare_known_answers(oracle_port):
         assert abs(r.u0[0, 0] - c["u0"]) < 1e-9 and abs(r.V[0] - c["V"]) < 1e-9
 
 
-@pytest.mark.parametrize("tag", ["g099", "g09"])
-def test_port_vs_golden_linear(oracle_port, tag):
-    from oracle.problems import make_linear_system
-    g = np.load(os.path.join(GOLD, f"g2_linear_{tag}.npz"))
-    P = make_linear_system(gamma=float(g["gamma"]))
-    r = oracle_port.solve(P, g["x0"])
-    assert np.all(r.status == 0) and np.abs(r.sqp_iter - g["sqp_iter"]).max() <= 1 and np.abs(r.ipm_iter - g["ipm_iter"]).max() <= 3
-    assert rel(r.u0, g["u0"]) < 1e-9 and rel(r.V, g["V"]) < 1e-9 and rel(r.X, g["X"]) < 1e-9 and rel(r.PI, g["PI"]) < 1e-8
-    assert rel(r.dV, g["dV"]) < 1e-8
-    strict = g["smax"] < 1e-9                  # du0/dp is ill-posed where a soft bound is active (quirk q1)
-    assert rel(r.dpi[strict], g["dpi"][strict]) < 1e-6
-    q = oracle_port.solve(P, g["q_x0"], u0fix=g["q_u0fix"])
-    assert rel(q.V, g["q_V"]) < 1e-9 and rel(q.dV, g["q_dV"]) < 1e-8 and np.all(q.dpi == 0.0)
-    assert np.abs(g["q_dpi"]).max() < 1e-6     # the mirror's own value: ~0 (u_0 pinned by lbu_0 = ubu_0)
-
-
-def test_port_vs_golden_cartpole(oracle_port):
+def cartpole_gold():
+    """G3 (tests/golden/make_golden.py): inputs + outputs of the dense oracle in its frozen exact-QP mode."""
     from oracle.problems import make_cartpole
     g = np.load(os.path.join(GOLD, "g3_cartpole.npz"))
     P = make_cartpole()
-    r = oracle_port.solve(P, g["x0"], p=g["theta"])
-    # iteration counts may differ by one where a stopping test is met to within rounding (dense KKT solves vs Riccati)
-    assert np.all(r.status == 0) and np.abs(r.sqp_iter - g["sqp_iter"]).max() <= 1 and np.abs(r.ipm_iter - g["ipm_iter"]).max() <= 3
-    # where the counts differ the two runs stop at different iterates, both within tol = 1e-6 of the KKT point: the bar is 1e-6
-    for k, a in (("u0", r.u0), ("V", r.V), ("X", r.X), ("U", r.U), ("PI", r.PI), ("dV", r.dV)):
-        assert rel(a, g[k]) < 1e-6, k
-    assert rel(r.dpi, g["dpi"]) < 1e-6
-    assert np.all(r.res < P.tol)               # assert_kkt_residual (nlp.py:1295-1299)
-    q = oracle_port.solve(P, g["q_x0"], u0fix=g["q_u0fix"])
-    assert rel(q.V, g["q_V"]) < 1e-9 and rel(q.dV, g["q_dV"]) < 1e-8
+    theta = np.tile(P.p0, (len(g["x0"]), 1))
+    theta[:, :3] = g["theta_model"]
+    return P, g, theta
+
+
+def close_fraction(a, b, tol=1e-6):
+    a, b = np.asarray(a, float).reshape(len(a), -1), np.asarray(b, float).reshape(len(b), -1)
+    e = (np.abs(a - b) / np.maximum(np.abs(b).max(1, keepdims=True), 1.0)).max(1)
+    return float((e < tol).mean()), float(e.max())
+
+
+@pytest.mark.parametrize("tag", ["g099", "g09"])
+def test_port_vs_golden_linear(oracle_port, tag):
+    """Linear system: a QP, so the exact mode (golden) and the tuned mode agree to the interior-point tolerance."""
+    from oracle.problems import make_linear_system
+    g = np.load(os.path.join(GOLD, f"g2_linear_{tag}.npz"))
+    P = make_linear_system(gamma=float(g["gamma"]))
+    for exact in (True, False):
+        r = oracle_port.solve(P, g["x0"], exact=exact)
+        assert np.all(r.status == 0) and np.abs(r.sqp_iter - g["sqp_iter"]).max() <= 1
+        assert rel(r.u0, g["u0"]) < 1e-8 and rel(r.V, g["V"]) < 1e-8 and rel(r.X, g["X"]) < 1e-8 and rel(r.PI, g["PI"]) < 1e-7
+        assert rel(r.dV, g["dV"]) < 1e-7
+        strict = g["smax"] < 1e-9                  # du0/dp is ill-posed where a soft bound is active (quirk q1)
+        assert rel(r.dpi[strict], g["dpi"][strict]) < 1e-6
+        q = oracle_port.solve(P, g["q_x0"], u0fix=g["q_u0fix"], exact=exact)
+        assert rel(q.V, g["q_V"]) < 1e-8 and rel(q.dV, g["q_dV"]) < 1e-7 and np.all(q.dpi == 0.0)
+    assert np.abs(g["q_dpi"]).max() < 1e-6     # the mirror's own value: ~0 (u_0 pinned by lbu_0 = ubu_0)
+
+
+def check_against_kkt_golden(g, u0, V, dV, dpi, tight):
+    """The golden vectors are the KKT point (NLP tolerance 1e-8, tests/golden/make_golden.py).  ``tight``: the run under test was
+    also taken to 1e-8 — then the bar of BASELINE.json's north_star (1e-6 relative) holds for EVERY instance, for du0*/dp on the
+    instances that pass the strict-complementarity filter of SURVEY.md §8c (sc >= 1e-3: no weakly active bound; an interior-point
+    solution leaves lam t ~ 1e-11 per row, so where lam ~ 1e-4 the bound is missed by ~1e-7 and du0*/dp, which divides by that,
+    moves in the 6th digit).  A run stopped at the solver's default tolerance 1e-6 (the reference's setting) can itself only be within
+    ~1e-6 x conditioning of the KKT point: V and dV/dp still meet 1e-6 everywhere, u0* and du0*/dp on >= 99 % of the instances and
+    to 1e-5 / 2e-5 on all of them."""
+    strict = g["sc"] >= 1e-3
+    fu, wu = close_fraction(u0, g["u0"])
+    fv, wv = close_fraction(V, g["V"])
+    fd, wd = close_fraction(dV, g["dV"])
+    fp, wp = close_fraction(dpi[strict], g["dpi"][strict])
+    _, wpa = close_fraction(dpi, g["dpi"])
+    print(f"tight={tight}: worst rel err u0 {wu:.1e} V {wv:.1e} dV {wd:.1e} dpi(strict) {wp:.1e} dpi(all) {wpa:.1e}; "
+          f"fraction within 1e-6: u0 {fu:.4f} dpi {fp:.4f}; strict-complementarity filter keeps {strict.mean():.4f}")
+    assert wv < 1e-6 and wd < 1e-6 and wpa < 2e-5
+    if tight:
+        assert wu < 1e-6 and wp < 1e-6
+    else:
+        assert wu < 1e-5 and fu >= 0.99 and fp >= 0.99
+
+
+def test_port_vs_golden_cartpole(oracle_port):
+    """G3 = 64 + 64 states x theta {1, 0.9, 1.1}, generated by the dense exact-QP oracle + autograd mirror at NLP
+    tolerance 1e-8.  The C++ port reproduces it in its exact mode (two linear-algebra paths, same iteration), in the tuned inexact
+    mode the product runs (a different iterate sequence that must land on the same KKT point), and at the default tolerance."""
+    P, g, theta = cartpole_gold()
+    assert np.all(g["status"] == 0) and len(g["x0"]) == 384 and g["res"].max() < 1e-8
+    for exact, tol in ((True, 1e-8), (False, 1e-8), (False, None)):
+        r = oracle_port.solve(P, g["x0"], p=theta, exact=exact, tol=tol)
+        assert np.all(r.status == 0)
+        if exact:
+            assert np.abs(r.sqp_iter - g["sqp_iter"]).max() <= 1
+        check_against_kkt_golden(g, r.u0, r.V, r.dV, r.dpi, tight=tol is not None)
+        assert rel(r.X[:12], g["X"]) < 1e-5 and rel(r.U[:12], g["U"]) < 1e-5 and rel(r.PI[:12], g["PI"]) < 1e-5
+        assert np.all(r.res < (tol or P.tol))      # assert_kkt_residual (nlp.py:1295-1299)
+        q = oracle_port.solve(P, g["q_x0"], u0fix=g["q_u0fix"], exact=exact, tol=tol)
+        assert rel(q.V, g["q_V"]) < 1e-8 and rel(q.dV, g["q_dV"]) < 1e-6
 
 
 def test_port_vs_golden_chain(oracle_port):
-    """The sweep of tests/test_chain_mass.py (C_3_0 over [0.05, 0.15]): u0* and du0*/dp[:, p_idx]."""
+    """G4: all ten points of the sweep of tests/test_chain_mass.py (C_3_0 over [0.05, 0.15]); G5: n_mass = 7 (nx = 33)."""
     from oracle.problems import make_chain_mass
     g = np.load(os.path.join(GOLD, "g4_chain5.npz"))
     P = make_chain_mass()
-    assert rel(P.extra["x_ss"], g["x_ss"]) < 1e-12
+    assert rel(P.extra["x_ss"], g["x_ss"]) < 1e-12 and len(g["p_vals"]) == 10
     theta = np.tile(P.p0, (len(g["p_vals"]), 1))
     theta[:, int(g["p_idx"])] = g["p_vals"]
-    r = oracle_port.solve(P, g["x0"], p=theta)
-    assert np.all(r.status == 0) and np.abs(r.sqp_iter - g["sqp_iter"]).max() <= 1
-    assert rel(r.u0, g["u0"]) < 1e-8 and rel(r.V, g["V"]) < 1e-9 and rel(r.dV, g["dV"]) < 1e-7
-    assert rel(r.dpi, g["dpi"], floor=np.abs(g["dpi"]).max()) < 1e-6
+    assert g["res"].max() < 1e-8 and g["sc"].min() > 1e-3        # KKT point to 1e-8, strictly complementary
+    for exact, tol in ((True, 1e-8), (False, 1e-8), (True, None), (False, None)):
+        r = oracle_port.solve(P, g["x0"], p=theta, exact=exact, tol=tol)
+        assert np.all(r.status == 0)
+        # at the golden's tolerance: the 1e-6 bar; stopped at the chain's default 1e-5 (ocp_utils.py:311-312) a run is itself only
+        # within ~1e-5 x conditioning of the KKT point (measured: dV/dp 3.6e-6 in the exact mode)
+        bar = 1e-6 if tol is not None else 2e-5
+        assert rel(r.u0, g["u0"]) < bar and rel(r.V, g["V"]) < 1e-8 and rel(r.dV, g["dV"]) < bar
+        assert rel(r.dpi, g["dpi"], floor=np.abs(g["dpi"]).max()) < bar
+    g = np.load(os.path.join(GOLD, "g5_chain7.npz"))
+    P = make_chain_mass(n_mass=7)
+    assert rel(P.extra["x_ss"], g["x_ss"]) < 1e-12
+    for tol, bar in ((1e-8, 1e-6), (None, 2e-5)):
+        r = oracle_port.solve(P, g["x0"], tol=tol)
+        assert np.all(r.status == 0)
+        assert rel(r.u0, g["u0"]) < bar and rel(r.V, g["V"]) < 1e-8 and rel(r.dV, g["dV"]) < bar
+        assert rel(r.dpi, g["dpi"], floor=np.abs(g["dpi"]).max()) < bar
+
+
+def test_cost_block_of_p_reaches_the_solve(oracle_port):
+    """set_parameter / cost_set semantics (mpc.py:233-257): W_0, W, W_e, yref_0, yref, yref_e inside p are what the solver uses;
+    their gradient entries stay zero (non-parameterised NLS mirror, nlp.py:1039-1055).  Dense Python vs C++ port."""
+    from oracle import nlp_mirror, sqp_dense
+    from oracle.problems import make_cartpole
+    P = make_cartpole()
+    p = P.p0.copy()
+    W = np.diag([5.0, 0.2, 20.0, 0.1, 0.02])
+    W[0, 2] = W[2, 0] = 0.5
+    p[28:53], p[3:28] = W.flatten("F"), (2 * W).flatten("F")
+    p[74:79], p[69:74], p[79:83] = [0.1, 0, 0.05, 0, 0.5], [0.2, 0, 0, 0, 0], [0.1, 0, 0, 0]
+    x0 = np.array([0.2, -0.5, 0.25, 0.4])
+    sol = sqp_dense.solve(P, x0, p=p)
+    mr = nlp_mirror.evaluate(P, sol, x0, p=p)
+    r = oracle_port.solve(P, x0[None], p=p[None])
+    nominal = oracle_port.solve(P, x0[None])
+    assert sol.status == 0 and r.status[0] == 0
+    assert abs(r.u0[0, 0] - nominal.u0[0, 0]) > 1.0                       # the weights matter
+    assert rel(r.u0[0], sol.u[0]) < 1e-6 and rel(r.V[0], sol.cost) < 1e-8
+    assert rel(r.dV[0], mr.dL_dp[0]) < 1e-6 and rel(r.dpi[0], mr.dpi_dp) < 1e-6
+    assert np.all(r.dV[0, 3:] == 0.0) and np.all(mr.dL_dp[0, 3:] == 0.0)
 
 
 def test_dense_python_vs_port_cartpole(oracle_port):
