@@ -214,31 +214,12 @@ def chain_bench(args):
     print(json.dumps(out), flush=True)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=B_PER_GPU)
-    ap.add_argument("--no-sens", action="store_true", help="forward solve only (BASELINE config 2)")
-    ap.add_argument("--rti", action="store_true", help="one SQP iteration from the stored iterate (build-side mode)")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--workload", default="cartpole", choices=["cartpole", "chain5", "chain7"],
-                    help="cartpole = the headline metric (default); chain5/chain7 = BASELINE config 4 (not the headline line)")
-    args = ap.parse_args()
-    rc = maybe_spawn(args, sys.argv[1:])
-    if rc is not None:
-        sys.exit(rc)
-    if os.environ.get("MPCRL_BENCH_DRYRUN"):
-        return dryrun(args)
-    if args.workload != "cartpole":
-        return chain_bench(args)
-
+def init_ranks(args):
+    """(world, rank, local, dist module or None, device): one process per GPU, RCCL ("nccl") when there is more than one rank."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != max(1, args.gpus) and not os.environ.get("MPCRL_BENCH_FORCE_DIST"):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1 or os.environ.get("MPCRL_BENCH_FORCE_DIST"):   # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
@@ -248,6 +229,73 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    return world, rank, local, dist, dev
+
+
+def td3_bench(args):
+    """BASELINE config 5: cartpole TD3 closed loop — 4096 batched environments per GPU, the MPC as the actor (one launch per
+    environment step, warm-started, cold only where an episode ended), device replay, critic TD update with the target actor's
+    batched solve, delayed deterministic policy gradient through du0*/dtheta, ONE all-reduce (critic gradients + theta-gradient)
+    per update.  A step = one environment step of all environments + one TD3 update (batch 4096 per rank)."""
+    world, rank, local, dist, dev = init_ranks(args)
+    from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedTD3, cartpole_ocp
+    E = args.batch
+    env = BatchedCartPoleSwingUpEnv(E, device=dev, seed=rank)
+    agent = BatchedTD3(cartpole_ocp(), env, batch_size=E, buffer_steps=64, policy_delay=2, lr_actor=1e-6, seed=0, device=dev)
+    agent.collect(4)                       # something to sample from
+    for _ in range(args.warmup):
+        agent.collect(1), agent.train(1)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = agent.collect(1)
+        tr = agent.train(1)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = job_aggregate(time.perf_counter() - t0, dist, dev)
+    if rank == 0:
+        # MPC solves per step and rank: E (roll-out, warm) + E (target actor, cold) + E / policy_delay (policy + sensitivities, cold)
+        solves = world * args.steps * (E + E + E / agent.policy_delay)
+        print(json.dumps({
+            "metric": "closed-loop environment steps/sec, cartpole TD3 with the MPC as actor", "value": world * E * args.steps / elapsed,
+            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"cartpole TD3 closed loop (BASELINE config 5): {E} environments/GPU, one environment step + one "
+                                   f"TD3 update (batch {E}, policy_delay 2) per step; MPC solves per step and GPU: {E} warm (actor) "
+                                   f"+ {E} cold (target actor) + {E // 2} cold with du0*/dtheta (policy gradient)",
+                       "parallelism": f"environments sharded over {world} GPU(s); one all-reduce of the critic + theta gradients per update",
+                       "mpc_solves_per_s": solves / elapsed, "converged_fraction": st["converged_fraction"],
+                       "critic_loss": tr["critic_loss"]}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU)
+    ap.add_argument("--no-sens", action="store_true", help="forward solve only (BASELINE config 2)")
+    ap.add_argument("--rti", action="store_true", help="one SQP iteration from the stored iterate (build-side mode)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", default="cartpole", choices=["cartpole", "chain5", "chain7", "td3"],
+                    help="cartpole = the headline metric (default); chain5/chain7 = BASELINE config 4; td3 = config 5 (not the headline line)")
+    args = ap.parse_args()
+    rc = maybe_spawn(args, sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
+    if os.environ.get("MPCRL_BENCH_DRYRUN"):
+        return dryrun(args)
+    if args.workload == "td3":
+        return td3_bench(args)
+    if args.workload != "cartpole":
+        return chain_bench(args)
+
+    world, rank, local, dist, dev = init_ranks(args)
 
     from mpc4rl_amd import MPCBatch, cartpole_ocp
     from mpc4rl_amd.distributed import allreduce_weighted_grad

@@ -10,7 +10,7 @@
 
 namespace mpcrl {
 
-constexpr int ORDER_NT = 1024, ORDER_MAX = 8192, ORDER_PER = ORDER_MAX / ORDER_NT;
+constexpr int ORDER_NT = 1024, ORDER_MAX = 8192, ORDER_PER = ORDER_MAX / ORDER_NT, ORDER_BUCKET_MAX = 64;
 
 __global__ void __launch_bounds__(ORDER_NT) order_kernel(const double *x0, int B, int nx, int *perm) {
     __shared__ int cnt[ORDER_NT], off[ORDER_NT], wsum[ORDER_NT / 64], tmp[ORDER_MAX];
@@ -51,6 +51,19 @@ __global__ void __launch_bounds__(ORDER_NT) order_kernel(const double *x0, int B
         }
     }
     __syncthreads();
+    {   // A heavily populated bucket means the batch is clustered along the chosen coordinate (all environments reset to one state,
+        // say): its members are similar problems whatever their order, and ordering it by index below would be a serial insertion
+        // sort of up to B entries on one thread.  Then the identity permutation is the packing order.
+        __shared__ int crowded;
+        if (tid == 0) crowded = 0;
+        __syncthreads();
+        if (cnt[tid] > ORDER_BUCKET_MAX) crowded = 1;
+        __syncthreads();
+        if (crowded) {
+            for (int i = tid; i < B; i += ORDER_NT) perm[i] = i;
+            return;
+        }
+    }
     {   // exclusive scan of the bucket counts
         const int c = cnt[tid];
         int incl = c;

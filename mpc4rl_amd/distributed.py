@@ -27,13 +27,14 @@ def allreduce_weighted_grad(grad: torch.Tensor, weight: torch.Tensor, group: Opt
 
     Returns (sum_i w_i g_i over ALL ranks [n_theta], sum_i w_i, total count) with a single all-reduce of
     n_theta + 2 doubles; all three are device tensors (no host synchronisation: the caller's next launches queue up
-    behind the collective instead of waiting for it).  ``deterministic=True`` uses all-gather + fixed-order summation instead so the result is
-    bitwise independent of the reduction tree."""
+    behind the collective instead of waiting for it).  ``deterministic=True`` sums the local shard with a fixed-shape framework
+    reduction (no atomics) and combines the ranks by all-gather + fixed-order summation, so the result is reproducible run to run
+    and independent of the collective's reduction tree."""
     g = grad.to(torch.float64)
     w = weight.to(torch.float64).reshape(-1)
     n_theta = g.shape[1]
     buf = torch.empty(n_theta + 2, dtype=torch.float64, device=g.device)
-    if g.is_cuda and g.stride(1) == 1:
+    if g.is_cuda and g.stride(1) == 1 and not deterministic:
         # K5 (csrc/reduce_kernel.hpp): one launch instead of a chain of elementwise / reduction kernels
         import ctypes as C
         from . import _lib
@@ -44,7 +45,8 @@ def allreduce_weighted_grad(grad: torch.Tensor, weight: torch.Tensor, group: Opt
                                                      C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream))
         if rc != 0:
             raise RuntimeError(f"mpcrl_weighted_grad_sum failed with {rc}")
-    else:   # CPU tensors (gloo tests)
+    else:   # CPU tensors (gloo tests), and the deterministic path: the reduction kernel combines its per-wave partial sums with
+        #         floating-point atomics, whose order varies from run to run; a framework reduction of one shape does not
         buf[:n_theta] = (w[:, None] * g).sum(0)
         buf[n_theta] = w.sum()
         buf[n_theta + 1] = float(g.shape[0])
@@ -59,7 +61,16 @@ def allreduce_weighted_grad(grad: torch.Tensor, weight: torch.Tensor, group: Opt
 
 
 def mean_update(grad: torch.Tensor, weight: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
-                deterministic: bool = False) -> torch.Tensor:
-    """``mean_i(w_i * g_i)`` over all instances on all ranks — the parameter step of the Q-learning example."""
-    s, _, n = allreduce_weighted_grad(grad, weight, group, deterministic)
+                deterministic: bool = False, valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``mean_i(w_i * g_i)`` over all instances on all ranks — the parameter step of the Q-learning example
+    (linear_system_mpc_qlearning.py:203).  ``valid`` [b] (0/1): samples whose solve failed carry weight 0 and are left out of the
+    mean's denominator as well (the reference raises on a failed solve instead, mpc.py:81-83,197-198; a batch cannot)."""
+    if valid is None:
+        s, _, n = allreduce_weighted_grad(grad, weight, group, deterministic)
+    else:
+        v = valid.to(torch.float64).reshape(-1)
+        s, _, _ = allreduce_weighted_grad(grad, weight.to(torch.float64).reshape(-1) * v, group, deterministic)
+        n = v.sum()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
     return s / torch.clamp(n, min=1.0)

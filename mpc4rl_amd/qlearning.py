@@ -76,7 +76,7 @@ class BatchedQLearning:
         valid = (ok[:-1] & ok[1:]).to(td.dtype)
         w = (self.lr * td * valid).reshape(-1)
         g = dq[: n - 1].reshape(-1, dq.shape[-1])
-        step = mean_update(g, w, self.group)                          # mean_i(LR * td_i * dQ/dp_i), all ranks (203)
+        step = mean_update(g, w, self.group, valid=valid.reshape(-1))   # mean_i(LR * td_i * dQ/dp_i) over the valid samples of all ranks (203)
         self.theta = self.theta + step
         for m in (self.rollout_mpc, self.sample_mpc):
             m.set_theta(self.theta)                                   # mpc.set_parameter (204-205)
