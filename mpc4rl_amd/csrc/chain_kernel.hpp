@@ -1354,33 +1354,95 @@ __global__ void __launch_bounds__(64) chain_init_kernel(const LargeSpec sp, cons
     }
 }
 
-// ---- dynamics linearisation: one (instance, stage, direction) item per lane; fills [B A]_k and r_k = F(x_k, u_k) - x_{k+1}.
-// Forward-mode jet through the 2-step RK4 map, parameters as plain doubles, all state in registers.
+// ---- dynamics linearisation: fills [B A]_k and r_k = F(x_k, u_k) - x_{k+1}.
+// One workgroup = LIN_G consecutive stages of one instance, one lane per (stage, direction).  The RK4 map is split into what depends
+// on the point and what is linear in the direction (ChainDev::ode_coef / ode_tan): every lane first walks the 4 x rk_steps evaluation
+// points of its stage in plain doubles and the first lane of the stage leaves the per-link coefficients of each point in LDS; then
+// each lane propagates ONLY its tangent through the same points.  A forward jet per lane (value + tangent through the whole map)
+// needs both sets of arrays live at once — 2 x 4 NX doubles, 528 registers at NX = 33, i.e. spills whose scratch traffic made this
+// kernel HBM-bound (profiles/r02_hbm_traffic.json: 46 GB per step at n_mass = 7) — and recomputes the point NW times.
+template <class M>
+struct LinCfg {
+    static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU;
+    static constexpr int G = 256 / NW;               // stages per workgroup
+    static constexpr int NT = G * NW;                // lanes used (<= 256)
+    static constexpr int EV = 8;                     // evaluation points: 4 RK stages x 2 steps (rk_steps <= 2)
+};
+
 template <class M>
 __global__ void __launch_bounds__(256) chain_lin_kernel(const LargeSpec sp, const LargeArgs a) {
-    constexpr int NX = M::NX, NU = M::NU, NW = NX + NU;
-    const int N = sp.N;
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const int per = N * NW;
-    const int inst = (int)(gid / per);
-    if (inst >= a.B) return;
+    using LC = LinCfg<M>;
+    constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NL = M::NL, TAB = M::TAB;
+    __shared__ double tab[LC::G * LC::EV * NL * TAB];
+    const int N = sp.N, nblk = (N + LC::G - 1) / LC::G;
+    const int inst = blockIdx.x / nblk, k0 = (blockIdx.x - inst * nblk) * LC::G;
     const LargeLayout<M> lay(N);
     double *w = a.ws + (size_t)inst * a.ws_stride;
-    if (w[lay.state + ST_ACTIVE] == 0.0) return;
-    const int it = (int)(gid - (long)inst * per), k = it / NW, d = it - k * NW;
+    if (w[lay.state + ST_ACTIVE] == 0.0) return;     // uniform over the workgroup
+    const int t = threadIdx.x, g = t / NW, d = t - g * NW;
+    const bool lane_on = t < LC::NT && k0 + g < N;
+    const int k = lane_on ? k0 + g : N - 1;          // idle lanes shadow the last stage and never store
     const double *X = a.X + (size_t)inst * (N + 1) * NX, *U = a.U + (size_t)inst * N * NU;
     const double *th = a.theta + (size_t)inst * a.theta_stride;
-    Jet1<1> jx[NX], ju[NU], jn[NX];
+    const double h = sp.h;
+    const int steps = sp.rk_steps;
+    double *mytab = tab + (size_t)(t < LC::NT ? g : 0) * LC::EV * NL * TAB;
+    double u[NU];
 #pragma unroll
-    for (int i = 0; i < NU; ++i) ju[i] = Jet1<1>(U[k * NU + i]), ju[i].d[0] = (d == i) ? 1.0 : 0.0;
+    for (int i = 0; i < NU; ++i) u[i] = U[k * NU + i];
+    {   // the point: RK4 in plain doubles, coefficients of every evaluation point to LDS
+        const bool wr = lane_on && d == 0;
+        double xc[NX], acc[NX], kk[NX], xt[NX];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) jx[i] = Jet1<1>(X[k * NX + i]), jx[i].d[0] = (d == NU + i) ? 1.0 : 0.0;
-    disc_map_p<M, Jet1<1>>(jx, ju, th, jn, sp.h, sp.rk_steps);
-    double *BA = w + lay.BA + (size_t)k * NX * NW, *r = w + lay.r + k * NX;
+        for (int i = 0; i < NX; ++i) xc[i] = X[k * NX + i];
+        for (int s = 0; s < steps; ++s) {
+            double *tb = mytab + (size_t)(4 * s) * NL * TAB;
+            M::template ode_coef<false>(xc, u, th, kk, tb, wr);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        BA[i * NW + d] = jn[i].d[0];
-        if (d == 0) r[i] = jn[i].v - X[(k + 1) * NX + i];
+            for (int i = 0; i < NX; ++i) acc[i] = kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
+            M::template ode_coef<false>(xt, u, th, kk, tb + NL * TAB, wr);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
+            M::template ode_coef<false>(xt, u, th, kk, tb + 2 * NL * TAB, wr);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + h * kk[i];
+            M::template ode_coef<false>(xt, u, th, kk, tb + 3 * NL * TAB, wr);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xc[i] = xc[i] + (h / 6.0) * (acc[i] + kk[i]);
+        }
+        if (wr) {
+            double *r = w + lay.r + k * NX;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) r[i] = xc[i] - X[(k + 1) * NX + i];
+        }
+    }
+    __syncthreads();
+    {   // the direction: tangent e_d through the same evaluation points
+        double dxc[NX], acc[NX], dk[NX], dxt[NX], du[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) du[i] = d == i ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dxc[i] = d == NU + i ? 1.0 : 0.0;
+        for (int s = 0; s < steps; ++s) {
+            const double *tb = mytab + (size_t)(4 * s) * NL * TAB;
+            M::template ode_tan<TAB, false>(tb, th, dxc, du, dk, nullptr);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
+            M::template ode_tan<TAB, false>(tb + NL * TAB, th, dxt, du, dk, nullptr);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
+            M::template ode_tan<TAB, false>(tb + 2 * NL * TAB, th, dxt, du, dk, nullptr);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + h * dk[i];
+            M::template ode_tan<TAB, false>(tb + 3 * NL * TAB, th, dxt, du, dk, nullptr);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) dxc[i] = dxc[i] + (h / 6.0) * (acc[i] + dk[i]);
+        }
+        if (lane_on) {
+            double *BA = w + lay.BA + (size_t)k * NX * NW;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) BA[i * NW + d] = dxc[i];
+        }
     }
 }
 
@@ -1493,41 +1555,202 @@ __global__ void __launch_bounds__(64, 1) chain_qp_kernel(const LargeSpec sp, con
 //   sens_out      wavefront per instance: du0*/dp reductions
 // They re-use [B A], lam, t, nu left in the workspace by the last SQP round (its linearisation is at the final iterate).
 // =====================================================================================================
+// grad_theta (nu_{k+1}' F_k): one reverse sweep of the RK4 map per (instance, stage), one lane each.
 template <class M>
-__global__ void __launch_bounds__(256) chain_sens_ad_kernel(const LargeSpec sp, const LargeArgs a) {
-    constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD;
+__global__ void __launch_bounds__(64) chain_sens_th_kernel(const LargeSpec sp, const LargeArgs a) {
+    constexpr int NX = M::NX, NU = M::NU, NTD = M::NTD;
     const int N = sp.N;
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const int per = N * (NW + 1);
-    const int inst = (int)(gid / per);
+    const long gid = (long)blockIdx.x * 64 + threadIdx.x;
+    const int inst = (int)(gid / N);
     if (inst >= a.B) return;
     const int status = a.status[inst];
     if (!(status == 0 || status == 2)) return;
-    const int it = (int)(gid - (long)inst * per), k = it / (NW + 1), j = it - k * (NW + 1);
-    const bool want_pi = (a.flags & 2) && a.dpi && !a.u0fix;
+    const int k = (int)(gid - (long)inst * N);
     const LargeLayout<M> lay(N);
     double *w = a.ws + (size_t)inst * a.ws_stride;
     const double *X = a.X + (size_t)inst * (N + 1) * NX, *U = a.U + (size_t)inst * N * NU;
     const double *th = a.theta + (size_t)inst * a.theta_stride, *nu = w + lay.ynu;
-    if (j == NW) {   // grad_theta (nu_{k+1}' F_k)
-        double jx[NX], ju[NU], lm[NX], xb[NX], ub[NU], tb[NTD];
-        for (int i = 0; i < NU; ++i) ju[i] = U[k * NU + i];
-        for (int i = 0; i < NX; ++i) jx[i] = X[k * NX + i], lm[i] = nu[(k + 1) * NX + i];
-        disc_map_adj_p<M, true, double>(jx, ju, th, lm, xb, ub, tb, sp.h, sp.rk_steps);
-        double *term = w + lay.term + (size_t)k * NTD;
-        for (int d = 0; d < NTD; ++d) term[d] = tb[d];
-        return;
+    double jx[NX], ju[NU], lm[NX], xb[NX], ub[NU], tb[NTD];
+    for (int i = 0; i < NU; ++i) ju[i] = U[k * NU + i];
+    for (int i = 0; i < NX; ++i) jx[i] = X[k * NX + i], lm[i] = nu[(k + 1) * NX + i];
+    disc_map_adj_p<M, true, double>(jx, ju, th, lm, xb, ub, tb, sp.h, sp.rk_steps);
+    double *term = w + lay.term + (size_t)k * NTD;
+    for (int d = 0; d < NTD; ++d) term[d] = tb[d];
+}
+
+// Exact Lagrangian Hessian of a stage, Hex_k = c_k hess l_k + hess (nu_{k+1}' F_k)(x_k, u_k), ONE WAVEFRONT PER (instance, stage).
+// F is the composition of 4 x rk_steps evaluations of the ODE with linear combinations, and the ODE is nonlinear only through the
+// spring forces of the links, so the second-order chain rule collapses to
+//     hess (nu' F) = sum over evaluation points e and links i of   (d dist_{e,i} / dv)'  G_{e,i}  (d dist_{e,i} / dv),
+// G_{e,i} = the 3 x 3 Hessian of (adjoint of the link force at e)' Fs(dist) (ChainDev::link_hessian), d dist / dv = the first-order
+// tangents of the link vectors.  Three passes over the evaluation points, each with a quarter of the live state a forward-over-
+// reverse jet sweep needs (which spilled ~1000 registers per lane and was bound by its own scratch traffic):
+//   1. the point: RK4 in plain doubles; per-link coefficients of every evaluation point -> LDS          (all lanes, redundantly)
+//   2. the adjoint: reverse sweep of nu_{k+1} through the same points; G_{e,i} -> LDS                      (all lanes, redundantly)
+//   3. the tangents: lane j < NW carries direction e_j forward; at every evaluation point the wave publishes Y = d dist / dv
+//      (3 NL x NW) and W = G Y and accumulates  Hex += Y' W  on the matrix cores: v_mfma_f64_16x16x4, lower tile triangle, operands
+//      straight out of LDS in their register layout (A(i, k) and B(k, j) both at lane 16 k + i|j: measured,
+//      profiles/microbench/mfma_f64_16x16x4_probe.hip), results D[r](4 r + lane / 16, lane % 16) stored row-coalesced.
+template <class M>
+struct HexCfg {
+    static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NL = M::NL, TAB2 = M::TAB2, EV = 8;
+    static constexpr int NTI = (NW + 15) / 16;                 // 16-wide tiles per side
+    static constexpr int R = 3 * NL, RP = (R + 3) / 4 * 4;      // rows of Y / W per evaluation point, padded to whole k-steps
+    static constexpr int LD = 48;                               // row stride of Y / W (doubles): 384 B, so that the two 32-lane halves
+                                                                // of a 64-bit LDS read fall on disjoint bank sets
+    static constexpr int oTab = 0, oG = oTab + EV * NL * TAB2, oY = (oG + EV * NL * 6 + 1) & ~1, oW = oY + RP * LD, TOTAL = oW + RP * LD;
+    static_assert(NTI * 16 <= LD && NW <= 64, "one direction per lane, tiles inside the padded row");
+};
+
+template <class M>
+__global__ void __launch_bounds__(64, 1) chain_sens_ad_kernel(const LargeSpec sp, const LargeArgs a) {
+    using HC = HexCfg<M>;
+    constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NL = M::NL, TAB2 = M::TAB2, LD = HC::LD, RP = HC::RP, NTI = HC::NTI;
+    typedef double d4_t __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) double lds[HC::TOTAL];
+    const int N = sp.N, lane = threadIdx.x;
+    const int inst = blockIdx.x / N, k = blockIdx.x - inst * N;
+    const int status = a.status[inst];
+    if (!(status == 0 || status == 2)) return;
+    const LargeLayout<M> lay(N);
+    double *w = a.ws + (size_t)inst * a.ws_stride;
+    const double *X = a.X + (size_t)inst * (N + 1) * NX, *U = a.U + (size_t)inst * N * NU;
+    const double *th = a.theta + (size_t)inst * a.theta_stride, *nu = w + lay.ynu;
+    const double h = sp.h;
+    const int steps = sp.rk_steps;
+    double *tab = lds + HC::oTab, *Gt = lds + HC::oG, *Y = lds + HC::oY, *W = lds + HC::oW;
+    const bool wr = lane == 0;
+    double u[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) u[i] = U[k * NU + i];
+    {   // 1. the point
+        double xc[NX], acc[NX], kk[NX], xt[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xc[i] = X[k * NX + i];
+        for (int s = 0; s < steps; ++s) {
+            double *tb = tab + (size_t)(4 * s) * NL * TAB2;
+            M::template ode_coef<true>(xc, u, th, kk, tb, wr);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
+            M::template ode_coef<true>(xt, u, th, kk, tb + NL * TAB2, wr);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
+            M::template ode_coef<true>(xt, u, th, kk, tb + 2 * NL * TAB2, wr);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + h * kk[i];
+            M::template ode_coef<true>(xt, u, th, kk, tb + 3 * NL * TAB2, wr);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xc[i] = xc[i] + (h / 6.0) * (acc[i] + kk[i]);
+        }
     }
-    if (!want_pi) return;
-    // column j of c_k hess l + hess (nu_{k+1}' F_k): tangent e_j through the reverse sweep of F
-    Jet1<1> jx[NX], ju[NU], lm[NX], xb[NX], ub[NU];
-    for (int c = 0; c < NU; ++c) ju[c] = Jet1<1>(U[k * NU + c]);
-    for (int c = 0; c < NX; ++c) jx[c] = Jet1<1>(X[k * NX + c]), lm[c] = Jet1<1>(nu[(k + 1) * NX + c]);
-    if (j < NU) ju[j].d[0] = 1.0; else jx[j - NU].d[0] = 1.0;
-    disc_map_adj_p<M, false, Jet1<1>>(jx, ju, th, lm, xb, ub, (Jet1<1> *)nullptr, sp.h, sp.rk_steps);
-    const double ckk = sp.cost_kind == 0 ? sp.dT : (k == 0 ? sp.dT : pow(sp.gamma, (double)k) * sp.dT);
-    double *Hex = w + lay.Hex + (size_t)k * NW * NW;
-    for (int i = 0; i < NW; ++i) Hex[i * NW + j] = fma(ckk, M::hess(false, i, j, th), i < NU ? ub[i].d[0] : xb[i - NU].d[0]);
+    wave_sync();
+    {   // 2. the adjoint: kb_e = d(nu' F) / d(k_e) at every evaluation point, last step first; G_{e,i} from its force part
+        double lb[NX], acc[NX], kb[NX], Xb[NX], q[3 * NL];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) lb[i] = nu[(k + 1) * NX + i];
+        for (int s = steps - 1; s >= 0; --s) {
+            auto node = [&](int e) {   // Xb = J(e)' kb, and the link Hessians of this evaluation point
+                const double *tb = tab + (size_t)e * NL * TAB2;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) Xb[i] = 0.0;
+                M::template ode_tan_T<TAB2>(tb, th, kb, Xb, q);
+                if (wr) {
+#pragma unroll
+                    for (int i = 0; i < NL; ++i) M::link_hessian(tb + i * TAB2, q + 3 * i, Gt + ((size_t)e * NL + i) * 6);
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < NX; ++i) kb[i] = (h / 6.0) * lb[i];
+            node(4 * s + 3);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = lb[i] + Xb[i], kb[i] = (h / 3.0) * lb[i] + h * Xb[i];
+            node(4 * s + 2);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + Xb[i], kb[i] = (h / 3.0) * lb[i] + (0.5 * h) * Xb[i];
+            node(4 * s + 1);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + Xb[i], kb[i] = (h / 6.0) * lb[i] + (0.5 * h) * Xb[i];
+            node(4 * s);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) lb[i] = acc[i] + Xb[i];
+        }
+    }
+    wave_sync();
+    // 3. the tangents and the Hessian accumulation
+    d4_t D[NTI * (NTI + 1) / 2];
+#pragma unroll
+    for (int t_ = 0; t_ < NTI * (NTI + 1) / 2; ++t_) D[t_] = d4_t{0.0, 0.0, 0.0, 0.0};
+    for (int r = lane; r < RP * LD; r += 64) Y[r] = 0.0, W[r] = 0.0;   // padding rows / columns stay zero
+    wave_sync();
+    {
+        double dxc[NX], acc[NX], dk[NX], dxt[NX], du[NU], dd[3 * NL];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) du[i] = lane == i ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dxc[i] = lane == NU + i ? 1.0 : 0.0;      // lanes >= NW carry the zero direction
+        const int lr = lane >> 4, lc = lane & 15;
+        auto accumulate = [&](int e) {   // publish this evaluation point's Y, W = G Y and add Y' W to the tiles
+            const double *G = Gt + (size_t)e * NL * 6;
+            if (lane < NW) {
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    const double *g = G + i * 6, d0 = dd[3 * i], d1 = dd[3 * i + 1], d2 = dd[3 * i + 2];
+                    Y[(3 * i) * LD + lane] = d0, Y[(3 * i + 1) * LD + lane] = d1, Y[(3 * i + 2) * LD + lane] = d2;
+                    W[(3 * i) * LD + lane] = g[0] * d0 + g[1] * d1 + g[3] * d2;
+                    W[(3 * i + 1) * LD + lane] = g[1] * d0 + g[2] * d1 + g[4] * d2;
+                    W[(3 * i + 2) * LD + lane] = g[3] * d0 + g[4] * d1 + g[5] * d2;
+                }
+            }
+            wave_sync();
+#pragma unroll
+            for (int ks = 0; ks < RP / 4; ++ks) {
+                double ya[NTI], wb[NTI];
+#pragma unroll
+                for (int t_ = 0; t_ < NTI; ++t_) ya[t_] = Y[(4 * ks + lr) * LD + 16 * t_ + lc], wb[t_] = W[(4 * ks + lr) * LD + 16 * t_ + lc];
+#pragma unroll
+                for (int ti = 0; ti < NTI; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj <= ti; ++tj)
+                        D[ti * (ti + 1) / 2 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[ti], wb[tj], D[ti * (ti + 1) / 2 + tj], 0, 0, 0);
+            }
+            wave_sync();
+        };
+        for (int s = 0; s < steps; ++s) {
+            const double *tb = tab + (size_t)(4 * s) * NL * TAB2;
+            M::template ode_tan<TAB2, true>(tb, th, dxc, du, dk, dd);
+            accumulate(4 * s);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
+            M::template ode_tan<TAB2, true>(tb + NL * TAB2, th, dxt, du, dk, dd);
+            accumulate(4 * s + 1);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
+            M::template ode_tan<TAB2, true>(tb + 2 * NL * TAB2, th, dxt, du, dk, dd);
+            accumulate(4 * s + 2);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + h * dk[i];
+            M::template ode_tan<TAB2, true>(tb + 3 * NL * TAB2, th, dxt, du, dk, dd);
+            accumulate(4 * s + 3);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) dxc[i] = dxc[i] + (h / 6.0) * (acc[i] + dk[i]);
+        }
+        // Hex_k = c_k hess l_k + the accumulated second-order term; D[r] holds (row 4 r + lane / 16, column lane % 16) of its tile
+        const double ckk = sp.cost_kind == 0 ? sp.dT : (k == 0 ? sp.dT : pow(sp.gamma, (double)k) * sp.dT);
+        double *Hex = w + lay.Hex + (size_t)k * NW * NW;
+#pragma unroll
+        for (int ti = 0; ti < NTI; ++ti)
+#pragma unroll
+            for (int tj = 0; tj <= ti; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * ti + 4 * r + lr, j = 16 * tj + lc;
+                    if (i < NW && j < NW) {
+                        const double v = fma(ckk, M::hess(false, i, j, th), D[ti * (ti + 1) / 2 + tj][r]);
+                        Hex[i * NW + j] = v;
+                        if (ti != tj) Hex[j * NW + i] = v;
+                    }
+                }
+    }
 }
 
 template <class M>

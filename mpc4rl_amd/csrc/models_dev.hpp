@@ -326,6 +326,124 @@ struct ChainDev {
             }
         }
     }
+    // ---- the same ODE split into what depends on the POINT (x, u) and what is linear in a DIRECTION ------------------------------
+    // ode_coef: f(x, u) and, per link i, the 9 numbers the tangent of f needs at this point:
+    //   dist_i (3),  a_ij = D_ij / m_i (1 - L_ij / n_i),  b_ij = D_ij / m_i  L_ij dist_ij / n_i^3        (n_i = |dist_i|)
+    // so that  d Fs_ij = a_ij d dist_ij + b_ij (dist_i . d dist_i).  `tab` ([NL][TAB] doubles, LDS) is written when `store` is set.
+    // With SECOND also the second-order pieces  c_ij = D_ij / m_i  L_ij / n_i^3  and  e_i = 3 / n_i^2  (Hessian of the spring force).
+    static constexpr int TAB = 9, TAB2 = 13;
+    template <bool SECOND>
+    MPCRL_DI static void ode_coef(const double *x, const double *u, const double *p, double *f, double *tab, bool store) {
+        constexpr int TS_ = SECOND ? TAB2 : TAB;
+        const double *pos = x, *vel = x + 3 * (M + 1);
+        const double *m = p, *D = p + NL, *L = p + 4 * NL, *C = p + 7 * NL, *w = p + OFF_W;
+        double *acc = f + 3 * (M + 1);
+#pragma unroll
+        for (int i = 0; i < 3 * M; ++i) acc[i] = (i % 3 == 2) ? w[i] + (-9.81) : w[i];
+#pragma unroll
+        for (int i = 0; i <= M; ++i) {
+            double dist[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dist[j] = i ? pos[3 * i + j] - pos[3 * (i > 0 ? i - 1 : 0) + j] : pos[j];
+            const double n2 = dist[0] * dist[0] + dist[1] * dist[1] + dist[2] * dist[2];
+            const double inrm = 1.0 / sqrt(n2), im = 1.0 / m[i], in3 = inrm * inrm * inrm;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double dm = D[3 * i + j] * im, lj = L[3 * i + j];
+                const double aj = dm * (1.0 - lj * inrm);
+                const double vr = i < M ? vel[3 * (i < M ? i : 0) + j] : u[j];
+                const double dv = i ? vr - vel[3 * (i > 0 ? i - 1 : 0) + j] : vr;
+                const double Ft = aj * dist[j] + C[3 * i + j] * dv;
+                if (i < M) acc[3 * (i < M ? i : 0) + j] -= Ft;
+                if (i > 0) acc[3 * (i > 0 ? i - 1 : 0) + j] += Ft;
+                if (store) {
+                    tab[i * TS_ + j] = dist[j], tab[i * TS_ + 3 + j] = aj, tab[i * TS_ + 6 + j] = dm * lj * dist[j] * in3;
+                    if constexpr (SECOND) tab[i * TS_ + 9 + j] = dm * lj * in3;
+                }
+            }
+            if constexpr (SECOND)
+                if (store) tab[i * TS_ + 12] = 3.0 * inrm * inrm;
+        }
+#pragma unroll
+        for (int i = 0; i < 3 * M; ++i) f[i] = vel[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) f[3 * M + j] = u[j];
+    }
+    // ode_tan: df = (df/dx) dx + (df/du) du at the point whose coefficients are in `tab` (stride TS_ per link).  With DD the dist
+    // tangents d dist_i of this direction are also returned (the second-order sweep of the sensitivities publishes them).
+    template <int TS_, bool DD>
+    MPCRL_DI static void ode_tan(const double *tab, const double *p, const double *dx, const double *du, double *df, double *dd) {
+        const double *C = p + 7 * NL;
+        const double *dpos = dx, *dvel = dx + 3 * (M + 1);
+        double *dacc = df + 3 * (M + 1);
+#pragma unroll
+        for (int i = 0; i < 3 * M; ++i) dacc[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i <= M; ++i) {
+            const double *t = tab + i * TS_;
+            double dd_[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dd_[j] = i ? dpos[3 * i + j] - dpos[3 * (i > 0 ? i - 1 : 0) + j] : dpos[j];
+            const double dot = t[0] * dd_[0] + t[1] * dd_[1] + t[2] * dd_[2];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double dvr = i < M ? dvel[3 * (i < M ? i : 0) + j] : du[j];
+                const double ddv = i ? dvr - dvel[3 * (i > 0 ? i - 1 : 0) + j] : dvr;
+                const double dFt = fma(t[3 + j], dd_[j], fma(t[6 + j], dot, C[3 * i + j] * ddv));
+                if (i < M) dacc[3 * (i < M ? i : 0) + j] -= dFt;
+                if (i > 0) dacc[3 * (i > 0 ? i - 1 : 0) + j] += dFt;
+                if constexpr (DD) dd[3 * i + j] = dd_[j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3 * M; ++i) df[i] = dvel[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) df[3 * M + j] = du[j];
+    }
+    // ode_tan_T: the transpose of ode_tan at the same point — xb += (df/dx)' kb (ub is not needed by its caller) — and, per link,
+    // the force adjoint q_i = (adjoint of acc_{i-1}) - (adjoint of acc_i), which weights the link's spring force in kb' f.
+    template <int TS_>
+    MPCRL_DI static void ode_tan_T(const double *tab, const double *p, const double *kb, double *xb, double *q) {
+        const double *C = p + 7 * NL;
+        double *posb = xb, *velb = xb + 3 * (M + 1);
+        const double *accb = kb + 3 * (M + 1);
+#pragma unroll
+        for (int i = 0; i < 3 * M; ++i) velb[i] += kb[i];
+#pragma unroll
+        for (int i = 0; i <= M; ++i) {
+            const double *t = tab + i * TS_;
+            double qi[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double v = 0.0;
+                if (i < M) v -= accb[3 * (i < M ? i : 0) + j];
+                if (i > 0) v += accb[3 * (i > 0 ? i - 1 : 0) + j];
+                qi[j] = v, q[3 * i + j] = v;
+            }
+            const double bq = t[6] * qi[0] + t[7] * qi[1] + t[8] * qi[2];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double ddb = fma(t[3 + j], qi[j], t[j] * bq), dvb = C[3 * i + j] * qi[j];
+                posb[3 * i + j] += ddb;
+                if (i > 0) posb[3 * (i > 0 ? i - 1 : 0) + j] -= ddb;
+                if (i < M) velb[3 * (i < M ? i : 0) + j] += dvb;
+                if (i > 0) velb[3 * (i > 0 ? i - 1 : 0) + j] -= dvb;
+            }
+        }
+    }
+    // Hessian of q' Fs(dist) with respect to dist (3x3 symmetric, packed [00, 10, 11, 20, 21, 22]) from the second-order coefficients
+    // of ode_coef<true>: with chat_j = q_j c_j (c_j = D_j / m L_j / n^3) and s = chat . dist,
+    //   G = chat dist' + dist chat' + s (I - (3 / n^2) dist dist').
+    MPCRL_DI static void link_hessian(const double *t /* TAB2 entries of the link */, const double *q, double *G) {
+        const double c0 = q[0] * t[9], c1 = q[1] * t[10], c2 = q[2] * t[11];
+        const double s = c0 * t[0] + c1 * t[1] + c2 * t[2], se = s * t[12];
+        G[0] = 2.0 * c0 * t[0] + s - se * t[0] * t[0];
+        G[1] = c1 * t[0] + t[1] * c0 - se * t[1] * t[0];
+        G[2] = 2.0 * c1 * t[1] + s - se * t[1] * t[1];
+        G[3] = c2 * t[0] + t[2] * c0 - se * t[2] * t[0];
+        G[4] = c2 * t[1] + t[2] * c1 - se * t[2] * t[1];
+        G[5] = 2.0 * c2 * t[2] + s - se * t[2] * t[2];
+    }
     // symmetrised cost weights from p (Q, R column-major; ocp_utils.py:267,273)
     MPCRL_DI static double Qs(const double *p, int i, int j) { return 0.5 * (p[OFF_Q + j * NX + i] + p[OFF_Q + i * NX + j]); }
     MPCRL_DI static double Rs(const double *p, int i, int j) { return 0.5 * (p[OFF_R + j * NU + i] + p[OFF_R + i * NU + j]); }

@@ -97,7 +97,7 @@ int fill_small_spec(const MpcrlProblemSpec &s, SmallSpec &d) {
 
 int fill_large_spec(const MpcrlProblemSpec &s, LargeSpec &d) {
     const int nw = s.nx + s.nu;
-    if (nw > LARGE_MAXNW || s.nu > 4 || s.N + 1 > 64 || s.N < 1) return MPCRL_E_ARG;
+    if (nw > LARGE_MAXNW || s.nu > 4 || s.N + 1 > 64 || s.N < 1 || s.rk_steps < 1 || s.rk_steps > 2) return MPCRL_E_ARG;
     if (s.soft)
         for (int i = 0; i < nw; ++i)
             if (s.soft[i]) return MPCRL_E_ARG;   // hard bounds only in the large kernel
@@ -123,14 +123,15 @@ int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
     // SQP rounds: the instances carry an `active` flag, finished ones return at once (no host synchronisation, the call stays
     // asynchronous); round r evaluates iterate r and, unless it stops there, takes the full step to iterate r + 1
     for (int r = 0; r <= max_iter; ++r) {
-        hipLaunchKernelGGL(chain_lin_kernel<M>, blocks((long)B * N * NW), dim3(256), 0, st, h->large, a);
+        hipLaunchKernelGGL(chain_lin_kernel<M>, dim3((unsigned)(B * ((N + LinCfg<M>::G - 1) / LinCfg<M>::G))), dim3(256), 0, st, h->large, a);
         hipLaunchKernelGGL(chain_qp_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
     }
     HIP_OK(hipGetLastError());
     if (a.flags & (MPCRL_SENS_V | MPCRL_SENS_PI)) {
-        hipLaunchKernelGGL(chain_sens_ad_kernel<M>, blocks((long)B * N * (NW + 1)), dim3(256), 0, st, h->large, a);
+        hipLaunchKernelGGL(chain_sens_th_kernel<M>, dim3((unsigned)(((long)B * N + 63) / 64)), dim3(64), 0, st, h->large, a);
         const bool want_pi = (a.flags & MPCRL_SENS_PI) && a.dpi && !a.u0fix;
         if (want_pi) {
+            hipLaunchKernelGGL(chain_sens_ad_kernel<M>, dim3((unsigned)(B * N)), dim3(64), 0, st, h->large, a);
             hipLaunchKernelGGL(chain_sens_riccati_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
             hipLaunchKernelGGL(chain_sens_mix_kernel<M>, blocks((long)B * N * M::NU), dim3(256), 0, st, h->large, a);
         }
