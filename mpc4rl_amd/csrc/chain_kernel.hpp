@@ -188,6 +188,34 @@ MPCRL_DI void staged_loop(int n, Fetch &&fetch, Body &&body) {
     });
 }
 
+// Element-wise pass over n workspace entries, lane-strided, in batches of CH: the loads of a whole batch are issued before any of
+// its results is stored.  Written as a plain `for (e = lane; e < n; e += 64)` such a pass is one global-memory round trip (1-2 us)
+// per iteration: the arrays of the workspace hang off one base pointer, so every store may alias the next load and the compiler
+// keeps them in program order.  load(e) returns the operands of entry e (entries past n re-read the last one), body(e, v) stores.
+template <int CH, class Load, class Body>
+MPCRL_DI void batched_pass(int n, int lane, Load &&load, Body &&body) {
+    for (int base = lane; base < n; base += 64 * CH) {
+        decltype(load(0)) v[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int e = base + 64 * c;
+            v[c] = load(e < n ? e : n - 1);
+        }
+        MPCRL_SCHED_FENCE();
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int e = base + 64 * c;
+            if (e < n) body(e, v[c]);
+        }
+    }
+}
+struct Pair2 {
+    double a, b;
+};
+struct Quad4 {
+    double a, b, c, d;
+};
+
 // tile shapes of the two stage GEMMs: one tile per lane, at most 64 tiles
 template <class M>
 struct ChainCfg {
@@ -197,6 +225,8 @@ struct ChainCfg {
     static constexpr int TS = NX <= 9 ? 2 : (NX <= 21 ? 3 : 4);   // M = [B A]' T  : TS x TS outputs per lane, lower-triangular tile grid
     static constexpr int NTR = (NX + TI - 1) / TI, NTC = (NW + TJ - 1) / TJ, NMT = (NW + TS - 1) / TS;
     static constexpr int NTT = NTR * NTC, NMM = NMT * (NMT + 1) / 2;
+    // the stage GEMMs on the matrix cores: 16-wide tiles of the [u; x] index (NT16 per side), of the state index (NTX), k-steps of 4
+    static constexpr int NT16 = (NW + 15) / 16, NTX = (NX + 15) / 16, KS = (NX + 3) / 4;
     static_assert(NTT <= 64 && NMM <= 64, "one GEMM tile per lane");
     static_assert(NW % TJ == 0 && NW % TS == 0, "column tiles are full");
     static constexpr int NBA2 = (NX * NW / 2 + 63) / 64;    // 16-byte pieces per lane of one [B A] block
@@ -229,52 +259,67 @@ struct ChainCfg {
 };
 
 // Hessian source of the Riccati factorisation: the SQP uses c_k * (Q, R) from the parameter vector — constant per lane, kept in
-// registers; the sensitivities use the exact Lagrangian Hessian blocks the kernel wrote to the workspace (one tile per stage).
+// registers; the sensitivities use the exact Lagrangian Hessian blocks the kernel wrote to the workspace (read one stage ahead).
+// Both hand out the lower-triangular 16 x 16 tiles of the [u; x] Hessian in the RESULT layout of v_mfma_f64_16x16x4 (register r of
+// tile (tm, tj) at lane l = entry (16 tm + 4 r + l / 16, 16 tj + l % 16)), which is what the M = H + D + [B A]' T accumulators start from.
 template <class M>
 struct HessConst {
     using Cfg = ChainCfg<M>;
-    double h[Cfg::TS][Cfg::TS];     // unscaled, this lane's tile of the [u; x] Hessian
+    static constexpr int NW = Cfg::NW, NT16 = Cfg::NT16, NLT = NT16 * (NT16 + 1) / 2;
+    double h[NLT][4];     // unscaled, this lane's entries of the lower tiles
     const double *th;
     const double *sck;
-    MPCRL_DI void begin(int i0, int j0, bool live) {
+    MPCRL_DI void begin(int lane) {
+        const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
-        for (int a = 0; a < Cfg::TS; ++a)
+        for (int tm = 0; tm < NT16; ++tm)
 #pragma unroll
-            for (int b = 0; b < Cfg::TS; ++b) h[a][b] = live ? M::hess(false, i0 + a, j0 + b, th) : 0.0;
+            for (int tj = 0; tj <= tm; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * tm + 4 * r + lr, j = 16 * tj + lc;
+                    h[tm * (tm + 1) / 2 + tj][r] = (i < NW && j < NW) ? M::hess(false, i < NW ? i : 0, j < NW ? j : 0, th) : 0.0;
+                }
     }
     template <class S_>
     MPCRL_DI void rebind(const S_ &S) { th = S.th, sck = S.sCK(); }
     MPCRL_DI void prefetch(int) {}
     MPCRL_DI void advance(int) {}
-    MPCRL_DI double tile(int k, int a, int b) const { return sck[k] * h[a][b]; }
+    MPCRL_DI double tile(int k, int t, int r) const { return sck[k] * h[t][r]; }
     MPCRL_DI double term(int N, int i, int j) const { return sck[N] * M::Qs(th, i, j); }
 };
 template <class M>
 struct HessGlobal {
     using Cfg = ChainCfg<M>;
-    static constexpr int NW = Cfg::NW, NU = Cfg::NU;
+    static constexpr int NW = Cfg::NW, NU = Cfg::NU, NT16 = Cfg::NT16, NLT = NT16 * (NT16 + 1) / 2;
     WsArr Hex;                      // [(N+1), NW, NW]
-    int i0, j0;
-    bool live;
-    double hn[Cfg::TS][Cfg::TS], hc[Cfg::TS][Cfg::TS];
-    MPCRL_DI void begin(int i0_, int j0_, bool live_) { i0 = i0_, j0 = j0_, live = live_; }
+    int lr, lc;
+    double hn[NLT][4], hc[NLT][4];
+    MPCRL_DI void begin(int lane) { lr = lane >> 4, lc = lane & 15; }
     template <class S_>
     MPCRL_DI void rebind(const S_ &S) { S.uni(Hex); }
     MPCRL_DI void prefetch(int k) {
 #pragma unroll
-        for (int a = 0; a < Cfg::TS; ++a)
+        for (int tm = 0; tm < NT16; ++tm)
 #pragma unroll
-            for (int b = 0; b < Cfg::TS; ++b) hn[a][b] = live ? Hex[k * NW * NW + (i0 + a) * NW + j0 + b] : 0.0;
+            for (int tj = 0; tj <= tm; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * tm + 4 * r + lr, j = 16 * tj + lc;
+                    const bool in = i < NW && j < NW;
+                    const double v = Hex[k * NW * NW + (in ? i * NW + j : 0)];      // rows of 16 lanes: 128-byte segments
+                    hn[tm * (tm + 1) / 2 + tj][r] = in ? v : 0.0;
+                }
     }
-    // the tile of stage k becomes current; the tile of stage k - 1 is requested (one stage ahead, independent of the operand ring)
+    // the tiles of stage k become current; those of stage k - 1 are requested (one stage ahead, independent of the operand ring)
     MPCRL_DI void advance(int k) {
 #pragma unroll
-        for (int a = 0; a < Cfg::TS; ++a)
+        for (int t = 0; t < NLT; ++t)
 #pragma unroll
-            for (int b = 0; b < Cfg::TS; ++b) hc[a][b] = hn[a][b];
+            for (int r = 0; r < 4; ++r) hc[t][r] = hn[t][r];
         if (k > 0) prefetch(k - 1);
     }
-    MPCRL_DI double tile(int, int a, int b) const { return hc[a][b]; }
+    MPCRL_DI double tile(int, int t, int r) const { return hc[t][r]; }
     MPCRL_DI double term(int N, int i, int j) const { return Hex[N * NW * NW + (NU + i) * NW + NU + j]; }
 };
 
@@ -465,11 +510,11 @@ struct ChainSolver {
         const int ne = (N + 1) * NW;
         double *lQ = lds + Cfg::oQ, *lX = lds + Cfg::oX, *lU = lds + Cfg::oU;
         for (int e = lane; e < NX * NX; e += NT) lQ[e] = M::Qs(th, e / NX, e % NX);
-        for (int e = lane; e < (N + 1) * NX; e += NT) lX[e] = X[e] - xs[e % NX];
-        for (int e = lane; e < N * NU; e += NT) lU[e] = U[e];
+        batched_pass<8>((N + 1) * NX, lane, [&](int e) { return X[e]; }, [&](int e, double v) { lX[e] = v - xs[e % NX]; });
+        batched_pass<2>(N * NU, lane, [&](int e) { return U[e]; }, [&](int e, double v) { lU[e] = v; });
         wave_sync();
         double val = 0.0;
-        for (int e = lane; e < ne; e += NT) {
+        batched_pass<4>(ne, lane, [&](int e) { return Pair2{lam[e], lam[ne + e]}; }, [&](int e, const Pair2 &lm) {
             const int k = e / NW, i = e - k * NW;
             const bool term = k == N;
             double a = 0.0, v = 0.0;
@@ -489,11 +534,11 @@ struct ChainSolver {
             val = fma(0.5 * qe, v, val);
             double g = qe;
             if (!skipc(k, i)) {
-                if (has(0, k, i)) g -= lam[e];
-                if (has(1, k, i)) g += lam[ne + e];
+                if (has(0, k, i)) g -= lm.a;
+                if (has(1, k, i)) g += lm.b;
             }
             rg[e] = g;   // q -+ lam: the stage pass below adds the multiplier terms of the dynamics
-        }
+        });
         wave_sync();
         double rs = 0, re = 0, ri = 0, rc = 0;
         {
@@ -540,7 +585,7 @@ struct ChainSolver {
                 ri = fmax(ri, h), rc = fmax(rc, fabs(lam[ne + e] * h));
             }
         }
-        for (int e = lane; e < N * NX; e += NT) re = fmax(re, fabs(r[e]));
+        batched_pass<8>(N * NX, lane, [&](int e) { return r[e]; }, [&](int, double v) { re = fmax(re, fabs(v)); });
         if (lane < NX) re = fmax(re, fabs(X[lane] - x0[lane]));
         if (qmode && lane < NU) re = fmax(re, fabs(U[lane] - u0f[lane]));
         res[0] = wave_max(rs), res[1] = wave_max(re), res[2] = wave_max(ri), res[3] = wave_max(rc);
@@ -554,15 +599,16 @@ struct ChainSolver {
         const int ne = (N + 1) * NW;
         double *lQ = lds + Cfg::oQ, *lBA = sBA(), *ldv = sG(), *lnu = sBB();
         for (int e = lane; e < NX * NX; e += NT) lQ[e] = M::Qs(th, e / NX, e % NX);
-        for (int e = lane; e < ne; e += NT) {
-            const int k = e / NW, i = e - k * NW;
-            double g = q[e];
-            if (!skipc(k, i)) {
-                if (has(0, k, i)) g -= lam[e];
-                if (has(1, k, i)) g += lam[ne + e];
-            }
-            rg[e] = g;
-        }
+        batched_pass<4>(ne, lane, [&](int e) { return Quad4{q[e], lam[e], lam[ne + e], 0.0}; },
+                        [&](int e, const Quad4 &v) {
+                            const int k = e / NW, i = e - k * NW;
+                            double g = v.a;
+                            if (!skipc(k, i)) {
+                                if (has(0, k, i)) g -= v.b;
+                                if (has(1, k, i)) g += v.c;
+                            }
+                            rg[e] = g;
+                        });
         double Rrow[NU];
 #pragma unroll
         for (int j = 0; j < NU; ++j) Rrow[j] = lane < NU ? M::Rs(th, lane < NU ? lane : 0, j) : 0.0;
@@ -643,7 +689,7 @@ struct ChainSolver {
     // Leaves in the workspace: P_k, p_k, K_k, L_k, kff_k, Acl_k = A_k - B_k K_k, hb_k = P_{k+1} b_k.
     template <class HS>
     MPCRL_DI bool factor(HS &hs, const WsArr g, const WsArr bb) {
-        hs.begin(m_i0, m_j0, m_live);
+        hs.begin(lane);
         bool ok = true;
         double *const lP = sP(), *const lBA = sBA(), *const lT = sT(), *const lM = sM();
         constexpr int AST = Cfg::AST, FD = Cfg::FDEPTH;
@@ -662,9 +708,6 @@ struct ChainSolver {
         d2_t nB[FD][Cfg::NBA2];
         double ng[FD], nbb[FD], nDg[FD];
         const int lj = lane < NW ? lane : 0, lx = lane < NX ? lane : 0;
-        int ia[TI];
-#pragma unroll
-        for (int a = 0; a < TI; ++a) ia[a] = t_i0 + a < NX ? t_i0 + a : NX - 1;
         hs.prefetch(N - 1);   // the Hessian source keeps one stage ahead itself (HessGlobal::advance)
         staged_loop<FD>(
             N,
@@ -686,119 +729,88 @@ struct ChainSolver {
                 hs.advance(k);
                 refill();
                 wave_sync();
-                // ---- T = P [B A]  (TI x TJ tile per lane; P symmetric: row m of P is column m) and cc = p + P b
+                // ---- T = P [B A] and M = H + D + [B A]' T on the matrix cores (v_mfma_f64_16x16x4; operand / result layouts measured,
+                // profiles/microbench/mfma_f64_16x16x4_probe.hip: A(i, k) and B(k, j) both sit at lane 16 k + (i | j), result register r
+                // of a tile holds (4 r + lane / 16, lane % 16)).  Per k-step of 4 rows one LDS read per tile brings
+                //   pa = P[4 ks + lane / 16][16 ti + lane % 16]    A operand of T (P is symmetric: read along its rows, conflict-free)
+                //   bb = [B A][4 ks + lane / 16][16 tj + lane % 16]  B operand of T — and, unchanged, the A operand [B A]' of M;
+                // T comes out in the result layout, whose register r IS the B operand of k-step r of the next product, so T never
+                // touches LDS.  (The register-tiled VALU version read TI + TJ operands out of LDS per 12 FMAs and ran at a fifth of the
+                // FMA issue rate; fp64 MFMA has the same peak as the vector ALU, the gain is the operand traffic.)
                 {
-                    double acc[TI][TJ];
+                    typedef double d4_t __attribute__((ext_vector_type(4)));
+                    constexpr int NT16 = Cfg::NT16, NTX = Cfg::NTX, KS = Cfg::KS;
+                    const int lr = lane >> 4, lc = lane & 15;
+                    double pa[NTX][KS], bb_[NT16][KS];
 #pragma unroll
-                    for (int a = 0; a < TI; ++a)
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const int kr = 4 * ks + lr;
+                        const bool krow = kr < NX;
 #pragma unroll
-                        for (int b = 0; b < TJ; ++b) acc[a][b] = 0.0;
-                    // groups of UNR inner indices, double-buffered: the operands of the next group are requested before the
-                    // arithmetic of the current one starts (LDS returns in order, so waiting for one group leaves the next in flight)
-                    constexpr int UNR = Cfg::UNR, NG = NX / UNR;
-                    static_assert(NG * UNR == NX, "NX = groups x UNR");
-                    double pa[2][UNR][TI], bv[2][UNR][TJ];
-                    auto ldg = [&](int g_, auto bi) {
-                        constexpr int b_ = decltype(bi)::value;
-#pragma unroll
-                        for (int u = 0; u < UNR; ++u) {
-#pragma unroll
-                            for (int a = 0; a < TI; ++a) pa[b_][u][a] = lP[(g_ * UNR + u) * NX + ia[a]];
-#pragma unroll
-                            for (int b = 0; b < TJ; ++b) bv[b_][u][b] = lBA[(g_ * UNR + u) * NW + t_j0 + b];
+                        for (int ti = 0; ti < NTX; ++ti) {
+                            const int c = 16 * ti + lc;
+                            const double v = lP[(krow ? kr : 0) * NX + (c < NX ? c : 0)];
+                            pa[ti][ks] = (krow && c < NX) ? v : 0.0;
                         }
-                    };
-                    auto mac = [&](auto bi) {
-                        constexpr int b_ = decltype(bi)::value;
-                        MPCRL_SCHED_FENCE();
 #pragma unroll
-                        for (int u = 0; u < UNR; ++u)
-#pragma unroll
-                            for (int a = 0; a < TI; ++a)
-#pragma unroll
-                                for (int b = 0; b < TJ; ++b) acc[a][b] = fma(pa[b_][u][a], bv[b_][u][b], acc[a][b]);
-                        MPCRL_SCHED_FENCE();
-                    };
-                    const std::integral_constant<int, 0> B0{};
-                    const std::integral_constant<int, 1> B1{};
-                    ldg(0, B0);
-                    for (int g_ = 0; g_ + 1 < NG; g_ += 2) {
-                        ldg(g_ + 1, B1);
-                        mac(B0);
-                        ldg(g_ + 2 < NG ? g_ + 2 : NG - 1, B0);   // past the end: re-request the last group (no branch)
-                        mac(B1);
+                        for (int tj = 0; tj < NT16; ++tj) {
+                            const int c = 16 * tj + lc;
+                            const double v = lBA[(krow ? kr : 0) * NW + (c < NW ? c : 0)];
+                            bb_[tj][ks] = (krow && c < NW) ? v : 0.0;
+                        }
                     }
-                    if constexpr (NG % 2 == 1) mac(B0);
-                    const double a = lds_dot<NX>(lP + lx * NX, 1, sBB(), 0.0);
-                    if (t_live) {
+                    const double a = lds_dot<NX>(lP + lx * NX, 1, sBB(), 0.0);      // (P b)_lane, before M overwrites P
+                    MPCRL_SCHED_FENCE();
+                    d4_t Tt[NTX][NT16];
 #pragma unroll
-                        for (int a_ = 0; a_ < TI; ++a_)
-                            if (t_i0 + a_ < NX) {
+                    for (int ti = 0; ti < NTX; ++ti)
 #pragma unroll
-                                for (int b = 0; b < TJ; ++b) lT[(t_i0 + a_) * NW + t_j0 + b] = acc[a_][b];
-                            }
-                    }
+                        for (int tj = 0; tj < NT16; ++tj) {
+                            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ti][ks], bb_[tj][ks], acc, 0, 0, 0);
+                            Tt[ti][tj] = acc;
+                        }
                     if (lane < NX) {
                         sCC()[lane] = sPV()[lane] + a;
                         hb[k * NX + lane] = a;
                     }
-                }
-                wave_sync();
-                ph(10);
-                // ---- M = H + D + [B A]' T (lower-triangular tile grid, mirrored) and mv = g + [B A]' cc
-                {
-                    double acc[TS][TS];
+                    ph(10);
+                    d4_t Mt[NT16 * (NT16 + 1) / 2];
 #pragma unroll
-                    for (int a = 0; a < TS; ++a)
+                    for (int tm = 0; tm < NT16; ++tm)
 #pragma unroll
-                        for (int b = 0; b < TS; ++b) acc[a][b] = hs.tile(k, a, b) + ((m_diag && a == b) ? sDG()[m_i0 + a] : 0.0);
-                    constexpr int UNR = Cfg::UNR, NG = NX / UNR;
-                    double av[2][UNR][TS], tv[2][UNR][TS];
-                    auto ldg = [&](int g_, auto bi) {
-                        constexpr int b_ = decltype(bi)::value;
+                        for (int tj = 0; tj <= tm; ++tj) {
+                            const int t_ = tm * (tm + 1) / 2 + tj;
+                            d4_t acc;
 #pragma unroll
-                        for (int u = 0; u < UNR; ++u) {
-#pragma unroll
-                            for (int a = 0; a < TS; ++a) av[b_][u][a] = lBA[(g_ * UNR + u) * NW + m_i0 + a];
-#pragma unroll
-                            for (int b = 0; b < TS; ++b) tv[b_][u][b] = lT[(g_ * UNR + u) * NW + m_j0 + b];
-                        }
-                    };
-                    auto mac = [&](auto bi) {
-                        constexpr int b_ = decltype(bi)::value;
-                        MPCRL_SCHED_FENCE();
-#pragma unroll
-                        for (int u = 0; u < UNR; ++u)
-#pragma unroll
-                            for (int a = 0; a < TS; ++a)
-#pragma unroll
-                                for (int b = 0; b < TS; ++b) acc[a][b] = fma(av[b_][u][a], tv[b_][u][b], acc[a][b]);
-                        MPCRL_SCHED_FENCE();
-                    };
-                    const std::integral_constant<int, 0> B0{};
-                    const std::integral_constant<int, 1> B1{};
-                    ldg(0, B0);
-                    for (int g_ = 0; g_ + 1 < NG; g_ += 2) {
-                        ldg(g_ + 1, B1);
-                        mac(B0);
-                        ldg(g_ + 2 < NG ? g_ + 2 : NG - 1, B0);   // past the end: re-request the last group (no branch)
-                        mac(B1);
-                    }
-                    if constexpr (NG % 2 == 1) mac(B0);
-                    const double a = lds_dot<NX>(lBA + lj, NW, sCC(), sG()[lj]);
-                    // M overwrites P_{k+1} (same LDS region): every lane is past its reads of P here (T and cc are complete)
-                    wave_sync();
-                    if (m_live) {
-#pragma unroll
-                        for (int a_ = 0; a_ < TS; ++a_)
-#pragma unroll
-                            for (int b = 0; b < TS; ++b) {
-                                if (m_diag && b > a_) continue;   // the diagonal tile keeps its lower triangle, mirrored like the rest
-                                lM[(m_i0 + a_) * NW + m_j0 + b] = acc[a_][b];
-                                lM[(m_j0 + b) * NW + m_i0 + a_] = acc[a_][b];
+                            for (int r = 0; r < 4; ++r) {
+                                const int i = 16 * tm + 4 * r + lr;
+                                acc[r] = hs.tile(k, t_, r) + ((tm == tj && i == 16 * tj + lc && i < NW) ? sDG()[i < NW ? i : 0] : 0.0);
                             }
-                    }
-                    if (lane < NW) sMV()[lane] = a;
+#pragma unroll
+                            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bb_[tm][ks], Tt[ks / 4][tj][ks % 4], acc, 0, 0, 0);
+                            Mt[t_] = acc;
+                        }
+                    wave_sync();                                                      // cc is complete
+                    const double mv_l = lds_dot<NX>(lBA + lj, NW, sCC(), sG()[lj]);   // mv = g + [B A]' cc
+                    // M overwrites P_{k+1} (same LDS region): every lane is past its reads of P (operands and P b are in registers).
+                    // Lower triangle, mirrored: exactly symmetric.
+                    wave_sync();
+#pragma unroll
+                    for (int tm = 0; tm < NT16; ++tm)
+#pragma unroll
+                        for (int tj = 0; tj <= tm; ++tj)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int i = 16 * tm + 4 * r + lr, j = 16 * tj + lc;
+                                if (i < NW && j <= i) {
+                                    const double v = Mt[tm * (tm + 1) / 2 + tj][r];
+                                    lM[i * NW + j] = v;
+                                    lM[j * NW + i] = v;
+                                }
+                            }
+                    if (lane < NW) sMV()[lane] = mv_l;
                 }
                 wave_sync();
                 ph(11);
@@ -1137,10 +1149,11 @@ struct ChainSolver {
             bool fail = false;
             for (int pass = 0; pass < 2; ++pass) {
                 // barrier diagonal + modified gradient: rt = rg everywhere, corrected on the bounded rows
-                for (int e = lane; e < ne; e += NT) {
-                    rt[e] = rg[e];
-                    if (pass == 0) Dg[e] = 0.0;
-                }
+                batched_pass<8>(ne, lane, [&](int e) { return rg[e]; },
+                                [&](int e, double v) {
+                                    rt[e] = v;
+                                    if (pass == 0) Dg[e] = 0.0;
+                                });
                 wave_sync();
                 for (int r_ = lane; r_ < nrows; r_ += NT) {
                     int k, i;
@@ -1233,8 +1246,10 @@ struct ChainSolver {
                     }
             }
             wave_sync();
-            for (int e = lane; e < (N + 1) * NX; e += NT) dx[e] = fma(alpha, Dx[e], dx[e]), nuq[e] = fma(alpha, Dnu[e], nuq[e]);
-            for (int e = lane; e < N * NU; e += NT) du[e] = fma(alpha, Du[e], du[e]);
+            batched_pass<4>((N + 1) * NX, lane, [&](int e) { return Quad4{Dx[e], dx[e], Dnu[e], nuq[e]}; },
+                            [&](int e, const Quad4 &v) { dx[e] = fma(alpha, v.a, v.b), nuq[e] = fma(alpha, v.c, v.d); });
+            batched_pass<2>(N * NU, lane, [&](int e) { return Pair2{Du[e], du[e]}; },
+                            [&](int e, const Pair2 &v) { du[e] = fma(alpha, v.a, v.b); });
             wave_sync();
         }
         return ok;
@@ -1501,11 +1516,11 @@ __global__ void __launch_bounds__(64, 1) chain_qp_kernel(const LargeSpec sp, con
             status = 4;
         else {
             double sl = 0.0;
-            for (int e = lane; e < (N + 1) * NX; e += NT) sl = fmax(sl, fabs(S.dx[e]));
-            for (int e = lane; e < N * NU; e += NT) sl = fmax(sl, fabs(S.du[e]));
+            batched_pass<4>((N + 1) * NX, lane, [&](int e) { return Quad4{S.dx[e], S.X[e], S.nuq[e], 0.0}; },
+                            [&](int e, const Quad4 &v) { sl = fmax(sl, fabs(v.a)), S.X[e] = v.b + v.a, S.NUv[e] = v.c; });
+            batched_pass<2>(N * NU, lane, [&](int e) { return Pair2{S.du[e], S.U[e]}; },
+                            [&](int e, const Pair2 &v) { sl = fmax(sl, fabs(v.a)), S.U[e] = v.b + v.a; });
             sl = wave_max(sl);
-            for (int e = lane; e < (N + 1) * NX; e += NT) S.X[e] += S.dx[e], S.NUv[e] = S.nuq[e];
-            for (int e = lane; e < N * NU; e += NT) S.U[e] += S.du[e];
             if (lane == 0) S.state[ST_IT] = it + 1, S.state[ST_NIPM] = n_ipm, S.state[ST_TIGHT] = tight ? 1.0 : 0.0, S.state[ST_STEPN] = sl;
             S.ph(14);
             S.ph_flush();
