@@ -251,10 +251,11 @@ struct ChainCfg {
     static constexpr int oP = oBig, oM = oBig, oBA = oBig + NW * NW, oT = oBA + NX * NW;
     // vector sweeps: Acl_k where P / M sit, P_k where [B A] sits; residual passes: Q where P / M sit, [B A] in place;
     // start of an SQP round: Q, then X - x_ss and U of the whole horizon (up to 64 stages)
-    static constexpr int oA = oBig, oPk = oBig + BST, oQ = oBig, oX = oBig + NW * NW, oU = oX + 64 * NX;
+    static constexpr int ASP = ev(NX * (NW + 1)) + 2;         // [B A]-shaped block published with the odd row stride NW + 1 (+ a dump slot)
+    static constexpr int oA = oBig, oPk = oBig + (BST > ASP ? BST : ASP), oQ = oBig, oX = oBig + NW * NW, oU = oX + 64 * NX;
     static constexpr int BIG_F = NW * NW + 2 * NX * NW, BIG_R = NW * NW + 64 * NW;
     static constexpr int LDS_TOTAL = oBig + (BIG_F > BIG_R ? BIG_F : BIG_R);
-    static_assert(oBig % 2 == 0 && BST + AST <= BIG_F && NX * NX <= NW * NW, "aligned / overlays fit");
+    static_assert(oBig % 2 == 0 && (BST > ASP ? BST : ASP) + AST <= BIG_F && NX * NX <= NW * NW, "aligned / overlays fit");
     static_assert(LDS_TOTAL * 8 <= 40 * 1024, "four wavefronts per CU");
 };
 
@@ -839,7 +840,7 @@ struct ChainSolver {
                     double y[NU], z[NU];
 #pragma unroll
                     for (int i = 0; i < NU; ++i) {
-                        double a = j < NX ? lM[(NU + j) * NW + i] : sMV()[i];
+                        double a = j < NX ? lM[i * NW + NU + j] : sMV()[i];   // S(i, j) read along row i of the (exactly symmetric) M: conflict-free
 #pragma unroll
                         for (int m = 0; m < i; ++m) a -= Lc[i][m] * y[m];
                         y[i] = a * Lc[i][i];
@@ -875,35 +876,36 @@ struct ChainSolver {
                 }
                 wave_sync();
                 ph(12);
-                // ---- P_k = Q - S' K, p_k = mv_x - K' mv_u, Acl = A - B K: lane i takes row i (own-row base + immediate offsets, no
-                // per-element address arithmetic to keep live).  P_k is written lower + mirrored into T (exactly symmetric), Acl
-                // replaces A in this lane's own row of [B A]; both blocks then leave for HBM as 16-byte coalesced copies.
+                // ---- P_k = Q - S' K, p_k = mv_x - K' mv_u, Acl = A - B K: lane j takes COLUMN j — the lanes of a group then read
+                // consecutive LDS words (row-per-lane with the even row stride NW put a whole lane group on four banks), S(., i) and
+                // B(i, .) are wave-uniform reads, K(., j) sits in three registers.  P_k is written lower + mirrored into T (exactly
+                // symmetric), Acl replaces A inside [B A]; both blocks then leave for HBM as 16-byte coalesced copies.
                 {
                     const double *lK = sK();
-                    const double *mrow = lM + (NU + lx) * NW, *brow = lBA + lx * NW;
-                    double Si[NU], Bi[NU];
+                    double Kj[NU];
 #pragma unroll
-                    for (int m = 0; m < NU; ++m) Si[m] = mrow[m], Bi[m] = brow[m];
-                    constexpr int JC = NX % 7 == 0 ? 7 : 3;
-                    static_assert(NX % JC == 0, "column chunks");
-                    for (int j0 = 0; j0 < NX; j0 += JC) {
-                        double mv_[JC], av_[JC], kk[NU][JC];
+                    for (int m = 0; m < NU; ++m) Kj[m] = lK[m * NX + lx];
+                    constexpr int IC = NX % 7 == 0 ? 7 : 3;
+                    static_assert(NX % IC == 0, "row chunks");
+                    for (int i0 = 0; i0 < NX; i0 += IC) {
+                        double mq[IC], aq[IC], si[IC][NU], bi[IC][NU];
 #pragma unroll
-                        for (int jj = 0; jj < JC; ++jj) {
-                            mv_[jj] = mrow[NU + j0 + jj], av_[jj] = brow[NU + j0 + jj];
+                        for (int ii = 0; ii < IC; ++ii) {
+                            const int i = i0 + ii;
+                            mq[ii] = lM[(NU + i) * NW + NU + lx], aq[ii] = lBA[i * NW + NU + lx];
 #pragma unroll
-                            for (int m = 0; m < NU; ++m) kk[m][jj] = lK[m * NX + j0 + jj];
+                            for (int m = 0; m < NU; ++m) si[ii][m] = lM[m * NW + NU + i], bi[ii][m] = lBA[i * NW + m];
                         }
                         MPCRL_SCHED_FENCE();
 #pragma unroll
-                        for (int jj = 0; jj < JC; ++jj) {
-                            double a = mv_[jj], c = av_[jj];
+                        for (int ii = 0; ii < IC; ++ii) {
+                            const int i = i0 + ii;
+                            double a = mq[ii], c = aq[ii];
 #pragma unroll
-                            for (int m = 0; m < NU; ++m) a -= Si[m] * kk[m][jj], c -= Bi[m] * kk[m][jj];
-                            const int j = j0 + jj;
+                            for (int m = 0; m < NU; ++m) a -= si[ii][m] * Kj[m], c -= bi[ii][m] * Kj[m];
                             if (lane < NX) {
-                                if (j <= lane) lT[lane * NX + j] = a, lT[j * NX + lane] = a;
-                                lBA[lane * NW + NU + j] = c;
+                                if (i >= lane) lT[i * NX + lane] = a, lT[lane * NX + i] = a;
+                                lBA[i * NW + NU + lane] = c;
                             }
                         }
                     }
@@ -1026,6 +1028,17 @@ struct ChainSolver {
         d2_t nA[D][Cfg::NBA2], nP[D][Cfg::NAC2];
         double nbb[D], npv[D], nkf[D][NU];
         double *lA = sA(), *lPk = sPk(), *lv = sSV(0);
+        // Lane i takes ROW i of Acl_k here: with the block's own row stride NW (even) a whole lane group would sit on four LDS banks
+        // (16-way conflicts on every operand read), so the block is published with the odd stride NW + 1 (as in qp_residuals).
+        constexpr int NWP = NW + 1;
+        int pdst[Cfg::NBA2][2];
+#pragma unroll
+        for (int s_ = 0; s_ < Cfg::NBA2; ++s_)
+#pragma unroll
+            for (int h_ = 0; h_ < 2; ++h_) {
+                const int e = 2 * (lane + 64 * s_) + h_;
+                pdst[s_][h_] = e < NX * NW ? (e / NW) * NWP + e % NW : NX * NWP + (e & 1);   // past the block: a dump slot
+            }
         // stage k: dx_{k+1} = Acl_k dx_k + (b_k - B_k kff_k)  (B_k sits beside Acl_k in the staged block);
         // with want_nu also the multiplier step of stage k, Dnu_k = p_k + P_k dx_k (k >= 1)
         staged_loop<D>(
@@ -1044,7 +1057,8 @@ struct ChainSolver {
             [&](int k, auto sl, auto refill) {
                 constexpr int d = decltype(sl)::value;
                 if (lane < NX) lv[lane] = xcur;
-                blk_to_lds(lA, NX * NW / 2, nA[d], lane);
+#pragma unroll
+                for (int s_ = 0; s_ < Cfg::NBA2; ++s_) lA[pdst[s_][0]] = nA[d][s_].x, lA[pdst[s_][1]] = nA[d][s_].y;
                 if (want_nu) blk_to_lds(lPk, AST / 2, nP[d], lane);
                 double a = nbb[d], b = want_nu ? npv[d] : 0.0;
                 double kf[NU];
@@ -1052,7 +1066,7 @@ struct ChainSolver {
                 for (int m = 0; m < NU; ++m) kf[m] = nkf[d][m];
                 refill();
                 wave_sync();
-                const double *row = lA + li * NW;
+                const double *row = lA + li * NWP;
 #pragma unroll
                 for (int m = 0; m < NU; ++m) a = fma(-row[m], kf[m], a);
                 a = lds_dot<NX>(row + NU, 1, lv, a);   // row li of Acl_k
