@@ -282,8 +282,9 @@ def main():
     ap.add_argument("--no-sens", action="store_true", help="forward solve only (BASELINE config 2)")
     ap.add_argument("--rti", action="store_true", help="one SQP iteration from the stored iterate (build-side mode)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--workload", default="cartpole", choices=["cartpole", "chain5", "chain7", "td3"],
-                    help="cartpole = the headline metric (default); chain5/chain7 = BASELINE config 4; td3 = config 5 (not the headline line)")
+    ap.add_argument("--workload", default="cartpole", choices=["cartpole", "linear", "chain5", "chain7", "td3"],
+                    help="cartpole = the headline metric (default); linear = the 2-state OCP of config 1 batched; chain5/chain7 = BASELINE "
+                         "config 4; td3 = config 5 (none of these is the headline line)")
     args = ap.parse_args()
     rc = maybe_spawn(args, sys.argv[1:])
     if rc is not None:
@@ -292,18 +293,24 @@ def main():
         return dryrun(args)
     if args.workload == "td3":
         return td3_bench(args)
-    if args.workload != "cartpole":
+    if args.workload in ("chain5", "chain7"):
         return chain_bench(args)
+    linear = args.workload == "linear"
 
     world, rank, local, dist, dev = init_ranks(args)
 
-    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    from mpc4rl_amd import MPCBatch, cartpole_ocp, linear_system_ocp
     from mpc4rl_amd.distributed import allreduce_weighted_grad
-    ocp = cartpole_ocp()
+    ocp = linear_system_ocp(discount_factor=0.99) if linear else cartpole_ocp()
+    n_theta = 12 if linear else N_THETA
     B = args.batch
     sens = not args.no_sens
     mpc = MPCBatch(ocp, B, device=dev)
-    x0_np = make_inputs(B, rank)
+    if linear:   # the state box of the linear-system environment (linear_system/environment.py: x in [0, 1] x [-1, 1]), interior part
+        rng = np.random.default_rng(rank)
+        x0_np = np.column_stack([rng.uniform(0.15, 0.85, B), rng.uniform(-0.5, 0.5, B)])
+    else:
+        x0_np = make_inputs(B, rank)
     x0 = torch.as_tensor(x0_np, device=dev)
 
     def step():
@@ -311,7 +318,7 @@ def main():
         r = mpc.solve(x0, sens_v=sens, sens_pi=sens, cold=not args.rti, rti=args.rti)
         if dist is not None and sens:
             # data-parallel RL update: one all-reduce of [sum_i dV_i/dtheta, sum_i V_i, count]
-            allreduce_weighted_grad(r.dV_dp[:, :N_THETA], r.V)   # K5 reduction kernel + one all_reduce of 5 doubles
+            allreduce_weighted_grad(r.dV_dp[:, :n_theta], r.V)   # K5 reduction kernel + one all_reduce of 5 doubles
         return r
 
     if args.rti:
@@ -339,23 +346,25 @@ def main():
     iters = r.iters.cpu().numpy()
     if rank == 0:
         solves = B * world * args.steps
-        bytes_per = algorithmic_bytes_per_solve(ocp.N, ocp.nx, ocp.nu, N_THETA, sens)
+        bytes_per = algorithmic_bytes_per_solve(ocp.N, ocp.nx, ocp.nu, n_theta, sens)
         achieved = bytes_per * B / (kern_ms * 1e-3) / 1e9
         # matrix-core work of the factor sweep: 7 v_mfma_f64_4x4x4 block-products (128 flop each) per stage step and instance
-        mfma_tflops = float(iters[:, 1].sum()) * ocp.N * 7 * 128 / (kern_ms * 1e-3) / 1e12
+        mfma_tflops = 0.0 if linear else float(iters[:, 1].sum()) * ocp.N * 7 * 128 / (kern_ms * 1e-3) / 1e12
         # algorithmic flops = Riccati sweeps x F_sweep, sweeps per solve = interior-point iterations (+ 1 sensitivity
         # factorisation + nu adjoint solves)
         sweeps = float(iters[:, 1].mean()) + (1 + ocp.nu if sens else 0)
         fp64_tflops = sweeps * riccati_sweep_flops(ocp.N, ocp.nx, ocp.nu) * B / (kern_ms * 1e-3) / 1e12
-        traffic, traffic_src = measured_traffic("cartpole", B, sens, args.rti)
+        traffic, traffic_src = measured_traffic(args.workload, B, sens, args.rti)
+        name = "linear system N=40 nx=2 nu=1" if linear else "cartpole N=20 nx=4 nu=1"
         out = {
-            "metric": "MPC+KKT-sens solves/sec, cartpole N=20 batch=4096" if sens else "MPC solves/sec, cartpole N=20 batch=4096",
+            "metric": ("MPC+KKT-sens solves/sec, %s batch=%d" if sens else "MPC solves/sec, %s batch=%d") % (
+                "linear_system N=40" if linear else "cartpole N=20", B),
             "value": solves / elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("cartpole N=20 nx=4 nu=1, %d instances/GPU, %s" % (
-                B, "RTI (1 SQP iteration, warm)" if args.rti else "cold-start full-step SQP to tol 1e-6")) +
-                (" + dV/dp + du0*/dp (BASELINE config 3)" if sens else " (BASELINE config 2)"),
+            "config": {"workload": ("%s, %d instances/GPU, %s" % (
+                name, B, "RTI (1 SQP iteration, warm)" if args.rti else "cold-start full-step SQP to tol 1e-6")) +
+                (" + dV/dp + du0*/dp" if sens else "") + ("" if linear else (" (BASELINE config 3)" if sens else " (BASELINE config 2)")),
                 "batch_per_gpu": B, "parallelism": f"instances sharded over {world} GPU(s)" +
                 ("; one all-reduce of the theta-gradient per step" if world > 1 and sens else ""),
                 "converged_fraction": float((status == 0).mean()), "sqp_iters_mean": float(iters[:, 0].mean()),
@@ -373,7 +382,7 @@ def main():
                                          "note": "hardware flops of the 7 v_mfma_f64_4x4x4 per factor-sweep stage step (padded 4x4x4 "
                                                  "products; vector sweeps excluded): the MFMAs of the recursion wait on each other"}},
         }
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and not linear:
             try:
                 out["cpu_baseline"] = cpu_baseline(x0_np, sens)
             except Exception as e:   # the bench line must still come out

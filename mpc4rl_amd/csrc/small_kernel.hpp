@@ -1144,8 +1144,11 @@ struct SmallSolver {
 // =====================================================================================================
 // kernel: floor(64/(N+1)) instances per 64-lane workgroup
 // =====================================================================================================
+#ifndef MPCRL_LINEAR_OCC
+#define MPCRL_LINEAR_OCC 2   // linear system (one instance per wavefront, N = 40): two wavefronts per SIMD measured faster than one
+#endif
 template <class M>
-__global__ void __launch_bounds__(64, M::DISCRETE ? 2 : 1) small_solve_kernel(const SmallSpec sp, const SmallArgs a) {
+__global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_solve_kernel(const SmallSpec sp, const SmallArgs a) {
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NP = M::NP, NTD = M::NTD, NTC = M::NTC;
     constexpr bool SOFT = M::HAS_SOFT;
     const int lane = threadIdx.x;
