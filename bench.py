@@ -214,6 +214,21 @@ def chain_bench(args):
     print(json.dumps(out), flush=True)
 
 
+class _StdoutToStderr:
+    """Sends everything written to file descriptor 1 (C libraries included) to stderr for the duration of the block: RCCL prints a
+    banner when its first communicator is created, and stdout has to carry exactly ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def init_ranks(args):
     """(world, rank, local, dist module or None, device): one process per GPU, RCCL ("nccl") when there is more than one rank."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -225,7 +240,11 @@ def init_ranks(args):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            probe = torch.zeros(1, device=torch.device("cuda", local))
+            dist.all_reduce(probe)             # creates the communicator now (and has RCCL say what it has to say)
+            torch.cuda.synchronize()
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
