@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -32,6 +33,8 @@ struct MpcrlSolver {
     int theta_stride = 0;
     double *X = nullptr, *U = nullptr, *PI = nullptr, *BND = nullptr, *RES = nullptr, *LAG = nullptr;
     int64_t bytes = 0;
+    int n_simd = 1024;          // SIMDs of the device (one resident wavefront each for the small solve kernel)
+    int slice_mode = 0;         // MPCRL_TIME_SLICE: 0 = automatic, 1 = whenever legal, -1 = never (tests, profiling)
     bool have_iterate = false;
     bool dual_cold = false;   // the stored bound multipliers are placeholders (set_iterate without bnd): next solve = MPCRL_COLD_DUAL
 };
@@ -144,9 +147,21 @@ int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
 
 template <class M>
 int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
-    const int ipw = std::min(64 / (h->N + 1), M::MAX_IPW);
+    const int lpi = h->N + 1, ipw = std::min(64 / lpi, M::MAX_IPW);
     const int blocks = (h->B + ipw - 1) / ipw;
-    hipLaunchKernelGGL(small_solve_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
+    bool sliced = false;
+    if constexpr (!M::HAS_SOFT) {
+        // Time-sliced launch (small_solve_sliced_kernel): ipw + 1 instances per wavefront, ipw of them advancing per round.  A wavefront
+        // then lives (ipw + 1) / ipw as long, so it pays when it saves more than that in rounds of wavefronts on the chip's SIMDs:
+        // 4096 cartpole instances are 2 rounds of 3-instance wavefronts or 1 round of 4-instance ones (2 vs 1.33 wave lifetimes).
+        const int ips = std::min(64 / lpi, M::MAX_IPW - 1), q = ips + 1;
+        const bool legal = ips >= 1 && 64 - ips * lpi >= 1 && (a.flags & MPCRL_COLD) && !(a.flags & MPCRL_RTI);
+        const long waves3 = (h->B + ipw - 1) / ipw, waves4 = (h->B + q - 1) / q;
+        const long rounds3 = (waves3 + h->n_simd - 1) / h->n_simd, rounds4 = (waves4 + h->n_simd - 1) / h->n_simd;
+        sliced = legal && (h->slice_mode > 0 || (h->slice_mode == 0 && rounds4 * q < rounds3 * ips));
+        if (sliced) hipLaunchKernelGGL(small_solve_sliced_kernel<M>, dim3((unsigned)waves4), dim3(64), 0, st, h->small, a);
+    }
+    if (!sliced) hipLaunchKernelGGL(small_solve_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
     HIP_OK(hipGetLastError());
     if (a.flags & (MPCRL_SENS_V | MPCRL_SENS_PI)) {
         hipLaunchKernelGGL(small_sens_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
@@ -188,6 +203,12 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
     MpcrlSolver *h = new (std::nothrow) MpcrlSolver();
     if (!h) return MPCRL_E_NOMEM;
     h->model = spec->model, h->B = batch, h->device = device, h->nx = spec->nx, h->nu = spec->nu, h->np = spec->np, h->N = spec->N;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->n_simd = 4 * cus;
+        const char *e = std::getenv("MPCRL_TIME_SLICE");
+        if (e && *e) h->slice_mode = (*e == '0') ? -1 : 1;
+    }
     int rc = 0;
     switch (spec->model) {
         case MPCRL_MODEL_CARTPOLE:

@@ -1366,6 +1366,291 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
 }
 
 // =====================================================================================================
+// time-sliced variant of the solve kernel for COLD calls: a wavefront OWNS ipw + 1 instances and has lanes for ipw of them.
+//
+// One wavefront per SIMD is all the registers allow, and a wavefront has lanes for floor(64 / (N + 1)) instances (cartpole N = 20:
+// 3), so a batch of 4096 is 1366 wavefronts on 1024 SIMDs: two wave lifetimes, the second one on a third of the chip.  Here the
+// batch is cut into ceil(B / (ipw + 1)) wavefronts (4096 -> 1024: one round) and each wavefront advances its ipw + 1 instances one
+// SQP iteration at a time, ipw of them per round: after every round one slot parks its instance (x, u, nu, lam, t go to the
+// instance's stored-iterate arrays in HBM, which they are written to at the end of a solve anyway; a dozen scalars go to LDS) and
+// takes the parked one.  All instances progress at ipw / (ipw + 1) of full speed, so the wavefront lives (ipw + 1) / ipw as long
+// and the launch takes 1.33 instead of 2 wave lifetimes.  The exchange stays inside one wavefront — its memory operations are
+// performed in order, a wavefront-scope fence is all the ordering needed (as in chain_kernel.hpp) — which is what the cross-wavefront
+// attempt of round 1 (claims by compare-and-swap) could not have.  An instance that finishes is written out at once and
+// its slot goes to the parked instance for good.  The iteration of an instance is bit-for-bit the one of small_solve_kernel.
+// =====================================================================================================
+template <class M>
+__global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSpec sp, const SmallArgs a) {
+    constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NP = M::NP, NTD = M::NTD, NTC = M::NTC;
+    static_assert(!M::HAS_SOFT, "hard bounds only");
+    const int lane = threadIdx.x;
+    const int N = sp.N, lpi = N + 1, ipw = min(64 / lpi, M::MAX_IPW - 1), q = ipw + 1;
+    const int slot = lane / lpi, k = lane - slot * lpi, base = slot * lpi;
+    const long w0 = (long)blockIdx.x * q;            // first instance (batch order) of this wavefront
+    const bool slot_on = slot < ipw;
+    // ---- binding of this lane to an instance: changes when its slot takes the parked instance
+    int loc = slot_on ? slot : ipw;                   // local index; the first lane past the slots speaks for the parked instance
+    long inst = 0;
+    bool valid = false;
+    const double *x0 = nullptr, *u0f = nullptr, *th = nullptr;
+    double *bnd = nullptr;
+    const size_t nb = (size_t)(N + 1) * NW;
+    SmallSolver<M> S(sp, k, lpi, base);
+    __shared__ __attribute__((aligned(16))) double mx_lds[SmallSolver<M>::MX ? 64 * SmallSolver<M>::MSLOT : 2];
+    __shared__ double c_lds[M::MAX_IPW * SmallSolver<M>::CTAB];
+    __shared__ double sc_lds[M::MAX_IPW * 12];        // parked scalars: live, status, iterations, interior-point iterations, ...
+    S.ms = mx_lds;
+    S.qmode = a.u0fix != nullptr;
+    auto bind = [&](int l) {
+        long i = w0 + l;
+        valid = slot_on && i < a.B;
+        if (i >= a.B) i = a.B - 1;                    // lanes without an instance shadow the last one and never store
+        if (a.perm) i = a.perm[i];
+        inst = i;
+        th = a.theta + (size_t)i * a.theta_stride;
+        x0 = a.x0 + i * NX;
+        u0f = S.qmode ? a.u0fix + i * NU : a.x0 + i * NX;
+        bnd = a.BND + (size_t)i * 10 * nb + (size_t)k * NW;
+    };
+    bind(loc);
+    const bool term = S.term, first = S.first;
+    if (sp.cost_kind == 0)
+        S.ck = term ? 1.0 : sp.dT;
+    else
+        S.ck = first ? sp.dT : (term ? pow(sp.gamma, (double)N) : pow(sp.gamma, (double)k) * sp.dT);
+    // cost tables of all ipw + 1 instances (the parked one's by the first lane past the slots, which is a stage-0 lane)
+    S.fill_cost_table(c_lds, loc, (slot_on || (slot == ipw && k == 0)) && w0 + loc < a.B, th);
+    if (!slot_on) loc = 0, bind(0);                   // from here on the lanes past the slots shadow slot 0's instance
+    SmallSolver<M>::wave_lds_sync();
+    auto load_params = [&]() {
+        S.ctab = c_lds + loc * SmallSolver<M>::CTAB + S.stage_kind() * SmallSolver<M>::CSET;
+        S.load_hc();
+#pragma unroll
+        for (int i = 0; i < NTD; ++i) S.thd[i] = th[M::td_index(i)];
+#pragma unroll
+        for (int i = 0; i < NTC; ++i) S.thc[i] = th[M::tc_index(i)];
+    };
+    load_params();
+    // ---- cold start of the resident instances (MPC.reset, mpc.py:204-210)
+#pragma unroll
+    for (int i = 0; i < NX; ++i) S.x[i] = x0[i], S.nu_[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) S.u[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) S.lam[0][i] = S.lam[1][i] = 0.0, S.t[0][i] = S.t[1][i] = 1.0, S.aff[0][i] = S.aff[1][i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < S.NPK; ++i) S.P[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) S.p[i] = 0.0, S.dx[i] = 0.0, S.nuq[i] = 0.0, S.Dx[i] = 0.0, S.Dnu[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) S.du[i] = 0.0, S.Du[i] = 0.0, S.kff[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NU * NX; ++i) S.K[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < S.NLK; ++i) S.Li[i] = 0.0;
+    const int max_iter = sp.max_iter;
+    // per-instance scalars of the resident instance (uniform over the lanes of a slot)
+    bool live = valid, last_tight = true;
+    int status = 2, iti = 0, n_ipm = 0;
+    double stepn = -1.0;
+    // the parked instance (wave-uniform): local index or -1, and whether it has run at all
+    int pk = (w0 + ipw < a.B) ? ipw : -1;
+    bool pk_started = false;
+    int rr = 0;
+    double nun[NX];
+    for (;;) {
+        double xn[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xn[i] = lane_dn(S.x[i]), nun[i] = lane_dn(S.nu_[i]);
+        const double cl = S.linearize(xn);
+        double rl[4];
+        S.nlp_res_local(nun, x0, u0f, rl);
+        double res[4] = {rl[0], rl[1], rl[2], rl[3]}, cost = cl;
+        seg_reduce<4, 1>(res, &cost, k, lpi, base);
+        const double rmax = fmax(fmax(res[0], res[1]), fmax(res[2], res[3]));
+        bool fin_now = false;
+        if (live) {
+            if (!(rmax < 1e300))
+                status = 1, live = false;
+            else if (rmax < sp.tol && last_tight)
+                status = 0, live = false;
+            else if (iti >= max_iter)
+                status = rmax < sp.tol ? 0 : 2, live = false;
+            fin_now = !live;
+        }
+        if (__any(fin_now)) {   // ---- results + iterate of the instances that finish here (wave-uniform branch: the reduction inside is safe)
+            double lag = 0.0;
+            if (a.LAG) {
+                if (!term) {
+#pragma unroll
+                    for (int m = 0; m < NX; ++m) lag = fma(nun[m], S.r[m], lag);
+                }
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    if (term && i < NU) continue;
+#pragma unroll
+                    for (int sd = 0; sd < 2; ++sd)
+                        if (S.has(sd, i)) lag = fma(-S.lam[sd][i], S.bslack(sd, i, S.vc(i)), lag);
+                }
+                lag = seg_sum(lag, k, lpi, base);
+            }
+            if (fin_now && valid) {
+                if (first) {
+                    if (a.LAG) a.LAG[inst] = cost + lag;
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) a.u0_out[inst * NU + i] = S.u[i];
+                    a.V[inst] = cost;
+                    a.status[inst] = status;
+                    if (a.iters) a.iters[inst * 2] = iti, a.iters[inst * 2 + 1] = n_ipm;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a.RES[inst * 4 + j] = res[j];
+                }
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    a.X[(inst * (N + 1) + k) * NX + i] = S.x[i];
+                    if (!first) a.PI[(inst * N + k - 1) * NX + i] = S.nu_[i];
+                }
+                if (!term) {
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) a.U[(inst * N + k) * NU + i] = S.u[i];
+                }
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    bnd[0 * nb + i] = S.has(0, i) ? S.lam[0][i] : 0.0, bnd[1 * nb + i] = S.has(1, i) ? S.lam[1][i] : 0.0;
+                    bnd[2 * nb + i] = S.has(0, i) ? S.t[0][i] : 1.0, bnd[3 * nb + i] = S.has(1, i) ? S.t[1][i] : 1.0;
+                }
+            }
+        }
+        const double rr_ = fmin(1.0, rmax), ad_ = rmax < sp.tol ? 0.0 : IPM_ADAPT_C * rr_ * rr_;
+        const double tol_res = fmin(IPM_ADAPT_CAP, fmax(IPM_TOL_RES, ad_)), tol_mu = fmin(0.1 * IPM_ADAPT_CAP, fmax(IPM_TOL_MU, 1e-2 * ad_));
+        if (live) last_tight = tol_res <= IPM_TOL_RES && tol_mu <= IPM_TOL_MU;
+        const bool any_live = __any(live);
+        if (!any_live && pk < 0) break;
+        if (any_live) {
+            const double warm_mu = stepn < 0.0 ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
+            const bool ok = S.qp_solve(live, x0, u0f, n_ipm, warm_mu, tol_res, tol_mu);
+            bool qp_failed = live && !ok;
+            {
+                double sl = 0.0;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) sl = fmax(sl, fabs(S.dx[i]));
+                if (!term) {
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) sl = fmax(sl, fabs(S.du[i]));
+                }
+                const double sn = seg_max(sl, k, lpi, base);
+                if (live) stepn = sn;
+            }
+            if (live && ok) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) S.x[i] += S.dx[i], S.nu_[i] = S.nuq[i];
+#pragma unroll
+                for (int i = 0; i < NU; ++i) S.u[i] += S.du[i];
+                ++iti;
+            }
+            if (__any(qp_failed)) {   // QP failure: status 4 with the last iterate (the same outputs small_solve_kernel leaves)
+                double cst = cost;
+                if (qp_failed && valid) {
+                    if (first) {
+                        if (a.LAG) a.LAG[inst] = cst;
+#pragma unroll
+                        for (int i = 0; i < NU; ++i) a.u0_out[inst * NU + i] = S.u[i];
+                        a.V[inst] = cst;
+                        a.status[inst] = 4;
+                        if (a.iters) a.iters[inst * 2] = iti, a.iters[inst * 2 + 1] = n_ipm;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a.RES[inst * 4 + j] = res[j];
+                    }
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) {
+                        a.X[(inst * (N + 1) + k) * NX + i] = S.x[i];
+                        if (!first) a.PI[(inst * N + k - 1) * NX + i] = S.nu_[i];
+                    }
+                    if (!term) {
+#pragma unroll
+                        for (int i = 0; i < NU; ++i) a.U[(inst * N + k) * NU + i] = S.u[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < NW; ++i) {
+                        bnd[0 * nb + i] = S.has(0, i) ? S.lam[0][i] : 0.0, bnd[1 * nb + i] = S.has(1, i) ? S.lam[1][i] : 0.0;
+                        bnd[2 * nb + i] = S.has(0, i) ? S.t[0][i] : 1.0, bnd[3 * nb + i] = S.has(1, i) ? S.t[1][i] : 1.0;
+                    }
+                }
+                if (qp_failed) status = 4, live = false;
+            }
+        }
+        if (pk < 0) continue;
+        // ---- rotation: one slot hands its instance over to the parked one.  The slot of a finished instance first (for good),
+        // else round robin.  Every decision below is a function of wave-uniform values.
+        int v = -1;
+        for (int s_ = 0; s_ < ipw; ++s_)
+            if (v < 0 && !__shfl(live ? 1 : 0, s_ * lpi)) v = s_;
+        const bool for_good = v >= 0;
+        if (v < 0) v = rr % ipw, ++rr;
+        const bool sw = slot_on && slot == v;
+        const int lo = __shfl(loc, v * lpi);            // local index of the outgoing instance
+        if (sw && !for_good) {                          // park: state to the instance's stored-iterate arrays, scalars to LDS
+            if (valid) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    a.X[(inst * (N + 1) + k) * NX + i] = S.x[i];
+                    if (!first) a.PI[(inst * N + k - 1) * NX + i] = S.nu_[i];
+                }
+                if (!term) {
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) a.U[(inst * N + k) * NU + i] = S.u[i];
+                }
+#pragma unroll
+                for (int i = 0; i < NW; ++i)
+                    bnd[0 * nb + i] = S.lam[0][i], bnd[1 * nb + i] = S.lam[1][i], bnd[2 * nb + i] = S.t[0][i], bnd[3 * nb + i] = S.t[1][i];
+            }
+            if (first) {
+                double *sc = sc_lds + lo * 12;
+                sc[0] = live ? 1.0 : 0.0, sc[1] = (double)status, sc[2] = (double)iti, sc[3] = (double)n_ipm, sc[4] = last_tight ? 1.0 : 0.0,
+                sc[5] = stepn;
+            }
+        }
+        SmallSolver<M>::wave_lds_sync();                // orders the stores above before the loads below (same wavefront: in order)
+        // take the parked instance: every lane runs the same loads, the lanes of the slot keep the results
+        const int newloc = sw ? pk : loc;
+        loc = newloc;
+        bind(loc);
+        load_params();
+        {
+            const double *sc = sc_lds + pk * 12;
+            const double l_ = sc[0], st_ = sc[1], it_ = sc[2], ni_ = sc[3], lt_ = sc[4], sn_ = sc[5];
+            if (sw) {
+                live = pk_started ? (l_ != 0.0) : valid;
+                status = pk_started ? (int)st_ : 2;
+                iti = pk_started ? (int)it_ : 0;
+                n_ipm = pk_started ? (int)ni_ : 0;
+                last_tight = pk_started ? (lt_ != 0.0) : true;
+                stepn = pk_started ? sn_ : -1.0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const double xs = a.X[(inst * (N + 1) + k) * NX + i], ns = a.PI[(inst * N + (first ? 0 : k - 1)) * NX + i];
+            S.x[i] = sw ? (pk_started ? xs : x0[i]) : S.x[i];
+            S.nu_[i] = sw ? ((first || !pk_started) ? 0.0 : ns) : S.nu_[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const double us = a.U[(inst * N + (term ? 0 : k)) * NU + i];
+            S.u[i] = sw ? ((term || !pk_started) ? 0.0 : us) : S.u[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const double l0 = bnd[0 * nb + i], l1 = bnd[1 * nb + i], t0 = bnd[2 * nb + i], t1 = bnd[3 * nb + i];
+            S.lam[0][i] = sw ? (pk_started ? l0 : 0.0) : S.lam[0][i], S.lam[1][i] = sw ? (pk_started ? l1 : 0.0) : S.lam[1][i];
+            S.t[0][i] = sw ? (pk_started ? t0 : 1.0) : S.t[0][i], S.t[1][i] = sw ? (pk_started ? t1 : 1.0) : S.t[1][i];
+        }
+        pk = for_good ? -1 : lo;
+        pk_started = true;
+    }
+}
+
+// =====================================================================================================
 // sensitivity kernel: re-reads the converged iterate (x, u, nu, lam, t) written by small_solve_kernel.
 // Kept separate so that the second-order jets do not set the register budget of the SQP loop.
 // =====================================================================================================

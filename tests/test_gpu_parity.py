@@ -368,3 +368,43 @@ def test_auto_order_does_not_change_results():
     mpc.lib.mpcrl_set_order(mpc._h, None, None)
     r2 = mpc.solve(xt, sens_v=True, cold=True, reorder=False)
     assert torch.equal(r1.u0, r2.u0) and torch.equal(r1.V, r2.V) and torch.equal(r1.dV_dp, r2.dV_dp)
+
+
+@pytest.mark.parametrize("B", [4, 7, 100, 4096, 5000])
+def test_time_sliced_launch_is_bitwise_the_plain_one(B, monkeypatch):
+    """small_solve_sliced_kernel (ipw + 1 instances per wavefront, one parked in HBM between SQP iterations) runs the same iteration
+    per instance as small_solve_kernel: every output bit-identical, for ragged batches too.  MPCRL_TIME_SLICE forces / forbids it."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    x0 = cartpole_x0(B, seed=13)
+    theta = np.tile(cartpole_ocp().p0, (B, 1))
+    theta[:, :3] *= np.random.default_rng(1).uniform(0.95, 1.05, (B, 3))
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MPCRL_TIME_SLICE", mode)
+        mpc = MPCBatch(cartpole_ocp(), B)
+        mpc.set_theta(torch.as_tensor(theta))
+        r = mpc.solve(x0, sens_v=True, sens_pi=True, cold=True)
+        out[mode] = (r, mpc.get_iterate(), mpc.get_lagrangian())
+    (ra, ia, la), (rb, ib, lb) = out["0"], out["1"]
+    assert int((ra.status == 0).sum()) > 0.9 * B
+    for t1, t2 in ((ra.u0, rb.u0), (ra.V, rb.V), (ra.status, rb.status), (ra.iters, rb.iters), (ra.dV_dp, rb.dV_dp), (ra.dpi_dp, rb.dpi_dp), (la, lb)):
+        assert torch.equal(t1, t2)
+    for t1, t2 in zip(ia, ib):
+        assert torch.equal(t1, t2)
+    # a warm call after the sliced cold one starts at the solution (the parked / finished iterates were all written back)
+    r2 = mpc.solve(x0)
+    ok = rb.status == 0
+    assert int(r2.iters[ok][:, 0].max()) == 0 and torch.equal(r2.V[ok], rb.V[ok])
+
+
+def test_time_sliced_launch_status_codes(monkeypatch):
+    """max-iter status inside the sliced launch: iteration counts and statuses equal the plain launch's."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    x0 = cartpole_x0(301, seed=9)
+    res = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MPCRL_TIME_SLICE", mode)
+        r = MPCBatch(cartpole_ocp(max_iter=3), 301).solve(x0, cold=True)
+        res.append(r)
+    assert torch.equal(res[0].status, res[1].status) and torch.equal(res[0].iters, res[1].iters) and torch.equal(res[0].V, res[1].V)
+    assert int((res[1].status == 2).sum()) > 0 and int(res[1].iters[:, 0].max()) == 3
