@@ -1401,18 +1401,24 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
     __shared__ double sc_lds[M::MAX_IPW * 12];        // parked scalars: live, status, iterations, interior-point iterations, ...
     S.ms = mx_lds;
     S.qmode = a.u0fix != nullptr;
-    auto bind = [&](int l) {
-        long i = w0 + l;
-        valid = slot_on && i < a.B;
+    // Batch index (after the packing order) and dynamics parameters of the ipw + 1 instances, looked up ONCE: a rebinding between
+    // rounds must not cost global round trips of its own (perm -> theta -> state would be three in a row).
+    __shared__ long gi_lds[M::MAX_IPW];
+    __shared__ double th_lds[M::MAX_IPW * (NTD + (NTC > 0 ? NTC : 1))];
+    {
+        long i = w0 + loc;
         if (i >= a.B) i = a.B - 1;                    // lanes without an instance shadow the last one and never store
         if (a.perm) i = a.perm[i];
         inst = i;
         th = a.theta + (size_t)i * a.theta_stride;
-        x0 = a.x0 + i * NX;
-        u0f = S.qmode ? a.u0fix + i * NU : a.x0 + i * NX;
-        bnd = a.BND + (size_t)i * 10 * nb + (size_t)k * NW;
-    };
-    bind(loc);
+        if (k == 0 && slot <= ipw) {                  // the stage-0 lane of every slot, and the first lane past the slots (parked instance)
+            gi_lds[loc] = i;
+#pragma unroll
+            for (int j = 0; j < NTD; ++j) th_lds[loc * (NTD + (NTC > 0 ? NTC : 1)) + j] = th[M::td_index(j)];
+#pragma unroll
+            for (int j = 0; j < NTC; ++j) th_lds[loc * (NTD + (NTC > 0 ? NTC : 1)) + NTD + j] = th[M::tc_index(j)];
+        }
+    }
     const bool term = S.term, first = S.first;
     if (sp.cost_kind == 0)
         S.ck = term ? 1.0 : sp.dT;
@@ -1420,15 +1426,24 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
         S.ck = first ? sp.dT : (term ? pow(sp.gamma, (double)N) : pow(sp.gamma, (double)k) * sp.dT);
     // cost tables of all ipw + 1 instances (the parked one's by the first lane past the slots, which is a stage-0 lane)
     S.fill_cost_table(c_lds, loc, (slot_on || (slot == ipw && k == 0)) && w0 + loc < a.B, th);
-    if (!slot_on) loc = 0, bind(0);                   // from here on the lanes past the slots shadow slot 0's instance
     SmallSolver<M>::wave_lds_sync();
+    auto bind = [&](int l) {
+        valid = slot_on && w0 + l < a.B;
+        const long i = gi_lds[l];
+        inst = i;
+        x0 = a.x0 + i * NX;
+        u0f = S.qmode ? a.u0fix + i * NU : a.x0 + i * NX;
+        bnd = a.BND + (size_t)i * 10 * nb + (size_t)k * NW;
+    };
+    if (!slot_on) loc = 0;                            // from here on the lanes past the slots shadow slot 0's instance
+    bind(loc);
     auto load_params = [&]() {
         S.ctab = c_lds + loc * SmallSolver<M>::CTAB + S.stage_kind() * SmallSolver<M>::CSET;
         S.load_hc();
 #pragma unroll
-        for (int i = 0; i < NTD; ++i) S.thd[i] = th[M::td_index(i)];
+        for (int i = 0; i < NTD; ++i) S.thd[i] = th_lds[loc * (NTD + (NTC > 0 ? NTC : 1)) + i];
 #pragma unroll
-        for (int i = 0; i < NTC; ++i) S.thc[i] = th[M::tc_index(i)];
+        for (int i = 0; i < NTC; ++i) S.thc[i] = th_lds[loc * (NTD + (NTC > 0 ? NTC : 1)) + NTD + i];
     };
     load_params();
     // ---- cold start of the resident instances (MPC.reset, mpc.py:204-210)
@@ -1462,11 +1477,17 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
         double xn[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) xn[i] = lane_dn(S.x[i]), nun[i] = lane_dn(S.nu_[i]);
+#ifdef MPCRL_PROFILE_PHASES
+        { unsigned long long n_ = clock64(); if (S.pht) S.phw[15] += n_ - S.pht; S.pht = n_; }
+#endif
         const double cl = S.linearize(xn);
         double rl[4];
         S.nlp_res_local(nun, x0, u0f, rl);
         double res[4] = {rl[0], rl[1], rl[2], rl[3]}, cost = cl;
         seg_reduce<4, 1>(res, &cost, k, lpi, base);
+#ifdef MPCRL_PROFILE_PHASES
+        { unsigned long long n_ = clock64(); S.phw[9] += n_ - S.pht; S.pht = n_; }
+#endif
         const double rmax = fmax(fmax(res[0], res[1]), fmax(res[2], res[3]));
         bool fin_now = false;
         if (live) {
@@ -1580,6 +1601,9 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
             }
         }
         if (pk < 0) continue;
+#ifdef MPCRL_PROFILE_PHASES
+        { unsigned long long n_ = clock64(); S.phw[10] += n_ - S.pht; S.pht = n_; }
+#endif
         // ---- rotation: one slot hands its instance over to the parked one.  The slot of a finished instance first (for good),
         // else round robin.  Every decision below is a function of wave-uniform values.
         int v = -1;
@@ -1648,6 +1672,9 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
         pk = for_good ? -1 : lo;
         pk_started = true;
     }
+#ifdef MPCRL_PROFILE_PHASES
+    if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_phase_ticks[i_], S.phw[i_]);
+#endif
 }
 
 // =====================================================================================================
