@@ -152,16 +152,15 @@ int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
     bool sliced = false;
     if constexpr (!M::HAS_SOFT) {
         // Time-sliced launch (small_solve_sliced_kernel): ipw + 1 instances per wavefront, ipw of them advancing per round.  Such a
-        // wavefront lives longer than (ipw + 1) / ipw plain lifetimes: the first QP of a cold solve (interior point from its default
-        // point, ~40 % of all interior-point work) is paid twice in sequence — in round 1 by the resident instances, in round 2 by the
-        // parked one — and every round reloads one instance.  Measured on cartpole N = 20: 1.82 plain lifetimes (0.729 vs 0.40 ms).
-        // It pays when it saves more than that in rounds of wavefronts on the chip's SIMDs: 4096 instances are 2 rounds of
-        // 3-instance wavefronts or 1 round of 4-instance ones (4.62 -> 5.27 M solves/s); 32768 are 11 vs 8 rounds (plain wins).
+        // wavefront lives longer than (ipw + 1) / ipw plain lifetimes — measured on cartpole N = 20: 1.52 (rotation 3.3 us per round,
+        // write-outs inside the loop, 3 % for mixing QPs of instances one SQP iteration apart) — so it pays only when it saves a round
+        // of wavefronts on the chip's SIMDs: 4096 instances are 2 rounds of 3-instance wavefronts or 1 round of 4-instance ones
+        // (4.62 -> 5.27 M solves/s); 32768 are 11 vs 8 rounds (plain wins, measured 6.83 vs 6.17 M solves/s).
         const int ips = std::min(64 / lpi, M::MAX_IPW - 1), q = ips + 1;
         const bool legal = ips >= 1 && 64 - ips * lpi >= 1 && (a.flags & MPCRL_COLD) && !(a.flags & MPCRL_RTI);
         const long waves3 = (h->B + ipw - 1) / ipw, waves4 = (h->B + q - 1) / q;
         const long rounds3 = (waves3 + h->n_simd - 1) / h->n_simd, rounds4 = (waves4 + h->n_simd - 1) / h->n_simd;
-        sliced = legal && (h->slice_mode > 0 || (h->slice_mode == 0 && 19 * rounds4 <= 10 * rounds3));
+        sliced = legal && (h->slice_mode > 0 || (h->slice_mode == 0 && 16 * rounds4 <= 10 * rounds3));
         if (sliced) hipLaunchKernelGGL(small_solve_sliced_kernel<M>, dim3((unsigned)waves4), dim3(64), 0, st, h->small, a);
     }
     if (!sliced) hipLaunchKernelGGL(small_solve_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
