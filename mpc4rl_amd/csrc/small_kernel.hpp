@@ -1386,7 +1386,11 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
     const int lane = threadIdx.x;
     const int N = sp.N, lpi = N + 1, ipw = min(64 / lpi, M::MAX_IPW - 1), q = ipw + 1;
     const int slot = lane / lpi, k = lane - slot * lpi, base = slot * lpi;
-    const long w0 = (long)blockIdx.x * q;            // first instance (batch order) of this wavefront
+    // Instance l of wavefront w is entry l * (number of wavefronts) + w of the packing order: a wavefront takes one instance from each
+    // q-quantile of the order.  The order puts similar problems side by side, and with consecutive entries the wavefronts of the hard
+    // end of the batch need more rounds than the others — with a single round of wavefronts the launch lasts as long as the slowest.
+    const long nwave = gridDim.x;
+    auto posof = [&](int l) { return (long)l * nwave + blockIdx.x; };
     const bool slot_on = slot < ipw;
     // ---- binding of this lane to an instance: changes when its slot takes the parked instance
     int loc = slot_on ? slot : ipw;                   // local index; the first lane past the slots speaks for the parked instance
@@ -1406,7 +1410,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
     __shared__ long gi_lds[M::MAX_IPW];
     __shared__ double th_lds[M::MAX_IPW * (NTD + (NTC > 0 ? NTC : 1))];
     {
-        long i = w0 + loc;
+        long i = posof(loc);
         if (i >= a.B) i = a.B - 1;                    // lanes without an instance shadow the last one and never store
         if (a.perm) i = a.perm[i];
         inst = i;
@@ -1425,10 +1429,10 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
     else
         S.ck = first ? sp.dT : (term ? pow(sp.gamma, (double)N) : pow(sp.gamma, (double)k) * sp.dT);
     // cost tables of all ipw + 1 instances (the parked one's by the first lane past the slots, which is a stage-0 lane)
-    S.fill_cost_table(c_lds, loc, (slot_on || (slot == ipw && k == 0)) && w0 + loc < a.B, th);
+    S.fill_cost_table(c_lds, loc, (slot_on || (slot == ipw && k == 0)) && posof(loc) < a.B, th);
     SmallSolver<M>::wave_lds_sync();
     auto bind = [&](int l) {
-        valid = slot_on && w0 + l < a.B;
+        valid = slot_on && posof(l) < a.B;
         const long i = gi_lds[l];
         inst = i;
         x0 = a.x0 + i * NX;
@@ -1469,7 +1473,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
     int status = 2, iti = 0, n_ipm = 0;
     double stepn = -1.0;
     // the parked instance (wave-uniform): local index or -1, and whether it has run at all
-    int pk = (w0 + ipw < a.B) ? ipw : -1;
+    int pk = (posof(ipw) < a.B) ? ipw : -1;
     bool pk_started = false;
     int rr = 0;
     double nun[NX];

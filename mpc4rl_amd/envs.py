@@ -7,6 +7,8 @@ Restates (no gymnasium dependency, tensors in / tensors out, B environments per 
       terminated when |x| < 0.1, |x_dot| < 0.1, |theta| < 2 deg, |theta_dot| < 0.1 all hold (84-103)
   * LinearSystemEnv                rlmpc/gym/linear_system/environment.py:6-66
       s+ = A s + B a + [U(lb_noise, ub_noise), 0]; reset to [0.5, 0.5]; cost = 1/2 s's + 1/2 a'a + 100 per violated side
+Observations are returned in ``dtype`` (float64 by default: they feed the fp64 solve directly, no conversion kernel); the reference's
+gymnasium envs return float32 observations (continuous_cartpole/environment.py:166,186) — pass ``dtype=torch.float32`` for that.
 The reference's own numpy VectorEnv (environment.py:302-458) computes the reward from env 0's action and resets to
 exactly [0, 0, pi, 0]; the single-env semantics above are the ones reproduced here, per environment.
 """
