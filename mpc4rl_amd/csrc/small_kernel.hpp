@@ -1475,7 +1475,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
     // the parked instance (wave-uniform): local index or -1, and whether it has run at all
     int pk = (posof(ipw) < a.B) ? ipw : -1;
     bool pk_started = false;
-    int rr = 0;
+    int rr = 0, rounds_since = 0;
     double nun[NX];
     for (;;) {
         double xn[NX];
@@ -1614,6 +1614,10 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
         for (int s_ = 0; s_ < ipw; ++s_)
             if (v < 0 && !__shfl(live ? 1 : 0, s_ * lpi)) v = s_;
         const bool for_good = v >= 0;
+#ifndef MPCRL_SLICE_PERIOD
+#define MPCRL_SLICE_PERIOD 1
+#endif
+        if (!for_good && (++rounds_since % MPCRL_SLICE_PERIOD) != 0) continue;   // rotate every MPCRL_SLICE_PERIOD-th round only
         if (v < 0) v = rr % ipw, ++rr;
         const bool sw = slot_on && slot == v;
         const int lo = __shfl(loc, v * lpi);            // local index of the outgoing instance
