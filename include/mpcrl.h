@@ -37,6 +37,9 @@
  *     int status, update/q_update raise on != 0, rlmpc/mpc/common/mpc.py:81-83,197-198).
  *   - one handle per (device, stream); handles are independent across GPUs; not re-entrant (stateful
  *     warm start, like the reference's solver object).
+ *   - how a batch is laid out over wavefronts (packing order, plain or time-sliced launch of the small
+ *     solve kernel; environment MPCRL_TIME_SLICE=0/1 read at mpcrl_create overrides the automatic choice)
+ *     never changes a result bit.
  */
 #ifndef MPCRL_H
 #define MPCRL_H
