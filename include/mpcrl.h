@@ -106,6 +106,9 @@ int mpcrl_set_order(mpcrl_handle h, const int32_t *perm, void *stream);
 /* Builds that permutation on the device from the initial states themselves (x0: [B, nx] device): the batch ordered along the
  * coordinate of x0 with the largest spread.  One small kernel; batch <= 8192, else MPCRL_E_ARG (use mpcrl_set_order). */
 int mpcrl_auto_order(mpcrl_handle h, const double *x0, void *stream);
+/* 1 if an mpcrl_solve with these flags would use the time-sliced launch (whose wavefronts take one instance from each quarter of the
+ * batch: a packing order buys nothing there and the caller can skip building one), 0 if not, < 0 on misuse. */
+int mpcrl_query_time_sliced(mpcrl_handle h, int flags);
 
 /* Box bounds after creation — ocp_solver.constraints_set(stage, "lbu"|"ubu"|"lbx"|"ubx", v) (rlmpc/mpc/common/mpc.py:72-73,87-88).
  * HOST pointers, stage-vector order v = [u; x]; |bound| >= 1e29 = absent.  which: U0 = controls of stage 0 (nu values),

@@ -139,11 +139,15 @@ class MPCBatch:
             with torch.cuda.device(self.device):
                 self._check(self.lib.mpcrl_set_cold_mask(self._h, _ptr(cm), self._stream()), "mpcrl_set_cold_mask")
         u0f = None if u0 is None else self._dev(u0, (self.B, self.nu))
-        if reorder:
-            with torch.cuda.device(self.device):
-                self._pack_order(x0)
         flags = (_lib.SENS_V if sens_v else 0) | (_lib.SENS_PI if sens_pi else 0) | (_lib.RTI if rti else 0) | \
             (_lib.COLD if cold else 0)
+        if reorder:
+            if self.lib.mpcrl_query_time_sliced(self._h, flags) == 1:
+                # the time-sliced launch deals the batch out in quarters: no packing order needed (and none left over from before)
+                self._check(self.lib.mpcrl_set_order(self._h, None, self._stream()), "mpcrl_set_order")
+            else:
+                with torch.cuda.device(self.device):
+                    self._pack_order(x0)
         kw = dict(dtype=torch.float64, device=self.device)
         u0_out = torch.empty((self.B, self.nu), **kw)
         V = torch.empty((self.B,), **kw)

@@ -145,22 +145,34 @@ int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
     return 0;
 }
 
+// Time-sliced launch (small_solve_sliced_kernel): ipw + 1 instances per wavefront, ipw of them advancing per round.  Such a
+// wavefront lives longer than (ipw + 1) / ipw plain lifetimes — measured on cartpole N = 20: 1.52 (rotation 3.3 us per round,
+// write-outs inside the loop, 3 % for mixing QPs of instances one SQP iteration apart) — so it pays only when it saves a round
+// of wavefronts on the chip's SIMDs: 4096 instances are 2 rounds of 3-instance wavefronts or 1 round of 4-instance ones
+// (4.62 -> 5.4 M solves/s); 32768 are 11 vs 8 rounds (plain wins, measured 6.83 vs 6.17 M solves/s).
+template <class M>
+bool plan_time_sliced(const MpcrlSolver *h, int flags, long *waves) {
+    if constexpr (M::HAS_SOFT) {
+        return false;
+    } else {
+        const int lpi = h->N + 1, ipw = std::min(64 / lpi, M::MAX_IPW);
+        const int ips = std::min(64 / lpi, M::MAX_IPW - 1), q = ips + 1;
+        const bool legal = ips >= 1 && 64 - ips * lpi >= 1 && (flags & MPCRL_COLD) && !(flags & MPCRL_RTI);
+        const long waves3 = (h->B + ipw - 1) / ipw, waves4 = (h->B + q - 1) / q;
+        const long rounds3 = (waves3 + h->n_simd - 1) / h->n_simd, rounds4 = (waves4 + h->n_simd - 1) / h->n_simd;
+        if (waves) *waves = waves4;
+        return legal && (h->slice_mode > 0 || (h->slice_mode == 0 && 16 * rounds4 <= 10 * rounds3));
+    }
+}
+
 template <class M>
 int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
     const int lpi = h->N + 1, ipw = std::min(64 / lpi, M::MAX_IPW);
     const int blocks = (h->B + ipw - 1) / ipw;
     bool sliced = false;
     if constexpr (!M::HAS_SOFT) {
-        // Time-sliced launch (small_solve_sliced_kernel): ipw + 1 instances per wavefront, ipw of them advancing per round.  Such a
-        // wavefront lives longer than (ipw + 1) / ipw plain lifetimes — measured on cartpole N = 20: 1.52 (rotation 3.3 us per round,
-        // write-outs inside the loop, 3 % for mixing QPs of instances one SQP iteration apart) — so it pays only when it saves a round
-        // of wavefronts on the chip's SIMDs: 4096 instances are 2 rounds of 3-instance wavefronts or 1 round of 4-instance ones
-        // (4.62 -> 5.27 M solves/s); 32768 are 11 vs 8 rounds (plain wins, measured 6.83 vs 6.17 M solves/s).
-        const int ips = std::min(64 / lpi, M::MAX_IPW - 1), q = ips + 1;
-        const bool legal = ips >= 1 && 64 - ips * lpi >= 1 && (a.flags & MPCRL_COLD) && !(a.flags & MPCRL_RTI);
-        const long waves3 = (h->B + ipw - 1) / ipw, waves4 = (h->B + q - 1) / q;
-        const long rounds3 = (waves3 + h->n_simd - 1) / h->n_simd, rounds4 = (waves4 + h->n_simd - 1) / h->n_simd;
-        sliced = legal && (h->slice_mode > 0 || (h->slice_mode == 0 && 16 * rounds4 <= 10 * rounds3));
+        long waves4 = 0;
+        sliced = plan_time_sliced<M>(h, a.flags, &waves4);
         if (sliced) hipLaunchKernelGGL(small_solve_sliced_kernel<M>, dim3((unsigned)waves4), dim3(64), 0, st, h->small, a);
     }
     if (!sliced) hipLaunchKernelGGL(small_solve_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
@@ -320,6 +332,17 @@ int mpcrl_set_cold_mask(mpcrl_handle h, const int32_t *mask, void *stream) {
     if (mask) HIP_OK(hipMemcpyAsync(h->cold_mask, mask, (size_t)h->B * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     h->have_cold_mask = mask != nullptr;
     return 0;
+}
+
+int mpcrl_query_time_sliced(mpcrl_handle h, int flags) {
+    if (!h) return MPCRL_E_ARG;
+    if (h->is_large) return 0;
+    if (!h->have_iterate) flags |= MPCRL_COLD;
+    switch (h->model) {
+        case MPCRL_MODEL_CARTPOLE: return plan_time_sliced<CartpoleDev>(h, flags, nullptr) ? 1 : 0;
+        case MPCRL_MODEL_LINEAR: return plan_time_sliced<LinearDev>(h, flags, nullptr) ? 1 : 0;
+        default: return 0;
+    }
 }
 
 int mpcrl_auto_order(mpcrl_handle h, const double *x0, void *stream) {
