@@ -408,3 +408,28 @@ def test_time_sliced_launch_status_codes(monkeypatch):
         res.append(r)
     assert torch.equal(res[0].status, res[1].status) and torch.equal(res[0].iters, res[1].iters) and torch.equal(res[0].V, res[1].V)
     assert int((res[1].status == 2).sum()) > 0 and int(res[1].iters[:, 0].max()) == 3
+
+
+@pytest.mark.parametrize("N,tf", [(15, 1.5), (30, 3.0), (10, 1.0)])
+def test_time_sliced_launch_other_horizons(N, tf, monkeypatch, oracle_port):
+    """Horizons with a different number of instance slots per wavefront (N = 30: 2 slots + 1 parked, N = 15: 3 + 1 with 16-lane
+    slots, N = 10: the matrix-core sweep caps the slots at 4, sliced 3 + 1): sliced == plain bitwise, and both match the oracle."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    from oracle.problems import make_cartpole
+    B = 97
+    x0 = cartpole_x0(B, seed=21)
+    out = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MPCRL_TIME_SLICE", mode)
+        mpc = MPCBatch(cartpole_ocp(N=N, tf=tf), B)
+        out.append(mpc.solve(x0, sens_v=True, sens_pi=True, cold=True))
+    ra, rb = out
+    for t1, t2 in ((ra.u0, rb.u0), (ra.V, rb.V), (ra.status, rb.status), (ra.iters, rb.iters), (ra.dV_dp, rb.dV_dp), (ra.dpi_dp, rb.dpi_dp)):
+        assert torch.equal(t1, t2)
+    ref = oracle_port.solve(make_cartpole(N=N, tf=tf), x0)
+    st = rb.status.cpu().numpy()
+    assert np.array_equal(st, ref.status)
+    ok = st == 0
+    assert ok.mean() > 0.8
+    assert rel_err(rb.u0.cpu().numpy()[ok], ref.u0[ok]) < RTOL and rel_err(rb.V.cpu().numpy()[ok], ref.V[ok]) < RTOL
+    assert rel_err(rb.dV_dp.cpu().numpy()[ok], ref.dV[ok]) < RTOL and rel_err(rb.dpi_dp.cpu().numpy()[ok], ref.dpi[ok]) < RTOL
