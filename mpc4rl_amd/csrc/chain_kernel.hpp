@@ -68,7 +68,7 @@ template <class M>
 struct LargeLayout {
     static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD;
     size_t BA, r, q, dx, du, nuq, Dx, Du, Dnu, rg, rb, rt, Dg, lamw, tw, aff, P, p, K, L, kff, Acl, hb, ccv, cvec, Hex, term, ynu, state, Ydx, Ydu, Ydnu,
-        term2, total;
+        term2, ptab, gtab, total;
     __host__ __device__ explicit LargeLayout(int N) {
         size_t o = 0;
         auto take = [&](size_t n) { size_t s = o; o += (n + 1) & ~(size_t)1; return s; };   // every array 16-byte aligned
@@ -84,6 +84,8 @@ struct LargeLayout {
         state = take(16);   // ST_* below: the SQP loop's per-instance state between launches
         Ydx = take((size_t)NU * (N + 1) * NX), Ydu = take((size_t)NU * N * NU), Ydnu = take((size_t)NU * (N + 1) * NX);   // adjoint solutions
         term2 = take((size_t)NU * N * NTD);
+        // per stage: coefficients of the 8 evaluation points of the RK4 map (chain_point_kernel), and the link Hessians of the adjoint
+        ptab = take((size_t)N * 8 * M::NL * M::TAB2), gtab = take((size_t)N * 8 * M::NL * 6);
         total = (o + 7) & ~(size_t)7;
     }
 };
@@ -1383,13 +1385,99 @@ __global__ void __launch_bounds__(64) chain_init_kernel(const LargeSpec sp, cons
     }
 }
 
-// ---- dynamics linearisation: fills [B A]_k and r_k = F(x_k, u_k) - x_{k+1}.
-// One workgroup = LIN_G consecutive stages of one instance, one lane per (stage, direction).  The RK4 map is split into what depends
-// on the point and what is linear in the direction (ChainDev::ode_coef / ode_tan): every lane first walks the 4 x rk_steps evaluation
-// points of its stage in plain doubles and the first lane of the stage leaves the per-link coefficients of each point in LDS; then
-// each lane propagates ONLY its tangent through the same points.  A forward jet per lane (value + tangent through the whole map)
-// needs both sets of arrays live at once — 2 x 4 NX doubles, 528 registers at NX = 33, i.e. spills whose scratch traffic made this
-// kernel HBM-bound (profiles/r02_hbm_traffic.json: 46 GB per step at n_mass = 7) — and recomputes the point NW times.
+// ---- the POINT pass of the derivative kernels: one lane per (instance, stage) walks the 4 x rk_steps evaluation points of the RK4
+// map in plain doubles and leaves, per evaluation point and link, what the tangent of the ODE needs there (ChainDev::ode_coef) in the
+// instance's workspace; it also writes r_k = F(x_k, u_k) - x_{k+1}.  With SECOND (sensitivities) the tables carry the second-order
+// coefficients as well and a reverse sweep of nu_{k+1} through the same points adds the 3 x 3 Hessian of every link force
+// (ChainDev::link_hessian).  The direction kernels below (one lane per direction) then start from these tables: done inside them, this
+// pass was repeated by every lane of a stage — 60 % of the linearisation's and half of the Hessian kernel's instructions.
+template <class M, bool SECOND>
+__global__ void __launch_bounds__(64) chain_point_kernel(const LargeSpec sp, const LargeArgs a) {
+    constexpr int NX = M::NX, NU = M::NU, NL = M::NL, TS = SECOND ? M::TAB2 : M::TAB;
+    const int N = sp.N;
+    const long gid = (long)blockIdx.x * 64 + threadIdx.x;
+    const int inst = (int)(gid / N);
+    if (inst >= a.B) return;
+    const LargeLayout<M> lay(N);
+    double *w = a.ws + (size_t)inst * a.ws_stride;
+    if constexpr (SECOND) {
+        const int status = a.status[inst];
+        if (!(status == 0 || status == 2)) return;
+    } else {
+        if (w[lay.state + ST_ACTIVE] == 0.0) return;
+    }
+    const int k = (int)(gid - (long)inst * N);
+    const double *X = a.X + (size_t)inst * (N + 1) * NX, *U = a.U + (size_t)inst * N * NU;
+    const double *th = a.theta + (size_t)inst * a.theta_stride;
+    const double h = sp.h;
+    const int steps = sp.rk_steps;
+    double *tab = w + lay.ptab + (size_t)k * 8 * NL * M::TAB2;
+    double u[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) u[i] = U[k * NU + i];
+    {
+        double xc[NX], acc[NX], kk[NX], xt[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xc[i] = X[k * NX + i];
+        for (int s = 0; s < steps; ++s) {
+            double *tb = tab + (size_t)(4 * s) * NL * TS;
+            M::template ode_coef<SECOND>(xc, u, th, kk, tb, true);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
+            M::template ode_coef<SECOND>(xt, u, th, kk, tb + NL * TS, true);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
+            M::template ode_coef<SECOND>(xt, u, th, kk, tb + 2 * NL * TS, true);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + h * kk[i];
+            M::template ode_coef<SECOND>(xt, u, th, kk, tb + 3 * NL * TS, true);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xc[i] = xc[i] + (h / 6.0) * (acc[i] + kk[i]);
+        }
+        if constexpr (!SECOND) {
+            double *r = w + lay.r + k * NX;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) r[i] = xc[i] - X[(k + 1) * NX + i];
+        }
+    }
+    if constexpr (SECOND) {   // the adjoint: kb_e = d(nu' F) / d(k_e) at every evaluation point, last step first; G_{e,i} from its force part
+        const double *nu = w + lay.ynu;
+        double *Gt = w + lay.gtab + (size_t)k * 8 * NL * 6;
+        double lb[NX], acc[NX], kb[NX], Xb[NX], q[3 * NL];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) lb[i] = nu[(k + 1) * NX + i];
+        for (int s = steps - 1; s >= 0; --s) {
+            auto node = [&](int e) {   // Xb = J(e)' kb, and the link Hessians of this evaluation point
+                const double *tb = tab + (size_t)e * NL * TS;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) Xb[i] = 0.0;
+                M::template ode_tan_T<TS>(tb, th, kb, Xb, q);
+#pragma unroll
+                for (int i = 0; i < NL; ++i) M::link_hessian(tb + i * TS, q + 3 * i, Gt + ((size_t)e * NL + i) * 6);
+            };
+#pragma unroll
+            for (int i = 0; i < NX; ++i) kb[i] = (h / 6.0) * lb[i];
+            node(4 * s + 3);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = lb[i] + Xb[i], kb[i] = (h / 3.0) * lb[i] + h * Xb[i];
+            node(4 * s + 2);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + Xb[i], kb[i] = (h / 3.0) * lb[i] + (0.5 * h) * Xb[i];
+            node(4 * s + 1);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + Xb[i], kb[i] = (h / 6.0) * lb[i] + (0.5 * h) * Xb[i];
+            node(4 * s);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) lb[i] = acc[i] + Xb[i];
+        }
+    }
+}
+
+// ---- dynamics linearisation, the DIRECTION pass: fills [B A]_k.  One workgroup = LIN_G consecutive stages of one instance, one lane
+// per (stage, direction): the stages' coefficient tables (chain_point_kernel) are copied into LDS, 16 bytes per lane and step, then each
+// lane propagates ONLY its tangent through the evaluation points.  A forward jet per lane (value + tangent through the whole map)
+// needs both sets of arrays live at once — 2 x 4 NX doubles, 528 registers at NX = 33, i.e. spills whose scratch traffic made the round-1
+// kernel HBM-bound (46 GB per step at n_mass = 7) — and recomputes the point NW times.
 template <class M>
 struct LinCfg {
     static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU;
@@ -1401,8 +1489,9 @@ struct LinCfg {
 template <class M>
 __global__ void __launch_bounds__(256) chain_lin_kernel(const LargeSpec sp, const LargeArgs a) {
     using LC = LinCfg<M>;
-    constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NL = M::NL, TAB = M::TAB;
-    __shared__ double tab[LC::G * LC::EV * NL * TAB];
+    constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NL = M::NL, TAB = M::TAB, STG = LC::EV * NL * M::TAB2;   // doubles per stage in the workspace
+    static_assert(STG % 2 == 0, "16-byte copies");
+    __shared__ __attribute__((aligned(16))) double tab[LC::G * STG];
     const int N = sp.N, nblk = (N + LC::G - 1) / LC::G;
     const int inst = blockIdx.x / nblk, k0 = (blockIdx.x - inst * nblk) * LC::G;
     const LargeLayout<M> lay(N);
@@ -1411,42 +1500,18 @@ __global__ void __launch_bounds__(256) chain_lin_kernel(const LargeSpec sp, cons
     const int t = threadIdx.x, g = t / NW, d = t - g * NW;
     const bool lane_on = t < LC::NT && k0 + g < N;
     const int k = lane_on ? k0 + g : N - 1;          // idle lanes shadow the last stage and never store
-    const double *X = a.X + (size_t)inst * (N + 1) * NX, *U = a.U + (size_t)inst * N * NU;
     const double *th = a.theta + (size_t)inst * a.theta_stride;
     const double h = sp.h;
     const int steps = sp.rk_steps;
-    double *mytab = tab + (size_t)(t < LC::NT ? g : 0) * LC::EV * NL * TAB;
-    double u[NU];
-#pragma unroll
-    for (int i = 0; i < NU; ++i) u[i] = U[k * NU + i];
-    {   // the point: RK4 in plain doubles, coefficients of every evaluation point to LDS
-        const bool wr = lane_on && d == 0;
-        double xc[NX], acc[NX], kk[NX], xt[NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) xc[i] = X[k * NX + i];
-        for (int s = 0; s < steps; ++s) {
-            double *tb = mytab + (size_t)(4 * s) * NL * TAB;
-            M::template ode_coef<false>(xc, u, th, kk, tb, wr);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
-            M::template ode_coef<false>(xt, u, th, kk, tb + NL * TAB, wr);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
-            M::template ode_coef<false>(xt, u, th, kk, tb + 2 * NL * TAB, wr);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + h * kk[i];
-            M::template ode_coef<false>(xt, u, th, kk, tb + 3 * NL * TAB, wr);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) xc[i] = xc[i] + (h / 6.0) * (acc[i] + kk[i]);
-        }
-        if (wr) {
-            double *r = w + lay.r + k * NX;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) r[i] = xc[i] - X[(k + 1) * NX + i];
-        }
+    {   // the tables of this workgroup's stages are one contiguous piece of the workspace
+        const int ng = min(LC::G, N - k0);
+        const d2_t *src = (const d2_t *)(w + lay.ptab + (size_t)k0 * STG);
+        d2_t *dst = (d2_t *)tab;
+        for (int e = t; e < ng * STG / 2; e += 256) dst[e] = src[e];
     }
     __syncthreads();
-    {   // the direction: tangent e_d through the same evaluation points
+    const double *mytab = tab + (size_t)(lane_on ? g : 0) * STG;
+    {   // the direction: tangent e_d through the evaluation points
         double dxc[NX], acc[NX], dk[NX], dxt[NX], du[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) du[i] = d == i ? 1.0 : 0.0;
@@ -1614,8 +1679,8 @@ __global__ void __launch_bounds__(64) chain_sens_th_kernel(const LargeSpec sp, c
 // G_{e,i} = the 3 x 3 Hessian of (adjoint of the link force at e)' Fs(dist) (ChainDev::link_hessian), d dist / dv = the first-order
 // tangents of the link vectors.  Three passes over the evaluation points, each with a quarter of the live state a forward-over-
 // reverse jet sweep needs (which spilled ~1000 registers per lane and was bound by its own scratch traffic):
-//   1. the point: RK4 in plain doubles; per-link coefficients of every evaluation point -> LDS          (all lanes, redundantly)
-//   2. the adjoint: reverse sweep of nu_{k+1} through the same points; G_{e,i} -> LDS                      (all lanes, redundantly)
+//   1. the point: RK4 in plain doubles; per-link coefficients of every evaluation point        (chain_point_kernel, one lane per stage)
+//   2. the adjoint: reverse sweep of nu_{k+1} through the same points; G_{e,i}                    (chain_point_kernel)
 //   3. the tangents: lane j < NW carries direction e_j forward; at every evaluation point the wave publishes Y = d dist / dv
 //      (3 NL x NW) and W = G Y and accumulates  Hex += Y' W  on the matrix cores: v_mfma_f64_16x16x4, lower tile triangle, operands
 //      straight out of LDS in their register layout (A(i, k) and B(k, j) both at lane 16 k + i|j: measured,
@@ -1643,66 +1708,14 @@ __global__ void __launch_bounds__(64, 1) chain_sens_ad_kernel(const LargeSpec sp
     if (!(status == 0 || status == 2)) return;
     const LargeLayout<M> lay(N);
     double *w = a.ws + (size_t)inst * a.ws_stride;
-    const double *X = a.X + (size_t)inst * (N + 1) * NX, *U = a.U + (size_t)inst * N * NU;
-    const double *th = a.theta + (size_t)inst * a.theta_stride, *nu = w + lay.ynu;
+    const double *th = a.theta + (size_t)inst * a.theta_stride;
     const double h = sp.h;
     const int steps = sp.rk_steps;
     double *tab = lds + HC::oTab, *Gt = lds + HC::oG, *Y = lds + HC::oY, *W = lds + HC::oW;
-    const bool wr = lane == 0;
-    double u[NU];
-#pragma unroll
-    for (int i = 0; i < NU; ++i) u[i] = U[k * NU + i];
-    {   // 1. the point
-        double xc[NX], acc[NX], kk[NX], xt[NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) xc[i] = X[k * NX + i];
-        for (int s = 0; s < steps; ++s) {
-            double *tb = tab + (size_t)(4 * s) * NL * TAB2;
-            M::template ode_coef<true>(xc, u, th, kk, tb, wr);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
-            M::template ode_coef<true>(xt, u, th, kk, tb + NL * TAB2, wr);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
-            M::template ode_coef<true>(xt, u, th, kk, tb + 2 * NL * TAB2, wr);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + h * kk[i];
-            M::template ode_coef<true>(xt, u, th, kk, tb + 3 * NL * TAB2, wr);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) xc[i] = xc[i] + (h / 6.0) * (acc[i] + kk[i]);
-        }
-    }
-    wave_sync();
-    {   // 2. the adjoint: kb_e = d(nu' F) / d(k_e) at every evaluation point, last step first; G_{e,i} from its force part
-        double lb[NX], acc[NX], kb[NX], Xb[NX], q[3 * NL];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) lb[i] = nu[(k + 1) * NX + i];
-        for (int s = steps - 1; s >= 0; --s) {
-            auto node = [&](int e) {   // Xb = J(e)' kb, and the link Hessians of this evaluation point
-                const double *tb = tab + (size_t)e * NL * TAB2;
-#pragma unroll
-                for (int i = 0; i < NX; ++i) Xb[i] = 0.0;
-                M::template ode_tan_T<TAB2>(tb, th, kb, Xb, q);
-                if (wr) {
-#pragma unroll
-                    for (int i = 0; i < NL; ++i) M::link_hessian(tb + i * TAB2, q + 3 * i, Gt + ((size_t)e * NL + i) * 6);
-                }
-            };
-#pragma unroll
-            for (int i = 0; i < NX; ++i) kb[i] = (h / 6.0) * lb[i];
-            node(4 * s + 3);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = lb[i] + Xb[i], kb[i] = (h / 3.0) * lb[i] + h * Xb[i];
-            node(4 * s + 2);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + Xb[i], kb[i] = (h / 3.0) * lb[i] + (0.5 * h) * Xb[i];
-            node(4 * s + 1);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + Xb[i], kb[i] = (h / 6.0) * lb[i] + (0.5 * h) * Xb[i];
-            node(4 * s);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) lb[i] = acc[i] + Xb[i];
-        }
+    {   // 1. + 2. the point and the adjoint were done per stage by chain_point_kernel<M, true>: its tables -> LDS
+        const double *pt = w + lay.ptab + (size_t)k * HC::EV * NL * TAB2, *gt = w + lay.gtab + (size_t)k * HC::EV * NL * 6;
+        for (int e = lane; e < HC::EV * NL * TAB2; e += 64) tab[e] = pt[e];
+        for (int e = lane; e < HC::EV * NL * 6; e += 64) Gt[e] = gt[e];
     }
     wave_sync();
     // 3. the tangents and the Hessian accumulation

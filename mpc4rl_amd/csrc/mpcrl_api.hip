@@ -126,6 +126,7 @@ int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
     // SQP rounds: the instances carry an `active` flag, finished ones return at once (no host synchronisation, the call stays
     // asynchronous); round r evaluates iterate r and, unless it stops there, takes the full step to iterate r + 1
     for (int r = 0; r <= max_iter; ++r) {
+        hipLaunchKernelGGL((chain_point_kernel<M, false>), dim3((unsigned)(((long)B * N + 63) / 64)), dim3(64), 0, st, h->large, a);
         hipLaunchKernelGGL(chain_lin_kernel<M>, dim3((unsigned)(B * ((N + LinCfg<M>::G - 1) / LinCfg<M>::G))), dim3(256), 0, st, h->large, a);
         hipLaunchKernelGGL(chain_qp_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
     }
@@ -134,6 +135,7 @@ int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
         hipLaunchKernelGGL(chain_sens_th_kernel<M>, dim3((unsigned)(((long)B * N + 63) / 64)), dim3(64), 0, st, h->large, a);
         const bool want_pi = (a.flags & MPCRL_SENS_PI) && a.dpi && !a.u0fix;
         if (want_pi) {
+            hipLaunchKernelGGL((chain_point_kernel<M, true>), dim3((unsigned)(((long)B * N + 63) / 64)), dim3(64), 0, st, h->large, a);
             hipLaunchKernelGGL(chain_sens_ad_kernel<M>, dim3((unsigned)(B * N)), dim3(64), 0, st, h->large, a);
             hipLaunchKernelGGL(chain_sens_riccati_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
             hipLaunchKernelGGL(chain_sens_mix_kernel<M>, blocks((long)B * N * M::NU), dim3(256), 0, st, h->large, a);
