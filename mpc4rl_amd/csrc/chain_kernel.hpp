@@ -92,6 +92,9 @@ struct LargeLayout {
 
 enum { ST_ACTIVE = 0, ST_IT = 1, ST_NIPM = 2, ST_TIGHT = 3, ST_STEPN = 4, ST_COST = 5, ST_RES = 6, ST_STATUS = 10 };
 
+template <class M, bool SECOND>
+__device__ void chain_point_pass(const double *X, const double *U, const double *th, double *w, int N, int k, double h, int steps);
+
 // An array inside the instance's workspace: one base pointer for all of them (scalar registers) plus a 32-bit offset, so that
 // every access is `global_load/store v, voffset, s[base]` — no 64-bit per-lane address arithmetic to keep live.
 struct WsArr {
@@ -1383,6 +1386,9 @@ __global__ void __launch_bounds__(64) chain_init_kernel(const LargeSpec sp, cons
         st[ST_STATUS] = 2.0;
         for (int j = 0; j < 4; ++j) st[ST_RES + j] = 0.0;
     }
+    // the point pass of the first linearisation (lane k = stage k); every later one runs at the end of the QP kernel's round
+    wave_sync();
+    if (lane < N) chain_point_pass<M, false>(X, U, a.theta + (size_t)inst * a.theta_stride, w, N, lane, sp.h, sp.rk_steps);
 }
 
 // ---- the POINT pass of the derivative kernels: one lane per (instance, stage) walks the 4 x rk_steps evaluation points of the RK4
@@ -1391,26 +1397,12 @@ __global__ void __launch_bounds__(64) chain_init_kernel(const LargeSpec sp, cons
 // coefficients as well and a reverse sweep of nu_{k+1} through the same points adds the 3 x 3 Hessian of every link force
 // (ChainDev::link_hessian).  The direction kernels below (one lane per direction) then start from these tables: done inside them, this
 // pass was repeated by every lane of a stage — 60 % of the linearisation's and half of the Hessian kernel's instructions.
+// the pass itself, for stage k of one instance (X, U, th: the instance's iterate and parameters, w: its workspace).  A real call: the
+// QP kernel runs it at the end of a round on N of its lanes, with a register allocation of its own.
 template <class M, bool SECOND>
-__global__ void __launch_bounds__(64) chain_point_kernel(const LargeSpec sp, const LargeArgs a) {
+__device__ __attribute__((noinline)) void chain_point_pass(const double *X, const double *U, const double *th, double *w, int N, int k, double h, int steps) {
     constexpr int NX = M::NX, NU = M::NU, NL = M::NL, TS = SECOND ? M::TAB2 : M::TAB;
-    const int N = sp.N;
-    const long gid = (long)blockIdx.x * 64 + threadIdx.x;
-    const int inst = (int)(gid / N);
-    if (inst >= a.B) return;
     const LargeLayout<M> lay(N);
-    double *w = a.ws + (size_t)inst * a.ws_stride;
-    if constexpr (SECOND) {
-        const int status = a.status[inst];
-        if (!(status == 0 || status == 2)) return;
-    } else {
-        if (w[lay.state + ST_ACTIVE] == 0.0) return;
-    }
-    const int k = (int)(gid - (long)inst * N);
-    const double *X = a.X + (size_t)inst * (N + 1) * NX, *U = a.U + (size_t)inst * N * NU;
-    const double *th = a.theta + (size_t)inst * a.theta_stride;
-    const double h = sp.h;
-    const int steps = sp.rk_steps;
     double *tab = w + lay.ptab + (size_t)k * 8 * NL * M::TAB2;
     double u[NU];
 #pragma unroll
@@ -1473,6 +1465,25 @@ __global__ void __launch_bounds__(64) chain_point_kernel(const LargeSpec sp, con
     }
 }
 
+template <class M, bool SECOND>
+__global__ void __launch_bounds__(64) chain_point_kernel(const LargeSpec sp, const LargeArgs a) {
+    constexpr int NX = M::NX, NU = M::NU;
+    const int N = sp.N;
+    const long gid = (long)blockIdx.x * 64 + threadIdx.x;
+    const int inst = (int)(gid / N);
+    if (inst >= a.B) return;
+    const LargeLayout<M> lay(N);
+    double *w = a.ws + (size_t)inst * a.ws_stride;
+    if constexpr (SECOND) {
+        const int status = a.status[inst];
+        if (!(status == 0 || status == 2)) return;
+    } else {
+        if (w[lay.state + ST_ACTIVE] == 0.0) return;
+    }
+    chain_point_pass<M, SECOND>(a.X + (size_t)inst * (N + 1) * NX, a.U + (size_t)inst * N * NU, a.theta + (size_t)inst * a.theta_stride, w, N,
+                                (int)(gid - (long)inst * N), sp.h, sp.rk_steps);
+}
+
 // ---- dynamics linearisation, the DIRECTION pass: fills [B A]_k.  One workgroup = LIN_G consecutive stages of one instance, one lane
 // per (stage, direction): the stages' coefficient tables (chain_point_kernel) are copied into LDS, 16 bytes per lane and step, then each
 // lane propagates ONLY its tangent through the evaluation points.  A forward jet per lane (value + tangent through the whole map)
@@ -1484,6 +1495,10 @@ struct LinCfg {
     static constexpr int G = 256 / NW;               // stages per workgroup
     static constexpr int NT = G * NW;                // lanes used (<= 256)
     static constexpr int EV = 8;                     // evaluation points: 4 RK stages x 2 steps (rk_steps <= 2)
+    // NX = 21: ONE workgroup per instance walks all its stage groups (the kernel then fits two wavefronts per SIMD, and a finished
+    // instance costs a single workgroup that leaves at once — most rounds of a solve find nothing to do).  NX = 33: one workgroup
+    // per stage group (with the loop around it the kernel needs 397 registers instead of 256 and drops to one wavefront per SIMD).
+    static constexpr bool WALK = NX <= 21;
 };
 
 template <class M>
@@ -1492,52 +1507,63 @@ __global__ void __launch_bounds__(256) chain_lin_kernel(const LargeSpec sp, cons
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NL = M::NL, TAB = M::TAB, STG = LC::EV * NL * M::TAB2;   // doubles per stage in the workspace
     static_assert(STG % 2 == 0, "16-byte copies");
     __shared__ __attribute__((aligned(16))) double tab[LC::G * STG];
-    const int N = sp.N, nblk = (N + LC::G - 1) / LC::G;
-    const int inst = blockIdx.x / nblk, k0 = (blockIdx.x - inst * nblk) * LC::G;
+    // one workgroup per instance, walking its stages in groups of LIN_G: a finished instance costs one workgroup that leaves at once
+    // (most rounds of a solve find nothing to do, and four workgroups per instance made each of them four times as expensive)
+    const int N = sp.N, nblk = LC::WALK ? 1 : (N + LC::G - 1) / LC::G;
+    const int inst = blockIdx.x / nblk, part = blockIdx.x - inst * nblk;
     const LargeLayout<M> lay(N);
     double *w = a.ws + (size_t)inst * a.ws_stride;
     if (w[lay.state + ST_ACTIVE] == 0.0) return;     // uniform over the workgroup
     const int t = threadIdx.x, g = t / NW, d = t - g * NW;
-    const bool lane_on = t < LC::NT && k0 + g < N;
-    const int k = lane_on ? k0 + g : N - 1;          // idle lanes shadow the last stage and never store
     const double *th = a.theta + (size_t)inst * a.theta_stride;
     const double h = sp.h;
     const int steps = sp.rk_steps;
-    {   // the tables of this workgroup's stages are one contiguous piece of the workspace
-        const int ng = min(LC::G, N - k0);
-        const d2_t *src = (const d2_t *)(w + lay.ptab + (size_t)k0 * STG);
-        d2_t *dst = (d2_t *)tab;
-        for (int e = t; e < ng * STG / 2; e += 256) dst[e] = src[e];
-    }
-    __syncthreads();
-    const double *mytab = tab + (size_t)(lane_on ? g : 0) * STG;
-    {   // the direction: tangent e_d through the evaluation points
-        double dxc[NX], acc[NX], dk[NX], dxt[NX], du[NU];
-#pragma unroll
-        for (int i = 0; i < NU; ++i) du[i] = d == i ? 1.0 : 0.0;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) dxc[i] = d == NU + i ? 1.0 : 0.0;
-        for (int s = 0; s < steps; ++s) {
-            const double *tb = mytab + (size_t)(4 * s) * NL * TAB;
-            M::template ode_tan<TAB, false>(tb, th, dxc, du, dk, nullptr);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
-            M::template ode_tan<TAB, false>(tb + NL * TAB, th, dxt, du, dk, nullptr);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
-            M::template ode_tan<TAB, false>(tb + 2 * NL * TAB, th, dxt, du, dk, nullptr);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + h * dk[i];
-            M::template ode_tan<TAB, false>(tb + 3 * NL * TAB, th, dxt, du, dk, nullptr);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) dxc[i] = dxc[i] + (h / 6.0) * (acc[i] + dk[i]);
+    auto group = [&](const int k0) {
+        const bool lane_on = t < LC::NT && k0 + g < N;
+        const int k = lane_on ? k0 + g : N - 1;      // idle lanes shadow the last stage and never store
+        {   // the tables of this group's stages are one contiguous piece of the workspace
+            const int ng = min(LC::G, N - k0);
+            const d2_t *src = (const d2_t *)(w + lay.ptab + (size_t)k0 * STG);
+            d2_t *dst = (d2_t *)tab;
+            for (int e = t; e < ng * STG / 2; e += 256) dst[e] = src[e];
         }
-        if (lane_on) {
-            double *BA = w + lay.BA + (size_t)k * NX * NW;
+        __syncthreads();
+        const double *mytab = tab + (size_t)(lane_on ? g : 0) * STG;
+        {   // the direction: tangent e_d through the evaluation points
+            double dxc[NX], acc[NX], dk[NX], dxt[NX], du[NU];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) BA[i * NW + d] = dxc[i];
+            for (int i = 0; i < NU; ++i) du[i] = d == i ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) dxc[i] = d == NU + i ? 1.0 : 0.0;
+            for (int s = 0; s < steps; ++s) {
+                const double *tb = mytab + (size_t)(4 * s) * NL * TAB;
+                M::template ode_tan<TAB, false>(tb, th, dxc, du, dk, nullptr);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) acc[i] = dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
+                M::template ode_tan<TAB, false>(tb + NL * TAB, th, dxt, du, dk, nullptr);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
+                M::template ode_tan<TAB, false>(tb + 2 * NL * TAB, th, dxt, du, dk, nullptr);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + h * dk[i];
+                M::template ode_tan<TAB, false>(tb + 3 * NL * TAB, th, dxt, du, dk, nullptr);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) dxc[i] = dxc[i] + (h / 6.0) * (acc[i] + dk[i]);
+            }
+            if (lane_on) {
+                double *BA = w + lay.BA + (size_t)k * NX * NW;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) BA[i * NW + d] = dxc[i];
+            }
         }
-    }
+    };
+    if constexpr (LC::WALK) {
+        for (int k0 = 0; k0 < N; k0 += LC::G) {
+            group(k0);
+            __syncthreads();                         // the next group's tables overwrite these
+        }
+    } else
+        group(part * LC::G);
 }
 
 // ---- one SQP round of one instance: cost, residuals, stopping test, QP by the Riccati interior-point method, full step.
@@ -1601,6 +1627,10 @@ __global__ void __launch_bounds__(64, 1) chain_qp_kernel(const LargeSpec sp, con
                             [&](int e, const Pair2 &v) { sl = fmax(sl, fabs(v.a)), S.U[e] = v.b + v.a; });
             sl = wave_max(sl);
             if (lane == 0) S.state[ST_IT] = it + 1, S.state[ST_NIPM] = n_ipm, S.state[ST_TIGHT] = tight ? 1.0 : 0.0, S.state[ST_STEPN] = sl;
+            // the point pass of the next round's linearisation, at the new iterate: lane k = stage k.  (As a launch of its own it
+            // cost a kernel boundary per round, 51 of them per solve, for ~100 us of work in the rounds that have any.)
+            wave_sync();
+            if (lane < N) chain_point_pass<M, false>(S.X, S.U, S.th, w, N, lane, sp.h, sp.rk_steps);
             S.ph(14);
             S.ph_flush();
             return;

@@ -126,8 +126,7 @@ int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
     // SQP rounds: the instances carry an `active` flag, finished ones return at once (no host synchronisation, the call stays
     // asynchronous); round r evaluates iterate r and, unless it stops there, takes the full step to iterate r + 1
     for (int r = 0; r <= max_iter; ++r) {
-        hipLaunchKernelGGL((chain_point_kernel<M, false>), dim3((unsigned)(((long)B * N + 63) / 64)), dim3(64), 0, st, h->large, a);
-        hipLaunchKernelGGL(chain_lin_kernel<M>, dim3((unsigned)(B * ((N + LinCfg<M>::G - 1) / LinCfg<M>::G))), dim3(256), 0, st, h->large, a);
+        hipLaunchKernelGGL(chain_lin_kernel<M>, dim3((unsigned)(B * (LinCfg<M>::WALK ? 1 : (N + LinCfg<M>::G - 1) / LinCfg<M>::G))), dim3(256), 0, st, h->large, a);
         hipLaunchKernelGGL(chain_qp_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
     }
     HIP_OK(hipGetLastError());
