@@ -1386,9 +1386,6 @@ __global__ void __launch_bounds__(64) chain_init_kernel(const LargeSpec sp, cons
         st[ST_STATUS] = 2.0;
         for (int j = 0; j < 4; ++j) st[ST_RES + j] = 0.0;
     }
-    // the point pass of the first linearisation (lane k = stage k); every later one runs at the end of the QP kernel's round
-    wave_sync();
-    if (lane < N) chain_point_pass<M, false>(X, U, a.theta + (size_t)inst * a.theta_stride, w, N, lane, sp.h, sp.rk_steps);
 }
 
 // ---- the POINT pass of the derivative kernels: one lane per (instance, stage) walks the 4 x rk_steps evaluation points of the RK4
@@ -1484,91 +1481,77 @@ __global__ void __launch_bounds__(64) chain_point_kernel(const LargeSpec sp, con
                                 (int)(gid - (long)inst * N), sp.h, sp.rk_steps);
 }
 
-// ---- dynamics linearisation, the DIRECTION pass: fills [B A]_k.  One workgroup = LIN_G consecutive stages of one instance, one lane
-// per (stage, direction): the stages' coefficient tables (chain_point_kernel) are copied into LDS, 16 bytes per lane and step, then each
-// lane propagates ONLY its tangent through the evaluation points.  A forward jet per lane (value + tangent through the whole map)
-// needs both sets of arrays live at once — 2 x 4 NX doubles, 528 registers at NX = 33, i.e. spills whose scratch traffic made the round-1
-// kernel HBM-bound (46 GB per step at n_mass = 7) — and recomputes the point NW times.
+// ---- dynamics linearisation, the DIRECTION pass: fills [B A]_k of all stages of ONE instance, run by the instance's own wavefront
+// inside the SQP kernel.  One lane per (stage, direction), 64 of them per step; the coefficient tables (chain_point_pass) of the
+// stages a step touches are copied to LDS, then each lane propagates ONLY its tangent through the evaluation points.  A forward jet
+// per lane (value + tangent through the whole map) needs both sets of arrays live at once — 2 x 4 NX doubles, 528 registers at
+// NX = 33, i.e. spills whose scratch traffic made the round-1 kernel HBM-bound (46 GB per step at n_mass = 7) — and recomputes the
+// point NW times.  As a grid-wide kernel of its own (first half of round 2) it cost the same SIMD time — an instance's 40 x NW
+// directions are 15 (23) wavefront-steps either way, and a batch of 1024 is one wavefront per SIMD — plus a kernel boundary per round.
 template <class M>
-struct LinCfg {
-    static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU;
-    static constexpr int G = 256 / NW;               // stages per workgroup
-    static constexpr int NT = G * NW;                // lanes used (<= 256)
-    static constexpr int EV = 8;                     // evaluation points: 4 RK stages x 2 steps (rk_steps <= 2)
-    // NX = 21: ONE workgroup per instance walks all its stage groups (the kernel then fits two wavefronts per SIMD, and a finished
-    // instance costs a single workgroup that leaves at once — most rounds of a solve find nothing to do).  NX = 33: one workgroup
-    // per stage group (with the loop around it the kernel needs 397 registers instead of 256 and drops to one wavefront per SIMD).
-    static constexpr bool WALK = NX <= 21;
+struct DirCfg {
+    static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NL = M::NL, EV = 8;
+    static constexpr int TSZ = EV * NL * M::TAB;                    // doubles of one stage's first-order table
+    static constexpr int SPAN = (64 + NW - 1) / NW + 1;              // stages a step of 64 consecutive (stage, direction) items can touch
+    static constexpr int BIG = ChainCfg<M>::LDS_TOTAL - ChainCfg<M>::oBig;
+    static constexpr bool FITS = SPAN * TSZ <= BIG;                  // else whole stages per step
+    static constexpr int LP = FITS ? 64 : (64 / NW) * NW;            // items per step
+    static_assert((FITS ? SPAN : 64 / NW) * TSZ <= BIG, "tables of a step fit the LDS region");
 };
 
 template <class M>
-__global__ void __launch_bounds__(256) chain_lin_kernel(const LargeSpec sp, const LargeArgs a) {
-    using LC = LinCfg<M>;
-    constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NL = M::NL, TAB = M::TAB, STG = LC::EV * NL * M::TAB2;   // doubles per stage in the workspace
-    static_assert(STG % 2 == 0, "16-byte copies");
-    __shared__ __attribute__((aligned(16))) double tab[LC::G * STG];
-    // one workgroup per instance, walking its stages in groups of LIN_G: a finished instance costs one workgroup that leaves at once
-    // (most rounds of a solve find nothing to do, and four workgroups per instance made each of them four times as expensive)
-    const int N = sp.N, nblk = LC::WALK ? 1 : (N + LC::G - 1) / LC::G;
-    const int inst = blockIdx.x / nblk, part = blockIdx.x - inst * nblk;
+__device__ __attribute__((noinline)) void chain_dir_pass(const double *th, double *w, double *tabl, int N, int lane, double h, int steps) {
+    using DC = DirCfg<M>;
+    constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NL = M::NL, TAB = M::TAB, TSZ = DC::TSZ, STG = DC::EV * NL * M::TAB2;
     const LargeLayout<M> lay(N);
-    double *w = a.ws + (size_t)inst * a.ws_stride;
-    if (w[lay.state + ST_ACTIVE] == 0.0) return;     // uniform over the workgroup
-    const int t = threadIdx.x, g = t / NW, d = t - g * NW;
-    const double *th = a.theta + (size_t)inst * a.theta_stride;
-    const double h = sp.h;
-    const int steps = sp.rk_steps;
-    auto group = [&](const int k0) {
-        const bool lane_on = t < LC::NT && k0 + g < N;
-        const int k = lane_on ? k0 + g : N - 1;      // idle lanes shadow the last stage and never store
-        {   // the tables of this group's stages are one contiguous piece of the workspace
-            const int ng = min(LC::G, N - k0);
-            const d2_t *src = (const d2_t *)(w + lay.ptab + (size_t)k0 * STG);
-            d2_t *dst = (d2_t *)tab;
-            for (int e = t; e < ng * STG / 2; e += 256) dst[e] = src[e];
+    const int items = N * NW;
+    for (int i0 = 0; i0 < items; i0 += DC::LP) {
+        const int k_lo = i0 / NW, k_hi = min(N - 1, (i0 + DC::LP - 1) / NW);
+        for (int e = lane; e < (k_hi - k_lo + 1) * TSZ; e += 64) {
+            const int ks = e / TSZ;
+            tabl[e] = w[lay.ptab + (size_t)(k_lo + ks) * STG + (e - ks * TSZ)];
         }
-        __syncthreads();
-        const double *mytab = tab + (size_t)(lane_on ? g : 0) * STG;
-        {   // the direction: tangent e_d through the evaluation points
-            double dxc[NX], acc[NX], dk[NX], dxt[NX], du[NU];
+        wave_sync();
+        const int it_ = i0 + lane;
+        const bool on = lane < DC::LP && it_ < items;
+        const int k = on ? it_ / NW : k_lo, d = on ? it_ - k * NW : 0;
+        const double *mytab = tabl + (size_t)(k - k_lo) * TSZ;
+        double dxc[NX], acc[NX], dk[NX], dxt[NX], du[NU];
 #pragma unroll
-            for (int i = 0; i < NU; ++i) du[i] = d == i ? 1.0 : 0.0;
+        for (int i = 0; i < NU; ++i) du[i] = d == i ? 1.0 : 0.0;
 #pragma unroll
-            for (int i = 0; i < NX; ++i) dxc[i] = d == NU + i ? 1.0 : 0.0;
-            for (int s = 0; s < steps; ++s) {
-                const double *tb = mytab + (size_t)(4 * s) * NL * TAB;
-                M::template ode_tan<TAB, false>(tb, th, dxc, du, dk, nullptr);
+        for (int i = 0; i < NX; ++i) dxc[i] = d == NU + i ? 1.0 : 0.0;
+        for (int s_ = 0; s_ < steps; ++s_) {
+            const double *tb = mytab + (size_t)(4 * s_) * NL * TAB;
+            M::template ode_tan<TAB, false>(tb, th, dxc, du, dk, nullptr);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) acc[i] = dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
-                M::template ode_tan<TAB, false>(tb + NL * TAB, th, dxt, du, dk, nullptr);
+            for (int i = 0; i < NX; ++i) acc[i] = dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
+            M::template ode_tan<TAB, false>(tb + NL * TAB, th, dxt, du, dk, nullptr);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
-                M::template ode_tan<TAB, false>(tb + 2 * NL * TAB, th, dxt, du, dk, nullptr);
+            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
+            M::template ode_tan<TAB, false>(tb + 2 * NL * TAB, th, dxt, du, dk, nullptr);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + h * dk[i];
-                M::template ode_tan<TAB, false>(tb + 3 * NL * TAB, th, dxt, du, dk, nullptr);
+            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + h * dk[i];
+            M::template ode_tan<TAB, false>(tb + 3 * NL * TAB, th, dxt, du, dk, nullptr);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) dxc[i] = dxc[i] + (h / 6.0) * (acc[i] + dk[i]);
-            }
-            if (lane_on) {
-                double *BA = w + lay.BA + (size_t)k * NX * NW;
-#pragma unroll
-                for (int i = 0; i < NX; ++i) BA[i * NW + d] = dxc[i];
-            }
+            for (int i = 0; i < NX; ++i) dxc[i] = dxc[i] + (h / 6.0) * (acc[i] + dk[i]);
         }
-    };
-    if constexpr (LC::WALK) {
-        for (int k0 = 0; k0 < N; k0 += LC::G) {
-            group(k0);
-            __syncthreads();                         // the next group's tables overwrite these
+        if (on) {
+            double *BA = w + lay.BA + (size_t)k * NX * NW;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) BA[i * NW + d] = dxc[i];
         }
-    } else
-        group(part * LC::G);
+        wave_sync();                                 // the next step's tables overwrite these
+    }
 }
 
-// ---- one SQP round of one instance: cost, residuals, stopping test, QP by the Riccati interior-point method, full step.
+// ---- the SQP loop of one instance, ONE WAVEFRONT, one launch: per round the linearisation at the current iterate (point pass on N
+// lanes, direction pass on all of them), cost / residuals / stopping test, the QP by the Riccati interior-point method, the full step.
+// (Until the middle of round 2 every round was a pair of launches and (max_iter + 1) of them were queued per solve: ~43 of the 51
+// found nothing to do and cost 19 us of kernel boundaries each.)  The per-round scalars still travel through ws.state, which is
+// what the phase functions read.
 template <class M>
-__global__ void __launch_bounds__(64, 1) chain_qp_kernel(const LargeSpec sp, const LargeArgs a) {
+__global__ void __launch_bounds__(64, 1) chain_sqp_kernel(const LargeSpec sp, const LargeArgs a) {
     using Cfg = ChainCfg<M>;
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NT = 64;
     __shared__ __attribute__((aligned(16))) double lds[Cfg::LDS_TOTAL];
@@ -1576,7 +1559,6 @@ __global__ void __launch_bounds__(64, 1) chain_qp_kernel(const LargeSpec sp, con
     const int lane = threadIdx.x, inst = blockIdx.x, N = sp.N;
     const LargeLayout<M> lay(N);
     double *w = a.ws + (size_t)inst * a.ws_stride;
-    if (w[lay.state + ST_ACTIVE] == 0.0) return;
     ChainSolver<M> S(sp, lane);
     S.th = a.theta + (size_t)inst * a.theta_stride;
     S.qmode = a.u0fix != nullptr;
@@ -1588,53 +1570,58 @@ __global__ void __launch_bounds__(64, 1) chain_qp_kernel(const LargeSpec sp, con
     const int ne = (N + 1) * NW;
     const bool rti = (a.flags & 4) != 0;
     const int max_iter = rti ? 1 : sp.max_iter;
-    const int it = (int)S.state[ST_IT];
-    int n_ipm = (int)S.state[ST_NIPM];
-    const bool last_tight = S.state[ST_TIGHT] != 0.0;
-    const double stepn = S.state[ST_STEPN];
 #ifdef MPCRL_PROFILE_PHASES
     __shared__ unsigned long long ph_buf[16];
     S.ph_init(ph_buf);
 #endif
     S.ph0();
-    const auto rs0 = ChainSolver<M>::round_start_call(S, x0, u0f);
-    const double cost = rs0.cost;
-    const double res[4] = {rs0.res[0], rs0.res[1], rs0.res[2], rs0.res[3]};
-    S.ph(9);
-    const double rmax = fmax(fmax(res[0], res[1]), fmax(res[2], res[3]));
-    int status = -1;   // -1: carry on
-    if (!(rmax < 1e300))
-        status = 1;
-    else if (rmax < sp.tol && last_tight && !(rti && it == 0))
-        status = 0;
-    else if (it >= max_iter)
-        status = rmax < sp.tol ? 0 : 2;
-    if (status < 0) {
+    int it, n_ipm, status;
+    double cost, res[4];
+    for (;;) {
+        it = (int)S.state[ST_IT];
+        n_ipm = (int)S.state[ST_NIPM];
+        const bool last_tight = S.state[ST_TIGHT] != 0.0;
+        const double stepn = S.state[ST_STEPN];
+        // ---- linearisation at the current iterate
+        wave_sync();
+        if (lane < N) chain_point_pass<M, false>(S.X, S.U, S.th, w, N, lane, sp.h, sp.rk_steps);
+        wave_sync();
+        S.ph(6);
+        chain_dir_pass<M>(S.th, w, lds + Cfg::oBig, N, lane, sp.h, sp.rk_steps);
+        S.ph(8);
+        const auto rs0 = ChainSolver<M>::round_start_call(S, x0, u0f);
+        cost = rs0.cost;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) res[j] = rs0.res[j];
+        S.ph(9);
+        const double rmax = fmax(fmax(res[0], res[1]), fmax(res[2], res[3]));
+        status = -1;   // -1: carry on
+        if (!(rmax < 1e300))
+            status = 1;
+        else if (rmax < sp.tol && last_tight && !(rti && it == 0))
+            status = 0;
+        else if (it >= max_iter)
+            status = rmax < sp.tol ? 0 : 2;
+        if (status >= 0) break;
         const double rr_ = fmin(1.0, rmax), ad_ = rmax < sp.tol ? 0.0 : IPM_ADAPT_C * rr_ * rr_;
         const double tol_res = fmin(IPM_ADAPT_CAP, fmax(IPM_TOL_RES, ad_)), tol_mu = fmin(0.1 * IPM_ADAPT_CAP, fmax(IPM_TOL_MU, 1e-2 * ad_));
         const bool tight = tol_res <= IPM_TOL_RES && tol_mu <= IPM_TOL_MU;
         const double warm_mu = stepn < 0.0 ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
-        // the SQP Hessian: this lane's tile of (R, Q) without c_k, in registers
+        // the SQP Hessian: this lane's tiles of (R, Q) without c_k, in registers
         HessConst<M> hs;
         hs.th = S.th, hs.sck = S.sCK();
-        if (!S.qp_solve(hs, x0, u0f, n_ipm, warm_mu, tol_res, tol_mu))
+        if (!S.qp_solve(hs, x0, u0f, n_ipm, warm_mu, tol_res, tol_mu)) {
             status = 4;
-        else {
-            double sl = 0.0;
-            batched_pass<4>((N + 1) * NX, lane, [&](int e) { return Quad4{S.dx[e], S.X[e], S.nuq[e], 0.0}; },
-                            [&](int e, const Quad4 &v) { sl = fmax(sl, fabs(v.a)), S.X[e] = v.b + v.a, S.NUv[e] = v.c; });
-            batched_pass<2>(N * NU, lane, [&](int e) { return Pair2{S.du[e], S.U[e]}; },
-                            [&](int e, const Pair2 &v) { sl = fmax(sl, fabs(v.a)), S.U[e] = v.b + v.a; });
-            sl = wave_max(sl);
-            if (lane == 0) S.state[ST_IT] = it + 1, S.state[ST_NIPM] = n_ipm, S.state[ST_TIGHT] = tight ? 1.0 : 0.0, S.state[ST_STEPN] = sl;
-            // the point pass of the next round's linearisation, at the new iterate: lane k = stage k.  (As a launch of its own it
-            // cost a kernel boundary per round, 51 of them per solve, for ~100 us of work in the rounds that have any.)
-            wave_sync();
-            if (lane < N) chain_point_pass<M, false>(S.X, S.U, S.th, w, N, lane, sp.h, sp.rk_steps);
-            S.ph(14);
-            S.ph_flush();
-            return;
+            break;
         }
+        double sl = 0.0;
+        batched_pass<4>((N + 1) * NX, lane, [&](int e) { return Quad4{S.dx[e], S.X[e], S.nuq[e], 0.0}; },
+                        [&](int e, const Quad4 &v) { sl = fmax(sl, fabs(v.a)), S.X[e] = v.b + v.a, S.NUv[e] = v.c; });
+        batched_pass<2>(N * NU, lane, [&](int e) { return Pair2{S.du[e], S.U[e]}; },
+                        [&](int e, const Pair2 &v) { sl = fmax(sl, fabs(v.a)), S.U[e] = v.b + v.a; });
+        sl = wave_max(sl);
+        if (lane == 0) S.state[ST_IT] = it + 1, S.state[ST_NIPM] = n_ipm, S.state[ST_TIGHT] = tight ? 1.0 : 0.0, S.state[ST_STEPN] = sl;
+        S.ph(14);
     }
     // ---- finished (converged, failed or out of iterations): results + iterate
     double *PIg = a.PI + (size_t)inst * N * NX;

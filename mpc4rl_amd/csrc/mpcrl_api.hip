@@ -123,12 +123,9 @@ int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
     const int max_iter = (a.flags & MPCRL_RTI) ? 1 : h->large.max_iter;
     auto blocks = [](long items) { return dim3((unsigned)((items + 255) / 256)); };
     hipLaunchKernelGGL(chain_init_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
-    // SQP rounds: the instances carry an `active` flag, finished ones return at once (no host synchronisation, the call stays
-    // asynchronous); round r evaluates iterate r and, unless it stops there, takes the full step to iterate r + 1
-    for (int r = 0; r <= max_iter; ++r) {
-        hipLaunchKernelGGL(chain_lin_kernel<M>, dim3((unsigned)(B * (LinCfg<M>::WALK ? 1 : (N + LinCfg<M>::G - 1) / LinCfg<M>::G))), dim3(256), 0, st, h->large, a);
-        hipLaunchKernelGGL(chain_qp_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
-    }
+    // the whole SQP loop of an instance runs inside one wavefront of one launch (linearisation, QP, step; chain_kernel.hpp)
+    (void)max_iter, (void)blocks;
+    hipLaunchKernelGGL(chain_sqp_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
     HIP_OK(hipGetLastError());
     if (a.flags & (MPCRL_SENS_V | MPCRL_SENS_PI)) {
         hipLaunchKernelGGL(chain_sens_th_kernel<M>, dim3((unsigned)(((long)B * N + 63) / 64)), dim3(64), 0, st, h->large, a);

@@ -19,9 +19,9 @@ mpc.solve(x0t, cold=True); torch.cuda.synchronize()
 lib.mpcrl_debug_phases(out, 1)
 t = time.perf_counter(); r = mpc.solve(x0t, cold=True); torch.cuda.synchronize(); dt = time.perf_counter() - t
 lib.mpcrl_debug_phases(out, 1)
-names = ["0 resid", "1 barrier", "2 factor:rest", "3 bwd_vec", "4 forward", "5 steplen", "6", "7 update+qp setup", "8 linearize_dyn",
+names = ["0 resid", "1 barrier", "2 factor (= 10..13)", "3 bwd_vec", "4 forward", "5 steplen", "6 lin: point pass", "7 update+qp setup", "8 lin: direction pass",
          "9 cost+nlp res", "10 fac:T", "11 fac:M", "12 fac:chol/K", "13 fac:P", "14 sqp step", "15"]
-tot = sum(out[i] for i in range(16))
+tot = sum(out[i] for i in range(16) if i != 2)   # bucket 2 is stamped by the caller of the factor sweep: it repeats 10..13
 it = r.iters.cpu().numpy()
 print("n_mass %d: solve %.2f ms, sqp mean %.2f, ipm mean %.2f" % (n_mass, dt*1e3, it[:, 0].mean(), it[:, 1].mean()))
 for i in range(16):
