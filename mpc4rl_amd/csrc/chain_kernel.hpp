@@ -6,9 +6,10 @@
 //   update_nlp(): dL_dp, dpi_dp   rlmpc/mpc/nlp.py:1399-1424            (dense 2385 x 2385 Jacobian + SuperLU, 499 right-hand sides)
 //
 // Mapping on gfx950 (MI355X-first).  The work has two shapes and each gets the launch geometry that suits it:
-//   * DERIVATIVES of the 2-step RK4 map (Jacobians for the SQP, Hessian columns and parameter gradients for the sensitivities)
-//     are independent per (instance, stage, direction): grid-wide kernels with one item per lane, everything in registers
-//     (chain_lin_kernel, chain_sens_ad_kernel, chain_sens_mix_kernel).  They want ~350-500 registers per lane.
+//   * DERIVATIVES of the 2-step RK4 map for the sensitivities (Hessian columns, parameter gradients) are independent per (instance,
+//     stage, direction): grid-wide kernels with one item per lane, everything in registers (chain_sens_ad_kernel,
+//     chain_sens_mix_kernel).  They want ~350-500 registers per lane.  The Jacobians [B A]_k of the SQP rounds are computed by the
+//     instance's own wavefront (chain_point_pass / chain_dir_pass, non-inlined calls with register allocations of their own).
 //   * the RICCATI interior-point solve of one QP is a dependency chain over the stages: ONE WAVEFRONT PER OCP INSTANCE, one
 //     wavefront per SIMD (a batch of 1024 instances is exactly one wavefront on each of the chip's 1024 SIMDs).  There is no
 //     workgroup barrier anywhere: lanes of one wavefront exchange data through LDS or through the instance's HBM workspace, and
@@ -21,10 +22,10 @@
 //       - the vector sweeps of the corrector / the extra right-hand sides are pure matrix-vector chains on Acl_k
 //             p_k = (g_x - K' g_u) + Acl_k' (p_{k+1} + P_{k+1} b_k),        dx_{k+1} = Acl_k dx_k + (b_k - B_k kff_k)
 //         with everything that does not sit on the chain (P_{k+1} b_k, kff_k, du_k, the multiplier step) done stage-parallel.
-//   * the SQP loop is a sequence of launches (linearise, QP) x (max_iter + 1); every instance carries an `active` flag in its
-//     workspace and finished instances return at once.  Keeping the two shapes in separate kernels is what keeps both free of
-//     scratch memory: fused, the jets of the derivative code pushed the Riccati loops' operands into scratch, and every scratch
-//     reload is an s_waitcnt vmcnt(0) that also drains the streaming stores.
+//   * the SQP loop of an instance runs inside ONE launch (chain_sqp_kernel): per round linearisation, cost / residuals / stopping
+//     test, QP, full step.  What keeps the Riccati loops free of spills next to the derivative code is the call boundary: fused by
+//     inlining, the jets of the derivative code pushed the loops' operands into scratch, and every scratch reload is an
+//     s_waitcnt vmcnt(0) that also drains the streaming stores.
 // Only hard box bounds are supported here (the chain problem has bounds on u only).
 //
 // The iteration is the one of small_kernel.hpp / DESIGN.md §2 (same constants), so results agree with the oracle to rounding.
