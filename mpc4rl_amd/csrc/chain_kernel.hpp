@@ -1899,6 +1899,14 @@ __global__ void __launch_bounds__(256) chain_sens_out_kernel(const LargeSpec sp,
     constexpr int NX = M::NX, NU = M::NU, NTD = M::NTD, NP = M::NP;
     constexpr int NE = NTD + NX * NX + NU * NU;   // elements per slot: dynamics parameters, Q (column-major), R
     const int N = sp.N;
+    // stage weights c_k once per workgroup (a pow() per stage and lane was most of this kernel's time)
+    __shared__ double cks[64];   // N + 1 <= 64 (mpcrl_create)
+    for (int k = threadIdx.x; k <= N; k += 256) {
+        double c = k == N ? 1.0 : sp.dT;
+        if (sp.cost_kind != 0) c = k == 0 ? sp.dT : (k == N ? pow(sp.gamma, (double)N) : pow(sp.gamma, (double)k) * sp.dT);
+        cks[k] = c;
+    }
+    __syncthreads();
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const int per = (NU + 1) * NE;
     const int inst = (int)(gid / per);
@@ -1911,10 +1919,7 @@ __global__ void __launch_bounds__(256) chain_sens_out_kernel(const LargeSpec sp,
     const LargeLayout<M> lay(N);
     const double *w = a.ws + (size_t)inst * a.ws_stride;
     const double *X = a.X + (size_t)inst * (N + 1) * NX, *U = a.U + (size_t)inst * N * NU, *xs = sp.consts;
-    auto ck = [&](int k) {
-        if (sp.cost_kind == 0) return k == N ? 1.0 : sp.dT;
-        return k == 0 ? sp.dT : (k == N ? pow(sp.gamma, (double)N) : pow(sp.gamma, (double)k) * sp.dT);
-    };
+    auto ck = [&](int k) { return cks[k]; };
     const int iu = slot - 1;
     const double *tm = slot == 0 ? w + lay.term : w + lay.term2 + (size_t)iu * N * NTD;
     const double *Dx = w + lay.Ydx + (size_t)(iu < 0 ? 0 : iu) * (N + 1) * NX, *Du = w + lay.Ydu + (size_t)(iu < 0 ? 0 : iu) * N * NU;

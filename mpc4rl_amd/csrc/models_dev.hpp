@@ -37,6 +37,7 @@ struct CartpoleDev {
     static constexpr int NX = 4, NU = 1, NW = 5, NP = 83, NTD = 3, NTC = 0;
     static constexpr bool DISCRETE = false, HAS_SOFT = false;
     static constexpr int MAX_IPW = 4;   // instances per wavefront: the matrix-core factor sweep has four 4x4 blocks
+    static constexpr bool SEG_SKIP = false;   // segmented reductions: full trees (small_kernel.hpp, measured)
     MPCRL_DI static int td_index(int i) { return i; }
     MPCRL_DI static int tc_index(int) { return 0; }
     // cost block of the parameter vector (nlp.py:969-989, each field column-major): W_0 (5x5), W (5x5), W_e (4x4), yref_0 (5),
@@ -108,6 +109,7 @@ struct LinearDev {
     static constexpr int NX = 2, NU = 1, NW = 3, NP = 12, NTD = 8, NTC = 4;
     static constexpr bool DISCRETE = true, HAS_SOFT = true;
     static constexpr int MAX_IPW = 21;   // N >= 2
+    static constexpr bool SEG_SKIP = true;
     MPCRL_DI static int td_index(int i) { return i; }
     MPCRL_DI static int tc_index(int i) { return 8 + i; }   // V_0, f_0, f_1, f_2
     static constexpr int NLD = NX + NU;

@@ -84,28 +84,37 @@ MPCRL_DI double fast_rcp(double x) {
 }
 
 // segmented reductions over the LPI lanes of one instance; result broadcast to all of its lanes
+// SKIP (a model constant, M::SEG_SKIP): leave out the tree levels at which no lane has a partner (s >= lpi, wave-uniform).  One
+// cross-lane round trip less per reduction on paper; measured with everything else equal it is 2.3 % SLOWER for the cartpole kernels
+// (the branches change the schedule around the reductions) and 4 % faster for the linear system's, so each model states its own.
+template <bool SKIP>
 MPCRL_DI double seg_sum(double v, int k, int lpi, int base) {
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
+        if (SKIP && s >= lpi) continue;   // wave-uniform: no lane has a partner at this distance (a cross-lane round trip saved)
         const double o = __shfl_down(v, s);
         if (k + s < lpi) v += o;
     }
     return __shfl(v, base);
 }
+template <bool SKIP>
 MPCRL_DI double seg_max(double v, int k, int lpi, int base) {
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
+        if (SKIP && s >= lpi) continue;
         const double o = __shfl_down(v, s);
         if (k + s < lpi) v = fmax(v, o);
     }
     return __shfl(v, base);
 }
-MPCRL_DI double seg_min(double v, int k, int lpi, int base) { return -seg_max(-v, k, lpi, base); }
+template <bool SKIP>
+MPCRL_DI double seg_min(double v, int k, int lpi, int base) { return -seg_max<SKIP>(-v, k, lpi, base); }
 // several reductions in one pass: the cross-lane moves of the different values overlap instead of queueing behind each other
-template <int NMAX, int NSUM>
+template <int NMAX, int NSUM, bool SKIP>
 MPCRL_DI void seg_reduce(double *mx, double *sm, int k, int lpi, int base) {
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
+        if (SKIP && s >= lpi) continue;
         double om[NMAX > 0 ? NMAX : 1], os[NSUM > 0 ? NSUM : 1];
 #pragma unroll
         for (int i = 0; i < NMAX; ++i) om[i] = __shfl_down(mx[i], s);
@@ -132,7 +141,7 @@ struct SmallSolver {
     MPCRL_DI static constexpr int sym(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
     const SmallSpec &sp;
-    const int N, lpi, k, base;
+    const int N, lpi, k, base, blkidx;   // blkidx: which instance slot of the wavefront (base / lpi)
     const bool term, first;
     bool qmode;
     double ck;                    // cost scaling c_k of this stage
@@ -155,7 +164,7 @@ struct SmallSolver {
     double hscale = 1.0;   // multiplies the Hs accessor of the Riccati stage (c_k for the SQP Hessian, 1 for the exact one)
 
     MPCRL_DI SmallSolver(const SmallSpec &sp_, int k_, int lpi_, int base_)
-        : sp(sp_), N(sp_.N), lpi(lpi_), k(k_), base(base_), term(k_ == sp_.N), first(k_ == 0) {}
+        : sp(sp_), N(sp_.N), lpi(lpi_), k(k_), base(base_), blkidx(base_ / lpi_), term(k_ == sp_.N), first(k_ == 0) {}
 
     // ---- static problem data of this stage -------------------------------------------------------
     MPCRL_DI double lbv(int i) const {
@@ -454,9 +463,11 @@ struct SmallSolver {
     //   [0,32)   (A(r,c), Hxx(r,c) + D_x) pairs at 2 (4 r + c); the sweep overwrites the second member with P_k(r,c)
     //   [32,48)  per row r: (B[r], Hxu[r]) at 32 + 4 r, (bb[r], g_x[r]) at 34 + 4 r
     //   [48,56)  per column c: (Huu + D_u | g_u | 0 | 0, Hxu[c]) at 48 + 2 c
-    //   56 K[4], 60 p[4], 64 kff, 65 1/R, 66 ok flag (stage 0's slot), 68/69 write-only dump for lanes with nothing to store
-    static constexpr int mxAH = 0, mxCol = 32, mxRow = 48, mxK = 56, mxp = 60, mxkff = 64, mxLi = 65, mxFlag = 66, mxDump = 68,
-                         MSLOT = 70;   // 64 slots = 35 KB: four single-wave workgroups still fit one CU's LDS
+    //   56 K[4], 60 p[4], 64 kff, 65 1/R
+    // After the 64 slots: one ok flag per block, and a write-only dump pair for lanes with nothing to store.
+    static constexpr int mxAH = 0, mxCol = 32, mxRow = 48, mxK = 56, mxp = 60, mxkff = 64, mxLi = 65,
+                         MSLOT = 66,   // 64 slots = 33 KB: four single-wave workgroups fit one CU's LDS, with room for a parked instance
+                         mxFlag = 64 * MSLOT, mxDump = mxFlag + 4, MX_LDS = mxDump + 2;
     double *ms = nullptr;   // LDS, 64 slots of MSLOT doubles (one per stage lane)
     // LDS cost table, one per instance of the wavefront: for each stage kind (0 = stage 0, 1 = interior, 2 = terminal) the packed
     // lower triangle of the UNSCALED stage-cost Hessian and the reference point of the residual (cartpole: W_0 / W / W_e and
@@ -536,8 +547,11 @@ struct SmallSolver {
         const bool live = blk < ipw;
         double *S0 = ms + (live ? blk : 0) * lpi * MSLOT;   // an idle block shadows block 0 and stores to the dump
         const int oAH = mxAH + 2 * (4 * r + c), oCol = mxCol + 4 * r + (c == 1 ? 2 : 0), oB = mxCol + 4 * r, oRow = mxRow + 2 * c;
-        const int oPw = live ? oAH + 1 : mxDump;
-        const int oMw = !live ? mxDump + 1 : (c == 0 ? mxK + r : (c == 1 ? mxp + r : (r == 0 ? (c == 2 ? mxkff : mxLi) : mxDump + 1)));
+        // store targets: slot-relative for lanes with something to store, else the dump pair (stride 0)
+        const bool hasM = live && (c < 2 || r == 0);
+        double *const wP = live ? S0 + oAH + 1 : ms + mxDump;
+        double *const wM = hasM ? S0 + (c == 0 ? mxK + r : (c == 1 ? mxp + r : (c == 2 ? mxkff : mxLi))) : ms + mxDump + 1;
+        const int sP = live ? MSLOT : 0, sM = hasM ? MSLOT : 0;
         double Pm, pcol;
         {
             const double *sl = S0 + N * MSLOT;
@@ -554,7 +568,6 @@ struct SmallSolver {
         };
         fetch(N - 1);
         for (int kk = N - 1; kk >= 0; --kk) {
-            double *sl = S0 + kk * MSLOT;
             const double Am = nah.x, CH = nah.y, Br = nBr;
             const double Wb = c < 2 ? ncp.x : 0.0, CZc = c < 2 ? ncp.y : 0.0, CB = nrp.x, CZr = r == 0 ? nrp.y : 0.0;
             fetch(kk > 0 ? kk - 1 : 0);
@@ -574,10 +587,10 @@ struct SmallSolver {
             const double Xb = r == 0 ? Zr : 0.0;
             const double Xa = pin ? 0.0 : -Xb * Rinv;
             Pm = mfma4(Xa, Xb, Qt);
-            sl[oPw] = Pm;
-            sl[oMw] = c == 0 ? Kr : (c == 1 ? pnew : (c == 2 ? kf : Rinv));
+            wP[kk * sP] = Pm;
+            wM[kk * sM] = c == 0 ? Kr : (c == 1 ? pnew : (c == 2 ? kf : Rinv));
         }
-        if (live && r == 0 && c == 0) S0[mxFlag] = ok ? 1.0 : 0.0;
+        if (live && r == 0 && c == 0) ms[mxFlag + blk] = ok ? 1.0 : 0.0;
     }
     // slot -> stage lane: the factors of this stage
     MPCRL_DI bool mx_fetch(const double *g) {
@@ -593,7 +606,7 @@ struct SmallSolver {
             for (int i = 0; i < NX; ++i) K[i] = sl[mxK + i];
             kff[0] = sl[mxkff], Li[0] = sl[mxLi];
         }
-        return ms[base * MSLOT + mxFlag] != 0.0;
+        return ms[mxFlag + blkidx] != 0.0;
     }
     bool mx_dyn_dirty = true;   // A, B changed since they were last published (set by linearize)
     template <class HF>
@@ -812,7 +825,7 @@ struct SmallSolver {
                 }
             }
         }
-        const double n_rows = seg_sum(cnt, k, lpi, base);
+        const double n_rows = seg_sum<M::SEG_SKIP>(cnt, k, lpi, base);
         PHW(11);
         bool qlive = act, ok = false;
         for (int it = 0;; ++it) {
@@ -861,7 +874,7 @@ struct SmallSolver {
                     }
                 }
             }
-            seg_reduce<1, 1>(&rloc, &muloc, k, lpi, base);
+            seg_reduce<1, 1, M::SEG_SKIP>(&rloc, &muloc, k, lpi, base);
             const double rinf = rloc;
             const double mu = n_rows > 0.0 ? muloc / n_rows : 0.0;
             if (qlive) {
@@ -908,7 +921,7 @@ struct SmallSolver {
             }
             {
                 double two[2] = {rmax, okbad};
-                seg_reduce<2, 0>(two, nullptr, k, lpi, base);
+                seg_reduce<2, 0, M::SEG_SKIP>(two, nullptr, k, lpi, base);
                 rmax = two[0];
                 if (two[1] > 0.5) qlive = false;   // non-positive pivot: QP failure
             }
@@ -929,7 +942,7 @@ struct SmallSolver {
                     }
                 }
             }
-            const double mu_aff = n_rows > 0.0 ? seg_sum(muaff, k, lpi, base) / n_rows : 0.0;
+            const double mu_aff = n_rows > 0.0 ? seg_sum<M::SEG_SKIP>(muaff, k, lpi, base) / n_rows : 0.0;
             const double ratio = mu > 0.0 ? mu_aff / mu : 0.0;
             const double smu = ratio * ratio * ratio * mu;
             PHW(4);
@@ -959,7 +972,7 @@ struct SmallSolver {
                     rmax = fmax(rmax, rat);
                 }
             }
-            const double alpha = fmin(1.0, (M::DISCRETE ? IPM_FRAC : fmax(IPM_FRAC, 1.0 - mu)) / seg_max(rmax, k, lpi, base));   // fraction to the boundary -> 1 as mu -> 0 (LQ model: fixed)
+            const double alpha = fmin(1.0, (M::DISCRETE ? IPM_FRAC : fmax(IPM_FRAC, 1.0 - mu)) / seg_max<M::SEG_SKIP>(rmax, k, lpi, base));   // fraction to the boundary -> 1 as mu -> 0 (LQ model: fixed)
             if (qlive) {
                 // rows of (i, sd) only read their own side's state, so they can be advanced in place
 #pragma unroll
@@ -1022,12 +1035,12 @@ struct SmallSolver {
                 double a = 0.0;
 #pragma unroll
                 for (int m = 0; m < NX; ++m) a = fma(nun[m], Fth[m * NTD + d], a);
-                a = seg_sum(a, k, lpi, base);
+                a = seg_sum<M::SEG_SKIP>(a, k, lpi, base);
                 if (first && valid) dVa[M::td_index(d)] = a;
             }
 #pragma unroll
             for (int d = 0; d < NTC; ++d) {
-                const double a = seg_sum(cpart[d], k, lpi, base);
+                const double a = seg_sum<M::SEG_SKIP>(cpart[d], k, lpi, base);
                 if (first && valid) dVa[M::tc_index(d)] = a;
             }
         }
@@ -1095,7 +1108,7 @@ struct SmallSolver {
                     okf = mx_backward(Hs, rt, zero);
                 else
                     okf = backward<true>(Hs, rt, zero);
-                okall = seg_max(okf ? 0.0 : 1.0, k, lpi, base) < 0.5;
+                okall = seg_max<M::SEG_SKIP>(okf ? 0.0 : 1.0, k, lpi, base) < 0.5;
             } else
                 backward<false>(Hs, rt, zero);
             forward(zero);
@@ -1129,12 +1142,12 @@ struct SmallSolver {
             }
 #pragma unroll
             for (int d = 0; d < NTD; ++d) {
-                const double a = seg_sum(outd[d], k, lpi, base);
+                const double a = seg_sum<M::SEG_SKIP>(outd[d], k, lpi, base);
                 if (first && valid) dpia[iu * NP + M::td_index(d)] = okall ? -a : NAN;
             }
 #pragma unroll
             for (int d = 0; d < NTC; ++d) {
-                const double a = seg_sum(outc[d], k, lpi, base);
+                const double a = seg_sum<M::SEG_SKIP>(outc[d], k, lpi, base);
                 if (first && valid) dpia[iu * NP + M::tc_index(d)] = okall ? -a : NAN;
             }
         }
@@ -1159,7 +1172,7 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
     if (!valid) inst = a.B - 1;   // dead lanes shadow the last instance and never store
     if (a.perm) inst = a.perm[inst];
     SmallSolver<M> S(sp, k, lpi, base);
-    __shared__ __attribute__((aligned(16))) double mx_lds[SmallSolver<M>::MX ? 64 * SmallSolver<M>::MSLOT : 2];
+    __shared__ __attribute__((aligned(16))) double mx_lds[SmallSolver<M>::MX ? SmallSolver<M>::MX_LDS : 2];
     S.ms = mx_lds;
     const bool term = S.term, first = S.first;
     S.qmode = a.u0fix != nullptr;
@@ -1250,7 +1263,7 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
                 for (int i = 0; i < NU; ++i) sl = fmax(sl, fabs(u0f[i] - S.u[i]));
             }
         }
-        stepn = seg_max(sl, k, lpi, base);
+        stepn = seg_max<M::SEG_SKIP>(sl, k, lpi, base);
         if (cold) stepn = -1.0;
     }
     double Vout = 0.0, res_out[4] = {0, 0, 0, 0};
@@ -1266,7 +1279,7 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
         double rl[4];
         S.nlp_res_local(nun, x0, u0f, rl);
         double res[4] = {rl[0], rl[1], rl[2], rl[3]}, cost = cl;
-        seg_reduce<4, 1>(res, &cost, k, lpi, base);
+        seg_reduce<4, 1, M::SEG_SKIP>(res, &cost, k, lpi, base);
 #ifdef MPCRL_PROFILE_PHASES
         { unsigned long long n_ = clock64(); S.phw[9] += n_ - S.pht; S.pht = n_; }
 #endif
@@ -1298,7 +1311,7 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
 #pragma unroll
                 for (int i = 0; i < NU; ++i) sl = fmax(sl, fabs(S.du[i]));
             }
-            stepn = seg_max(sl, k, lpi, base);
+            stepn = seg_max<M::SEG_SKIP>(sl, k, lpi, base);
         }
         if (live) {
 #pragma unroll
@@ -1331,7 +1344,7 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
                     }
                 }
         }
-        lag = seg_sum(lag, k, lpi, base);
+        lag = seg_sum<M::SEG_SKIP>(lag, k, lpi, base);
     }
     if (valid && first) {
         if (a.LAG) a.LAG[inst] = Vout + lag;
@@ -1400,15 +1413,24 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
     double *bnd = nullptr;
     const size_t nb = (size_t)(N + 1) * NW;
     SmallSolver<M> S(sp, k, lpi, base);
-    __shared__ __attribute__((aligned(16))) double mx_lds[SmallSolver<M>::MX ? 64 * SmallSolver<M>::MSLOT : 2];
+    __shared__ __attribute__((aligned(16))) double mx_lds[SmallSolver<M>::MX ? SmallSolver<M>::MX_LDS : 2];
     __shared__ double c_lds[M::MAX_IPW * SmallSolver<M>::CTAB];
-    __shared__ double sc_lds[M::MAX_IPW * 12];        // parked scalars: live, status, iterations, interior-point iterations, ...
+    __shared__ double sc_lds[M::MAX_IPW * 6];         // parked scalars: live, status, iterations, interior-point iterations, ...
+    // The parked instance's state (x, nu, u, lam, t of every stage), field-major so that the lanes of a slot touch consecutive
+    // words.  It fits next to the stage slots of the matrix-core sweep up to N + 1 = 21 stages (cartpole's horizon: 609 doubles —
+    // the LDS of a CU is shared by four wavefronts, 40 960 B each); longer horizons park in the instance's stored-iterate arrays
+    // in HBM, which costs a global round trip per round (3.3 us of a 45 us round: 8 % of the launch).
+    constexpr int PK = 2 * NX + NU + 4 * NW;
+    constexpr int PARK_CAP = SmallSolver<M>::MX ? 21 * PK : 64 * PK;
+    __shared__ double park_lds[PARK_CAP];
+    const bool lds_park = lpi * PK <= PARK_CAP;
     S.ms = mx_lds;
     S.qmode = a.u0fix != nullptr;
     // Batch index (after the packing order) and dynamics parameters of the ipw + 1 instances, looked up ONCE: a rebinding between
     // rounds must not cost global round trips of its own (perm -> theta -> state would be three in a row).
     __shared__ long gi_lds[M::MAX_IPW];
-    __shared__ double th_lds[M::MAX_IPW * (NTD + (NTC > 0 ? NTC : 1))];
+    constexpr int TH = NTD + NTC > 0 ? NTD + NTC : 1;
+    __shared__ double th_lds[M::MAX_IPW * TH];
     {
         long i = posof(loc);
         if (i >= a.B) i = a.B - 1;                    // lanes without an instance shadow the last one and never store
@@ -1418,9 +1440,9 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
         if (k == 0 && slot <= ipw) {                  // the stage-0 lane of every slot, and the first lane past the slots (parked instance)
             gi_lds[loc] = i;
 #pragma unroll
-            for (int j = 0; j < NTD; ++j) th_lds[loc * (NTD + (NTC > 0 ? NTC : 1)) + j] = th[M::td_index(j)];
+            for (int j = 0; j < NTD; ++j) th_lds[loc * TH + j] = th[M::td_index(j)];
 #pragma unroll
-            for (int j = 0; j < NTC; ++j) th_lds[loc * (NTD + (NTC > 0 ? NTC : 1)) + NTD + j] = th[M::tc_index(j)];
+            for (int j = 0; j < NTC; ++j) th_lds[loc * TH + NTD + j] = th[M::tc_index(j)];
         }
     }
     const bool term = S.term, first = S.first;
@@ -1445,9 +1467,9 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
         S.ctab = c_lds + loc * SmallSolver<M>::CTAB + S.stage_kind() * SmallSolver<M>::CSET;
         S.load_hc();
 #pragma unroll
-        for (int i = 0; i < NTD; ++i) S.thd[i] = th_lds[loc * (NTD + (NTC > 0 ? NTC : 1)) + i];
+        for (int i = 0; i < NTD; ++i) S.thd[i] = th_lds[loc * TH + i];
 #pragma unroll
-        for (int i = 0; i < NTC; ++i) S.thc[i] = th_lds[loc * (NTD + (NTC > 0 ? NTC : 1)) + NTD + i];
+        for (int i = 0; i < NTC; ++i) S.thc[i] = th_lds[loc * TH + NTD + i];
     };
     load_params();
     // ---- cold start of the resident instances (MPC.reset, mpc.py:204-210)
@@ -1488,7 +1510,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
         double rl[4];
         S.nlp_res_local(nun, x0, u0f, rl);
         double res[4] = {rl[0], rl[1], rl[2], rl[3]}, cost = cl;
-        seg_reduce<4, 1>(res, &cost, k, lpi, base);
+        seg_reduce<4, 1, M::SEG_SKIP>(res, &cost, k, lpi, base);
 #ifdef MPCRL_PROFILE_PHASES
         { unsigned long long n_ = clock64(); S.phw[9] += n_ - S.pht; S.pht = n_; }
 #endif
@@ -1517,7 +1539,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
                     for (int sd = 0; sd < 2; ++sd)
                         if (S.has(sd, i)) lag = fma(-S.lam[sd][i], S.bslack(sd, i, S.vc(i)), lag);
                 }
-                lag = seg_sum(lag, k, lpi, base);
+                lag = seg_sum<M::SEG_SKIP>(lag, k, lpi, base);
             }
             if (fin_now && valid) {
                 if (first) {
@@ -1563,7 +1585,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
 #pragma unroll
                     for (int i = 0; i < NU; ++i) sl = fmax(sl, fabs(S.du[i]));
                 }
-                const double sn = seg_max(sl, k, lpi, base);
+                const double sn = seg_max<M::SEG_SKIP>(sl, k, lpi, base);
                 if (live) stepn = sn;
             }
             if (live && ok) {
@@ -1621,8 +1643,8 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
         if (v < 0) v = rr % ipw, ++rr;
         const bool sw = slot_on && slot == v;
         const int lo = __shfl(loc, v * lpi);            // local index of the outgoing instance
-        if (sw && !for_good) {                          // park: state to the instance's stored-iterate arrays, scalars to LDS
-            if (valid) {
+        if (sw && !for_good) {                          // park: state to LDS (or the instance's stored-iterate arrays), scalars to LDS
+            if (valid && !lds_park) {
 #pragma unroll
                 for (int i = 0; i < NX; ++i) {
                     a.X[(inst * (N + 1) + k) * NX + i] = S.x[i];
@@ -1637,7 +1659,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
                     bnd[0 * nb + i] = S.lam[0][i], bnd[1 * nb + i] = S.lam[1][i], bnd[2 * nb + i] = S.t[0][i], bnd[3 * nb + i] = S.t[1][i];
             }
             if (first) {
-                double *sc = sc_lds + lo * 12;
+                double *sc = sc_lds + lo * 6;
                 sc[0] = live ? 1.0 : 0.0, sc[1] = (double)status, sc[2] = (double)iti, sc[3] = (double)n_ipm, sc[4] = last_tight ? 1.0 : 0.0,
                 sc[5] = stepn;
             }
@@ -1649,7 +1671,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
         bind(loc);
         load_params();
         {
-            const double *sc = sc_lds + pk * 12;
+            const double *sc = sc_lds + pk * 6;
             const double l_ = sc[0], st_ = sc[1], it_ = sc[2], ni_ = sc[3], lt_ = sc[4], sn_ = sc[5];
             if (sw) {
                 live = pk_started ? (l_ != 0.0) : valid;
@@ -1660,22 +1682,63 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
                 stepn = pk_started ? sn_ : -1.0;
             }
         }
+        if (lds_park) {
+            // the lanes of the slot swap their registers with the parked state (lane k <-> column k: no lane reads what another
+            // one writes); a parked instance that has not run yet starts cold
+            double *pl = park_lds + k;
+            double xc[NX];   // x0 of the incoming instance: a global read, on its first take only (wave-uniform branch)
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const double xs = a.X[(inst * (N + 1) + k) * NX + i], ns = a.PI[(inst * N + (first ? 0 : k - 1)) * NX + i];
-            S.x[i] = sw ? (pk_started ? xs : x0[i]) : S.x[i];
-            S.nu_[i] = sw ? ((first || !pk_started) ? 0.0 : ns) : S.nu_[i];
-        }
+            for (int i = 0; i < NX; ++i) xc[i] = 0.0;
+            if (!pk_started) {
 #pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const double us = a.U[(inst * N + (term ? 0 : k)) * NU + i];
-            S.u[i] = sw ? ((term || !pk_started) ? 0.0 : us) : S.u[i];
-        }
+                for (int i = 0; i < NX; ++i) xc[i] = x0[i];
+            }
+            // all reads first, then all writes: interleaved, every read would wait for the write before it (same array)
+            double in[PK], out[PK];
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const double l0 = bnd[0 * nb + i], l1 = bnd[1 * nb + i], t0 = bnd[2 * nb + i], t1 = bnd[3 * nb + i];
-            S.lam[0][i] = sw ? (pk_started ? l0 : 0.0) : S.lam[0][i], S.lam[1][i] = sw ? (pk_started ? l1 : 0.0) : S.lam[1][i];
-            S.t[0][i] = sw ? (pk_started ? t0 : 1.0) : S.t[0][i], S.t[1][i] = sw ? (pk_started ? t1 : 1.0) : S.t[1][i];
+            for (int j = 0; j < PK; ++j) in[j] = pl[j * lpi];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) out[i] = S.x[i], out[NX + i] = S.nu_[i];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) out[2 * NX + i] = S.u[i];
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                out[2 * NX + NU + 4 * i] = S.lam[0][i], out[2 * NX + NU + 4 * i + 1] = S.lam[1][i];
+                out[2 * NX + NU + 4 * i + 2] = S.t[0][i], out[2 * NX + NU + 4 * i + 3] = S.t[1][i];
+            }
+            if (sw && !for_good) {
+#pragma unroll
+                for (int j = 0; j < PK; ++j) pl[j * lpi] = out[j];
+            }
+            if (sw) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) S.x[i] = pk_started ? in[i] : xc[i], S.nu_[i] = pk_started ? in[NX + i] : 0.0;
+#pragma unroll
+                for (int i = 0; i < NU; ++i) S.u[i] = pk_started ? in[2 * NX + i] : 0.0;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    S.lam[0][i] = pk_started ? in[2 * NX + NU + 4 * i] : 0.0, S.lam[1][i] = pk_started ? in[2 * NX + NU + 4 * i + 1] : 0.0;
+                    S.t[0][i] = pk_started ? in[2 * NX + NU + 4 * i + 2] : 1.0, S.t[1][i] = pk_started ? in[2 * NX + NU + 4 * i + 3] : 1.0;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const double xs = a.X[(inst * (N + 1) + k) * NX + i], ns = a.PI[(inst * N + (first ? 0 : k - 1)) * NX + i];
+                S.x[i] = sw ? (pk_started ? xs : x0[i]) : S.x[i];
+                S.nu_[i] = sw ? ((first || !pk_started) ? 0.0 : ns) : S.nu_[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const double us = a.U[(inst * N + (term ? 0 : k)) * NU + i];
+                S.u[i] = sw ? ((term || !pk_started) ? 0.0 : us) : S.u[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const double l0 = bnd[0 * nb + i], l1 = bnd[1 * nb + i], t0 = bnd[2 * nb + i], t1 = bnd[3 * nb + i];
+                S.lam[0][i] = sw ? (pk_started ? l0 : 0.0) : S.lam[0][i], S.lam[1][i] = sw ? (pk_started ? l1 : 0.0) : S.lam[1][i];
+                S.t[0][i] = sw ? (pk_started ? t0 : 1.0) : S.t[0][i], S.t[1][i] = sw ? (pk_started ? t1 : 1.0) : S.t[1][i];
+            }
         }
         pk = for_good ? -1 : lo;
         pk_started = true;
@@ -1700,7 +1763,7 @@ __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, cons
     if (!valid) inst = a.B - 1;
     if (a.perm) inst = a.perm[inst];
     SmallSolver<M> S(sp, k, lpi, base);
-    __shared__ __attribute__((aligned(16))) double mx_lds[SmallSolver<M>::MX ? 64 * SmallSolver<M>::MSLOT : 2];
+    __shared__ __attribute__((aligned(16))) double mx_lds[SmallSolver<M>::MX ? SmallSolver<M>::MX_LDS : 2];
     S.ms = mx_lds;
     const bool term = S.term, first = S.first;
     S.qmode = a.u0fix != nullptr;
