@@ -223,6 +223,118 @@ MPCRL_DI Jet2<N> jsqrt(const Jet2<N> &a) {
     return r;
 }
 
+// ---- JetH<N>: value, gradient and the full symmetric Hessian along N directions (packed lower triangle, (i, j) at i (i + 1) / 2 + j).
+// One evaluation of a map yields all its second derivatives along the directions; N evaluations with Jet2<N> (one second direction
+// each) give the same numbers with every transcendental / reciprocal of the map computed N times.
+template <int N>
+struct JetH {
+    static constexpr int NH = N * (N + 1) / 2;
+    double v;
+    double g[N], h[NH];
+    MPCRL_DI JetH() {}
+    MPCRL_DI JetH(double c) : v(c) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) g[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) h[i] = 0.0;
+    }
+};
+// r = f(a) given f, f', f'' at a.v
+template <int N>
+MPCRL_DI JetH<N> jeth_chain(const JetH<N> &a, double f0, double f1, double f2) {
+    JetH<N> r;
+    r.v = f0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.g[i] = f1 * a.g[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) r.h[i * (i + 1) / 2 + j] = fma(f1, a.h[i * (i + 1) / 2 + j], f2 * a.g[i] * a.g[j]);
+    return r;
+}
+template <int N>
+MPCRL_DI JetH<N> operator+(const JetH<N> &a, const JetH<N> &b) {
+    JetH<N> r;
+    r.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.g[i] = a.g[i] + b.g[i];
+#pragma unroll
+    for (int i = 0; i < JetH<N>::NH; ++i) r.h[i] = a.h[i] + b.h[i];
+    return r;
+}
+template <int N>
+MPCRL_DI JetH<N> operator-(const JetH<N> &a, const JetH<N> &b) {
+    JetH<N> r;
+    r.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.g[i] = a.g[i] - b.g[i];
+#pragma unroll
+    for (int i = 0; i < JetH<N>::NH; ++i) r.h[i] = a.h[i] - b.h[i];
+    return r;
+}
+template <int N>
+MPCRL_DI JetH<N> operator*(const JetH<N> &a, const JetH<N> &b) {
+    JetH<N> r;
+    r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.g[i] = fma(a.g[i], b.v, a.v * b.g[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            const int e = i * (i + 1) / 2 + j;
+            r.h[e] = fma(a.h[e], b.v, fma(a.g[i], b.g[j], fma(a.g[j], b.g[i], a.v * b.h[e])));
+        }
+    return r;
+}
+template <int N>
+MPCRL_DI JetH<N> jrecip(const JetH<N> &b) {
+    const double i1 = 1.0 / b.v, i2 = i1 * i1;
+    return jeth_chain(b, i1, -i2, 2.0 * i2 * i1);
+}
+template <int N>
+MPCRL_DI JetH<N> operator/(const JetH<N> &a, const JetH<N> &b) {
+    return a * jrecip(b);
+}
+template <int N>
+MPCRL_DI JetH<N> operator*(double s, const JetH<N> &a) {
+    JetH<N> r;
+    r.v = s * a.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.g[i] = s * a.g[i];
+#pragma unroll
+    for (int i = 0; i < JetH<N>::NH; ++i) r.h[i] = s * a.h[i];
+    return r;
+}
+template <int N>
+MPCRL_DI JetH<N> operator+(const JetH<N> &a, double s) {
+    JetH<N> r = a;
+    r.v += s;
+    return r;
+}
+template <int N>
+MPCRL_DI JetH<N> operator-(double s, const JetH<N> &a) {
+    JetH<N> r;
+    r.v = s - a.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.g[i] = -a.g[i];
+#pragma unroll
+    for (int i = 0; i < JetH<N>::NH; ++i) r.h[i] = -a.h[i];
+    return r;
+}
+template <int N>
+MPCRL_DI void jsincos(const JetH<N> &a, JetH<N> &s, JetH<N> &c) {
+    double sv, cv;
+    sincos(a.v, &sv, &cv);
+    s = jeth_chain(a, sv, cv, -sv);
+    c = jeth_chain(a, cv, -sv, -cv);
+}
+template <int N>
+MPCRL_DI JetH<N> jsqrt(const JetH<N> &a) {
+    const double r = sqrt(a.v), h = 0.5 / r;
+    return jeth_chain(a, r, h, -0.5 * h / a.v);
+}
+
 // plain double overloads so model code can be instantiated for values only
 MPCRL_DI void jsincos(const double &a, double &s, double &c) { sincos(a, &s, &c); }
 MPCRL_DI double jsqrt(double a) { return sqrt(a); }

@@ -1052,36 +1052,32 @@ struct SmallSolver {
 #pragma unroll
             for (int j = 0; j <= i; ++j) Hx[sym(i, j)] = ck * hess_of_stage(i, j);
         if (!term) {
-            // second derivatives of F vanish along the coordinates whose Jacobian columns are constant (M::lin_coord lists the others)
+            // second derivatives of F vanish along the coordinates whose Jacobian columns are constant (M::lin_coord lists the others):
+            // ONE evaluation of the map with the full second-order jet along the remaining directions (until the end of round 2:
+            // one Jet2 evaluation per direction, i.e. every sin / cos / reciprocal of the RK4 map ND times)
             constexpr int ND = M::NLD;
+            JetH<ND> jx[NX], ju[NU], jt[NTD], jn[NX];
 #pragma unroll
-            for (int dj = 0; dj < ND; ++dj) {
-                const int cj = M::lin_coord(dj);
-                Jet2<ND> jx[NX], ju[NU], jt[NTD], jn[NX];
+            for (int i = 0; i < NU; ++i) ju[i] = JetH<ND>(u[i]);
 #pragma unroll
-                for (int i = 0; i < NU; ++i) ju[i] = Jet2<ND>(u[i]);
+            for (int i = 0; i < NX; ++i) jx[i] = JetH<ND>(x[i]);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) jx[i] = Jet2<ND>(x[i]);
+            for (int d = 0; d < ND; ++d) {
+                const int c = M::lin_coord(d);
+                if (c < NU) ju[c < NU ? c : 0].g[d] = 1.0; else jx[c >= NU ? c - NU : 0].g[d] = 1.0;
+            }
 #pragma unroll
-                for (int d = 0; d < ND; ++d) {
-                    const int c = M::lin_coord(d);
-                    if (c < NU) ju[c < NU ? c : 0].g[d] = 1.0; else jx[c >= NU ? c - NU : 0].g[d] = 1.0;
-                }
+            for (int i = 0; i < NTD; ++i) jt[i] = JetH<ND>(thd[i]);
+            disc_map<M, JetH<ND>>(jx, ju, jt, jn, sp.h, sp.rk_steps);
 #pragma unroll
-                for (int i = 0; i < NTD; ++i) jt[i] = Jet2<ND>(thd[i]);
-                if (cj < NU)
-                    ju[cj < NU ? cj : 0].e = 1.0;
-                else
-                    jx[cj >= NU ? cj - NU : 0].e = 1.0;
-                disc_map<M, Jet2<ND>>(jx, ju, jt, jn, sp.h, sp.rk_steps);
+            for (int di = 0; di < ND; ++di)
 #pragma unroll
-                for (int di = dj; di < ND; ++di) {
+                for (int dj = 0; dj <= di; ++dj) {
                     double a = 0.0;
 #pragma unroll
-                    for (int m = 0; m < NX; ++m) a = fma(nun[m], jn[m].m[di], a);
-                    Hx[sym(M::lin_coord(di), cj)] += a;
+                    for (int m = 0; m < NX; ++m) a = fma(nun[m], jn[m].h[di * (di + 1) / 2 + dj], a);
+                    Hx[sym(M::lin_coord(di), M::lin_coord(dj))] += a;
                 }
-            }
         }
         // barrier diagonal from the final (lam, t) of the BOUND rows; slacks are constants of the mirror (quirk q1)
 #pragma unroll
