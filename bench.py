@@ -295,8 +295,8 @@ def td3_bench(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--no-sens", action="store_true", help="forward solve only (BASELINE config 2)")
     ap.add_argument("--rti", action="store_true", help="one SQP iteration from the stored iterate (build-side mode)")
