@@ -272,6 +272,26 @@ def test_chain_mass_n7_vs_oracle_and_full_size_properties(oracle_port):
     assert rel_err(r.u0.cpu().numpy()[:8], ref8.u0) < RTOL and rel_err(r.dV_dp.cpu().numpy()[:8], ref8.dV) < RTOL
 
 
+def test_chain_mass_n3_vs_oracle(oracle_port):
+    """The smallest chain (n_mass = 3, nx = 9): its own instantiation of the chain kernels — the in-wavefront direction pass takes
+    whole stages per step there (the tables of seven stages do not fit the LDS region) — against the oracle port, and the RTI step."""
+    from mpc4rl_amd import MPCBatch, chain_mass_ocp
+    from oracle.problems import make_chain_mass
+    ocp, P = chain_mass_ocp(n_mass=3), make_chain_mass(n_mass=3)
+    assert ocp.nx == 9 and ocp.n_p == P.n_p
+    rng = np.random.default_rng(3)
+    B = 12
+    x0 = np.tile(ocp.x0, (B, 1))
+    x0[:, 3 * 2:] += rng.normal(0.0, 1e-2, (B, 3))
+    _, r, ref = run_both(ocp, P, oracle_port, x0)
+    st = r.status.cpu().numpy()
+    assert np.all(st == 0) and np.array_equal(st, ref.status)
+    assert np.abs(r.iters.cpu().numpy()[:, 0] - ref.sqp_iter).max() <= 1
+    assert rel_err(r.u0.cpu().numpy(), ref.u0) < RTOL and rel_err(r.V.cpu().numpy(), ref.V) < RTOL
+    assert rel_err(r.dV_dp.cpu().numpy(), ref.dV) < RTOL
+    assert rel_err(r.dpi_dp.cpu().numpy(), ref.dpi, floor=np.abs(ref.dpi).max()) < RTOL
+
+
 def test_cartpole_cost_parameters_reach_the_kernel(oracle_port):
     """W_0, W, W_e, yref_0, yref, yref_e are part of p and the solve uses them (set_parameter / cost_set, mpc.py:233-257), per
     instance; their gradient entries stay zero (non-parameterised NLS mirror, nlp.py:1039-1055)."""
