@@ -882,11 +882,97 @@ struct ChainSolver {
                 }
                 wave_sync();
                 ph(12);
-                // ---- P_k = Q - S' K, p_k = mv_x - K' mv_u, Acl = A - B K: lane j takes COLUMN j — the lanes of a group then read
-                // consecutive LDS words (row-per-lane with the even row stride NW put a whole lane group on four banks), S(., i) and
-                // B(i, .) are wave-uniform reads, K(., j) sits in three registers.  P_k is written lower + mirrored into T (exactly
-                // symmetric), Acl replaces A inside [B A]; both blocks then leave for HBM as 16-byte coalesced copies.
-                {
+                // ---- P_k = Q - S' K, p_k = mv_x - K' mv_u, Acl = A - B K: two rank-NU updates, on the matrix cores as well.  In stage-vector
+                // coordinates (v = [u; x]) with K' = [0 | K]:  P' = M - M(0..NU, .)' K' on the lower tiles of M's own tiling (the x-x block
+                // of P' is P_k), [B Acl] = [B A] - B K'.  One v_mfma_f64_16x16x4 per 16 x 16 tile (k = the NU rows of K, padded to 4); the
+                // operands are single LDS reads in their register layout.  (The column-per-lane VALU loop it replaces up to n_mass 5 — kept below
+                // for n_mass 7 — is 170 LDS reads and 63 writes per lane for 130 FMAs: LDS-instruction bound, 13 % of the kernel; 12.63 -> 12.24 ms.)
+                // P_k is written lower + mirrored into T (exactly symmetric), Acl replaces A inside [B A]; both blocks then leave for HBM
+                // as 16-byte coalesced copies.
+                if constexpr (NW <= 24) {
+                    typedef double d4_t __attribute__((ext_vector_type(4)));
+                    constexpr int NT16 = Cfg::NT16, NTX = Cfg::NTX;
+                    const int lr = lane >> 4, lc = lane & 15;
+                    const double *lK = sK();
+                    double kb[NT16], sa[NT16], bm[NTX];
+#pragma unroll
+                    for (int t = 0; t < NT16; ++t) {
+                        const int c = 16 * t + lc;
+                        const bool onk = lr < NU && c >= NU && c < NW, ons = lr < NU && c < NW;
+                        const double vk = lK[(onk ? lr : 0) * NX + (onk ? c - NU : 0)], vs = lM[(ons ? lr : 0) * NW + (ons ? c : 0)];
+                        kb[t] = onk ? -vk : 0.0;     // B operand of both products: -K'(k = lane / 16, column c)
+                        sa[t] = ons ? vs : 0.0;      // A operand of P': M(k, row c) = S'(c, k)
+                    }
+#pragma unroll
+                    for (int t = 0; t < NTX; ++t) {
+                        const int i = 16 * t + lc;
+                        const bool on = lr < NU && i < NX;
+                        const double v = lBA[(on ? i : 0) * NW + (on ? lr : 0)];
+                        bm[t] = on ? v : 0.0;        // A operand of the second product: B(row i, k)
+                    }
+                    // the C operands of both products are fetched before the first MFMA issues: their LDS latency is paid once
+                    d4_t Pc[NT16 * (NT16 + 1) / 2], Ac[NTX][NT16];
+#pragma unroll
+                    for (int tm = 0; tm < NT16; ++tm)
+#pragma unroll
+                        for (int tj = 0; tj <= tm; ++tj)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int a_ = 16 * tm + 4 * r + lr, b_ = 16 * tj + lc;
+                                const bool on = a_ < NW && b_ < NW;
+                                const double v = lM[(on ? a_ : 0) * NW + (on ? b_ : 0)];
+                                Pc[tm * (tm + 1) / 2 + tj][r] = on ? v : 0.0;
+                            }
+#pragma unroll
+                    for (int ti = 0; ti < NTX; ++ti)
+#pragma unroll
+                        for (int tb = 0; tb < NT16; ++tb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int i = 16 * ti + 4 * r + lr, b_ = 16 * tb + lc;
+                                const bool on = i < NX && b_ < NW;
+                                const double v = lBA[(on ? i : 0) * NW + (on ? b_ : 0)];
+                                Ac[ti][tb][r] = on ? v : 0.0;
+                            }
+                    MPCRL_SCHED_FENCE();
+#pragma unroll
+                    for (int tm = 0; tm < NT16; ++tm)
+#pragma unroll
+                        for (int tj = 0; tj <= tm; ++tj) {
+                            const int t_ = tm * (tm + 1) / 2 + tj;
+                            Pc[t_] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[tm], kb[tj], Pc[t_], 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int ti = 0; ti < NTX; ++ti)
+#pragma unroll
+                        for (int tb = 0; tb < NT16; ++tb) Ac[ti][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bm[ti], kb[tb], Ac[ti][tb], 0, 0, 0);
+                    wave_sync();   // every lane is past its operand reads of [B A] (one wavefront: LDS operations are performed in order)
+#pragma unroll
+                    for (int tm = 0; tm < NT16; ++tm)
+#pragma unroll
+                        for (int tj = 0; tj <= tm; ++tj)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int a_ = 16 * tm + 4 * r + lr, b_ = 16 * tj + lc;
+                                if (a_ < NW && b_ >= NU && b_ <= a_) {
+                                    const double v = Pc[tm * (tm + 1) / 2 + tj][r];
+                                    lT[(a_ - NU) * NX + (b_ - NU)] = v;
+                                    lT[(b_ - NU) * NX + (a_ - NU)] = v;
+                                }
+                            }
+#pragma unroll
+                    for (int ti = 0; ti < NTX; ++ti)
+#pragma unroll
+                        for (int tb = 0; tb < NT16; ++tb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {   // the B columns stay as they are
+                                const int i = 16 * ti + 4 * r + lr, b_ = 16 * tb + lc;
+                                if (i < NX && b_ >= NU && b_ < NW) lBA[i * NW + b_] = Ac[ti][tb][r];
+                            }
+                } else {
+                    // n_mass 7: the matrix-core version needs 9 + 6 result tiles next to a register file that is already full (measured: 39.1 ->
+                    // 40.0 ms with the two products one after the other, 44.9 ms fused); lane j takes COLUMN j of both updates — the lanes of a
+                    // group read consecutive LDS words, S(., i) and B(i, .) are wave-uniform reads, K(., j) sits in three registers
                     const double *lK = sK();
                     double Kj[NU];
 #pragma unroll
@@ -915,6 +1001,9 @@ struct ChainSolver {
                             }
                         }
                     }
+                }
+                {
+                    const double *lK = sK();
                     double pk = 0.0;
                     if (lane < NX) {
                         pk = sMV()[NU + lane];
