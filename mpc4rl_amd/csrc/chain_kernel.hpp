@@ -1595,13 +1595,27 @@ __device__ __attribute__((noinline)) void chain_dir_pass(const double *th, doubl
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NL = M::NL, TAB = M::TAB, TSZ = DC::TSZ, STG = DC::EV * NL * M::TAB2;
     const LargeLayout<M> lay(N);
     const int items = N * NW;
+    // the tables of step i + 1 are requested before step i is computed and go to LDS after it: one global round trip per step hidden
+    constexpr int NPF = ((DC::FITS ? DC::SPAN : 64 / NW) * TSZ + 63) / 64;
+    double pf[NPF];
+    auto request = [&](int i0) {
+        const int k_lo = i0 / NW, cnt = (min(N - 1, (i0 + DC::LP - 1) / NW) - k_lo + 1) * TSZ;
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int e = lane + 64 * j, ks = e / TSZ;
+            pf[j] = e < cnt ? w[lay.ptab + (size_t)(k_lo + ks) * STG + (e - ks * TSZ)] : 0.0;
+        }
+    };
+    request(0);
     for (int i0 = 0; i0 < items; i0 += DC::LP) {
         const int k_lo = i0 / NW, k_hi = min(N - 1, (i0 + DC::LP - 1) / NW);
-        for (int e = lane; e < (k_hi - k_lo + 1) * TSZ; e += 64) {
-            const int ks = e / TSZ;
-            tabl[e] = w[lay.ptab + (size_t)(k_lo + ks) * STG + (e - ks * TSZ)];
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int e = lane + 64 * j;
+            if (e < (k_hi - k_lo + 1) * TSZ) tabl[e] = pf[j];
         }
         wave_sync();
+        if (i0 + DC::LP < items) request(i0 + DC::LP);
         const int it_ = i0 + lane;
         const bool on = lane < DC::LP && it_ < items;
         const int k = on ? it_ / NW : k_lo, d = on ? it_ - k * NW : 0;
