@@ -65,6 +65,7 @@ struct LargeArgs {
 template <int NX, int NW>
 struct ChainCfgStride {   // stage strides of the streamed blocks (ChainCfg below): whole 16-byte x 64-lane pieces
     static constexpr int AST = 128 * (((NX * NX + 1) / 2 + 63) / 64), BST = 128 * ((NX * NW / 2 + 63) / 64);
+    static constexpr int PST = 128 * (((NX * (NX + 1) / 2 + 1) / 2 + 63) / 64);   // P_k in HBM: packed lower triangle
 };
 
 // per-instance workspace layout (doubles)
@@ -81,7 +82,7 @@ struct LargeLayout {
         Dx = take((size_t)(N + 1) * NX), Du = take((size_t)N * NU), Dnu = take((size_t)(N + 1) * NX);
         rg = take((size_t)(N + 1) * NW), rb = take((size_t)N * NX), rt = take((size_t)(N + 1) * NW), Dg = take((size_t)(N + 1) * NW);
         lamw = take((size_t)2 * (N + 1) * NW), tw = take((size_t)2 * (N + 1) * NW), aff = take((size_t)2 * (N + 1) * NW);
-        P = take((size_t)(N + 1) * ChainCfgStride<NX, NW>::AST), p = take((size_t)(N + 1) * NX), K = take((size_t)N * NU * NX), L = take((size_t)N * NU * NU);
+        P = take((size_t)(N + 1) * ChainCfgStride<NX, NW>::PST), p = take((size_t)(N + 1) * NX), K = take((size_t)N * NU * NX), L = take((size_t)N * NU * NU);
         kff = take((size_t)N * NU);
         Acl = take((size_t)N * ChainCfgStride<NX, NW>::BST), hb = take((size_t)N * NX), ccv = take((size_t)N * NX), cvec = take((size_t)N * NX);
         Hex = take((size_t)(N + 1) * NW * NW), term = take((size_t)N * NTD), ynu = take((size_t)(N + 1) * NX);
@@ -241,7 +242,10 @@ struct ChainCfg {
     static constexpr int NBA2 = (NX * NW / 2 + 63) / 64;    // 16-byte pieces per lane of one [B A] block
     static constexpr int NAC2 = ((NX * NX + 1) / 2 + 63) / 64;   // ... of one nx x nx block
     // stage strides of the streamed blocks in the workspace: whole pieces, so that the block copies need no tail predicate
-    static constexpr int AST = 128 * NAC2;                  // P_k
+    static constexpr int AST = 128 * NAC2;                  // P_k as a full block (its LDS staging area)
+    // P_k is symmetric and travels through HBM as its packed lower triangle, (i, j) at i (i + 1) / 2 + j: half the bytes of the two
+    // streams that carry it (factor sweep out, multiplier step of the forward sweep in)
+    static constexpr int NPK = NX * (NX + 1) / 2, NPK2 = ((NPK + 1) / 2 + 63) / 64, PST = 128 * NPK2;
     static constexpr int BST = 128 * NBA2;                  // Acl_k (kept in the [B A] block shape)
 #ifndef MPCRL_CHAIN_DEPTH
 #define MPCRL_CHAIN_DEPTH 2
@@ -449,6 +453,21 @@ struct ChainSolver {
             (void)n2;
             rr[s] = *(const d2_t *)&src[2 * e2];   // past the block: the next array of the workspace (never used)
         }
+    }
+    // full-block offsets (i NX + j) of the packed entries 2 (lane + 64 s) + h this lane carries; entries past the triangle -> dump words
+    // behind the block.  tr = true: the mirrored offsets (j NX + i).
+    MPCRL_DI void packed_offsets(int (&off)[Cfg::NPK2][2], bool tr) const {
+#pragma unroll
+        for (int s_ = 0; s_ < Cfg::NPK2; ++s_)
+#pragma unroll
+            for (int h_ = 0; h_ < 2; ++h_) {
+                const int q = 2 * (lane + 64 * s_) + h_;
+                int i = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
+                if ((i + 1) * (i + 2) / 2 <= q) ++i;
+                if (i * (i + 1) / 2 > q) --i;
+                const int j = q - i * (i + 1) / 2;
+                off[s_][h_] = q < Cfg::NPK ? (tr ? j * NX + i : i * NX + j) : NX * NX + h_;
+            }
     }
     template <int NV>
     MPCRL_DI void blk_to_lds(double *dst, int n2, const d2_t (&rr)[NV], int lane) const {
@@ -708,8 +727,10 @@ struct ChainSolver {
             const int i = e / NX, j = e - i * NX;
             const double v = hs.term(N, i > j ? i : j, i > j ? j : i) + (i == j ? Dg[N * NW + NU + i] : 0.0);
             lP[e] = v;
-            P[N * AST + e] = v;
+            if (j <= i) P[N * Cfg::PST + i * (i + 1) / 2 + j] = v;
         }
+        int pko[Cfg::NPK2][2];
+        packed_offsets(pko, false);
         if (lane < NX) {
             const double v = g[N * NW + NU + lane];
             sPV()[lane] = v;
@@ -1027,10 +1048,14 @@ struct ChainSolver {
                         const int e2 = lane + 64 * s_;
                         ca[s_] = *(const d2_t *)(lBA + 2 * e2);
                     }
+                    d2_t pp[Cfg::NPK2];
+#pragma unroll
+                    for (int s_ = 0; s_ < Cfg::NPK2; ++s_) pp[s_].x = lT[pko[s_][0]], pp[s_].y = lT[pko[s_][1]];   // past the triangle: words behind the block
+#pragma unroll
+                    for (int s_ = 0; s_ < Cfg::NPK2; ++s_) *(d2_t *)&P[k * Cfg::PST + 2 * (lane + 64 * s_)] = pp[s_];
 #pragma unroll
                     for (int s_ = 0; s_ < Cfg::NAC2; ++s_) {
                         const int e2 = lane + 64 * s_;
-                        *(d2_t *)&P[k * AST + 2 * e2] = cp[s_];
                         if (s_ + 1 < Cfg::NAC2 || 2 * e2 < NW * NW - 1) *(d2_t *)(lP + 2 * e2) = cp[s_];   // M is dead: every lane is past its reads (sync above)
                     }
 #pragma unroll
@@ -1123,8 +1148,18 @@ struct ChainSolver {
         const int li = lane < NX ? lane : 0;
         double xcur = 0.0;
         if (lane < NX) Dx[lane] = 0.0, Dnu[lane] = 0.0;
-        d2_t nA[D][Cfg::NBA2], nP[D][Cfg::NAC2];
+        d2_t nA[D][Cfg::NBA2], nP[D][Cfg::NPK2];
         double nbb[D], npv[D], nkf[D][NU];
+        // the packed P_k is unpacked (both triangles) while it is published to LDS
+        int pij[Cfg::NPK2][2], pji[Cfg::NPK2][2];
+        if (want_nu) packed_offsets(pij, false), packed_offsets(pji, true);
+        auto p_to_lds = [&](double *dst, const d2_t (&rr)[Cfg::NPK2]) {
+#pragma unroll
+            for (int s_ = 0; s_ < Cfg::NPK2; ++s_) {
+                dst[pij[s_][0]] = rr[s_].x, dst[pji[s_][0]] = rr[s_].x;
+                dst[pij[s_][1]] = rr[s_].y, dst[pji[s_][1]] = rr[s_].y;
+            }
+        };
         double *lA = sA(), *lPk = sPk(), *lv = sSV(0);
         // Lane i takes ROW i of Acl_k here: with the block's own row stride NW (even) a whole lane group would sit on four LDS banks
         // (16-way conflicts on every operand read), so the block is published with the odd stride NW + 1 (as in qp_residuals).
@@ -1148,7 +1183,7 @@ struct ChainSolver {
 #pragma unroll
                 for (int m = 0; m < NU; ++m) nkf[d][m] = kff[k * NU + m];
                 if (want_nu) {
-                    blk_load(P + k * AST, AST / 2, nP[d], lane);
+                    blk_load(P + k * Cfg::PST, Cfg::PST / 2, nP[d], lane);
                     npv[d] = p[k * NX + li];
                 }
             },
@@ -1157,7 +1192,7 @@ struct ChainSolver {
                 if (lane < NX) lv[lane] = xcur;
 #pragma unroll
                 for (int s_ = 0; s_ < Cfg::NBA2; ++s_) lA[pdst[s_][0]] = nA[d][s_].x, lA[pdst[s_][1]] = nA[d][s_].y;
-                if (want_nu) blk_to_lds(lPk, AST / 2, nP[d], lane);
+                if (want_nu) p_to_lds(lPk, nP[d]);
                 double a = nbb[d], b = want_nu ? npv[d] : 0.0;
                 double kf[NU];
 #pragma unroll
@@ -1177,11 +1212,11 @@ struct ChainSolver {
                 wave_sync();
             });
         if (want_nu) {   // terminal multiplier step
-            d2_t tP[Cfg::NAC2];
-            blk_load(P + N * AST, AST / 2, tP, lane);
+            d2_t tP[Cfg::NPK2];
+            blk_load(P + N * Cfg::PST, Cfg::PST / 2, tP, lane);
             double b = p[N * NX + li];
             if (lane < NX) lv[lane] = xcur;
-            blk_to_lds(lPk, AST / 2, tP, lane);
+            p_to_lds(lPk, tP);
             wave_sync();
             b = lds_dot<NX>(lPk + li * NX, 1, lv, b);
             if (lane < NX) Dnu[N * NX + lane] = b;
