@@ -2008,8 +2008,29 @@ __global__ void __launch_bounds__(64, 1) chain_sens_riccati_kernel(const LargeSp
         wave_sync();
         if (iu == 0)
             okall = ChainSolver<M>::factor_call(S, hs, S.rt, S.rb);
-        else
-            ChainSolver<M>::backward_vec_call(S, S.rt);
+        else if (lane == 0) {
+            // The right-hand side is -e_iu in the controls of stage 0 and zero elsewhere, and there is no dynamics offset: the backward
+            // vector recursion is identically zero from the terminal stage down to stage 1 (p_k = 0 — what the factor sweep left for
+            // iu = 0 as well), and at stage 0 only the feed-forward changes: kff_0 = (L_0 L_0')^{-1} (-e_iu).  No sweep.
+            double y[NU], z[NU];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                double a_ = i == iu ? -1.0 : 0.0;
+#pragma unroll
+                for (int m = 0; m < i; ++m) a_ -= S.L[i * NU + m] * y[m];
+                y[i] = a_ * S.L[i * NU + i];
+            }
+#pragma unroll
+            for (int i = NU - 1; i >= 0; --i) {
+                double a_ = y[i];
+#pragma unroll
+                for (int m = i + 1; m < NU; ++m) a_ -= S.L[m * NU + i] * z[m];
+                z[i] = a_ * S.L[i * NU + i];
+            }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) S.kff[i] = z[i];
+        }
+        wave_sync();
         ChainSolver<M>::template forward_call<true>(S, S.rb);
         for (int e = lane; e < (N + 1) * NX; e += NT) Ydx[iu * (N + 1) * NX + e] = S.Dx[e], Ydnu[iu * (N + 1) * NX + e] = S.Dnu[e];
         for (int e = lane; e < N * NU; e += NT) Ydu[iu * N * NU + e] = S.Du[e];
