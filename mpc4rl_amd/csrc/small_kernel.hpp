@@ -162,6 +162,7 @@ struct SmallSolver {
     unsigned long long phw[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pht = 0;
 #endif
     double hscale = 1.0;   // multiplies the Hs accessor of the Riccati stage (c_k for the SQP Hessian, 1 for the exact one)
+    double n_rows_c = -1.0;   // bound rows per instance, counted by the first QP of the launch
 
     MPCRL_DI SmallSolver(const SmallSpec &sp_, int k_, int lpi_, int base_)
         : sp(sp_), N(sp_.N), lpi(lpi_), k(k_), base(base_), blkidx(base_ / lpi_), term(k_ == sp_.N), first(k_ == 0) {}
@@ -825,7 +826,9 @@ struct SmallSolver {
                 }
             }
         }
-        const double n_rows = seg_sum<M::SEG_SKIP>(cnt, k, lpi, base);
+        // number of bound rows of the instance: a property of the problem's structure, the same for every QP of the launch
+        if (n_rows_c < 0.0) n_rows_c = seg_sum<M::SEG_SKIP>(cnt, k, lpi, base);
+        const double n_rows = n_rows_c;
         PHW(11);
         bool qlive = act, ok = false;
         for (int it = 0;; ++it) {
