@@ -879,7 +879,8 @@ struct SmallSolver {
             }
             seg_reduce<1, 1, M::SEG_SKIP>(&rloc, &muloc, k, lpi, base);
             const double rinf = rloc;
-            const double mu = n_rows > 0.0 ? muloc / n_rows : 0.0;
+            const double musum = muloc;   // sum of the complementarity products
+            const double mu = n_rows > 0.0 ? musum / n_rows : 0.0;
             if (qlive) {
                 if (rinf <= tol_res && mu <= tol_mu)
                     qlive = false, ok = true;
@@ -907,7 +908,11 @@ struct SmallSolver {
             forward(rb);
             PHW(3);
             double okbad = okf ? 0.0 : 1.0;   // reduced together with the predictor's step length below
-            double rmax = 1.0, muaff = 0.0;   // rmax = 1 / (step to the boundary), at least 1
+            double rmax = 1.0;                // rmax = 1 / (step to the boundary), at least 1
+            // mu_aff(a) = sum (lam + a dlam)(t + a dt) = sum lam t + a c1 + a^2 c2: the two sums travel in the reduction tree of the step
+            // length, so the predictor needs ONE cross-lane reduction and one pass over its rows (it was two of each: the rows were
+            // walked again, Newton quantities and all, once the step length was known)
+            double c12[2] = {0.0, 0.0};
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 if (term && i < NU) continue;
@@ -919,33 +924,22 @@ struct SmallSolver {
                     row_steps(i, sd, v, dv, 0, 0.0, dt1, dl1, dt2, dl2, dss, rat);
                     rmax = fmax(rmax, rat);
                     aff[sd][i] = dl1 * dt1;   // only read by the corrector (pass = 1)
-                    if (SOFT && softc(i)) affs[sd][SOFT ? i : 0] = dl2 * dt2;
+                    c12[0] = fma(lam[sd][i], dt1, fma(t[sd][i], dl1, c12[0])), c12[1] = fma(dl1, dt1, c12[1]);
+                    if (SOFT && softc(i)) {
+                        const int ii = SOFT ? i : 0;
+                        affs[sd][ii] = dl2 * dt2;
+                        c12[0] = fma(lams[sd][ii], dt2, fma(ts[sd][ii], dl2, c12[0])), c12[1] = fma(dl2, dt2, c12[1]);
+                    }
                 }
             }
             {
                 double two[2] = {rmax, okbad};
-                seg_reduce<2, 0, M::SEG_SKIP>(two, nullptr, k, lpi, base);
+                seg_reduce<2, 2, M::SEG_SKIP>(two, c12, k, lpi, base);
                 rmax = two[0];
                 if (two[1] > 0.5) qlive = false;   // non-positive pivot: QP failure
             }
             const double a_aff = 1.0 / rmax;
-#pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                if (term && i < NU) continue;
-                const double v = vc(i) + dvc(dx, du, i), dv = dvc(Dx, Du, i);
-#pragma unroll
-                for (int sd = 0; sd < 2; ++sd) {
-                    if (!has(sd, i)) continue;
-                    double dt1, dl1, dt2, dl2, dss, rat;
-                    row_steps(i, sd, v, dv, 0, 0.0, dt1, dl1, dt2, dl2, dss, rat);
-                    muaff = fma(fma(a_aff, dl1, lam[sd][i]), fma(a_aff, dt1, t[sd][i]), muaff);
-                    if (SOFT && softc(i)) {
-                        const int ii = SOFT ? i : 0;
-                        muaff = fma(fma(a_aff, dl2, lams[sd][ii]), fma(a_aff, dt2, ts[sd][ii]), muaff);
-                    }
-                }
-            }
-            const double mu_aff = n_rows > 0.0 ? seg_sum<M::SEG_SKIP>(muaff, k, lpi, base) / n_rows : 0.0;
+            const double mu_aff = n_rows > 0.0 ? fma(a_aff, fma(a_aff, c12[1], c12[0]), musum) / n_rows : 0.0;
             const double ratio = mu > 0.0 ? mu_aff / mu : 0.0;
             const double smu = ratio * ratio * ratio * mu;
             PHW(4);
