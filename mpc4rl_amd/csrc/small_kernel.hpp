@@ -83,6 +83,9 @@ MPCRL_DI double fast_rcp(double x) {
     return fma(fma(-x, r, 1.0), r, r);
 }
 
+#ifndef MPCRL_IPM_SCALE_RES
+#define MPCRL_IPM_SCALE_RES 1
+#endif
 // segmented reductions over the LPI lanes of one instance; result broadcast to all of its lanes
 // SKIP (a model constant, M::SEG_SKIP): leave out the tree levels at which no lane has a partner (s >= lpi, wave-uniform).  One
 // cross-lane round trip less per reduction on paper; measured with everything else equal it is 2.3 % SLOWER for the cartpole kernels
@@ -831,55 +834,64 @@ struct SmallSolver {
         const double n_rows = n_rows_c;
         PHW(11);
         bool qlive = act, ok = false;
+        double rinf_c = 0.0, musum_c = 0.0;   // residual norm and sum lam t carried to the next iteration
         for (int it = 0;; ++it) {
-            // ---- residuals
-            double dxn[NX], nuqn[NX];
+            // ---- residuals.  Evaluated for the first iteration of a QP only: every equation but the complementarity products is LINEAR in
+            // (dx, du, nuq, lam, t, s), so a step of length alpha along a direction that solves the Newton system takes all their
+            // residuals (r_b, r_g, the bound rows t - slack, the soft rows) to (1 - alpha) times their value exactly, and
+            // sum lam t becomes a quadratic in alpha whose coefficients ride in the reduction of the step length.  Later
+            // iterations scale what they have (MPCRL_IPM_SCALE_RES; the oracle re-evaluates everything every iteration, the parity
+            // tests are the check that the scaled residuals are the true ones to rounding).
+            double rinf, musum;
+            if (!MPCRL_IPM_SCALE_RES || it == 0) {
+                double dxn[NX], nuqn[NX];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) dxn[i] = lane_dn(dx[i]), nuqn[i] = lane_dn(nuq[i]);
-            double rloc = 0.0, muloc = 0.0;
+                for (int i = 0; i < NX; ++i) dxn[i] = lane_dn(dx[i]), nuqn[i] = lane_dn(nuq[i]);
+                double rloc = 0.0, muloc = 0.0;
 #pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                double a = 0.0;
-                if (!term) {
-                    a = r[i] - dxn[i];
+                for (int i = 0; i < NX; ++i) {
+                    double a = 0.0;
+                    if (!term) {
+                        a = r[i] - dxn[i];
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) a = fma(Aget(i * NX + j), dx[j], a);
+                        for (int j = 0; j < NX; ++j) a = fma(Aget(i * NX + j), dx[j], a);
 #pragma unroll
-                    for (int j = 0; j < NU; ++j) a = fma(Bget(i * NU + j), du[j], a);
+                        for (int j = 0; j < NU; ++j) a = fma(Bget(i * NU + j), du[j], a);
+                    }
+                    rb[i] = a;
+                    rloc = fmax(rloc, fabs(a));
                 }
-                rb[i] = a;
-                rloc = fmax(rloc, fabs(a));
-            }
 #pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                rg[i] = 0.0;
-                if (term && i < NU) continue;
-                double a = q[i] + GTnu(nuqn, nuq, i), hdv = 0.0;
+                for (int i = 0; i < NW; ++i) {
+                    rg[i] = 0.0;
+                    if (term && i < NU) continue;
+                    double a = q[i] + GTnu(nuqn, nuq, i), hdv = 0.0;
 #pragma unroll
-                for (int j = 0; j < NW; ++j) hdv = fma(Hs(i, j), dvc(dx, du, j), hdv);
-                a = fma(hscale, hdv, a);
-                if (has(0, i)) a -= lam[0][i];
-                if (has(1, i)) a += lam[1][i];
-                if (fixed(i)) a = 0.0;
-                rg[i] = a;
-                rloc = fmax(rloc, fabs(a));
-                const double v = vc(i) + dvc(dx, du, i);
+                    for (int j = 0; j < NW; ++j) hdv = fma(Hs(i, j), dvc(dx, du, j), hdv);
+                    a = fma(hscale, hdv, a);
+                    if (has(0, i)) a -= lam[0][i];
+                    if (has(1, i)) a += lam[1][i];
+                    if (fixed(i)) a = 0.0;
+                    rg[i] = a;
+                    rloc = fmax(rloc, fabs(a));
+                    const double v = vc(i) + dvc(dx, du, i);
 #pragma unroll
-                for (int sd = 0; sd < 2; ++sd) {
-                    if (!has(sd, i)) continue;
-                    rloc = fmax(rloc, fabs(t[sd][i] - bslack(sd, i, v)));
-                    muloc = fma(lam[sd][i], t[sd][i], muloc);
-                    if (SOFT && softc(i)) {
-                        const int ii = SOFT ? i : 0;
-                        rloc = fmax(rloc, fabs(ts[sd][ii] - s[sd][ii]));
-                        rloc = fmax(rloc, fabs(zw(sd, i) - lam[sd][i] - lams[sd][ii]));
-                        muloc = fma(lams[sd][ii], ts[sd][ii], muloc);
+                    for (int sd = 0; sd < 2; ++sd) {
+                        if (!has(sd, i)) continue;
+                        rloc = fmax(rloc, fabs(t[sd][i] - bslack(sd, i, v)));
+                        muloc = fma(lam[sd][i], t[sd][i], muloc);
+                        if (SOFT && softc(i)) {
+                            const int ii = SOFT ? i : 0;
+                            rloc = fmax(rloc, fabs(ts[sd][ii] - s[sd][ii]));
+                            rloc = fmax(rloc, fabs(zw(sd, i) - lam[sd][i] - lams[sd][ii]));
+                            muloc = fma(lams[sd][ii], ts[sd][ii], muloc);
+                        }
                     }
                 }
-            }
-            seg_reduce<1, 1, M::SEG_SKIP>(&rloc, &muloc, k, lpi, base);
-            const double rinf = rloc;
-            const double musum = muloc;   // sum of the complementarity products
+                seg_reduce<1, 1, M::SEG_SKIP>(&rloc, &muloc, k, lpi, base);
+                rinf = rloc, musum = muloc;   // musum: sum of the complementarity products
+            } else
+                rinf = rinf_c, musum = musum_c;
             const double mu = n_rows > 0.0 ? musum / n_rows : 0.0;
             if (qlive) {
                 if (rinf <= tol_res && mu <= tol_mu)
@@ -957,6 +969,7 @@ struct SmallSolver {
             forward(rb);
             PHW(7);
             rmax = 1.0;
+            double d12[2] = {0.0, 0.0};   // sum lam t after the step = musum + alpha d12[0] + alpha^2 d12[1]
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 if (term && i < NU) continue;
@@ -967,9 +980,15 @@ struct SmallSolver {
                     double dt1, dl1, dt2, dl2, dss, rat;
                     row_steps(i, sd, v, dv, 1, smu, dt1, dl1, dt2, dl2, dss, rat);
                     rmax = fmax(rmax, rat);
+                    d12[0] = fma(lam[sd][i], dt1, fma(t[sd][i], dl1, d12[0])), d12[1] = fma(dl1, dt1, d12[1]);
+                    if (SOFT && softc(i)) {
+                        const int ii = SOFT ? i : 0;
+                        d12[0] = fma(lams[sd][ii], dt2, fma(ts[sd][ii], dl2, d12[0])), d12[1] = fma(dl2, dt2, d12[1]);
+                    }
                 }
             }
-            const double alpha = fmin(1.0, (M::DISCRETE ? IPM_FRAC : fmax(IPM_FRAC, 1.0 - mu)) / seg_max<M::SEG_SKIP>(rmax, k, lpi, base));   // fraction to the boundary -> 1 as mu -> 0 (LQ model: fixed)
+            seg_reduce<1, 2, M::SEG_SKIP>(&rmax, d12, k, lpi, base);
+            const double alpha = fmin(1.0, (M::DISCRETE ? IPM_FRAC : fmax(IPM_FRAC, 1.0 - mu)) / rmax);   // fraction to the boundary -> 1 as mu -> 0 (LQ model: fixed)
             if (qlive) {
                 // rows of (i, sd) only read their own side's state, so they can be advanced in place
 #pragma unroll
@@ -995,6 +1014,15 @@ struct SmallSolver {
                 for (int i = 0; i < NX; ++i) dx[i] = fma(alpha, Dx[i], dx[i]), nuq[i] = fma(alpha, Dnu[i], nuq[i]);
 #pragma unroll
                 for (int i = 0; i < NU; ++i) du[i] = fma(alpha, Du[i], du[i]);
+                if (MPCRL_IPM_SCALE_RES) {
+                    const double om = 1.0 - alpha;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) rb[i] *= om;
+#pragma unroll
+                    for (int i = 0; i < NW; ++i) rg[i] *= om;
+                    rinf_c = om * rinf;
+                    musum_c = fma(alpha, fma(alpha, d12[1], d12[0]), musum);
+                }
             }
             PHW(8);
         }
