@@ -166,6 +166,9 @@ struct SmallSolver {
 #endif
     double hscale = 1.0;   // multiplies the Hs accessor of the Riccati stage (c_k for the SQP Hessian, 1 for the exact one)
     double n_rows_c = -1.0;   // bound rows per instance, counted by the first QP of the launch
+    // the instance's x0 (and pinned u0 in Q-mode) in registers: read through the batch pointers they cost a global round trip per SQP
+    // round (5.5 k of a round's 80 k cycles: the loads sit behind lane-dependent addresses and are not hoisted out of the loop)
+    double x0r[NX], u0r[NU];
 
     MPCRL_DI SmallSolver(const SmallSpec &sp_, int k_, int lpi_, int base_)
         : sp(sp_), N(sp_.N), lpi(lpi_), k(k_), base(base_), blkidx(base_ / lpi_), term(k_ == sp_.N), first(k_ == 0) {}
@@ -1213,6 +1216,10 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
     // x0 / u0 are only read by the lane of stage 0, a few times per QP: leave them in memory instead of in registers
     const double *x0 = a.x0 + inst * NX;
     const double *u0f = S.qmode ? a.u0fix + inst * NU : a.x0 + inst * NX;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) S.x0r[i] = x0[i];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) S.u0r[i] = u0f[i];   // (not Q-mode: u0f aliases x0, never read)
     // ---- iterate: stored (warm) or the reference's cold start (MPC.reset, mpc.py:204-210)
     const size_t nb = (size_t)(N + 1) * NW;
     double *bnd = a.BND + (size_t)inst * 10 * nb + (size_t)k * NW;
@@ -1221,7 +1228,7 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
     const bool cold = (a.flags & 8) || (a.cold && a.cold[inst]);
     if (a.flags & 8) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) S.x[i] = x0[i], S.nu_[i] = 0.0;
+        for (int i = 0; i < NX; ++i) S.x[i] = S.x0r[i], S.nu_[i] = 0.0;
 #pragma unroll
         for (int i = 0; i < NU; ++i) S.u[i] = 0.0;
 #pragma unroll
@@ -1234,7 +1241,7 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const double xs = a.X[(inst * (N + 1) + k) * NX + i], ns = a.PI[(inst * N + (first ? 0 : k - 1)) * NX + i];
-            S.x[i] = cold ? x0[i] : xs;
+            S.x[i] = cold ? S.x0r[i] : xs;
             S.nu_[i] = (first || cold) ? 0.0 : ns;
         }
 #pragma unroll
@@ -1278,10 +1285,10 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
         double sl = 0.0;
         if (first) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) sl = fmax(sl, fabs(x0[i] - S.x[i]));
+            for (int i = 0; i < NX; ++i) sl = fmax(sl, fabs(S.x0r[i] - S.x[i]));
             if (S.qmode) {
 #pragma unroll
-                for (int i = 0; i < NU; ++i) sl = fmax(sl, fabs(u0f[i] - S.u[i]));
+                for (int i = 0; i < NU; ++i) sl = fmax(sl, fabs(S.u0r[i] - S.u[i]));
             }
         }
         stepn = seg_max<M::SEG_SKIP>(sl, k, lpi, base);
@@ -1298,7 +1305,7 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
 #endif
         const double cl = S.linearize(xn);
         double rl[4];
-        S.nlp_res_local(nun, x0, u0f, rl);
+        S.nlp_res_local(nun, S.x0r, S.u0r, rl);
         double res[4] = {rl[0], rl[1], rl[2], rl[3]}, cost = cl;
         seg_reduce<4, 1, M::SEG_SKIP>(res, &cost, k, lpi, base);
 #ifdef MPCRL_PROFILE_PHASES
@@ -1322,7 +1329,7 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
         if (live) last_tight = tol_res <= IPM_TOL_RES && tol_mu <= IPM_TOL_MU;
         if (!__any(live)) break;
         const double warm_mu = stepn < 0.0 ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
-        const bool ok = S.qp_solve(live, x0, u0f, n_ipm, warm_mu, tol_res, tol_mu);
+        const bool ok = S.qp_solve(live, S.x0r, S.u0r, n_ipm, warm_mu, tol_res, tol_mu);
         if (live && !ok) status = 4, live = false;
         {
             double sl = 0.0;
@@ -1495,9 +1502,9 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
     load_params();
     // ---- cold start of the resident instances (MPC.reset, mpc.py:204-210)
 #pragma unroll
-    for (int i = 0; i < NX; ++i) S.x[i] = x0[i], S.nu_[i] = 0.0;
+    for (int i = 0; i < NX; ++i) S.x0r[i] = x0[i], S.x[i] = S.x0r[i], S.nu_[i] = 0.0;
 #pragma unroll
-    for (int i = 0; i < NU; ++i) S.u[i] = 0.0;
+    for (int i = 0; i < NU; ++i) S.u[i] = 0.0, S.u0r[i] = u0f[i];
 #pragma unroll
     for (int i = 0; i < NW; ++i) S.lam[0][i] = S.lam[1][i] = 0.0, S.t[0][i] = S.t[1][i] = 1.0, S.aff[0][i] = S.aff[1][i] = 0.0;
 #pragma unroll
@@ -1529,7 +1536,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
 #endif
         const double cl = S.linearize(xn);
         double rl[4];
-        S.nlp_res_local(nun, x0, u0f, rl);
+        S.nlp_res_local(nun, S.x0r, S.u0r, rl);
         double res[4] = {rl[0], rl[1], rl[2], rl[3]}, cost = cl;
         seg_reduce<4, 1, M::SEG_SKIP>(res, &cost, k, lpi, base);
 #ifdef MPCRL_PROFILE_PHASES
@@ -1596,7 +1603,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
         if (!any_live && pk < 0) break;
         if (any_live) {
             const double warm_mu = stepn < 0.0 ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
-            const bool ok = S.qp_solve(live, x0, u0f, n_ipm, warm_mu, tol_res, tol_mu);
+            const bool ok = S.qp_solve(live, S.x0r, S.u0r, n_ipm, warm_mu, tol_res, tol_mu);
             bool qp_failed = live && !ok;
             {
                 double sl = 0.0;
@@ -1719,7 +1726,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
 #pragma unroll
             for (int j = 0; j < PK; ++j) in[j] = pl[j * lpi];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) out[i] = S.x[i], out[NX + i] = S.nu_[i];
+            for (int i = 0; i < NX; ++i) out[i] = S.x[i], out[NX + i] = first ? S.x0r[i] : S.nu_[i];   // nu of stage 0 is identically zero: its words carry x0
 #pragma unroll
             for (int i = 0; i < NU; ++i) out[2 * NX + i] = S.u[i];
 #pragma unroll
@@ -1733,7 +1740,8 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
             }
             if (sw) {
 #pragma unroll
-                for (int i = 0; i < NX; ++i) S.x[i] = pk_started ? in[i] : xc[i], S.nu_[i] = pk_started ? in[NX + i] : 0.0;
+                for (int i = 0; i < NX; ++i)
+                    S.x[i] = pk_started ? in[i] : xc[i], S.nu_[i] = (pk_started && !first) ? in[NX + i] : 0.0, S.x0r[i] = pk_started ? in[NX + i] : xc[i];
 #pragma unroll
                 for (int i = 0; i < NU; ++i) S.u[i] = pk_started ? in[2 * NX + i] : 0.0;
 #pragma unroll
@@ -1746,7 +1754,9 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 const double xs = a.X[(inst * (N + 1) + k) * NX + i], ns = a.PI[(inst * N + (first ? 0 : k - 1)) * NX + i];
-                S.x[i] = sw ? (pk_started ? xs : x0[i]) : S.x[i];
+                const double x0n = x0[i];
+                S.x[i] = sw ? (pk_started ? xs : x0n) : S.x[i];
+                S.x0r[i] = sw ? x0n : S.x0r[i];
                 S.nu_[i] = sw ? ((first || !pk_started) ? 0.0 : ns) : S.nu_[i];
             }
 #pragma unroll
@@ -1759,6 +1769,13 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
                 const double l0 = bnd[0 * nb + i], l1 = bnd[1 * nb + i], t0 = bnd[2 * nb + i], t1 = bnd[3 * nb + i];
                 S.lam[0][i] = sw ? (pk_started ? l0 : 0.0) : S.lam[0][i], S.lam[1][i] = sw ? (pk_started ? l1 : 0.0) : S.lam[1][i];
                 S.t[0][i] = sw ? (pk_started ? t0 : 1.0) : S.t[0][i], S.t[1][i] = sw ? (pk_started ? t1 : 1.0) : S.t[1][i];
+            }
+        }
+        if (S.qmode) {   // the pinned u0 of the incoming instance (Q-mode only: one global read per rotation)
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const double un = u0f[i];
+                S.u0r[i] = sw ? un : S.u0r[i];
             }
         }
         pk = for_good ? -1 : lo;
