@@ -174,17 +174,27 @@ struct SmallSolver {
         : sp(sp_), N(sp_.N), lpi(lpi_), k(k_), base(base_), blkidx(base_ / lpi_), term(k_ == sp_.N), first(k_ == 0) {}
 
     // ---- static problem data of this stage -------------------------------------------------------
-    MPCRL_DI double lbv(int i) const {
-        if (first) return (i < NU && !qmode) ? sp.lb0[i < NU ? i : 0] : -1e30;
-        if (term) return i >= NU ? sp.lbe[i >= NU ? i - NU : 0] : -1e30;
-        return sp.lb[i];
+    // bounds of THIS lane's stage in registers (init_bounds, once per launch): read out of the problem descriptor at every use they
+    // cost a three-way select on the stage kind each time and keep ~40 scalar registers busy for the whole kernel
+    double lbr[NW], ubr[NW];
+    unsigned hasm = 0;   // bit 2 i + sd: the bound row (i, sd) exists
+    MPCRL_DI void init_bounds() {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            double l, u_;
+            if (first)
+                l = (i < NU && !qmode) ? sp.lb0[i < NU ? i : 0] : -1e30, u_ = (i < NU && !qmode) ? sp.ub0[i < NU ? i : 0] : 1e30;
+            else if (term)
+                l = i >= NU ? sp.lbe[i >= NU ? i - NU : 0] : -1e30, u_ = i >= NU ? sp.ube[i >= NU ? i - NU : 0] : 1e30;
+            else
+                l = sp.lb[i], u_ = sp.ub[i];
+            lbr[i] = l, ubr[i] = u_;
+            hasm |= (l > -NO_BOUND ? 1u : 0u) << (2 * i) | (u_ < NO_BOUND ? 1u : 0u) << (2 * i + 1);
+        }
     }
-    MPCRL_DI double ubv(int i) const {
-        if (first) return (i < NU && !qmode) ? sp.ub0[i < NU ? i : 0] : 1e30;
-        if (term) return i >= NU ? sp.ube[i >= NU ? i - NU : 0] : 1e30;
-        return sp.ub[i];
-    }
-    MPCRL_DI bool has(int sd, int i) const { return sd ? ubv(i) < NO_BOUND : lbv(i) > -NO_BOUND; }
+    MPCRL_DI double lbv(int i) const { return lbr[i]; }
+    MPCRL_DI double ubv(int i) const { return ubr[i]; }
+    MPCRL_DI bool has(int sd, int i) const { return (hasm >> (2 * i + sd)) & 1u; }
     MPCRL_DI bool softc(int i) const { return SOFT && !first && !term && sp.soft[i] != 0; }
     MPCRL_DI double zw(int sd, int i) const { return (sd ? sp.zu[i] : sp.zl[i]) * sp.dT * pow(sp.gamma, (double)k); }
     MPCRL_DI bool fixed(int i) const { return first && (i >= NU || qmode); }
@@ -1200,6 +1210,7 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
     S.ms = mx_lds;
     const bool term = S.term, first = S.first;
     S.qmode = a.u0fix != nullptr;
+    S.init_bounds();
     if (sp.cost_kind == 0)
         S.ck = term ? 1.0 : sp.dT;                                                        // nlp.py:1044-1055
     else
@@ -1454,6 +1465,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
     const bool lds_park = lpi * PK <= PARK_CAP;
     S.ms = mx_lds;
     S.qmode = a.u0fix != nullptr;
+    S.init_bounds();
     // Batch index (after the packing order) and dynamics parameters of the ipw + 1 instances, looked up ONCE: a rebinding between
     // rounds must not cost global round trips of its own (perm -> theta -> state would be three in a row).
     __shared__ long gi_lds[M::MAX_IPW];
@@ -1805,6 +1817,7 @@ __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, cons
     S.ms = mx_lds;
     const bool term = S.term, first = S.first;
     S.qmode = a.u0fix != nullptr;
+    S.init_bounds();
     if (sp.cost_kind == 0)
         S.ck = term ? 1.0 : sp.dT;
     else
