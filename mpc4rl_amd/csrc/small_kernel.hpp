@@ -905,7 +905,9 @@ struct SmallSolver {
                 rinf = rloc, musum = muloc;   // musum: sum of the complementarity products
             } else
                 rinf = rinf_c, musum = musum_c;
-            const double mu = n_rows > 0.0 ? musum / n_rows : 0.0;
+            // (scalars of the iteration by the refined hardware reciprocal, as everywhere else: their operands are positive and normal)
+            const double inv_rows = n_rows > 0.0 ? fast_rcp(n_rows) : 0.0;
+            const double mu = musum * inv_rows;
             if (qlive) {
                 if (rinf <= tol_res && mu <= tol_mu)
                     qlive = false, ok = true;
@@ -963,9 +965,9 @@ struct SmallSolver {
                 rmax = two[0];
                 if (two[1] > 0.5) qlive = false;   // non-positive pivot: QP failure
             }
-            const double a_aff = 1.0 / rmax;
-            const double mu_aff = n_rows > 0.0 ? fma(a_aff, fma(a_aff, c12[1], c12[0]), musum) / n_rows : 0.0;
-            const double ratio = mu > 0.0 ? mu_aff / mu : 0.0;
+            const double a_aff = fast_rcp(rmax);
+            const double mu_aff = fma(a_aff, fma(a_aff, c12[1], c12[0]), musum) * inv_rows;
+            const double ratio = mu > 0.0 ? mu_aff * fast_rcp(mu) : 0.0;
             const double smu = ratio * ratio * ratio * mu;
             PHW(4);
             // ---- corrector (same factorisation, vector sweep only)
@@ -1001,7 +1003,7 @@ struct SmallSolver {
                 }
             }
             seg_reduce<1, 2, M::SEG_SKIP>(&rmax, d12, k, lpi, base);
-            const double alpha = fmin(1.0, (M::DISCRETE ? IPM_FRAC : fmax(IPM_FRAC, 1.0 - mu)) / rmax);   // fraction to the boundary -> 1 as mu -> 0 (LQ model: fixed)
+            const double alpha = fmin(1.0, (M::DISCRETE ? IPM_FRAC : fmax(IPM_FRAC, 1.0 - mu)) * fast_rcp(rmax));   // fraction to the boundary -> 1 as mu -> 0 (LQ model: fixed)
             if (qlive) {
                 // rows of (i, sd) only read their own side's state, so they can be advanced in place
 #pragma unroll
@@ -1224,7 +1226,6 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
     for (int i = 0; i < NTD; ++i) S.thd[i] = th[M::td_index(i)];
 #pragma unroll
     for (int i = 0; i < NTC; ++i) S.thc[i] = th[M::tc_index(i)];
-    // x0 / u0 are only read by the lane of stage 0, a few times per QP: leave them in memory instead of in registers
     const double *x0 = a.x0 + inst * NX;
     const double *u0f = S.qmode ? a.u0fix + inst * NU : a.x0 + inst * NX;
 #pragma unroll
