@@ -14,6 +14,14 @@ namespace mpcrl {
 
 #define MPCRL_DI __device__ __forceinline__
 
+// 1 / x from the hardware seed and two Newton steps (~1 ulp) for the denominators of the dynamics: an IEEE division is ~15 instructions
+// of scaling, fix-up and special cases that a model's denominators (masses, lengths, norms) never need
+MPCRL_DI double jet_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
 template <int N>
 struct Jet1 {
     double v;
@@ -52,7 +60,7 @@ MPCRL_DI Jet1<N> operator*(const Jet1<N> &a, const Jet1<N> &b) {
 template <int N>
 MPCRL_DI Jet1<N> operator/(const Jet1<N> &a, const Jet1<N> &b) {
     Jet1<N> r;
-    const double inv = 1.0 / b.v;
+    const double inv = jet_rcp(b.v);
     r.v = a.v * inv;
 #pragma unroll
     for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
@@ -83,7 +91,7 @@ MPCRL_DI Jet1<N> operator-(double s, const Jet1<N> &a) {
 template <int N>
 MPCRL_DI Jet1<N> jrecip(const Jet1<N> &b) {
     Jet1<N> r;
-    r.v = 1.0 / b.v;
+    r.v = jet_rcp(b.v);
     const double m2 = -r.v * r.v;
 #pragma unroll
     for (int i = 0; i < N; ++i) r.d[i] = m2 * b.d[i];
@@ -155,7 +163,7 @@ MPCRL_DI Jet2<N> operator*(const Jet2<N> &a, const Jet2<N> &b) {
 template <int N>
 MPCRL_DI Jet2<N> jrecip(const Jet2<N> &b) {
     Jet2<N> r;
-    const double i1 = 1.0 / b.v, i2 = i1 * i1, i3 = 2.0 * i2 * i1;
+    const double i1 = jet_rcp(b.v), i2 = i1 * i1, i3 = 2.0 * i2 * i1;
     r.v = i1;
     r.e = -b.e * i2;
 #pragma unroll
@@ -289,7 +297,7 @@ MPCRL_DI JetH<N> operator*(const JetH<N> &a, const JetH<N> &b) {
 }
 template <int N>
 MPCRL_DI JetH<N> jrecip(const JetH<N> &b) {
-    const double i1 = 1.0 / b.v, i2 = i1 * i1;
+    const double i1 = jet_rcp(b.v), i2 = i1 * i1;
     return jeth_chain(b, i1, -i2, 2.0 * i2 * i1);
 }
 template <int N>
