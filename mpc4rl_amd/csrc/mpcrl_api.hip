@@ -144,10 +144,10 @@ int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
 }
 
 // Time-sliced launch (small_solve_sliced_kernel): ipw + 1 instances per wavefront, ipw of them advancing per round.  Such a
-// wavefront lives longer than (ipw + 1) / ipw plain lifetimes — measured on cartpole N = 20: 1.52 (rotation 3.3 us per round,
-// write-outs inside the loop, 3 % for mixing QPs of instances one SQP iteration apart) — so it pays only when it saves a round
-// of wavefronts on the chip's SIMDs: 4096 instances are 2 rounds of 3-instance wavefronts or 1 round of 4-instance ones
-// (4.62 -> 5.4 M solves/s); 32768 are 11 vs 8 rounds (plain wins, measured 6.83 vs 6.17 M solves/s).
+// wavefront lives longer than (ipw + 1) / ipw plain lifetimes — measured on cartpole N = 20 at the end of round 2: 1.62 (818 k vs
+// 1 328 k cycles: write-outs inside the loop, 3 % for mixing QPs of instances one SQP iteration apart, and more register spill traffic
+// than the plain kernel) — so it pays only when it saves enough rounds of wavefronts on the chip's SIMDs: 4096 instances are 2 rounds
+// of 3-instance wavefronts or 1 round of 4-instance ones (5.44 -> 6.36 M solves/s); 32768 are 11 vs 8 rounds (plain wins).
 template <class M>
 bool plan_time_sliced(const MpcrlSolver *h, int flags, long *waves) {
     if constexpr (M::HAS_SOFT) {
@@ -159,7 +159,7 @@ bool plan_time_sliced(const MpcrlSolver *h, int flags, long *waves) {
         const long waves3 = (h->B + ipw - 1) / ipw, waves4 = (h->B + q - 1) / q;
         const long rounds3 = (waves3 + h->n_simd - 1) / h->n_simd, rounds4 = (waves4 + h->n_simd - 1) / h->n_simd;
         if (waves) *waves = waves4;
-        return legal && (h->slice_mode > 0 || (h->slice_mode == 0 && 16 * rounds4 <= 10 * rounds3));
+        return legal && (h->slice_mode > 0 || (h->slice_mode == 0 && 162 * rounds4 <= 100 * rounds3));
     }
 }
 
