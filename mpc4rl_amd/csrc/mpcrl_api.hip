@@ -171,7 +171,12 @@ int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
     if constexpr (!M::HAS_SOFT) {
         long waves4 = 0;
         sliced = plan_time_sliced<M>(h, a.flags, &waves4);
-        if (sliced) hipLaunchKernelGGL(small_solve_sliced_kernel<M>, dim3((unsigned)waves4), dim3(64), 0, st, h->small, a);
+        if (sliced) {
+            if (sliced_parks_in_lds<M>(h->N))
+                hipLaunchKernelGGL((small_solve_sliced_kernel<M, true>), dim3((unsigned)waves4), dim3(64), 0, st, h->small, a);
+            else
+                hipLaunchKernelGGL((small_solve_sliced_kernel<M, false>), dim3((unsigned)waves4), dim3(64), 0, st, h->small, a);
+        }
     }
     if (!sliced) hipLaunchKernelGGL(small_solve_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
     HIP_OK(hipGetLastError());

@@ -1432,7 +1432,16 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
 // attempt of round 1 (claims by compare-and-swap) could not have.  An instance that finishes is written out at once and
 // its slot goes to the parked instance for good.  The iteration of an instance is bit-for-bit the one of small_solve_kernel.
 // =====================================================================================================
+// LDSPARK: where the parked instance lives (chosen by the host from the horizon: sliced_parks_in_lds); a template parameter so that
+// the kernel of the short horizons carries neither the code nor the pointers of the HBM exchange.
 template <class M>
+constexpr int sliced_park_words() { return 2 * M::NX + M::NU + 4 * (M::NX + M::NU); }
+template <class M>
+constexpr int sliced_park_cap() { return (M::NX == 4 && M::NU == 1) ? 21 * sliced_park_words<M>() : 64 * sliced_park_words<M>(); }
+template <class M>
+inline bool sliced_parks_in_lds(int N) { return (N + 1) * sliced_park_words<M>() <= sliced_park_cap<M>(); }
+
+template <class M, bool LDSPARK>
 __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSpec sp, const SmallArgs a) {
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NP = M::NP, NTD = M::NTD, NTC = M::NTC;
     static_assert(!M::HAS_SOFT, "hard bounds only");
@@ -1461,9 +1470,10 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
     // the LDS of a CU is shared by four wavefronts, 40 960 B each); longer horizons park in the instance's stored-iterate arrays
     // in HBM, which costs a global round trip per round (3.3 us of a 45 us round: 8 % of the launch).
     constexpr int PK = 2 * NX + NU + 4 * NW;
-    constexpr int PARK_CAP = SmallSolver<M>::MX ? 21 * PK : 64 * PK;
+    static_assert(PK == sliced_park_words<M>(), "host and kernel agree on the parked state");
+    constexpr int PARK_CAP = LDSPARK ? sliced_park_cap<M>() : 1;
     __shared__ double park_lds[PARK_CAP];
-    const bool lds_park = lpi * PK <= PARK_CAP;
+    constexpr bool lds_park = LDSPARK;
     S.ms = mx_lds;
     S.qmode = a.u0fix != nullptr;
     S.init_bounds();
@@ -1723,7 +1733,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
                 stepn = pk_started ? sn_ : -1.0;
             }
         }
-        if (lds_park) {
+        if constexpr (lds_park) {
             // the lanes of the slot swap their registers with the parked state (lane k <-> column k: no lane reads what another
             // one writes); a parked instance that has not run yet starts cold
             double *pl = park_lds + k;
