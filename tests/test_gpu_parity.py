@@ -392,8 +392,9 @@ def test_auto_order_does_not_change_results():
 
 @pytest.mark.parametrize("B", [4, 7, 100, 4096, 5000])
 def test_time_sliced_launch_is_bitwise_the_plain_one(B, monkeypatch):
-    """small_solve_sliced_kernel (ipw + 1 instances per wavefront, one parked in HBM between SQP iterations) runs the same iteration
-    per instance as small_solve_kernel: every output bit-identical, for ragged batches too.  MPCRL_TIME_SLICE forces / forbids it."""
+    """small_solve_sliced_kernel (ipw + 1 instances per wavefront, one parked — in LDS at this horizon — between SQP iterations) runs
+    the same iteration per instance as small_solve_kernel: every output bit-identical, for ragged batches too.  MPCRL_TIME_SLICE
+    forces / forbids it."""
     from mpc4rl_amd import MPCBatch, cartpole_ocp
     x0 = cartpole_x0(B, seed=13)
     theta = np.tile(cartpole_ocp().p0, (B, 1))
@@ -415,6 +416,26 @@ def test_time_sliced_launch_is_bitwise_the_plain_one(B, monkeypatch):
     r2 = mpc.solve(x0)
     ok = rb.status == 0
     assert int(r2.iters[ok][:, 0].max()) == 0 and torch.equal(r2.V[ok], rb.V[ok])
+
+
+@pytest.mark.parametrize("N,tf", [(20, 2.0), (30, 3.0)])
+def test_time_sliced_launch_q_mode(N, tf, monkeypatch):
+    """Q-mode (u0 pinned, mpc.py:71-76) through the sliced launch: the pinned u0 follows its instance through the rotation, with the
+    parked instance in LDS (N = 20) and in HBM (N = 30).  Bit-identical to the plain launch."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    B = 101
+    x0 = cartpole_x0(B, seed=21)
+    u0 = torch.as_tensor(np.random.default_rng(2).uniform(-20.0, 20.0, (B, 1)), device="cuda")
+    out = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MPCRL_TIME_SLICE", mode)
+        mpc = MPCBatch(cartpole_ocp(N=N, tf=tf), B)
+        out.append(mpc.solve(x0, u0, sens_v=True, cold=True))
+    ra, rb = out
+    assert int((ra.status == 0).sum()) > 0.8 * B
+    for f in ("u0", "V", "status", "iters", "dV_dp"):
+        assert torch.equal(getattr(ra, f), getattr(rb, f)), f
+    assert torch.equal(ra.u0[ra.status == 0], u0[ra.status == 0])
 
 
 def test_time_sliced_launch_status_codes(monkeypatch):
