@@ -1750,7 +1750,7 @@ __global__ void __launch_bounds__(64, 1) chain_sqp_kernel(const LargeSpec sp, co
         S.ph(9);
         const double rmax = fmax(fmax(res[0], res[1]), fmax(res[2], res[3]));
         status = -1;   // -1: carry on
-        if (!(rmax < 1e300))
+        if (!(rmax < 1e300) || !(fabs(cost) < 1e300))   // the max-reductions drop NaNs, the cost sum does not
             status = 1;
         else if (rmax < sp.tol && last_tight && !(rti && it == 0))
             status = 0;

@@ -40,6 +40,7 @@ struct CartpoleDev {
     static constexpr bool SEG_SKIP = false;   // segmented reductions: full trees (small_kernel.hpp, measured)
     MPCRL_DI static int td_index(int i) { return i; }
     MPCRL_DI static int tc_index(int) { return 0; }
+    MPCRL_DI static bool p_has_gradient(int e) { return e < NTD; }   // entries of p the sensitivity kernel computes; the rest are zeros
     // cost block of the parameter vector (nlp.py:969-989, each field column-major): W_0 (5x5), W (5x5), W_e (4x4), yref_0 (5),
     // yref (5), yref_e (4) in y = [x; u] order.  The solve uses whatever set_parameter / cost_set wrote there (mpc.py:233-257);
     // the mirror's cost is not parameterised by them (nlp.py:1039-1055): cost_dp / cost_mixed contribute nothing.
@@ -112,6 +113,7 @@ struct LinearDev {
     static constexpr bool SEG_SKIP = true;
     MPCRL_DI static int td_index(int i) { return i; }
     MPCRL_DI static int tc_index(int i) { return 8 + i; }   // V_0, f_0, f_1, f_2
+    MPCRL_DI static bool p_has_gradient(int) { return true; }
     static constexpr int NLD = NX + NU;
     MPCRL_DI static constexpr int lin_coord(int d) { return d; }
     template <class F>

@@ -405,8 +405,9 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
     a.X = h->X, a.U = h->U, a.PI = h->PI, a.BND = h->BND, a.RES = h->RES, a.LAG = h->LAG;
     a.u0_out = u0_out, a.V = V, a.dV = (flags & MPCRL_SENS_V) ? dV_dp : nullptr, a.dpi = (flags & MPCRL_SENS_PI) ? dpi_dp : nullptr;
     a.status = status, a.iters = iters;
-    if (a.dV) HIP_OK(hipMemsetAsync(dV_dp, 0, (size_t)h->B * h->np * sizeof(double), st));
-    if (a.dpi) HIP_OK(hipMemsetAsync(dpi_dp, 0, (size_t)h->B * h->nu * h->np * sizeof(double), st));
+    // chain: sens_out stores only the entries of solved instances that have a gradient; the small models' sensitivity kernel writes its rows in full
+    if (h->is_large && a.dV) HIP_OK(hipMemsetAsync(dV_dp, 0, (size_t)h->B * h->np * sizeof(double), st));
+    if (h->is_large && a.dpi) HIP_OK(hipMemsetAsync(dpi_dp, 0, (size_t)h->B * h->nu * h->np * sizeof(double), st));
     int rc;
     if (h->is_large) {
         LargeArgs la;

@@ -1328,7 +1328,7 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
             Vout = cost, n_sqp = it;
 #pragma unroll
             for (int j = 0; j < 4; ++j) res_out[j] = res[j];
-            if (!(rmax < 1e300))
+            if (!(rmax < 1e300) || !(fabs(cost) < 1e300))   // the max-reductions drop NaNs, the cost sum does not
                 status = 1, live = false;
             else if (rmax < sp.tol && last_tight && !(rti && it == 0))
                 status = 0, live = false;
@@ -1568,7 +1568,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
         const double rmax = fmax(fmax(res[0], res[1]), fmax(res[2], res[3]));
         bool fin_now = false;
         if (live) {
-            if (!(rmax < 1e300))
+            if (!(rmax < 1e300) || !(fabs(cost) < 1e300))   // the max-reductions drop NaNs, the cost sum does not
                 status = 1, live = false;
             else if (rmax < sp.tol && last_tight)
                 status = 0, live = false;
@@ -1864,6 +1864,17 @@ __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, cons
     for (int i = 0; i < NX; ++i) S.p[i] = 0.0;
     const int status = a.status[inst];
     const bool sv = valid && (status == 0 || status == 2);
+    // The output rows are written in full by this launch (no memset in front of it): the lanes of an instance zero every entry
+    // sensitivities() below does not store — the cost block of p (zero gradient of the mirror, nlp.py:1039-1055), everything of
+    // an instance that was not solved, du0*/dp in Q-mode.  The two sets of addresses are disjoint.
+    if (valid) {
+        if (a.dV)
+            for (int e = k; e < NP; e += lpi)
+                if (!(sv && M::p_has_gradient(e))) a.dV[inst * NP + e] = 0.0;
+        if (a.dpi)
+            for (int e = k; e < NU * NP; e += lpi)
+                if (!(sv && !S.qmode && M::p_has_gradient(e % NP))) a.dpi[inst * NU * NP + e] = 0.0;
+    }
     S.sensitivities(a.flags, sv, nun, a.dV ? a.dV + inst * NP : nullptr, a.dpi ? a.dpi + inst * NU * NP : nullptr);
 }
 

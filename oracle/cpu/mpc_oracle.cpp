@@ -512,7 +512,7 @@ struct Solver {
             cost = linearize();
             nlp_residuals(x0, u0fix, res);
             const double rmax = std::max(std::max(res[0], res[1]), std::max(res[2], res[3]));
-            if (!std::isfinite(rmax)) return 1;
+            if (!std::isfinite(rmax) || !std::isfinite(cost)) return 1;   // std::max drops NaNs, the cost sum does not
             if (rmax < tol && last_tight && !(rti && n_sqp == 0)) return 0;
             if (n_sqp == max_iter) return rmax < tol ? 0 : 2;
             {   // QP tolerances for this iteration

@@ -341,7 +341,7 @@ def solve(prob: Problem, x0, p=None, u0fix=None, gamma=None, warm: Optional[Solu
         res = nlp_residuals(P, st, X, U, S, pi0, pi, lam, A, B, Fv, gcost, x0, u0fix, slack_w)
         if verbose:
             print(f"sqp {it:3d} cost {cost:.10e} res {res}")
-        if not np.all(np.isfinite(res)):
+        if not (np.all(np.isfinite(res)) and np.isfinite(cost)):
             status = 1
             break
         if res.max() < tol and last_tight and not (rti and it == 0):

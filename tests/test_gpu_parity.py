@@ -474,3 +474,42 @@ def test_time_sliced_launch_other_horizons(N, tf, monkeypatch, oracle_port):
     assert ok.mean() > 0.8
     assert rel_err(rb.u0.cpu().numpy()[ok], ref.u0[ok]) < RTOL and rel_err(rb.V.cpu().numpy()[ok], ref.V[ok]) < RTOL
     assert rel_err(rb.dV_dp.cpu().numpy()[ok], ref.dV[ok]) < RTOL and rel_err(rb.dpi_dp.cpu().numpy()[ok], ref.dpi[ok]) < RTOL
+
+
+def test_sensitivity_rows_are_written_in_full():
+    """The small models' sensitivity kernel owns its output rows (no memset in front of it): with the output buffers poisoned
+    before mpcrl_solve, the cost block of p comes back exactly zero, du0*/dp is zero in Q-mode, an instance that was not solved
+    (NaN x0: status neither 0 nor 2) has zero rows, and the entries with a gradient equal those of an ordinary solve."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp, linear_system_ocp
+    from mpc4rl_amd import _lib
+    from mpc4rl_amd.batch import _ptr
+    for ocp, nx in ((cartpole_ocp(), 4), (linear_system_ocp(), 2)):
+        B = 131
+        x0 = cartpole_x0(B, seed=4) if nx == 4 else np.random.default_rng(4).uniform(-0.5, 0.5, (B, 2))
+        x0[7] = np.nan
+        ref = MPCBatch(ocp, B).solve(x0, sens_v=True, sens_pi=True, cold=True)
+        for qmode in (False, True):
+            mpc = MPCBatch(ocp, B)
+            kw = dict(dtype=torch.float64, device=mpc.device)
+            xd = torch.as_tensor(x0, **kw).contiguous()
+            ud = torch.zeros((B, mpc.nu), **kw) if qmode else None
+            u0o, V = torch.empty((B, mpc.nu), **kw), torch.empty((B,), **kw)
+            dV, dpi = torch.full((B, mpc.n_p), np.nan, **kw), torch.full((B, mpc.nu, mpc.n_p), np.nan, **kw)
+            st, it = torch.empty((B,), dtype=torch.int32, device=mpc.device), torch.empty((B, 2), dtype=torch.int32, device=mpc.device)
+            flags = _lib.SENS_V | _lib.SENS_PI | _lib.COLD
+            rc = mpc.lib.mpcrl_solve(mpc._h, _ptr(xd), _ptr(ud), flags, _ptr(u0o), _ptr(V), _ptr(dV), _ptr(dpi), _ptr(st), _ptr(it),
+                                     mpc._stream())
+            torch.cuda.synchronize()
+            assert rc == 0
+            solved = (st == 0) | (st == 2)
+            assert int(st[7]) == 1 and int(solved.sum()) >= B - 12   # NaN x0: status 1 (as in the oracle), not a silent "converged"
+            assert torch.all(dV[~solved] == 0.0) and torch.all(dpi[~solved] == 0.0)
+            assert torch.isfinite(dV[solved]).all()
+            if nx == 4:
+                assert torch.all(dV[:, 3:] == 0.0) and torch.all(dpi[:, :, 3:] == 0.0)
+            if qmode:
+                assert torch.all(dpi == 0.0)
+            else:
+                assert torch.equal(st, ref.status)
+                assert torch.equal(dV, ref.dV_dp)
+                assert torch.equal(torch.nan_to_num(dpi, nan=7.0), torch.nan_to_num(ref.dpi_dp, nan=7.0))

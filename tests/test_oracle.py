@@ -223,3 +223,20 @@ def test_edge_cases(oracle_port):
     r = oracle_port.solve(P, x0)
     w = oracle_port.solve(P, x0, warm=r)
     assert w.status[0] == 0 and w.sqp_iter[0] == 0 and rel(w.V, r.V) < 1e-14 and rel(w.dV, r.dV) < 1e-12
+
+
+def test_non_finite_initial_state_is_status_1(oracle_port):
+    """An instance whose x0 holds a NaN (or overflows) ends with status 1 in both oracle implementations: max() drops NaNs from the
+    residual norms, so the finiteness test includes the cost (a sum).  Its neighbours in the batch are untouched."""
+    from oracle.problems import make_cartpole, make_linear_system
+    from oracle import sqp_dense
+    for P, nx in ((make_cartpole(), 4), (make_linear_system(), 2)):
+        x0 = np.random.default_rng(3).uniform(-0.3, 0.3, (4, nx))
+        good = oracle_port.solve(P, x0)
+        x0[1, nx - 1] = np.nan
+        x0[2, 0] = 1e200
+        r = oracle_port.solve(P, x0)
+        assert r.status[1] == 1 and r.status[2] in (1, 4) and r.status[0] == 0 and r.status[3] == 0
+        assert r.V[0] == good.V[0] and r.V[3] == good.V[3]
+        d = sqp_dense.solve(P, x0[1])
+        assert d.status == 1
