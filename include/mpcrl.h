@@ -133,7 +133,9 @@ int mpcrl_set_cold_mask(mpcrl_handle h, const int32_t *mask, void *stream);
  *   V         [B]                optimal cost (V or Q)
  *   dV_dp     [B, np] or NULL    needs MPCRL_SENS_V
  *   dpi_dp    [B, nu, np] or NULL needs MPCRL_SENS_PI
- *   status    [B] int32          0 success, 1 NaN, 2 max-iter, 4 QP failure
+ *   status    [B] int32          0 success, 1 NaN (a residual or the cost is not finite, e.g. a NaN in x0), 2 max-iter, 4 QP failure
+ * The sensitivity rows are written in full by every call: zeros for the entries of p without a gradient, for instances whose
+ * status is neither 0 nor 2, and for du0* / dp in Q mode; NaN where the exact-Hessian KKT matrix is not positive definite.
  *   iters     [B, 2] int32 or NULL   SQP iterations, total interior-point iterations
  */
 int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int flags, double *u0_out, double *V,
