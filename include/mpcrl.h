@@ -157,6 +157,18 @@ int mpcrl_get_lagrangian(mpcrl_handle h, double *L, void *stream);
  * Device pointers on the current device; weight may be NULL (= 1). */
 int mpcrl_weighted_grad_sum(const double *grad, int64_t ld, const double *weight, int rows, int n, double *out, void *stream);
 
+/* K4, the batched cartpole swing-up environment (rlmpc/gym/continuous_cartpole/environment.py): B environments, one launch per call.
+ *   par [9] HOST: gravity, masscart, masspole, length, force_mag, tau, x_threshold, theta_threshold, max_episode_steps
+ *   state [B, 4], steps [B] int64: the environments (device, updated in place)
+ * step  — action [B] in [-1, 1]: explicit Euler step (environment.py:105-134), obs [B, 4] (may be NULL) = new state, reward [B] =
+ *         x^2 + theta^2 of the new state (:193-194), terminated [B] uint8 = the terminal box (:136-146), truncated [B] uint8 =
+ *         steps >= max_episode_steps (gymnasium TimeLimit).
+ * reset — environments with mask[i] != 0 (mask NULL: all) restart at (0, 0, (0.9 + 0.2 u01[i]) pi, 0) (:178-180), steps = 0;
+ *         u01 [B] uniform [0, 1) numbers drawn by the caller; obs [B, 4] (may be NULL) = the state of EVERY environment after it. */
+int mpcrl_env_cartpole_step(const double *par, int B, double *state, int64_t *steps, const double *action, double *obs, double *reward,
+                            uint8_t *terminated, uint8_t *truncated, void *stream);
+int mpcrl_env_cartpole_reset(int B, double *state, int64_t *steps, const uint8_t *mask, const double *u01, double *obs, void *stream);
+
 /* Bytes of device memory held by the handle; library version. */
 int64_t mpcrl_workspace_bytes(mpcrl_handle h);
 int mpcrl_version(void);

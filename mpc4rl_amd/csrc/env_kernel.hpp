@@ -1,0 +1,57 @@
+// env_kernel.hpp — K4 of SURVEY.md §2: the batched cartpole swing-up environment as one launch per call, one lane per environment.
+// step: the explicit Euler step of rlmpc/gym/continuous_cartpole/environment.py:105-134 (force = force_mag * a, the "as written"
+// accelerations, tau = 0.02), reward x^2 + theta^2 of the NEW state (:193-194), the terminal box test (:136-146) and the step-count
+// truncation of gymnasium's TimeLimit.  reset: theta ~ (0.9 + 0.2 u) pi, rest 0 (:178-180) for the masked environments, u drawn by
+// the caller (the generator stays the host framework's).  All arithmetic in fp64 like the reference's numpy state.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mpcrl {
+
+struct CartpoleEnvPar {
+    double gravity, masscart, masspole, length, force_mag, tau, x_threshold, theta_threshold;
+    long max_episode_steps;
+};
+
+__global__ void __launch_bounds__(256) env_cartpole_step_kernel(const CartpoleEnvPar p, int B, double *state, int64_t *steps, const double *action,
+                                                                double *obs, double *reward, uint8_t *terminated, uint8_t *truncated) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const double2 s01 = reinterpret_cast<const double2 *>(state)[2 * i], s23 = reinterpret_cast<const double2 *>(state)[2 * i + 1];
+    const double x = s01.x, xd = s01.y, th = s23.x, thd = s23.y;
+    const double total_mass = p.masspole + p.masscart, pml = p.masspole * p.length;
+    const double force = action[i] * p.force_mag;
+    const double c = cos(th), s = sin(th);
+    const double temp = (force + pml * (thd * thd) * s) / total_mass;
+    const double thacc = (p.gravity * s - c * temp) / (p.length * (4.0 / 3.0 - p.masspole * (c * c) / total_mass));
+    const double xacc = temp - pml * thacc * c / total_mass;
+    const double nx = x + p.tau * xd, nxd = xd + p.tau * xacc, nth = th + p.tau * thd, nthd = thd + p.tau * thacc;
+    reinterpret_cast<double2 *>(state)[2 * i] = make_double2(nx, nxd);
+    reinterpret_cast<double2 *>(state)[2 * i + 1] = make_double2(nth, nthd);
+    if (obs) {
+        reinterpret_cast<double2 *>(obs)[2 * i] = make_double2(nx, nxd);
+        reinterpret_cast<double2 *>(obs)[2 * i + 1] = make_double2(nth, nthd);
+    }
+    const int64_t n = steps[i] + 1;
+    steps[i] = n;
+    reward[i] = nx * nx + nth * nth;
+    terminated[i] = fabs(nx) < p.x_threshold && fabs(nxd) < 0.1 && fabs(nth) < p.theta_threshold && fabs(nthd) < 0.1;
+    truncated[i] = n >= p.max_episode_steps;
+}
+
+__global__ void __launch_bounds__(256) env_cartpole_reset_kernel(int B, double *state, int64_t *steps, const uint8_t *mask, const double *u01, double *obs) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    if (!mask || mask[i]) {
+        reinterpret_cast<double2 *>(state)[2 * i] = make_double2(0.0, 0.0);
+        reinterpret_cast<double2 *>(state)[2 * i + 1] = make_double2((0.9 + 0.2 * u01[i]) * 3.141592653589793, 0.0);
+        steps[i] = 0;
+    }
+    if (obs) {
+        reinterpret_cast<double2 *>(obs)[2 * i] = reinterpret_cast<const double2 *>(state)[2 * i];
+        reinterpret_cast<double2 *>(obs)[2 * i + 1] = reinterpret_cast<const double2 *>(state)[2 * i + 1];
+    }
+}
+
+}  // namespace mpcrl

@@ -16,6 +16,7 @@
 #include "reduce_kernel.hpp"
 #include "order_kernel.hpp"
 #include "iterate_kernel.hpp"
+#include "env_kernel.hpp"
 
 using namespace mpcrl;
 
@@ -438,6 +439,27 @@ int mpcrl_weighted_grad_sum(const double *grad, int64_t ld, const double *weight
         const int ysplit = std::max(1, std::min(64, rows / 64));
         hipLaunchKernelGGL(grad_reduce_cols_kernel, dim3((n + 255) / 256, ysplit), dim3(256), 0, st, grad, (long)ld, weight, rows, n, out);
     }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int mpcrl_env_cartpole_step(const double *par, int B, double *state, int64_t *steps, const double *action, double *obs, double *reward,
+                            uint8_t *terminated, uint8_t *truncated, void *stream) {
+    if (!par || B < 0 || !state || !steps || !action || !reward || !terminated || !truncated) return MPCRL_E_ARG;
+    if (B == 0) return 0;
+    CartpoleEnvPar p;
+    p.gravity = par[0], p.masscart = par[1], p.masspole = par[2], p.length = par[3], p.force_mag = par[4], p.tau = par[5];
+    p.x_threshold = par[6], p.theta_threshold = par[7], p.max_episode_steps = (long)par[8];
+    hipLaunchKernelGGL(env_cartpole_step_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, B, state, steps, action, obs, reward,
+                       terminated, truncated);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int mpcrl_env_cartpole_reset(int B, double *state, int64_t *steps, const uint8_t *mask, const double *u01, double *obs, void *stream) {
+    if (B < 0 || !state || !steps || !u01) return MPCRL_E_ARG;
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(env_cartpole_reset_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, state, steps, mask, u01, obs);
     HIP_OK(hipGetLastError());
     return 0;
 }

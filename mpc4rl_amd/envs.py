@@ -33,6 +33,7 @@ class BatchedCartPoleSwingUpEnv:
         self.gen = torch.Generator(device=self.device).manual_seed(seed)
         self.state = torch.zeros(num_envs, 4, dtype=dtype, device=self.device)
         self.steps = torch.zeros(num_envs, dtype=torch.int64, device=self.device)
+        self._par_c = None
 
     def _sample(self, n: int) -> torch.Tensor:
         s = torch.zeros(n, 4, dtype=self.dtype, device=self.device)
@@ -50,12 +51,61 @@ class BatchedCartPoleSwingUpEnv:
                 self.steps[mask] = 0
         return self.state.clone()
 
+    # ---- device path: one launch per call through the C ABI (mpcrl_env_cartpole_step / _reset, csrc/env_kernel.hpp) ----
+    def _native(self) -> bool:
+        return self.device.type == "cuda" and self.dtype == torch.float64
+
+    def _par(self):
+        if self._par_c is None:
+            import ctypes
+            self._par_c = (ctypes.c_double * 9)(self.gravity, self.masscart, self.masspole, self.length, self.force_mag, self.tau,
+                                                self.x_threshold, self.theta_threshold, float(self.max_episode_steps))
+        return self._par_c
+
+    def reset_where(self, mask: torch.Tensor) -> torch.Tensor:
+        """reset(mask) without a host synchronisation (no count of the ended environments is read back): B uniform numbers are
+        drawn and the masked environments take theirs.  Returns the observation of every environment after the reset."""
+        u01 = torch.rand(self.num_envs, generator=self.gen, dtype=torch.float64, device=self.device)
+        mask = mask.to(self.device)
+        if self._native():
+            from . import _lib
+            from .batch import _ptr
+            m8 = mask.to(torch.uint8).contiguous()
+            self.state = self.state.contiguous()
+            obs = torch.empty_like(self.state)
+            with torch.cuda.device(self.device):
+                rc = _lib.load().mpcrl_env_cartpole_reset(self.num_envs, _ptr(self.state), _ptr(self.steps), _ptr(m8), _ptr(u01), _ptr(obs),
+                                                          torch.cuda.current_stream(self.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"mpcrl_env_cartpole_reset failed with code {rc}")
+            return obs
+        fresh = torch.zeros_like(self.state)
+        fresh[:, 2] = ((0.9 + 0.2 * u01) * math.pi).to(self.dtype)
+        self.state = torch.where(mask[:, None], fresh, self.state)
+        self.steps = torch.where(mask, torch.zeros_like(self.steps), self.steps)
+        return self.state.clone()
+
     def is_terminal(self, s: torch.Tensor) -> torch.Tensor:
         return (s[:, 0].abs() < self.x_threshold) & (s[:, 1].abs() < 0.1) & (s[:, 2].abs() < self.theta_threshold) & (s[:, 3].abs() < 0.1)
 
     def step(self, action: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
         """action: [B, 1] in [-1, 1] (what CartpoleMPC.get_action returns).  Returns obs, reward, terminated, truncated."""
         a = action.to(self.dtype).reshape(self.num_envs)
+        if self._native():
+            from . import _lib
+            from .batch import _ptr
+            a = a.to(self.device).contiguous()
+            self.state = self.state.contiguous()
+            obs, reward = torch.empty_like(self.state), torch.empty(self.num_envs, dtype=torch.float64, device=self.device)
+            flags = torch.empty((2, self.num_envs), dtype=torch.uint8, device=self.device)
+            with torch.cuda.device(self.device):
+                rc = _lib.load().mpcrl_env_cartpole_step(self._par(), self.num_envs, _ptr(self.state), _ptr(self.steps), _ptr(a), _ptr(obs),
+                                                         _ptr(reward), _ptr(flags[0]), _ptr(flags[1]),
+                                                         torch.cuda.current_stream(self.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"mpcrl_env_cartpole_step failed with code {rc}")
+            fb = flags.view(torch.bool)
+            return obs, reward, fb[0], fb[1]
         x, x_dot, th, th_dot = self.state.unbind(1)
         force = a * self.force_mag
         c, s = torch.cos(th), torch.sin(th)

@@ -149,7 +149,8 @@ class BatchedTD3:
         self.critic = ContinuousCritic(ocp.nx, ocp.nu, net_arch).to(dev)
         self.critic_target = ContinuousCritic(ocp.nx, ocp.nu, net_arch).to(dev)
         self.critic_target.load_state_dict(self.critic.state_dict())
-        self.critic_opt = torch.optim.Adam(self.critic.parameters(), lr=lr_critic)
+        # fused / multi-tensor updates: the critic is 12 small tensors, one launch per tensor and operation is pure launch overhead
+        self.critic_opt = torch.optim.Adam(self.critic.parameters(), lr=lr_critic, **({"fused": True} if dev.type == "cuda" else {}))
         self.buffer = DeviceReplayBuffer(buffer_steps, self.E, ocp.nx, ocp.nu, dev)
         self.gamma, self.tau, self.policy_delay = gamma, tau, policy_delay
         self.action_noise, self.target_noise, self.noise_clip = action_noise, target_noise, noise_clip
@@ -178,9 +179,14 @@ class BatchedTD3:
             rew_sum += rew.sum()
             conv += (r.status == 0).sum()
             ended_total += done.sum()
-            any_done = bool(done.any())      # the one host synchronisation of a step (an episode end changes the control flow)
-            self.obs = self.env.reset(done.to(self.env.device)).to(self.device) if any_done else nxt
-            self._ended = done if any_done else None
+            if hasattr(self.env, "reset_where"):
+                # no host synchronisation in a step: the masked reset and the per-instance cold mask run every step (empty masks are no-ops)
+                self.obs = self.env.reset_where(done.to(self.env.device)).to(self.device)
+                self._ended = done
+            else:
+                any_done = bool(done.any())      # an episode end changes the control flow: one host synchronisation per step
+                self.obs = self.env.reset(done.to(self.env.device)).to(self.device) if any_done else nxt
+                self._ended = done if any_done else None
         n = n_steps * self.E
         return {"mean_reward": float(rew_sum.item()) / n, "converged_fraction": float(conv.item()) / n, "episodes_ended": int(ended_total.item())}
 
@@ -224,10 +230,12 @@ class BatchedTD3:
                 flat[self.n_crit: self.n_crit + n_theta] = g.sum(0)
                 flat[-1] = okp.sum()
             flat = self._allreduce(flat)
-            off = 0
-            for p in self.critic.parameters():
-                p.grad.copy_(flat[off: off + p.numel()].reshape(p.shape).to(p.dtype))
+            params = list(self.critic.parameters())
+            g32, off, views = flat[: self.n_crit].to(params[0].dtype), 0, []
+            for p in params:
+                views.append(g32[off: off + p.numel()].view(p.shape))
                 off += p.numel()
+            torch._foreach_copy_([p.grad for p in params], views)
             self.critic_opt.step()
             if do_policy:
                 step = self.lr_actor * self.learn_mask * flat[self.n_crit: self.n_crit + n_theta] / flat[-1].clamp(min=1.0)
@@ -237,7 +245,8 @@ class BatchedTD3:
                     m.theta = th
                     m.mpc.set_theta(th)
                 with torch.no_grad():
-                    for p, pt in zip(self.critic.parameters(), self.critic_target.parameters()):
-                        pt.mul_(1.0 - self.tau).add_(self.tau * p)
+                    pts = list(self.critic_target.parameters())
+                    torch._foreach_mul_(pts, 1.0 - self.tau)
+                    torch._foreach_add_(pts, params, alpha=self.tau)
         return {"critic_loss": float(loss.item()) if loss is not None else 0.0,
                 "theta_step_norm": float(step.norm().item()) if step is not None else 0.0}

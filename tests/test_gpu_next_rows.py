@@ -173,6 +173,23 @@ def test_device_envs_vs_reference_formulas():
         assert np.allclose(rew.cpu().numpy(), s[:, 0] ** 2 + s[:, 2] ** 2, rtol=1e-12)
         t_ref = (np.abs(s[:, 0]) < 0.1) & (np.abs(s[:, 1]) < 0.1) & (np.abs(s[:, 2]) < math.radians(2.0)) & (np.abs(s[:, 3]) < 0.1)
         assert np.array_equal(term.cpu().numpy(), t_ref) and not bool(trunc.any())
+    # the device path is the library's K4 kernels (mpcrl_env_cartpole_step / _reset), not torch ops
+    assert env._native()
+    # truncation by step count, and the masked reset without a host synchronisation
+    short = BatchedCartPoleSwingUpEnv(B, device="cuda", seed=5, max_episode_steps=2)
+    short.reset()
+    z = torch.zeros(B, 1, device="cuda", dtype=torch.float64)
+    _, _, _, tr1 = short.step(z)
+    _, _, _, tr2 = short.step(z)
+    assert not bool(tr1.any()) and bool(tr2.all()) and tr2.dtype == torch.bool
+    mask = torch.zeros(B, dtype=torch.bool, device="cuda")
+    mask[::3] = True
+    before, steps_before = short.state.clone(), short.steps.clone()
+    o = short.reset_where(mask)
+    assert torch.equal(o, short.state) and torch.equal(o[~mask], before[~mask]) and torch.equal(short.steps[~mask], steps_before[~mask])
+    om = o[mask].cpu().numpy()
+    assert np.all(om[:, [0, 1, 3]] == 0.0) and om[:, 2].min() >= 0.9 * math.pi and om[:, 2].max() < 1.1 * math.pi and len(np.unique(om[:, 2])) > 1000
+    assert bool((short.steps[mask] == 0).all())
     lin = BatchedLinearSystemEnv(B, device="cuda", lb_noise=-0.1, ub_noise=0.0, seed=1)
     o = lin.reset()
     assert bool((o == torch.tensor([0.5, 0.5], device="cuda", dtype=o.dtype)).all())

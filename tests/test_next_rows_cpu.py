@@ -37,6 +37,14 @@ def test_batched_cartpole_env_matches_reference_step_formulas():
     before = env.state.clone()
     env.reset(mask)
     assert torch.equal(env.state[:3], before[:3]) and env.state[3, 0] == 0.0
+    # reset_where: the same masked reset without reading the number of ended environments back
+    env.steps[:] = 7
+    mask[5] = True
+    before = env.state.clone()
+    o = env.reset_where(mask)
+    keep = ~mask
+    assert torch.equal(o, env.state) and torch.equal(o[keep], before[keep]) and bool((env.steps[keep] == 7).all()) and bool((env.steps[mask] == 0).all())
+    assert bool((o[mask][:, [0, 1, 3]] == 0).all()) and bool((o[mask][:, 2] >= 0.9 * np.pi).all()) and bool((o[mask][:, 2] < 1.1 * np.pi).all())
 
 
 def test_batched_linear_env_matches_reference():
