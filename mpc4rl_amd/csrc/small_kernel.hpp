@@ -1864,9 +1864,10 @@ __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, cons
     for (int i = 0; i < NX; ++i) S.p[i] = 0.0;
     const int status = a.status[inst];
     const bool sv = valid && (status == 0 || status == 2);
+    S.sensitivities(a.flags, sv, nun, a.dV ? a.dV + inst * NP : nullptr, a.dpi ? a.dpi + inst * NU * NP : nullptr);
     // The output rows are written in full by this launch (no memset in front of it): the lanes of an instance zero every entry
-    // sensitivities() below does not store — the cost block of p (zero gradient of the mirror, nlp.py:1039-1055), everything of
-    // an instance that was not solved, du0*/dp in Q-mode.  The two sets of addresses are disjoint.
+    // sensitivities() above does not store — the cost block of p (zero gradient of the mirror, nlp.py:1039-1055), everything of
+    // an instance that was not solved, du0*/dp in Q-mode.  The two sets of addresses are disjoint; the zeros go last so that no load of the pass waits behind these stores.
     if (valid) {
         if (a.dV)
             for (int e = k; e < NP; e += lpi)
@@ -1875,7 +1876,6 @@ __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, cons
             for (int e = k; e < NU * NP; e += lpi)
                 if (!(sv && !S.qmode && M::p_has_gradient(e % NP))) a.dpi[inst * NU * NP + e] = 0.0;
     }
-    S.sensitivities(a.flags, sv, nun, a.dV ? a.dV + inst * NP : nullptr, a.dpi ? a.dpi + inst * NU * NP : nullptr);
 }
 
 }  // namespace mpcrl
