@@ -214,26 +214,35 @@ struct SmallSolver {
     }
 
     // ---- linearise the dynamics leaving this stage and the stage cost; returns c_k * l_k ---------
-    MPCRL_DI double linearize(const double *xnext) {
+    // WITH_H (sensitivity pass): the same evaluation with the full second-order jet, so that the exact-Hessian term
+    // sum_m nu_{k+1,m} hess F_m along the non-trivial coordinates (hdd, packed lower triangle) comes out of the evaluation that
+    // yields A, B — the pass used to run the map once with Jet1 for [B A] and once more with JetH for the Hessian.
+    template <bool WITH_H = false>
+    MPCRL_DI double linearize(const double *xnext, const double *nu_next = nullptr, double *hdd = nullptr) {
         mx_dyn_dirty = true;
         {
             // The terminal lane has no dynamics (A = B = 0, r = 0).  It runs the same code and the results are SELECTED: with an
             // if/else the optimiser sinks the two branches' stores into one block through pointer phis, which keeps part of A, B,
             // r in scratch memory for the whole kernel (a global-memory round trip at every use).
             constexpr int ND = M::NLD;   // jet directions: the coordinates of v = [u; x] whose columns are not known in closed form
-            Jet1<ND> jx[NX], ju[NU], jt[NTD], jn[NX];
+            using J = std::conditional_t<WITH_H, JetH<ND>, Jet1<ND>>;
+            J jx[NX], ju[NU], jt[NTD], jn[NX];
 #pragma unroll
-            for (int i = 0; i < NU; ++i) ju[i] = Jet1<ND>(u[i]);
+            for (int i = 0; i < NU; ++i) ju[i] = J(u[i]);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) jx[i] = Jet1<ND>(x[i]);
+            for (int i = 0; i < NX; ++i) jx[i] = J(x[i]);
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 const int c = M::lin_coord(d);
-                if (c < NU) ju[c < NU ? c : 0].d[d] = 1.0; else jx[c >= NU ? c - NU : 0].d[d] = 1.0;
+                if constexpr (WITH_H) {
+                    if (c < NU) ju[c < NU ? c : 0].g[d] = 1.0; else jx[c >= NU ? c - NU : 0].g[d] = 1.0;
+                } else {
+                    if (c < NU) ju[c < NU ? c : 0].d[d] = 1.0; else jx[c >= NU ? c - NU : 0].d[d] = 1.0;
+                }
             }
 #pragma unroll
-            for (int i = 0; i < NTD; ++i) jt[i] = Jet1<ND>(thd[i]);
-            disc_map<M, Jet1<ND>>(jx, ju, jt, jn, sp.h, sp.rk_steps);
+            for (int i = 0; i < NTD; ++i) jt[i] = J(thd[i]);
+            disc_map<M, J>(jx, ju, jt, jn, sp.h, sp.rk_steps);
             M::lin_trivial(sp.h * sp.rk_steps, [&](int i, int j, double v) { Aset(i * NX + j, term ? 0.0 : v); });
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
@@ -241,10 +250,21 @@ struct SmallSolver {
 #pragma unroll
                 for (int d = 0; d < ND; ++d) {
                     const int c = M::lin_coord(d);
+                    double der;
+                    if constexpr (WITH_H) der = jn[i].g[d]; else der = jn[i].d[d];
                     if (c < NU)
-                        Bset(i * NU + (c < NU ? c : 0), term ? 0.0 : jn[i].d[d]);
+                        Bset(i * NU + (c < NU ? c : 0), term ? 0.0 : der);
                     else
-                        Aset(i * NX + (c >= NU ? c - NU : 0), term ? 0.0 : jn[i].d[d]);
+                        Aset(i * NX + (c >= NU ? c - NU : 0), term ? 0.0 : der);
+                }
+            }
+            if constexpr (WITH_H) {
+#pragma unroll
+                for (int e = 0; e < ND * (ND + 1) / 2; ++e) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int m = 0; m < NX; ++m) acc = fma(nu_next[m], jn[m].h[e], acc);
+                    hdd[e] = term ? 0.0 : acc;
                 }
             }
         }
@@ -1046,7 +1066,8 @@ struct SmallSolver {
 
     // ---- sensitivities: dV/dp = dL/dp (nlp.py:1211,1401) and du0*/dp (nlp.py:1413-1424) by an adjoint solve --
     // nun: multiplier nu_{k+1} of the dynamics leaving this stage.  dVa / dpia: per-instance output rows.
-    MPCRL_DI void sensitivities(int flags, bool valid, const double *nun, double *dVa, double *dpia) {
+    // hdd: sum_m nu_{k+1,m} hess F_m along the non-trivial coordinates, from linearize<true>() (only read when du0*/dp is wanted)
+    MPCRL_DI void sensitivities(int flags, bool valid, const double *nun, double *dVa, double *dpia, const double *hdd) {
         double Fth[NX * NTD];
         if (!term) {
             Jet1<NTD> jx[NX], ju[NU], jt[NTD], jn[NX];
@@ -1091,33 +1112,14 @@ struct SmallSolver {
         for (int i = 0; i < NW; ++i)
 #pragma unroll
             for (int j = 0; j <= i; ++j) Hx[sym(i, j)] = ck * hess_of_stage(i, j);
-        if (!term) {
-            // second derivatives of F vanish along the coordinates whose Jacobian columns are constant (M::lin_coord lists the others):
-            // ONE evaluation of the map with the full second-order jet along the remaining directions (until the end of round 2:
-            // one Jet2 evaluation per direction, i.e. every sin / cos / reciprocal of the RK4 map ND times)
+        {
+            // second derivatives of F vanish along the coordinates whose Jacobian columns are constant (M::lin_coord lists the others);
+            // the rest came out of the linearisation's own evaluation of the map (linearize<true>; zero on the terminal lane)
             constexpr int ND = M::NLD;
-            JetH<ND> jx[NX], ju[NU], jt[NTD], jn[NX];
-#pragma unroll
-            for (int i = 0; i < NU; ++i) ju[i] = JetH<ND>(u[i]);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) jx[i] = JetH<ND>(x[i]);
-#pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                const int c = M::lin_coord(d);
-                if (c < NU) ju[c < NU ? c : 0].g[d] = 1.0; else jx[c >= NU ? c - NU : 0].g[d] = 1.0;
-            }
-#pragma unroll
-            for (int i = 0; i < NTD; ++i) jt[i] = JetH<ND>(thd[i]);
-            disc_map<M, JetH<ND>>(jx, ju, jt, jn, sp.h, sp.rk_steps);
 #pragma unroll
             for (int di = 0; di < ND; ++di)
 #pragma unroll
-                for (int dj = 0; dj <= di; ++dj) {
-                    double a = 0.0;
-#pragma unroll
-                    for (int m = 0; m < NX; ++m) a = fma(nun[m], jn[m].h[di * (di + 1) / 2 + dj], a);
-                    Hx[sym(M::lin_coord(di), M::lin_coord(dj))] += a;
-                }
+                for (int dj = 0; dj <= di; ++dj) Hx[sym(M::lin_coord(di), M::lin_coord(dj))] += hdd[di * (di + 1) / 2 + dj];
         }
         // barrier diagonal from the final (lam, t) of the BOUND rows; slacks are constants of the mirror (quirk q1)
 #pragma unroll
@@ -1857,14 +1859,21 @@ __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, cons
     double xn[NX], nun[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) xn[i] = lane_dn(S.x[i]), nun[i] = lane_dn(S.nu_[i]);
-    S.linearize(xn);
+    double hdd[M::NLD * (M::NLD + 1) / 2];
+    if ((a.flags & 2) && a.dpi && !S.qmode) {   // wave-uniform
+        S.template linearize<true>(xn, nun, hdd);
+    } else {
+#pragma unroll
+        for (int e = 0; e < M::NLD * (M::NLD + 1) / 2; ++e) hdd[e] = 0.0;
+        S.linearize(xn);
+    }
 #pragma unroll
     for (int i = 0; i < S.NPK; ++i) S.P[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < NX; ++i) S.p[i] = 0.0;
     const int status = a.status[inst];
     const bool sv = valid && (status == 0 || status == 2);
-    S.sensitivities(a.flags, sv, nun, a.dV ? a.dV + inst * NP : nullptr, a.dpi ? a.dpi + inst * NU * NP : nullptr);
+    S.sensitivities(a.flags, sv, nun, a.dV ? a.dV + inst * NP : nullptr, a.dpi ? a.dpi + inst * NU * NP : nullptr, hdd);
     // The output rows are written in full by this launch (no memset in front of it): the lanes of an instance zero every entry
     // sensitivities() above does not store — the cost block of p (zero gradient of the mirror, nlp.py:1039-1055), everything of
     // an instance that was not solved, du0*/dp in Q-mode.  The two sets of addresses are disjoint; the zeros go last so that no load of the pass waits behind these stores.
