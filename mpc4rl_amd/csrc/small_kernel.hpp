@@ -1068,8 +1068,11 @@ struct SmallSolver {
     // nun: multiplier nu_{k+1} of the dynamics leaving this stage.  dVa / dpia: per-instance output rows.
     // hdd: sum_m nu_{k+1,m} hess F_m along the non-trivial coordinates, from linearize<true>() (only read when du0*/dp is wanted)
     MPCRL_DI void sensitivities(int flags, bool valid, const double *nun, double *dVa, double *dpia, const double *hdd) {
+        // dF/dtheta of the stage: from a first-order evaluation of the map when only dV/dp is wanted; with du0*/dp it is the
+        // first-order part of the mixed second-order evaluation below (one evaluation of the map less)
+        const bool want_pi = (flags & 2) && dpia && !qmode;   // wave-uniform.  Q-mode: u_0 is pinned (mpc.py:71-76), du0/dp = 0
         double Fth[NX * NTD];
-        if (!term) {
+        if (!term && !want_pi) {
             Jet1<NTD> jx[NX], ju[NU], jt[NTD], jn[NX];
 #pragma unroll
             for (int i = 0; i < NU; ++i) ju[i] = Jet1<NTD>(u[i]);
@@ -1086,7 +1089,8 @@ struct SmallSolver {
 #pragma unroll
             for (int i = 0; i < NX * NTD; ++i) Fth[i] = 0.0;
         }
-        if ((flags & 1) && dVa) {
+        auto emit_dV = [&]() {
+            if (!((flags & 1) && dVa)) return;
             double cpart[NTC > 0 ? NTC : 1];
 #pragma unroll
             for (int i = 0; i < (NTC > 0 ? NTC : 1); ++i) cpart[i] = 0.0;
@@ -1104,8 +1108,11 @@ struct SmallSolver {
                 const double a = seg_sum<M::SEG_SKIP>(cpart[d], k, lpi, base);
                 if (first && valid) dVa[M::tc_index(d)] = a;
             }
+        };
+        if (!want_pi) {
+            emit_dV();
+            return;
         }
-        if (!((flags & 2) && dpia) || qmode) return;   // Q-mode: u_0 is pinned (mpc.py:71-76), du0/dp = 0
         // exact Lagrangian Hessian of the stage (nlp.py:1202,1224): c hess l + sum_m nu_{k+1,m} hess F_m
         double Hx[NW * (NW + 1) / 2];
 #pragma unroll
@@ -1170,6 +1177,12 @@ struct SmallSolver {
 #pragma unroll
                 for (int i = 0; i < NTD; ++i) jt[i] = Jet2<NTD>(thd[i]), jt[i].g[i] = 1.0;
                 disc_map<M, Jet2<NTD>>(jx, ju, jt, jn, sp.h, sp.rk_steps);
+                if (iu == 0) {
+#pragma unroll
+                    for (int m = 0; m < NX; ++m)
+#pragma unroll
+                        for (int d = 0; d < NTD; ++d) Fth[m * NTD + d] = jn[m].g[d];
+                }
 #pragma unroll
                 for (int d = 0; d < NTD; ++d) {
                     double a = 0.0;
@@ -1178,6 +1191,7 @@ struct SmallSolver {
                     outd[d] = a;
                 }
             }
+            if (iu == 0) emit_dV();
 #pragma unroll
             for (int d = 0; d < NTD; ++d) {
                 const double a = seg_sum<M::SEG_SKIP>(outd[d], k, lpi, base);
