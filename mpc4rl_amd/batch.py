@@ -123,6 +123,9 @@ class MPCBatch:
         neighbours should be similar problems.  Order the batch along the coordinate of x0 with the largest spread."""
         if self.B < 128:
             return
+        if 64 // (self.N + 1) < 2:   # one instance per wavefront (the library also skips the chain at any horizon): no lock step to pack for
+            self._check(self.lib.mpcrl_set_order(self._h, None, self._stream()), "mpcrl_set_order")
+            return
         if self.B <= 8192:   # one small kernel inside the library (csrc/order_kernel.hpp)
             self._check(self.lib.mpcrl_auto_order(self._h, _ptr(x0), self._stream()), "mpcrl_auto_order")
             return

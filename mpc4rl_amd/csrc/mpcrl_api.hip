@@ -352,6 +352,10 @@ int mpcrl_query_time_sliced(mpcrl_handle h, int flags) {
 int mpcrl_auto_order(mpcrl_handle h, const double *x0, void *stream) {
     if (!h || !x0) return MPCRL_E_ARG;
     if (h->B > ORDER_MAX) return MPCRL_E_ARG;   // larger batches: build the permutation outside and pass it to mpcrl_set_order
+    if (h->is_large || 64 / (h->N + 1) < 2) {   // one instance per wavefront (chain; N + 1 > 32 stages): nothing shares a lock step
+        h->have_perm = false;
+        return 0;
+    }
     ON_DEVICE(h->device);
     hipLaunchKernelGGL(order_kernel, dim3(1), dim3(ORDER_NT), 0, (hipStream_t)stream, x0, h->B, h->nx, h->perm);
     HIP_OK(hipGetLastError());
