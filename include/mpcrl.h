@@ -104,7 +104,8 @@ int mpcrl_set_options(mpcrl_handle h, double tol, int max_iter);
  * instance perm[i], so that instances expected to need similar iteration counts share a wavefront. NULL = identity. */
 int mpcrl_set_order(mpcrl_handle h, const int32_t *perm, void *stream);
 /* Builds that permutation on the device from the initial states themselves (x0: [B, nx] device): the batch ordered along the
- * coordinate of x0 with the largest spread.  One small kernel; batch <= 8192, else MPCRL_E_ARG (use mpcrl_set_order). */
+ * coordinate of x0 with the largest spread.  One small kernel; batch <= 8192, else MPCRL_E_ARG (use mpcrl_set_order).  A no-op that
+ * clears the order where every instance has a wavefront to itself (chain of masses; horizons of more than 31 stages). */
 int mpcrl_auto_order(mpcrl_handle h, const double *x0, void *stream);
 /* 1 if an mpcrl_solve with these flags would use the time-sliced launch (whose wavefronts take one instance from each quarter of the
  * batch: a packing order buys nothing there and the caller can skip building one), 0 if not, < 0 on misuse. */
