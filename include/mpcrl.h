@@ -169,6 +169,12 @@ int mpcrl_weighted_grad_sum(const double *grad, int64_t ld, const double *weight
 int mpcrl_env_cartpole_step(const double *par, int B, double *state, int64_t *steps, const double *action, double *obs, double *reward,
                             uint8_t *terminated, uint8_t *truncated, void *stream);
 int mpcrl_env_cartpole_reset(int B, double *state, int64_t *steps, const uint8_t *mask, const double *u01, double *obs, void *stream);
+/* The linear-system environment (rlmpc/gym/linear_system/environment.py:28-58), B environments in one launch:
+ *   par [12] HOST: A (row-major 2x2), B (2), lb_noise, ub_noise, min_observation (2), max_observation (2)
+ *   state [B, 2] (device, updated in place): s+ = A s + B a + [lb_noise + (ub_noise - lb_noise) u01, 0]; action [B]; u01 [B] uniform
+ *   numbers of the caller; obs [B, 2] (may be NULL) = new state; cost [B] = 1/2 s's + 1/2 a'a + 100 per violated side of the box. */
+int mpcrl_env_linear_step(const double *par, int B, double *state, const double *action, const double *u01, double *obs, double *cost,
+                          void *stream);
 
 /* Bytes of device memory held by the handle; library version. */
 int64_t mpcrl_workspace_bytes(mpcrl_handle h);

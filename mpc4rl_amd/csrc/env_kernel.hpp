@@ -54,4 +54,27 @@ __global__ void __launch_bounds__(256) env_cartpole_reset_kernel(int B, double *
     }
 }
 
+// Linear-system environment (rlmpc/gym/linear_system/environment.py:28-58): s+ = A s + B a + [lb + (ub - lb) u01, 0], cost of the NEW
+// state = 1/2 s's + 1/2 a'a + 100 per violated side of the observation box.  par: A (row-major 2x2), B (2), lb_noise, ub_noise,
+// low (2), high (2).
+struct LinearEnvPar {
+    double A[4], B[2], lb_noise, ub_noise, low[2], high[2];
+};
+
+__global__ void __launch_bounds__(256) env_linear_step_kernel(const LinearEnvPar p, int B, double *state, const double *action, const double *u01,
+                                                              double *obs, double *cost) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const double2 s = reinterpret_cast<const double2 *>(state)[i];
+    const double a = action[i];
+    const double n0 = p.lb_noise + (p.ub_noise - p.lb_noise) * u01[i];
+    const double s0 = (s.x * p.A[0] + s.y * p.A[1]) + a * p.B[0] + n0;
+    const double s1 = (s.x * p.A[2] + s.y * p.A[3]) + a * p.B[1];
+    reinterpret_cast<double2 *>(state)[i] = make_double2(s0, s1);
+    if (obs) reinterpret_cast<double2 *>(obs)[i] = make_double2(s0, s1);
+    const double lower = (p.low[0] - s0 > 0.0 || p.low[1] - s1 > 0.0) ? 1e2 : 0.0;
+    const double upper = (s0 - p.high[0] > 0.0 || s1 - p.high[1] > 0.0) ? 1e2 : 0.0;
+    cost[i] = 0.5 * (s0 * s0 + s1 * s1) + 0.5 * (a * a) + lower + upper;
+}
+
 }  // namespace mpcrl

@@ -460,6 +460,19 @@ int mpcrl_env_cartpole_step(const double *par, int B, double *state, int64_t *st
     return 0;
 }
 
+int mpcrl_env_linear_step(const double *par, int B, double *state, const double *action, const double *u01, double *obs, double *cost,
+                          void *stream) {
+    if (!par || B < 0 || !state || !action || !u01 || !cost) return MPCRL_E_ARG;
+    if (B == 0) return 0;
+    LinearEnvPar p;
+    for (int i = 0; i < 4; ++i) p.A[i] = par[i];
+    p.B[0] = par[4], p.B[1] = par[5], p.lb_noise = par[6], p.ub_noise = par[7];
+    p.low[0] = par[8], p.low[1] = par[9], p.high[0] = par[10], p.high[1] = par[11];
+    hipLaunchKernelGGL(env_linear_step_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, B, state, action, u01, obs, cost);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int mpcrl_env_cartpole_reset(int B, double *state, int64_t *steps, const uint8_t *mask, const double *u01, double *obs, void *stream) {
     if (B < 0 || !state || !steps || !u01) return MPCRL_E_ARG;
     if (B == 0) return 0;

@@ -131,6 +131,7 @@ class BatchedLinearSystemEnv:
         self.low, self.high = torch.tensor(min_observation, **kw), torch.tensor(max_observation, **kw)
         self.gen = torch.Generator(device=self.device).manual_seed(seed)
         self.state = torch.zeros(num_envs, 2, **kw)
+        self._par_c = None
 
     def reset(self) -> torch.Tensor:
         self.state = torch.tensor([0.5, 0.5], dtype=self.dtype, device=self.device).repeat(self.num_envs, 1)   # environment.py:46
@@ -143,6 +144,24 @@ class BatchedLinearSystemEnv:
 
     def step(self, action: torch.Tensor):
         a = action.to(self.dtype).reshape(self.num_envs, 1)
+        if self.device.type == "cuda" and self.dtype == torch.float64:   # one launch through the C ABI (csrc/env_kernel.hpp)
+            import ctypes
+            from . import _lib
+            from .batch import _ptr
+            if self._par_c is None:
+                vals = self.A.reshape(-1).tolist() + self.B.reshape(-1).tolist() + [self.lb_noise, self.ub_noise] + self.low.tolist() + self.high.tolist()
+                self._par_c = (ctypes.c_double * 12)(*vals)
+            u01 = torch.rand(self.num_envs, generator=self.gen, dtype=self.dtype, device=self.device)
+            a = a.to(self.device).contiguous()
+            self.state = self.state.contiguous()
+            obs, cost = torch.empty_like(self.state), torch.empty(self.num_envs, dtype=self.dtype, device=self.device)
+            with torch.cuda.device(self.device):
+                rc = _lib.load().mpcrl_env_linear_step(self._par_c, self.num_envs, _ptr(self.state), _ptr(a), _ptr(u01), _ptr(obs), _ptr(cost),
+                                                       torch.cuda.current_stream(self.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"mpcrl_env_linear_step failed with code {rc}")
+            done = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+            return obs, cost, done, done.clone()
         noise = torch.zeros(self.num_envs, 2, dtype=self.dtype, device=self.device)
         noise[:, 0] = self.lb_noise + (self.ub_noise - self.lb_noise) * torch.rand(self.num_envs, generator=self.gen, dtype=self.dtype,
                                                                                       device=self.device)

@@ -190,7 +190,7 @@ def test_device_envs_vs_reference_formulas():
     om = o[mask].cpu().numpy()
     assert np.all(om[:, [0, 1, 3]] == 0.0) and om[:, 2].min() >= 0.9 * math.pi and om[:, 2].max() < 1.1 * math.pi and len(np.unique(om[:, 2])) > 1000
     assert bool((short.steps[mask] == 0).all())
-    lin = BatchedLinearSystemEnv(B, device="cuda", lb_noise=-0.1, ub_noise=0.0, seed=1)
+    lin = BatchedLinearSystemEnv(B, device="cuda", lb_noise=-0.1, ub_noise=0.0, seed=1)      # steps through mpcrl_env_linear_step
     o = lin.reset()
     assert bool((o == torch.tensor([0.5, 0.5], device="cuda", dtype=o.dtype)).all())
     A, Bm = np.array([[0.9, 0.35], [0.0, 1.1]]), np.array([[0.0813], [0.2]])
