@@ -44,21 +44,60 @@ def make_inputs(B, rank):
     return x0
 
 
-TRAFFIC_FILE = os.path.join("profiles", "r02_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_hbm_traffic.json")
+
+
+def csrc_hash():
+    """sha256 over the kernel sources (mpc4rl_amd/csrc/*, include/mpcrl.h), file names included, in sorted order: the counter
+    passes store it next to their figures so that a traffic figure is never reported for kernels it was not measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mpc4rl_amd", "csrc")
+    for f in sorted(os.listdir(d)) + [os.path.join("..", "..", "include", "mpcrl.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def measured_traffic(workload, B, sens, rti):
     """(HBM bytes per step, source) from the committed PMC passes: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3
-    --pmc runs of this very command (profiles/microbench/pmc.sh), summed over the kernels of one step and corrected as
+    --pmc runs of this very command (profiles/microbench/hbm_traffic.sh), summed over the kernels of one step and corrected as
     MI355X_MICROARCH.md prescribes.  A counter pass cannot run inside a timed bench run, so the figure is read from the file
-    that pass wrote; it is only valid for the default batch of each workload and is regenerated whenever the kernels change."""
+    that pass wrote; it is only valid for the default batch of each workload AND for the kernel sources it was collected on
+    (the file stores their hash: a mismatch returns None rather than a stale figure)."""
     try:
-        d = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))[workload]
+        doc = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
+        if doc.get("csrc_sha") != csrc_hash():
+            return None, None
+        d = doc[workload]
         if B != d["batch"] or not sens or rti:
             return None, None
         return float(d["traffic_bytes_per_step"]), TRAFFIC_FILE
     except Exception:
         return None, None
+
+
+def measured_hbm_peak(dev, nbytes=1 << 30, reps=5):
+    """the achievable HBM rate of THIS box from a device-to-device copy (read + write of 1 GiB, HIP events, best of
+    `reps` after a warm-up), reported beside the 8 TB/s spec as roofline.peak_measured.  GB/s."""
+    try:
+        src = torch.empty(nbytes // 8, dtype=torch.float64, device=dev).normal_()
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        torch.cuda.synchronize(dev)
+        best = None
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            dst.copy_(src)
+            b.record()
+            torch.cuda.synchronize(dev)
+            ms = a.elapsed_time(b)
+            best = ms if best is None else min(best, ms)
+        del src, dst
+        return 2.0 * nbytes / (best * 1e-3) / 1e9
+    except Exception:
+        return None
 
 
 def riccati_sweep_flops(N, nx, nu):
@@ -79,32 +118,48 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(x0_np, sens):
-    """The oracle's C++ port ("port") on this box's host cores, on a bounded sample of the same workload."""
+def cpu_baseline(P, x0_np, sens, label="", budget_s=12.0):
+    """The oracle's C++ port ("port"; acados cannot be built here: no sources, no network) on this box's host cores, on a bounded
+    sample of the same workload: SURVEY.md §8d — same inputs, tolerances and iteration caps, median of up to 10 runs after 2
+    warm-ups, all threads and one thread; the sample is sized from a probe so that the whole leg stays within ~budget_s seconds."""
     from oracle import cpu_port
-    from oracle.problems import make_cartpole
-    P = make_cartpole()
     cores = usable_cores()
     flags = (cpu_port.SENS_V | cpu_port.SENS_PI) if sens else 0
-    cpu_port.solve(P, x0_np[: 4 * cores], flags=flags, nthreads=cores)   # warm-up (page in, spawn threads)
-    # ~10-20 s of CPU work: the 4096 instances of the workload tiled so that every core gets >= 32 of them
-    tile = max(1, -(-64 * cores // len(x0_np)))
-    xs = np.tile(x0_np, (tile, 1))
-    n = len(xs)
-    reps, t_total, solved = 0, 0.0, 0
-    while t_total < 2.0 and reps < 6:
+    kw = dict(flags=flags, want_bnd=False)
+    def run(n, threads):
+        xs = np.tile(x0_np, (-(-n // len(x0_np)), 1))[:n]
         t0 = time.perf_counter()
-        r = cpu_port.solve(P, xs, flags=flags, nthreads=cores, want_bnd=False)
-        t_total += time.perf_counter() - t0
-        solved += n
-        reps += 1
-    t1 = time.perf_counter()
-    r1 = cpu_port.solve(P, x0_np[:256], flags=flags, nthreads=1, want_bnd=False)
-    one = 256 / (time.perf_counter() - t1)
-    return {"value": solved / t_total, "unit": "solves/s", "cores": cores, "kind": "port", "single_thread_value": one,
-            "sample": f"{reps} x {n} instances (the workload's 4096 tiled x{tile}; oracle/cpu C++ port, one workspace per thread, "
-                      f"OpenMP dynamic over instances; mean SQP iters {float(r.sqp_iter.mean()):.2f}, mean IPM iters "
-                      f"{float(r.ipm_iter.mean()):.1f}); single thread: 256 instances"}
+        r = cpu_port.solve(P, xs, nthreads=threads, **kw)
+        return time.perf_counter() - t0, r
+
+    # sample size: doubled from 4 instances per core until one run takes budget / 12 seconds (these runs are the warm-ups)
+    n, cap = 4 * cores, 4 * len(x0_np)
+    t, _ = run(n, cores)
+    t, _ = run(n, cores)
+    while t < budget_s / 24.0 and n < cap:
+        n = min(cap, 2 * n)
+        t, _ = run(n, cores)
+    tile = -(-n // len(x0_np))
+    times, t_total, r = [], 0.0, None
+    while len(times) < 10 and (t_total < 0.7 * budget_s or len(times) < 3):
+        t, r = run(n, cores)
+        times.append(t)
+        t_total += t
+    n1 = int(max(2, min(len(x0_np), 0.15 * budget_s * n / (float(np.median(times)) * cores))))
+    t1, _ = run(n1, 1)
+    one = n1 / t1
+    return {"value": n / float(np.median(times)), "unit": "solves/s", "cores": cores, "kind": "port", "single_thread_value": one,
+            "sample": f"median of {len(times)} runs x {n} instances after 2 warm-ups ({label}the workload's {len(x0_np)} instances"
+                      f"{' tiled' if tile > 1 else ''}; oracle/cpu C++ port, one workspace per thread, OpenMP dynamic over instances; "
+                      f"mean SQP iters {float(r.sqp_iter.mean()):.2f}, mean IPM iters {float(r.ipm_iter.mean()):.1f}); "
+                      f"single thread: {n1} instances"}
+
+
+def cpu_baseline_guarded(*a, **k):
+    try:
+        return cpu_baseline(*a, **k)
+    except Exception as e:   # the bench line must still come out
+        return {"value": None, "unit": "solves/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
 
 def spawn_command(args, argv, port):
@@ -150,6 +205,7 @@ def dryrun(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
         dist.barrier()
+    n_ranks = count_ranks(dist, torch.device("cpu"))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(1e-3 * (rank + 1))        # uneven ranks: the job time must be the slowest rank's
@@ -158,7 +214,8 @@ def dryrun(args):
     elapsed = job_aggregate(time.perf_counter() - t0, dist, torch.device("cpu"))
     if rank == 0:
         print(json.dumps({"metric": "dryrun", "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": 1e3 * elapsed / args.steps, "dryrun": True}), flush=True)
+                          "ms_per_step": 1e3 * elapsed / args.steps, "dryrun": True,
+                          **({"rccl_ranks": n_ranks} if n_ranks is not None else {})}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -199,18 +256,23 @@ def chain_bench(args):
     achieved = (b_alg + sweeps * b_sweep) * B / (kern_ms * 1e-3) / 1e9
     fp64 = sweeps * riccati_sweep_flops(N, nx, nu) * B / (kern_ms * 1e-3) / 1e12
     traffic, traffic_src = measured_traffic(args.workload, B, sens, False)
+    peak_meas = measured_hbm_peak(dev)
     out = {"metric": f"MPC+KKT-sens solves/sec, chain_mass n_mass={n_mass} N=40 batch={B}", "value": B * args.steps / elapsed,
            "unit": "solves/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"chain_mass n_mass={n_mass} nx={nx} nu={nu} N={N}, {B} instances, cold-start GN-SQP tol 1e-5"
-                                  + (" + dV/dp + du0*/dp (499-dim p)" if sens else ""),
+                                  + (f" + dV/dp + du0*/dp ({n_th}-dim p)" if sens else ""),
                       "converged_fraction": float((r.status == 0).float().mean().item()), "sqp_iters_mean": float(it[:, 0].mean()),
                       "ipm_iters_mean": float(it[:, 1].mean())},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "peak_measured": peak_meas, "frac_of_measured": (achieved / peak_meas) if peak_meas else None,
                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms,
                         "algorithmic_bytes_per_solve": b_alg + sweeps * b_sweep, "sweeps_per_solve": sweeps,
                         "fp64": {"achieved": fp64, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp64 / FP64_MFMA_PEAK_TFLOPS,
                                  "note": "SURVEY.md 8d: sweeps/s x F_sweep, sweeps = interior-point iterations + 1 + nu"}}}
+    if not args.no_cpu:
+        from oracle.problems import make_chain_mass
+        out["cpu_baseline"] = cpu_baseline_guarded(make_chain_mass(n_mass=n_mass), x0, sens, label=f"chain_mass n_mass={n_mass}: ")
     print(json.dumps(out), flush=True)
 
 
@@ -251,12 +313,22 @@ def init_ranks(args):
     return world, rank, local, dist, dev
 
 
+def count_ranks(dist_mod, dev):
+    """Number of ranks in the job's communicator as the collective itself reports it (all-reduce of ones), or None without one."""
+    if dist_mod is None:
+        return None
+    one = torch.ones(1, dtype=torch.float64, device=dev)
+    dist_mod.all_reduce(one)
+    return int(round(float(one.item())))
+
+
 def td3_bench(args):
     """BASELINE config 5: cartpole TD3 closed loop — 4096 batched environments per GPU, the MPC as the actor (one launch per
     environment step, warm-started, cold only where an episode ended), device replay, critic TD update with the target actor's
     batched solve, delayed deterministic policy gradient through du0*/dtheta, ONE all-reduce (critic gradients + theta-gradient)
     per update.  A step = one environment step of all environments + one TD3 update (batch 4096 per rank)."""
     world, rank, local, dist, dev = init_ranks(args)
+    rccl_ranks = count_ranks(dist, dev)
     from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedTD3, cartpole_ocp
     E = args.batch
     env = BatchedCartPoleSwingUpEnv(E, device=dev, seed=rank)
@@ -287,7 +359,8 @@ def td3_bench(args):
                                    f"+ {E} cold (target actor) + {E // 2} cold with du0*/dtheta (policy gradient)",
                        "parallelism": f"environments sharded over {world} GPU(s); one all-reduce of the critic + theta gradients per update",
                        "mpc_solves_per_s": solves / elapsed, "converged_fraction": st["converged_fraction"],
-                       "critic_loss": tr["critic_loss"]}}), flush=True)
+                       "critic_loss": tr["critic_loss"]},
+            **({"rccl_ranks": rccl_ranks} if rccl_ranks is not None else {})}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -317,6 +390,7 @@ def main():
     linear = args.workload == "linear"
 
     world, rank, local, dist, dev = init_ranks(args)
+    rccl_ranks = count_ranks(dist, dev)
 
     from mpc4rl_amd import MPCBatch, cartpole_ocp, linear_system_ocp
     from mpc4rl_amd.distributed import allreduce_weighted_grad
@@ -374,6 +448,7 @@ def main():
         sweeps = float(iters[:, 1].mean()) + (1 + ocp.nu if sens else 0)
         fp64_tflops = sweeps * riccati_sweep_flops(ocp.N, ocp.nx, ocp.nu) * B / (kern_ms * 1e-3) / 1e12
         traffic, traffic_src = measured_traffic(args.workload, B, sens, args.rti)
+        peak_meas = measured_hbm_peak(dev)
         name = "linear system N=40 nx=2 nu=1" if linear else "cartpole N=20 nx=4 nu=1"
         out = {
             "metric": ("MPC+KKT-sens solves/sec, %s batch=%d" if sens else "MPC solves/sec, %s batch=%d") % (
@@ -390,7 +465,9 @@ def main():
                 "sqp_iters_max": int(iters[:, 0].max()), "ipm_iters_mean": float(iters[:, 1].mean()),
                 "ipm_iters_max": int(iters[:, 1].max())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBS, "peak_measured": peak_meas,
+                         "frac_of_measured": (achieved / peak_meas) if peak_meas else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_solve": bytes_per, "sweeps_per_solve": sweeps,
                          "fp64": {"achieved": fp64_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": fp64_tflops / FP64_MFMA_PEAK_TFLOPS,
@@ -401,12 +478,11 @@ def main():
                                          "note": "hardware flops of the 7 v_mfma_f64_4x4x4 per factor-sweep stage step (padded 4x4x4 "
                                                  "products; vector sweeps excluded): the MFMAs of the recursion wait on each other"}},
         }
-        if world == 1 and not args.no_cpu and not linear:
-            try:
-                out["cpu_baseline"] = cpu_baseline(x0_np, sens)
-            except Exception as e:   # the bench line must still come out
-                out["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": os.cpu_count(), "kind": "port",
-                                       "sample": f"failed: {e}"}
+        if rccl_ranks is not None:
+            out["rccl_ranks"] = rccl_ranks   # an all-reduce of ones over the job's communicator: how many ranks RCCL really joined
+        if world == 1 and not args.no_cpu:
+            from oracle.problems import make_cartpole, make_linear_system
+            out["cpu_baseline"] = cpu_baseline_guarded(make_linear_system(gamma=0.99) if linear else make_cartpole(), x0_np, sens)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

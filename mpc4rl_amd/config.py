@@ -17,7 +17,7 @@ def read_config(config_file: str) -> dict:
 
 def cartpole_ocp_from_config(config: dict) -> OcpDescription:
     """``config`` = the ``mpc`` block of config/cartpole.yaml (or the whole file).  Keys used: ocp_options.{tf,
-    sim_method_num_stages, nlp_solver_max_iter}, dimensions.N, cost.{W, W_e, yref, yref_e}, model.params.{M,m,l}.value,
+    sim_method_num_stages, nlp_solver_max_iter}, dimensions.N, cost.{W_0, W, W_e, yref_0, yref, yref_e}, model.params.{M,m,l}.value,
     constraints.{lbu, ubu, lbx, ubx, lbx_e, ubx_e, x0}."""
     c = config.get("mpc", config)
     opt, dims, cost, cons = c["ocp_options"], c["dimensions"], c["cost"], c["constraints"]
@@ -26,15 +26,14 @@ def cartpole_ocp_from_config(config: dict) -> OcpDescription:
         raise ValueError("g is a compiled-in constant (9.8, fixed) of the cartpole model")
     ocp = cartpole_ocp(N=dims["N"], tf=opt["tf"], M=prm["M"]["value"], m=prm["m"]["value"], l=prm["l"]["value"],
                        W=np.array(cost["W"]), W_e=np.array(cost["W_e"]), yref=np.array(cost["yref"]),
-                       yref_e=np.array(cost["yref_e"]), max_iter=opt.get("nlp_solver_max_iter", 500))
+                       yref_e=np.array(cost["yref_e"]), W_0=np.array(cost["W_0"]) if "W_0" in cost else None,
+                       yref_0=np.array(cost["yref_0"]) if "yref_0" in cost else None, max_iter=opt.get("nlp_solver_max_iter", 500))
     stages = opt.get("sim_method_num_stages", 4)
     ocp.h = opt["tf"] / dims["N"] / stages                      # cartpole/acados.py:86-92
     ocp.lbu, ocp.ubu = np.array(cons["lbu"], float), np.array(cons["ubu"], float)
     ocp.idxbx, ocp.lbx, ocp.ubx = np.array(cons["idxbx"]), np.array(cons["lbx"], float), np.array(cons["ubx"], float)
     ocp.idxbx_e, ocp.lbx_e, ocp.ubx_e = np.array(cons["idxbx_e"]), np.array(cons["lbx_e"], float), np.array(cons["ubx_e"], float)
     ocp.x0 = np.array(cons["x0"], float)
-    if np.abs(np.array(cost["W_0"]) - np.array(cost["W"])).max() > 0 or np.abs(np.array(cost["yref_0"]) - np.array(cost["yref"])).max() > 0:
-        raise ValueError("W_0 / yref_0 different from W / yref are not supported by the cartpole kernel")
     return ocp
 
 

@@ -22,14 +22,15 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def allreduce_weighted_grad(grad: torch.Tensor, weight: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
-                            deterministic: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                            deterministic: bool = False, count: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """grad [b, n_theta] (e.g. dQ/dp rows), weight [b] (e.g. lr * td error) of the LOCAL shard.
 
     Returns (sum_i w_i g_i over ALL ranks [n_theta], sum_i w_i, total count) with a single all-reduce of
     n_theta + 2 doubles; all three are device tensors (no host synchronisation: the caller's next launches queue up
     behind the collective instead of waiting for it).  ``deterministic=True`` sums the local shard with a fixed-shape framework
     reduction (no atomics) and combines the ranks by all-gather + fixed-order summation, so the result is reproducible run to run
-    and independent of the collective's reduction tree."""
+    and independent of the collective's reduction tree.  ``count`` [b] (0/1): the count slot of the message carries
+    sum(count) instead of the number of rows — the denominator of a mean over the valid samples travels in the SAME message."""
     g = grad.to(torch.float64)
     w = weight.to(torch.float64).reshape(-1)
     n_theta = g.shape[1]
@@ -50,6 +51,8 @@ def allreduce_weighted_grad(grad: torch.Tensor, weight: torch.Tensor, group: Opt
         buf[:n_theta] = (w[:, None] * g).sum(0)
         buf[n_theta] = w.sum()
         buf[n_theta + 1] = float(g.shape[0])
+    if count is not None:
+        buf[n_theta + 1] = count.to(torch.float64).sum()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         if deterministic:
             parts = [torch.empty_like(buf) for _ in range(dist.get_world_size(group))]
@@ -69,8 +72,6 @@ def mean_update(grad: torch.Tensor, weight: torch.Tensor, group: Optional[dist.P
         s, _, n = allreduce_weighted_grad(grad, weight, group, deterministic)
     else:
         v = valid.to(torch.float64).reshape(-1)
-        s, _, _ = allreduce_weighted_grad(grad, weight.to(torch.float64).reshape(-1) * v, group, deterministic)
-        n = v.sum()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
+        # ONE collective per update: the number of valid samples rides in the count slot of the same message
+        s, _, n = allreduce_weighted_grad(grad, weight.to(torch.float64).reshape(-1) * v, group, deterministic, count=v)
     return s / torch.clamp(n, min=1.0)

@@ -56,10 +56,11 @@ class BatchedCartPoleSwingUpEnv:
         return self.device.type == "cuda" and self.dtype == torch.float64
 
     def _par(self):
-        if self._par_c is None:
-            import ctypes
-            self._par_c = (ctypes.c_double * 9)(self.gravity, self.masscart, self.masspole, self.length, self.force_mag, self.tau,
-                                                self.x_threshold, self.theta_threshold, float(self.max_episode_steps))
+        # rebuilt on every call (nine host scalars): an edit of env.force_mag, max_episode_steps, ... after construction reaches the
+        # kernel exactly as it reaches the torch formulation below
+        import ctypes
+        self._par_c = (ctypes.c_double * 9)(self.gravity, self.masscart, self.masspole, self.length, self.force_mag, self.tau,
+                                            self.x_threshold, self.theta_threshold, float(self.max_episode_steps))
         return self._par_c
 
     def reset_where(self, mask: torch.Tensor) -> torch.Tensor:
@@ -131,7 +132,7 @@ class BatchedLinearSystemEnv:
         self.low, self.high = torch.tensor(min_observation, **kw), torch.tensor(max_observation, **kw)
         self.gen = torch.Generator(device=self.device).manual_seed(seed)
         self.state = torch.zeros(num_envs, 2, **kw)
-        self._par_c = None
+        self._par_c, self._par_key = None, None
 
     def reset(self) -> torch.Tensor:
         self.state = torch.tensor([0.5, 0.5], dtype=self.dtype, device=self.device).repeat(self.num_envs, 1)   # environment.py:46
@@ -148,9 +149,14 @@ class BatchedLinearSystemEnv:
             import ctypes
             from . import _lib
             from .batch import _ptr
-            if self._par_c is None:
+            # the parameter block is cached against the identity and in-place version of the tensors it was read from (and the noise
+            # bounds), so that a later edit of env.A / env.B / env.low / env.high / the noise bounds is honoured like on the torch path
+            # without a device-to-host copy per step
+            key = (id(self.A), self.A._version, id(self.B), self.B._version, id(self.low), self.low._version, id(self.high),
+                   self.high._version, float(self.lb_noise), float(self.ub_noise))
+            if self._par_c is None or self._par_key != key:
                 vals = self.A.reshape(-1).tolist() + self.B.reshape(-1).tolist() + [self.lb_noise, self.ub_noise] + self.low.tolist() + self.high.tolist()
-                self._par_c = (ctypes.c_double * 12)(*vals)
+                self._par_c, self._par_key = (ctypes.c_double * 12)(*vals), key
             u01 = torch.rand(self.num_envs, generator=self.gen, dtype=self.dtype, device=self.device)
             a = a.to(self.device).contiguous()
             self.state = self.state.contiguous()

@@ -288,6 +288,7 @@ class MPC:
         ocp, nu = self.ocp, self.ocp.nu
         value = np.asarray(value, float).reshape(-1)
         lo = field.startswith("l")
+        self._sens_fresh = False               # whichever bound changes, the cached sensitivities belong to the old problem
         if field in ("lbx", "ubx") and stage == 0:
             self._x0 = value.copy()
             return
@@ -311,7 +312,6 @@ class MPC:
             raise Exception(f"Field {field} not supported.")
         if np.all(self._lb <= self._ub):
             self._batch.set_bounds(_lib.BOUNDS_STAGE, self._lb, self._ub)
-        self._sens_fresh = False
 
     # ---------------------------------------------------------------- reference surface
     def get_parameters(self) -> np.ndarray:          # mpc.py:24

@@ -73,11 +73,14 @@ class BatchedQLearning:
         q, v = rq.V.reshape(n, self.E), rv.V.reshape(n, self.E)
         dq = rq.dV_dp.reshape(n, self.E, -1)
         td = C[: n - 1] + self.gamma * v[1:] - q[:-1]                 # (193)
-        valid = (ok[:-1] & ok[1:]).to(td.dtype)
-        w = (self.lr * td * valid).reshape(-1)
+        okb = ok[:-1] & ok[1:]
+        valid = okb.to(td.dtype)
+        # failed samples are SELECTED out (their V / Q may be NaN, and NaN * 0 = NaN)
+        w = (self.lr * torch.where(okb, td, torch.zeros_like(td))).reshape(-1)
         g = dq[: n - 1].reshape(-1, dq.shape[-1])
+        g = torch.where(okb.reshape(-1, 1), torch.nan_to_num(g), torch.zeros_like(g))
         step = mean_update(g, w, self.group, valid=valid.reshape(-1))   # mean_i(LR * td_i * dQ/dp_i) over the valid samples of all ranks (203)
         self.theta = self.theta + step
         for m in (self.rollout_mpc, self.sample_mpc):
             m.set_theta(self.theta)                                   # mpc.set_parameter (204-205)
-        return EpisodeStats(float(C.sum().item()) / self.E, float(td.mean().item()), step, float(valid.mean().item()))
+        return EpisodeStats(float(C.sum().item()) / self.E, float(torch.where(okb, td, torch.zeros_like(td)).sum().item() / max(1.0, float(valid.sum().item()))), step, float(valid.mean().item()))

@@ -64,12 +64,15 @@ class MPCActor:
     def dpg_step(self, obs: torch.Tensor, critic: ContinuousCritic, lr: float, group=None) -> torch.Tensor:
         """theta += lr * mean_i( dpi/dtheta_i' grad_a Q_i )  (ascent on Q; use a negative lr for costs)."""
         r = self.mpc.solve(obs.to(torch.float64), sens_pi=True)
-        a = self.scale_action(r.u0).to(obs.dtype).detach().requires_grad_(True)
+        okb = (r.status == 0) & torch.isfinite(r.u0).all(dim=1)
+        u = torch.where(okb[:, None], torch.nan_to_num(r.u0), torch.zeros_like(r.u0))   # select, never multiply by a mask: NaN * 0 = NaN
+        a = self.scale_action(u).to(obs.dtype).detach().requires_grad_(True)
         q = critic.q1_forward(obs, a).sum()
         (dq_da,) = torch.autograd.grad(q, a)
         chain = (2.0 / (self.high - self.low)) if self.scale else torch.ones_like(self.low)
-        g = torch.einsum("bu,bup->bp", dq_da.to(torch.float64) * chain, r.dpi_dp)
-        ok = (r.status == 0).to(torch.float64)
+        g = torch.einsum("bu,bup->bp", dq_da.to(torch.float64) * chain, torch.nan_to_num(r.dpi_dp))
+        g = torch.where(okb[:, None], g, torch.zeros_like(g))
+        ok = okb.to(torch.float64)
         step = mean_update(g, lr * ok, group)
         self.theta = self.theta + step
         self.mpc.set_theta(self.theta)
@@ -102,6 +105,8 @@ class DeviceReplayBuffer:
 
     def sample(self, n: int, gen: Optional[torch.Generator] = None):
         steps = self.cap if self.full else self.pos
+        if steps == 0:
+            raise RuntimeError("DeviceReplayBuffer.sample: the buffer is empty (call collect() / add() first)")
         idx = torch.randint(0, steps * self.E, (n,), device=self.obs.device, generator=gen)
         f = lambda t: t[:steps].reshape(steps * self.E, *t.shape[2:])[idx]
         return f(self.obs), f(self.next_obs), f(self.act), f(self.rew), f(self.done)
@@ -170,7 +175,11 @@ class BatchedTD3:
         ended_total = torch.zeros((), dtype=torch.float64, device=self.device)
         for _ in range(n_steps):
             r = self.actor.mpc.solve(self.obs.to(torch.float64), cold_mask=self._ended)   # ONE launch for E policies
-            a = self.actor.scale_action(r.u0).to(torch.float32)
+            # a solve that ended with status 1 / 4 may hand back a non-finite u0: such an environment gets the zero action (a
+            # finite fallback; the reference raises instead, mpc.py:81-83).  The stored transition is the one that really happened
+            # (action 0 was applied), so no NaN ever reaches the environment, the replay buffer or the critic
+            u_ok = torch.isfinite(r.u0).all(dim=1) & ((r.status == 0) | (r.status == 2))
+            a = torch.where(u_ok[:, None], self.actor.scale_action(torch.nan_to_num(r.u0)), torch.zeros_like(r.u0)).to(torch.float32)
             a = (a + self.action_noise * torch.randn(a.shape, device=self.device, generator=self.gen)).clamp(-1.0, 1.0)
             nxt, rew, term, trunc = self.env.step(a.to(self.env.device))
             nxt, rew = nxt.to(self.device), rew.to(self.device)
@@ -208,12 +217,18 @@ class BatchedTD3:
             with torch.no_grad():
                 noise = (self.target_noise * torch.randn(act.shape, device=self.device, generator=self.gen)).clamp(-self.noise_clip, self.noise_clip)
                 rt = self.target_mpc.mpc.solve(nxt.to(torch.float64), cold=True)               # actor_target(s'), one launch
-                a_next = (self.target_mpc.scale_action(rt.u0).to(torch.float32) + noise).clamp(-1.0, 1.0)
-                q_next = torch.min(*self.critic_target(nxt, a_next)).squeeze(1)
-                ok_t = (rt.status == 0).to(torch.float32)
-                y = rew + self.gamma * (1.0 - done) * q_next
-            qs = self.critic(obs, act)
-            loss = sum((((q.squeeze(1) - y) ** 2) * ok_t).sum() for q in qs) / ok_t.sum().clamp(min=1.0)
+                # failed target solves are SELECTED out (a product with a 0 / 1 mask would keep their NaN: NaN * 0 = NaN), and so are
+                # transitions whose stored observations are not finite
+                ok_b = (rt.status == 0) & torch.isfinite(rt.u0).all(dim=1) & torch.isfinite(obs).all(dim=1) & torch.isfinite(nxt).all(dim=1) \
+                    & torch.isfinite(act).all(dim=1) & torch.isfinite(rew)
+                u_next = torch.where(ok_b[:, None], torch.nan_to_num(rt.u0), torch.zeros_like(rt.u0))
+                a_next = (self.target_mpc.scale_action(u_next).to(torch.float32) + noise).clamp(-1.0, 1.0)
+                nxt_s, obs_s, act_s = (torch.where(ok_b[:, None], t, torch.zeros_like(t)) for t in (nxt, obs, act))
+                q_next = torch.min(*self.critic_target(nxt_s, a_next)).squeeze(1)
+                ok_t = ok_b.to(torch.float32)
+                y = torch.where(ok_b, rew + self.gamma * (1.0 - done) * q_next, torch.zeros_like(rew))
+            qs = self.critic(obs_s, act_s)
+            loss = sum((torch.where(ok_b, q.squeeze(1) - y, torch.zeros_like(y)) ** 2).sum() for q in qs) / ok_t.sum().clamp(min=1.0)
             self.critic_opt.zero_grad(set_to_none=True)
             loss.backward()
             do_policy = self.n_updates % self.policy_delay == 0
@@ -222,11 +237,14 @@ class BatchedTD3:
             flat[: self.n_crit] = torch.cat([p.grad.reshape(-1) for p in self.critic.parameters()]).to(torch.float64) / world
             if do_policy:
                 rp = self.pi_mpc.mpc.solve(obs.to(torch.float64), sens_pi=True, cold=True)   # pi(s_i), dpi/dtheta_i: one launch
-                a_pi = self.pi_mpc.scale_action(rp.u0).to(torch.float32).detach().requires_grad_(True)
-                (dq_da,) = torch.autograd.grad(self.critic.q1_forward(obs, a_pi).sum(), a_pi)
+                okb = (rp.status == 0) & torch.isfinite(rp.u0).all(dim=1) & torch.isfinite(obs).all(dim=1)
+                u_pi = torch.where(okb[:, None], torch.nan_to_num(rp.u0), torch.zeros_like(rp.u0))
+                a_pi = self.pi_mpc.scale_action(u_pi).to(torch.float32).detach().requires_grad_(True)
+                (dq_da,) = torch.autograd.grad(self.critic.q1_forward(obs_s, a_pi).sum(), a_pi)
                 chain = (2.0 / (self.pi_mpc.high - self.pi_mpc.low)) if self.pi_mpc.scale else torch.ones_like(self.pi_mpc.low)
-                okp = (rp.status == 0).to(torch.float64)
-                g = torch.einsum("bu,bup->bp", dq_da.to(torch.float64) * chain * okp[:, None], torch.nan_to_num(rp.dpi_dp))
+                okp = okb.to(torch.float64)
+                g = torch.einsum("bu,bup->bp", torch.where(okb[:, None], dq_da.to(torch.float64) * chain, torch.zeros_like(chain)),
+                                 torch.nan_to_num(rp.dpi_dp))
                 flat[self.n_crit: self.n_crit + n_theta] = g.sum(0)
                 flat[-1] = okp.sum()
             flat = self._allreduce(flat)

@@ -25,11 +25,27 @@ def test_gpus_2_spawns_two_ranks_and_reports_the_slowest():
     line = _run(2)
     assert line["n_gpus"] == 2 and line["steps"] == 5 and line["dryrun"] is True
     assert line["ms_per_step"] >= 2.0          # rank 1 sleeps 2 ms per step: MAX over ranks, not rank 0's 1 ms
+    assert line["rccl_ranks"] == 2             # the collective's own count of the ranks that joined (all-reduce of ones)
 
 
 def test_gpus_1_stays_in_process():
     line = _run(1)
-    assert line["n_gpus"] == 1
+    assert line["n_gpus"] == 1 and "rccl_ranks" not in line      # no communicator, no claim
+
+
+def test_traffic_figure_is_bound_to_the_kernel_sources(tmp_path, monkeypatch):
+    """roofline.traffic comes from a committed counter pass: it must vanish when the kernels it was measured on have changed."""
+    sys.path.insert(0, ROOT)
+    import bench
+    doc = {"csrc_sha": bench.csrc_hash(), "cartpole": {"batch": 4096, "traffic_bytes_per_step": 123.0}}
+    f = tmp_path / "t.json"
+    f.write_text(json.dumps(doc))
+    monkeypatch.setattr(bench, "TRAFFIC_FILE", str(f))
+    assert bench.measured_traffic("cartpole", 4096, True, False)[0] == 123.0
+    assert bench.measured_traffic("cartpole", 2048, True, False)[0] is None
+    doc["csrc_sha"] = "0" * 16
+    f.write_text(json.dumps(doc))
+    assert bench.measured_traffic("cartpole", 4096, True, False)[0] is None
 
 
 def test_spawn_command_is_the_drivers_launch_line():

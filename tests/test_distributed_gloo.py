@@ -26,7 +26,14 @@ def _worker(rank, world, port, grads, weights, out):
     s, ws, n = allreduce_weighted_grad(g, w)
     s_det, _, _ = allreduce_weighted_grad(g, w, deterministic=True)
     step = mean_update(g, w)
-    out[rank] = (s.numpy().copy(), float(ws), int(round(float(n))), s_det.numpy().copy(), step.numpy().copy())
+    # mean over the valid samples: the denominator rides in the SAME message (one collective per update)
+    calls = []
+    real = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    valid = torch.as_tensor((np.arange(lo, hi) % 3 != 0).astype(np.float64))
+    step_v = mean_update(g, w, valid=valid)
+    dist.all_reduce = real
+    out[rank] = (s.numpy().copy(), float(ws), int(round(float(n))), s_det.numpy().copy(), step.numpy().copy(), step_v.numpy().copy(), len(calls))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -46,8 +53,12 @@ def test_theta_gradient_allreduce_world2(oracle_port):
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), q.dV, weights, out), nprocs=world, join=True)
     expect_sum = (weights[:, None] * q.dV).sum(0)
+    vmask = (np.arange(B) % 3 != 0).astype(float)
+    expect_v = ((weights * vmask)[:, None] * q.dV).sum(0) / vmask.sum()
     for r in range(world):
-        s, ws, n, s_det, step = out[r]
+        s, ws, n, s_det, step, step_v, n_coll = out[r]
+        assert n_coll == 1, "mean_update(valid=...) must issue exactly one collective"
+        assert np.allclose(step_v, expect_v, rtol=1e-12, atol=1e-15)
         assert n == B and abs(ws - weights.sum()) < 1e-15
         assert np.allclose(s, expect_sum, rtol=1e-12, atol=1e-15)
         assert np.allclose(s_det, expect_sum, rtol=1e-12, atol=1e-15)

@@ -1,0 +1,274 @@
+"""GPU parity at the sizes bench.py times (BASELINE.json configs 2-4) and a certification of the HIP iterate by the mirror of the
+reference's NLP.
+
+  * cartpole 4096 (the bench inputs) and a hard distribution of 2048 states, linear system 4096, chain n_mass 5 at B = 1024:
+    the HIP path through the C ABI against the oracle's C++ port on the same inputs — status, SQP / interior-point iteration
+    counts, u0*, V, dV/dp, du0*/dp within 1e-6 relative (north_star).
+  * mirror certification: x, u, pi, lam, t pulled out of the handle with mpcrl_get_iterate are fed to oracle/nlp_mirror.py (the
+    restatement of rlmpc/mpc/nlp.py's L, R, z) exactly as update_nlp copies them out of acados (nlp.py:1354-1398); the reference's
+    own consistency thresholds (nlp.py:1445-1537) must hold AT THE PRODUCT'S ITERATE, and the mirror's dL/dp and
+    dz/dp[:nu] = -(dR/dz)^-1 dR/dp (nlp.py:1401,1410-1424; torch autograd + a dense solve) must equal the kernel's dV/dp and
+    du0*/dp.  This ties the product to the reference-held checks without going through the SQP oracle.
+"""
+import multiprocessing as mp
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+
+
+def rel_rows(a, b, floor=1.0):
+    """per-instance max relative error, scaled by the largest entry of the instance's reference row"""
+    B = len(b)
+    a, b = np.asarray(a, float).reshape(B, -1), np.asarray(b, float).reshape(B, -1)
+    return (np.abs(a - b) / np.maximum(np.abs(b).max(1, keepdims=True), floor)).max(1)
+
+
+def compare(r, ref, min_conv, strict=None, name=""):
+    st, it = r.status.cpu().numpy(), r.iters.cpu().numpy()
+    same = st == ref.status
+    ok = (st == 0) & (ref.status == 0)
+    conv = (st == 0).mean()
+    e = {"u0": rel_rows(r.u0.cpu().numpy()[ok], ref.u0[ok]), "V": rel_rows(r.V.cpu().numpy()[ok], ref.V[ok]),
+         "dV": rel_rows(r.dV_dp.cpu().numpy()[ok], ref.dV[ok])}
+    sel = ok if strict is None else ok & strict
+    e["dpi"] = rel_rows(r.dpi_dp.cpu().numpy()[sel], ref.dpi[sel])
+    sqp_eq, ipm_eq = (it[ok, 0] == ref.sqp_iter[ok]).mean(), (it[ok, 1] == ref.ipm_iter[ok]).mean()
+    print(f"{name}: B {len(st)} status equal {same.mean():.4f} converged gpu {conv:.4f} port {(ref.status == 0).mean():.4f} "
+          f"sqp iters equal {sqp_eq:.4f} ipm iters equal {ipm_eq:.4f} " + " ".join(f"{k} {v.max():.2e}" for k, v in e.items()))
+    assert conv >= min_conv
+    # the same iteration in two arithmetic orders: iteration counts differ only where a stopping test is met to within rounding
+    assert np.abs(it[ok, 0] - ref.sqp_iter[ok]).max() <= 1 and sqp_eq > 0.97 and ipm_eq > 0.95
+    for k, v in e.items():
+        assert v.max() < RTOL, (k, float(v.max()))
+    return same, ok
+
+
+def test_cartpole_bench_inputs_vs_port(oracle_port):
+    """BASELINE config 2/3 at full size: the 4096 instances bench.py times (make_inputs(4096, rank 0)), every one against the port."""
+    import bench
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    from oracle.problems import make_cartpole
+    x0 = bench.make_inputs(4096, 0)
+    mpc = MPCBatch(cartpole_ocp(), 4096)
+    r = mpc.solve(torch.as_tensor(x0, device="cuda"), sens_v=True, sens_pi=True, cold=True)
+    ref = oracle_port.solve(make_cartpole(), x0)
+    same, ok = compare(r, ref, 1.0, name="cartpole bench inputs")
+    assert same.all() and ok.all()
+    res = mpc.get_iterate()[4].cpu().numpy()
+    assert res.max() < 1e-6 and np.abs(res - ref.res).max() < 1e-6
+
+
+def test_cartpole_hard_distribution_vs_port(oracle_port):
+    """2048 states from the box +-[2, 3, pi, 3] at max_iter = 60: full-step SQP without globalisation (what the reference runs,
+    config/cartpole.yaml:8-14) fails on part of them, on both sides alike; everything both sides solve must agree."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    from oracle.problems import make_cartpole
+    rng = np.random.default_rng(5)
+    lohi = np.array([2.0, 3.0, np.pi, 3.0])
+    x0 = rng.uniform(-lohi, lohi, (2048, 4))
+    mpc = MPCBatch(cartpole_ocp(max_iter=60), 2048)
+    r = mpc.solve(torch.as_tensor(x0, device="cuda"), sens_v=True, sens_pi=True, cold=True)
+    ref = oracle_port.solve(make_cartpole(), x0, max_iter=60)
+    st = r.status.cpu().numpy()
+    # du0*/dp is compared where strict complementarity holds at the port's solution (a weakly active bound makes it ill-defined)
+    lam, t = ref.BND[:, 0:2].reshape(2048, -1), ref.BND[:, 2:4].reshape(2048, -1)
+    strict = np.maximum(lam, t).min(1) >= 1e-3
+    same, ok = compare(r, ref, 0.8, strict=strict, name="cartpole hard distribution")
+    assert same.mean() > 0.995           # the rest: chaotic non-converging iterations that end differently in two arithmetic orders
+
+
+def test_linear_bench_inputs_vs_port(oracle_port):
+    """`bench.py --workload linear` at its size: 4096 states of the environment's box interior, gamma = 0.99."""
+    from mpc4rl_amd import MPCBatch, linear_system_ocp
+    from oracle.problems import make_linear_system
+    rng = np.random.default_rng(0)
+    B = 4096
+    x0 = np.column_stack([rng.uniform(0.15, 0.85, B), rng.uniform(-0.5, 0.5, B)])
+    mpc = MPCBatch(linear_system_ocp(discount_factor=0.99), B)
+    r = mpc.solve(torch.as_tensor(x0, device="cuda"), sens_v=True, sens_pi=True, cold=True)
+    ref = oracle_port.solve(make_linear_system(gamma=0.99), x0)
+    s = np.abs(ref.BND[:, 4:6]).reshape(B, -1).max(axis=1)      # quirk q1: du0/dp is ill-defined where a soft bound is active
+    same, ok = compare(r, ref, 1.0, strict=s < 1e-9, name="linear bench inputs")
+    assert same.all()
+
+
+def test_chain5_bench_size_vs_port(oracle_port):
+    """BASELINE config 4 (n_mass = 5, N = 40, B = 1024, the inputs of `bench.py --workload chain5`): 64 instances against the port,
+    the whole batch through size-independent properties."""
+    from mpc4rl_amd import MPCBatch, chain_mass_ocp
+    from oracle.problems import make_chain_mass
+    ocp, P = chain_mass_ocp(n_mass=5), make_chain_mass(n_mass=5)
+    B = 1024
+    rng = np.random.default_rng(0)
+    x0 = np.tile(ocp.x0, (B, 1))
+    x0[:, 12:] += rng.normal(0.0, 1e-2, (B, 9))
+    mpc = MPCBatch(ocp, B)
+    r = mpc.solve(x0, sens_v=True, sens_pi=True, cold=True)
+    assert bool((r.status == 0).all())
+    assert float(mpc.get_iterate()[4].max()) < 1e-5 and float(r.u0.abs().max()) <= 1.0 + 1e-9
+    assert bool(torch.isfinite(r.dV_dp).all()) and bool(torch.isfinite(r.dpi_dp).all())
+    pick = rng.choice(B, 64, replace=False)
+    ref = oracle_port.solve(P, x0[pick])
+    assert np.all(ref.status == 0)
+    it = r.iters.cpu().numpy()[pick]
+    assert np.abs(it[:, 0] - ref.sqp_iter).max() <= 1
+    for name, a, b in (("u0", r.u0, ref.u0), ("V", r.V, ref.V), ("dV", r.dV_dp, ref.dV)):
+        assert rel_rows(a.cpu().numpy()[pick], b).max() < RTOL, name
+    dpi = r.dpi_dp.cpu().numpy()[pick]
+    assert (np.abs(dpi - ref.dpi).reshape(64, -1).max(1) / np.abs(ref.dpi).reshape(64, -1).max(1)).max() < RTOL
+    # a second call from the stored iterate needs no iteration and reproduces the outputs; the batch order changes nothing
+    r2 = mpc.solve(x0, sens_v=True)
+    assert int(r2.iters[:, 0].max()) == 0 and torch.allclose(r2.V, r.V, rtol=1e-13)
+    perm = rng.permutation(B)
+    rp = MPCBatch(ocp, B).solve(x0[perm], sens_v=True, cold=True)
+    idx = torch.as_tensor(perm, device=r.V.device)
+    assert torch.equal(rp.V, r.V[idx]) and torch.equal(rp.dV_dp, r.dV_dp[idx])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# mirror certification of the HIP iterate
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _certify_one(job):
+    """worker (a fresh interpreter): (problem name, kwargs, iterate arrays, x0, p, u0fix, gamma, V) -> mirror figures"""
+    name, kw, x, u, pi, bnd, x0, p, u0fix, gamma, V = job
+    torch.set_num_threads(1)
+    from oracle.from_iterate import certify
+    from oracle.problems import make_cartpole, make_chain_mass, make_linear_system
+    P = {"cartpole": make_cartpole, "linear": make_linear_system, "chain": make_chain_mass}[name](**kw)
+    mr, sc, sol = certify(P, x, u, pi, bnd, x0, p=p, u0fix=u0fix, gamma=gamma, cost=V)     # raises if a reference threshold fails
+    smax = float(np.abs(sol.s).max()) if len(sol.s) else 0.0
+    return mr.dL_dp[0], mr.dpi_dp, mr.L, sc, smax, float(np.abs(mr.R[: P.N * P.nu + (P.N + 1) * P.nx]).max())
+
+
+def _certify_batch(name, kw, mpc, r, x0, theta=None, u0=None, gamma=None, idx=None):
+    x, u, pi, bnd, _ = [t.cpu().numpy() for t in mpc.get_iterate()]
+    V = r.V.cpu().numpy()
+    idx = range(len(x0)) if idx is None else idx
+    jobs = [(name, kw, x[i], u[i], pi[i], bnd[i], x0[i], None if theta is None else theta[i], None if u0 is None else u0[i], gamma,
+             float(V[i])) for i in idx]
+    with mp.get_context("spawn").Pool(min(8, len(jobs), os.cpu_count() or 1)) as pool:
+        rows = pool.map(_certify_one, jobs, chunksize=1)
+    return [np.array([row[c] for row in rows]) for c in range(6)]
+
+
+def _check_certified(r, L_dev, out, idx, q_mode=False, strict_margin=1e-3, soft=False):
+    dL, dpi, L, sc, smax, stat = out
+    sel = np.asarray(list(idx))
+    dV_k, dpi_k = r.dV_dp.cpu().numpy()[sel], r.dpi_dp.cpu().numpy()[sel]
+    e_dV = rel_rows(dV_k, dL)
+    assert e_dV.max() < RTOL, ("dV/dp vs mirror dL/dp", float(e_dV.max()))
+    assert rel_rows(L_dev.cpu().numpy()[sel], L).max() < RTOL                  # mpcrl_get_lagrangian == nlp.L at the iterate
+    if q_mode:
+        assert np.all(dpi_k == 0.0)                                             # u_0 pinned: the product reports exact zeros
+        return
+    # dz/dp of the mirror is only defined where strict complementarity holds (interior-point iterate: lam t ~ 1e-11 on every row)
+    # and, with L1-soft bounds, where no slack is active (quirk q1: the reference's own system is rank-deficient there)
+    good = (sc >= strict_margin) if not soft else (smax < 1e-9)
+    assert good.mean() >= 0.5
+    e = (np.abs(dpi_k - dpi).reshape(len(sel), -1).max(1) / np.maximum(np.abs(dpi).reshape(len(sel), -1).max(1), 1.0))
+    print("mirror certification: dV/dp", float(e_dV.max()), "du0/dp", float(e[good].max()), "on", int(good.sum()), "of", len(sel),
+          "stationarity at the HIP iterate", float(stat.max()))
+    assert e[good].max() < RTOL, float(e[good].max())
+
+
+def test_mirror_certifies_the_hip_iterate_cartpole():
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    ocp = cartpole_ocp()
+    rng = np.random.default_rng(11)
+    B = 32
+    x0 = np.zeros((B, 4))
+    x0[:16, 2] = rng.uniform(0.9 * np.pi, 1.1 * np.pi, 16)                         # the reference's reset distribution
+    x0[16:] = rng.uniform(-1, 1, (16, 4)) * np.array([0.5, 1.0, 0.3, 1.0])         # near upright: u0 not saturated
+    theta = np.tile(ocp.p0, (B, 1))
+    theta[:, :3] *= rng.uniform(0.9, 1.1, (B, 3))
+    mpc = MPCBatch(ocp, B)
+    mpc.set_theta(torch.as_tensor(theta))
+    r = mpc.solve(x0, sens_v=True, sens_pi=True, cold=True)
+    assert bool((r.status == 0).all())
+    out = _certify_batch("cartpole", {}, mpc, r, x0, theta=theta)
+    _check_certified(r, mpc.get_lagrangian(), out, range(B))
+    # Q(s, a): u_0 pinned (mpc.py:52-96)
+    u0 = rng.uniform(-25, 25, (8, 1))
+    mq = MPCBatch(ocp, 8)
+    rq = mq.solve(x0[16:24], u0, sens_v=True, sens_pi=True, cold=True)
+    assert bool((rq.status == 0).all())
+    outq = _certify_batch("cartpole", {}, mq, rq, x0[16:24], u0=u0)
+    _check_certified(rq, mq.get_lagrangian(), outq, range(8), q_mode=True)
+
+
+def test_mirror_certifies_the_hip_iterate_linear():
+    from mpc4rl_amd import MPCBatch, linear_system_ocp
+    rng = np.random.default_rng(12)
+    B = 32
+    x0 = np.column_stack([rng.uniform(0.15, 0.85, B), rng.uniform(-0.5, 0.5, B)])
+    x0[0] = [0.5, 0.5]                                                              # linear_system/environment.py:46
+    for gamma in (0.99, 0.9):
+        mpc = MPCBatch(linear_system_ocp(discount_factor=gamma), B)
+        r = mpc.solve(x0, sens_v=True, sens_pi=True, cold=True)
+        assert bool((r.status == 0).all())
+        out = _certify_batch("linear", {"gamma": gamma}, mpc, r, x0, gamma=gamma)
+        _check_certified(r, mpc.get_lagrangian(), out, range(B), soft=True)
+
+
+def test_mirror_certifies_the_hip_iterate_chain():
+    """n_mass 3 (4 instances) and n_mass 5 (2 instances; 2 385 KKT unknowns x 499 parameters, ~15 s of autograd + dense LU each)."""
+    from mpc4rl_amd import MPCBatch, chain_mass_ocp
+    rng = np.random.default_rng(13)
+    for n_mass, B in ((3, 4), (5, 2)):
+        ocp = chain_mass_ocp(n_mass=n_mass, tol=1e-8)   # the mirror's thresholds are looser, du0/dp at 1e-6 needs the KKT point
+        M = n_mass - 2
+        x0 = np.tile(ocp.x0, (B, 1))
+        x0[1:, 3 * (M + 1):] += rng.normal(0.0, 1e-2, (B - 1, 3 * M))
+        mpc = MPCBatch(ocp, B)
+        r = mpc.solve(x0, sens_v=True, sens_pi=True, cold=True)
+        assert bool((r.status == 0).all())
+        out = _certify_batch("chain", {"n_mass": n_mass}, mpc, r, x0)
+        dL, dpi, L, sc, smax, stat = out
+        assert rel_rows(r.dV_dp.cpu().numpy(), dL).max() < RTOL
+        dk = r.dpi_dp.cpu().numpy()
+        assert (np.abs(dk - dpi).reshape(B, -1).max(1) / np.abs(dpi).reshape(B, -1).max(1)).max() < RTOL
+        assert rel_rows(mpc.get_lagrangian().cpu().numpy(), L).max() < RTOL
+
+
+def test_rccl_world1_allreduce_and_td3_step():
+    """The `nccl` (= RCCL) path that multi-GPU runs take, exercised on one GPU: init_process_group("nccl") with world size 1,
+    allreduce_weighted_grad through the K5 reduction kernel + the collective, and one BatchedTD3.train step whose single
+    all-reduce carries the critic gradients and the theta-gradient."""
+    import socket
+    import torch.distributed as dist
+    from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedTD3, cartpole_ocp
+    from mpc4rl_amd.distributed import allreduce_weighted_grad, mean_update
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        one = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(one)
+        assert float(one.item()) == 1.0
+        rng = np.random.default_rng(0)
+        g, w = torch.as_tensor(rng.normal(size=(4096, 12)), device=dev), torch.as_tensor(rng.normal(size=4096), device=dev)
+        s_, ws, n = allreduce_weighted_grad(g, w)
+        assert torch.allclose(s_, (w[:, None] * g).sum(0), rtol=1e-11, atol=1e-11) and int(round(float(n))) == 4096
+        v = (torch.arange(4096, device=dev) % 3 != 0).to(torch.float64)
+        assert torch.allclose(mean_update(g, w, valid=v), ((w * v)[:, None] * g).sum(0) / v.sum(), rtol=1e-11, atol=1e-13)
+        E = 256
+        env = BatchedCartPoleSwingUpEnv(E, device=dev, seed=0)
+        agent = BatchedTD3(cartpole_ocp(), env, batch_size=E, buffer_steps=8, policy_delay=1, lr_actor=1e-6, seed=0, device=dev)
+        theta0 = agent.theta.clone()
+        agent.collect(2)
+        tr = agent.train(1)
+        torch.cuda.synchronize()
+        assert np.isfinite(tr["critic_loss"]) and bool(torch.isfinite(agent.theta).all())
+        assert float((agent.theta - theta0).abs().max()) > 0.0 and tr["theta_step_norm"] > 0.0
+    finally:
+        dist.destroy_process_group()

@@ -76,3 +76,14 @@ def test_yaml_loader_matches_reference_config_layout():
     for a, b in zip(o.stage_bounds(), ref.stage_bounds()):
         assert np.array_equal(a, b)
     assert np.allclose(o.x0, [0.0, 0.0, 3.14, 0.0]) and o.max_iter == 500
+    # a stage-0 cost of its own (W_0 != W, yref_0 != yref: the yaml has separate keys, cartpole/acados.py:111-186) lands in the W_0 /
+    # yref_0 fields of p, which the kernels read (csrc/models_dev.hpp CartpoleDev::P_W0, P_YREF0)
+    import copy
+    cfg2 = copy.deepcopy(cfg)
+    cfg2["mpc"]["cost"]["W_0"][0][0] = 3.0
+    cfg2["mpc"]["cost"]["yref_0"][2] = 0.25
+    o2 = cartpole_ocp_from_config(cfg2)
+    f = o2.cost_fields
+    W0 = o2.p0[f["W_0"][0]: f["W_0"][0] + 25].reshape(5, 5, order="F")
+    assert W0[0, 0] == 3.0 and np.allclose(W0[1:, 1:], np.asarray(cfg["mpc"]["cost"]["W"])[1:, 1:])
+    assert o2.p0[f["yref_0"][0] + 2] == 0.25 and np.allclose(o2.p0[f["W"][0]: f["W"][0] + 25], o.p0[f["W"][0]: f["W"][0] + 25])

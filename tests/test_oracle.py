@@ -240,3 +240,24 @@ def test_non_finite_initial_state_is_status_1(oracle_port):
         assert r.V[0] == good.V[0] and r.V[3] == good.V[3]
         d = sqp_dense.solve(P, x0[1])
         assert d.status == 1
+
+
+def test_mirror_certifies_an_iterate_it_did_not_produce(oracle_port):
+    """oracle/from_iterate.py: iterate arrays in the layouts of include/mpcrl.h -> the mirror of the reference's NLP, as update_nlp
+    copies the acados iterate (nlp.py:1354-1398).  Here the iterate is the C++ port's; the GPU suite feeds the product's.  The
+    reference's thresholds (nlp.py:1445-1537) hold and the mirror's dL/dp, dz/dp[:nu] equal the port's adjoint-Riccati values."""
+    from oracle.from_iterate import certify
+    from oracle.problems import make_cartpole, make_linear_system
+    rng = np.random.default_rng(4)
+    x0c = np.zeros((2, 4))
+    x0c[0, 2] = 0.95 * np.pi
+    x0c[1] = [0.1, 0.2, 0.1, -0.3]
+    x0l = np.column_stack([rng.uniform(0.3, 0.7, 2), rng.uniform(-0.3, 0.3, 2)])
+    for P, x0 in ((make_cartpole(), x0c), (make_linear_system(gamma=0.9), x0l)):
+        r = oracle_port.solve(P, x0)
+        for i in range(2):
+            assert r.status[i] == 0
+            mr, sc, sol = certify(P, r.X[i], r.U[i], r.PI[i], r.BND[i], x0[i], cost=r.V[i])
+            assert np.abs(mr.dL_dp[0] - r.dV[i]).max() <= 1e-6 * max(1.0, np.abs(r.dV[i]).max())
+            if sc >= 1e-3 or (len(sol.s) and np.abs(sol.s).max() < 1e-9):
+                assert np.abs(mr.dpi_dp - r.dpi[i]).max() <= 1e-6 * max(1.0, np.abs(r.dpi[i]).max())
