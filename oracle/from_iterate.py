@@ -69,3 +69,21 @@ def certify(P: Problem, x, u, pi, bnd, x0, p=None, u0fix=None, gamma=None, cost:
     M.assert_reference_consistency(P, sol, mr)
     sc = float(np.minimum(np.maximum(sol.lam, sol.t), 1e30).min()) if len(sol.lam) else 1e30
     return mr, sc, sol
+
+
+def certify_job(job):
+    """Process-pool worker of the GPU certification tests (a fresh interpreter): (problem name, kwargs, iterate arrays, x0, p, u0fix,
+    gamma, V) -> (dL/dp, dz/dp[:nu], L, strict-complementarity margin, largest slack, stationarity residual); raises if one of the
+    reference's update_nlp thresholds fails at the iterate."""
+    name, kw, x, u, pi, bnd, x0, p, u0fix, gamma, V = job
+    torch.set_num_threads(1)
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
+    from .problems import make_cartpole, make_chain_mass, make_linear_system
+    P = {"cartpole": make_cartpole, "linear": make_linear_system, "chain": make_chain_mass}[name](**kw)
+    mr, sc, sol = certify(P, x, u, pi, bnd, x0, p=p, u0fix=u0fix, gamma=gamma, cost=V)
+    smax = float(np.abs(sol.s).max()) if len(sol.s) else 0.0
+    return mr.dL_dp[0], mr.dpi_dp, mr.L, sc, smax, float(np.abs(mr.R[: P.N * P.nu + (P.N + 1) * P.nx]).max())

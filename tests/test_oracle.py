@@ -261,3 +261,19 @@ def test_mirror_certifies_an_iterate_it_did_not_produce(oracle_port):
             assert np.abs(mr.dL_dp[0] - r.dV[i]).max() <= 1e-6 * max(1.0, np.abs(r.dV[i]).max())
             if sc >= 1e-3 or (len(sol.s) and np.abs(sol.s).max() < 1e-9):
                 assert np.abs(mr.dpi_dp - r.dpi[i]).max() <= 1e-6 * max(1.0, np.abs(r.dpi[i]).max())
+
+
+def test_certification_worker_runs_in_a_process_pool(oracle_port):
+    """The GPU certification tests farm oracle.from_iterate.certify_job out to fresh interpreters (spawn): the worker must be
+    importable there and return what the in-process call returns."""
+    import multiprocessing as mp
+    from oracle.from_iterate import certify_job
+    from oracle.problems import make_linear_system
+    P = make_linear_system(gamma=0.9)
+    x0 = np.array([[0.4, 0.1], [0.6, -0.2]])
+    r = oracle_port.solve(P, x0)
+    jobs = [("linear", {"gamma": 0.9}, r.X[i], r.U[i], r.PI[i], r.BND[i], x0[i], None, None, 0.9, float(r.V[i])) for i in range(2)]
+    with mp.get_context("spawn").Pool(2) as pool:
+        rows = pool.map(certify_job, jobs, chunksize=1)
+    here = certify_job(jobs[0])
+    assert np.array_equal(rows[0][0], here[0]) and np.abs(rows[1][0] - r.dV[1]).max() < 1e-8
