@@ -480,30 +480,43 @@ struct SmallSolver {
     }
 
     // =====================================================================================================================
-    // Factor sweep in MATRIX layout on the matrix cores (NX = 4, NU = 1: v_mfma_f64_4x4x4_4b_f64).
-    // The stage-per-lane layout leaves the serial factor sweep with one useful lane per instance and step (and every 4x4 product
-    // as 64 wave-wide FMAs).  Here the wave switches layout through LDS for the sweep: each stage lane publishes its
+    // ALL Riccati sweeps in MATRIX layout on the matrix cores (NX = 4, NU = 1: v_mfma_f64_4x4x4_4b_f64).
+    // The stage-per-lane layout leaves the serial sweeps with one useful lane per instance and step (a factor step as ~300 wave-wide
+    // VALU instructions, a vector step as 45-60).  Here the wave switches layout through LDS: each stage lane publishes its
     // linearisation to a slot, then the 64 lanes act as 4 blocks x (4 x 4) matrix elements — block = instance of the wave,
     // lane = 16 r + 4 blk + c holds element (r, c) — and one MFMA is a 4x4x4 product for all blocks at once.  Measured operand
     // layout (profiles/microbench/mfma_f64_4x4x4_probe.hip): D(i,j) at lane 16 i + 4 blk + j, B-operand(k,j) at 16 k + 4 blk + j,
     // A-operand(i,k) at 16 k + 4 blk + i — so a matrix held in the D layout is its own B operand and, as A operand, its
     // TRANSPOSE:  mfma(X, Y, C) = X' Y + C.  Row r of a block is one quad (4 consecutive lanes): every broadcast the recursion
-    // needs is a quad_perm DPP; nothing crosses DPP rows.  One stage step (P = P_{k+1}, W = [B | bb | 0 | 0], BB = [B B B B]):
-    //   X1 = mfma(P, A)            = P A                      Y  = mfma(P, W, [0 | p | 0 | 0]) = [P B | p + P bb | 0 | 0]
-    //   Q  = mfma(A, X1, Hxx + D)  = A' P A + Hxx + D_x       Zc = mfma(A, Y, [Hxu | g_x])     = [S | mv_x]      (columns)
-    //   Zr = mfma(Y, A, [Hux; 0])  : row 0 = S'               Zb = mfma(BB, Y, [Huu + D_u | g_u]): every row = [R, mv_u]
-    //   K = S / R, kff = mv_u / R, p = mv_x - K mv_u,  P = mfma(-K' (row 0), S' (row 0), Q) = Q - K S'
-    // 7 MFMAs (~18 cycles each) + ~40 VALU per step instead of ~300 VALU instructions.
+    // needs is a quad_perm DPP; nothing crosses DPP rows.
+    //
+    // Factor step (P = P_{k+1}, W = [B | bb | bb | 0], pc = [0 | p_{k+1} | 0 | 0], BB = [B B B B]):
+    //   X1 = mfma(P, A)            = P A                      Y  = mfma(P, W, pc) = [P B | p + P bb | P bb | 0]
+    //   Q  = mfma(A, X1, Hxx + D)  = A' P A + Hxx + D_x       Zc = mfma(A, Y, [Hxu | g_x | 0 | 0]) = [S | mv_x | A' P bb | 0]  (columns)
+    //   Zr = mfma(Y, A, [Hux; 0])  : row 0 = S'               Zb = mfma(BB, Y, [Huu + D_u | g_u | 0 | 0]): every row = [R, mv_u, beta, 0]
+    //   K = S / R, kff = mv_u / R,  t = Zc - K Zb (own column): p_k in column 1, q_k = Acl_k' P_{k+1} bb_k in column 2,
+    //   P = mfma(-K' (row 0), S' (row 0), Q) = Q - K S',  Acl_k = A - B K (one FMA per element, stored over A),
+    //   d_k = bb - B kff.  7 MFMAs + ~50 VALU per step instead of ~300 VALU instructions.
+    //
+    // Vector sweeps (round 3): with the closed-loop matrices Acl_k left in the slots by the factor sweep, both vector recursions
+    // are AFFINE CHAINS  v <- Acl v + c  on the matrix cores, one dependent MFMA per stage (mx_chain):
+    //   forward   Dx_{k+1} = Acl_k Dx_k + d_k,                 d_k = bb_k - B_k kff_k
+    //   backward  p_k      = Acl_k' p_{k+1} + c_k,             c_k = q_k + g_x - K_k' g_u     (q_k does not depend on the right-hand side)
+    // and everything off the chain is stage-parallel in the stage lanes: Du_k = -K_k Dx_k - kff_k, the corrector's
+    // kff_k = (g_u + beta_k + B_k' p_{k+1}) / R_k, Dnu_k = P_k Dx_k + p_k.  A chain step is ~8 instructions against 45 (forward) / 60
+    // (backward) of the stage-layout sweeps they replace, and the stage lanes no longer hold K, kff, 1/R, P, p (20 doubles).
     static constexpr bool MX = (NX == 4 && NU == 1);
     // Slot of one stage (doubles; 16-byte aligned pairs so that one ds_read_b128 brings two operands — LDS instructions, not
-    // bytes, are what the sweep waits for: ~28 cycles each on a lone wavefront):
-    //   [0,32)   (A(r,c), Hxx(r,c) + D_x) pairs at 2 (4 r + c); the sweep overwrites the second member with P_k(r,c)
-    //   [32,48)  per row r: (B[r], Hxu[r]) at 32 + 4 r, (bb[r], g_x[r]) at 34 + 4 r
-    //   [48,56)  per column c: (Huu + D_u | g_u | 0 | 0, Hxu[c]) at 48 + 2 c
-    //   56 K[4], 60 p[4], 64 kff, 65 1/R
+    // bytes, are what the sweeps wait for).  Everything is (re)published by the stage lane before every factor sweep:
+    //   [0,32)   (A(r,c), Hxx(r,c) + D_x) pairs at 2 (4 r + c); the factor sweep overwrites them with (Acl_k(r,c), P_k(r,c))
+    //   [32,48)  per row r: (B[r], Hxu[r]) at 32 + 4 r — the factor sweep / the backward chain leave p_k[r] in the second member;
+    //            (bb[r], g_x[r]) at 34 + 4 r — second member: d_k[r] after the factor sweep, then c_k[r], then the corrector's d_k[r]
+    //   [48,56)  per column c: ([Huu + D_u | g_u | 0 | 0][c], Hxu[c]) at 48 + 2 c — afterwards (q_k[c], Dx_k[c])
+    //   56 K[4], 60 1/R (0 for a pinned u_0), 61 kff, 62 beta = B' P_{k+1} bb
     // After the 64 slots: one ok flag per block, and a write-only dump pair for lanes with nothing to store.
-    static constexpr int mxAH = 0, mxCol = 32, mxRow = 48, mxK = 56, mxp = 60, mxkff = 64, mxLi = 65,
-                         MSLOT = 66,   // 64 slots = 33 KB: four single-wave workgroups fit one CU's LDS, with room for a parked instance
+    static constexpr int mxAH = 0, mxCol = 32, mxRow = 48, mxK = 56, mxMisc = 60,
+                         MSLOT = 66,   // 64 slots = 33 KB: four single-wave workgroups fit one CU's LDS, with room for a parked instance;
+                                       // 66 doubles = 132 words = 4 mod 64 banks: the stage lanes' ds_*_b128 are conflict-free
                          mxFlag = 64 * MSLOT, mxDump = mxFlag + 4, MX_LDS = mxDump + 2;
     double *ms = nullptr;   // LDS, 64 slots of MSLOT doubles (one per stage lane)
     // LDS cost table, one per instance of the wavefront: for each stage kind (0 = stage 0, 1 = interior, 2 = terminal) the packed
@@ -553,112 +566,276 @@ struct SmallSolver {
     }
     MPCRL_DI static double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
     MPCRL_DI static mx_d2 lds_pair(const double *q) { return *(const mx_d2 *)__builtin_assume_aligned(q, 16); }
+    MPCRL_DI static void lds_pair_store(double *q, double a, double b) {
+        mx_d2 v;
+        v.x = a, v.y = b;
+        *(mx_d2 *)__builtin_assume_aligned(q, 16) = v;
+    }
 
-    // stage lane -> slot: dynamics and cross Hessian (only when they changed), right-hand side and Hessian + barrier diagonal
+    // stage lane -> slot: the whole linearisation of the stage (the sweeps overwrite most of it), 28 ds_write_b128
     template <class HF>
-    MPCRL_DI void mx_publish(HF Hs, const double *g, const double *bb, bool dyn) {
+    MPCRL_DI void mx_publish(HF Hs, const double *g, const double *bb) {
         double *sl = ms + (threadIdx.x & 63) * MSLOT;
-        if (dyn) {
-#pragma unroll
-            for (int i = 0; i < NX * NX; ++i) sl[mxAH + 2 * i] = A[i];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                const double hxu = hscale * Hs(NU + i, 0);
-                sl[mxCol + 4 * i] = Bm[i], sl[mxCol + 4 * i + 1] = hxu, sl[mxRow + 2 * i + 1] = hxu;
-            }
-            sl[mxRow + 4] = 0.0, sl[mxRow + 6] = 0.0;
-        }
 #pragma unroll
         for (int i = 0; i < NX; ++i)
 #pragma unroll
             for (int j = 0; j < NX; ++j)
-                sl[mxAH + 2 * (4 * i + j) + 1] = fma(hscale, Hs(NU + (i > j ? i : j), NU + (i > j ? j : i)), i == j ? Dg[NU + i] : 0.0);
+                lds_pair_store(sl + mxAH + 2 * (4 * i + j), A[i * NX + j],
+                               fma(hscale, Hs(NU + (i > j ? i : j), NU + (i > j ? j : i)), i == j ? Dg[NU + i] : 0.0));
 #pragma unroll
-        for (int i = 0; i < NX; ++i) sl[mxCol + 4 * i + 2] = bb[i], sl[mxCol + 4 * i + 3] = g[NU + i];
-        sl[mxRow] = fma(hscale, Hs(0, 0), Dg[0]), sl[mxRow + 2] = g[0];
+        for (int i = 0; i < NX; ++i) {
+            const double hxu = hscale * Hs(NU + i, 0);
+            lds_pair_store(sl + mxCol + 4 * i, Bm[i], hxu);
+            lds_pair_store(sl + mxCol + 4 * i + 2, bb[i], g[NU + i]);
+            lds_pair_store(sl + mxRow + 2 * i, i == 0 ? fma(hscale, Hs(0, 0), Dg[0]) : (i == 1 ? g[0] : 0.0), hxu);
+        }
     }
-    // the sweep itself, all lanes in matrix layout
+    // the factor sweep, all lanes in matrix layout.  WANT_P: also leave p_k of this right-hand side in the slots (adjoint solves
+    // of the sensitivity pass; the interior-point predictor never reads it).
+    // The rank-one update P = Q - K S' is ONE fma per element: S' arrives broadcast over the rows from an MFMA on the column-0
+    // broadcast of Y, so neither a seventh MFMA nor its operand selects sit on the chain.
+    struct MxOps {
+        mx_d2 ah, cp, rp;
+        double Br, At, Bc;
+    };
+#ifndef MPCRL_MX_TWOSETS
+#define MPCRL_MX_TWOSETS 0   // 1: two operand sets (loads two steps ahead, no register rotation) and stores deferred into the next step's
+                             //    MFMA shadow — measured slower while the kernel is short of registers (138 spilled registers, 300 B scratch)
+#endif
+    template <bool WANT_P>
     MPCRL_DI void mx_factor() {
         const int l = threadIdx.x & 63, r = l >> 4, blk = (l >> 2) & 3, c = l & 3;
         const int ipw = min(64 / lpi, M::MAX_IPW);
         const bool live = blk < ipw;
         double *S0 = ms + (live ? blk : 0) * lpi * MSLOT;   // an idle block shadows block 0 and stores to the dump
-        const int oAH = mxAH + 2 * (4 * r + c), oCol = mxCol + 4 * r + (c == 1 ? 2 : 0), oB = mxCol + 4 * r, oRow = mxRow + 2 * c;
+        const int oAH = mxAH + 2 * (4 * r + c), oAT = mxAH + 2 * (4 * c + r), oCol = mxCol + 4 * r + (c >= 1 ? 2 : 0), oB = mxCol + 4 * r,
+                  oBc = mxCol + 4 * c, oRow = mxRow + 2 * c;
         // store targets: slot-relative for lanes with something to store, else the dump pair (stride 0)
-        const bool hasM = live && (c < 2 || r == 0);
-        double *const wP = live ? S0 + oAH + 1 : ms + mxDump;
-        double *const wM = hasM ? S0 + (c == 0 ? mxK + r : (c == 1 ? mxp + r : (c == 2 ? mxkff : mxLi))) : ms + mxDump + 1;
-        const int sP = live ? MSLOT : 0, sM = hasM ? MSLOT : 0;
+        double *const dump = ms + mxDump;
+        const bool has1 = live && c < 3, has2 = live && r == 0 && c < 3, has3 = live && c == 1;
+        double *const wP = live ? S0 + oAH + 1 : dump;
+        double *const wA = live ? S0 + oAT : dump + 1;
+        double *const w1 = has1 ? S0 + (c == 0 ? mxK + r : (c == 1 ? mxCol + 4 * r + 3 : mxRow + 2 * r)) : dump;   // K[r] | d[r] | q[r]
+        double *const w2 = has2 ? S0 + mxMisc + c : dump + 1;                                                      // 1/R | kff | beta
+        double *const w3 = has3 ? S0 + mxCol + 4 * r + 1 : dump;                                                   // p[r]
+        const int sL = live ? MSLOT : 0, s1 = has1 ? MSLOT : 0, s2 = has2 ? MSLOT : 0, s3 = has3 ? MSLOT : 0;
         double Pm, pcol;
         {
             const double *sl = S0 + N * MSLOT;
             Pm = sl[oAH + 1];
-            pcol = c == 1 ? sl[oCol + 1] : 0.0;   // g_x of the terminal stage
+            pcol = c == 1 ? sl[oCol + 1] : 0.0;   // g_x of the terminal stage (column 1)
         }
-        bool ok = true;
-        // the operands of a stage do not depend on the recursion: those of stage kk - 1 are fetched while stage kk is computed
-        mx_d2 nah, ncp, nrp;
-        double nBr;
-        auto fetch = [&](int kk) {
-            const double *sl = S0 + kk * MSLOT;
-            nah = lds_pair(sl + oAH), ncp = lds_pair(sl + oCol), nrp = lds_pair(sl + oRow), nBr = sl[oB];
+        double okacc = 1.0;             // > 0 while every pivot was positive
+        auto load = [&](MxOps &o, int kk) {
+            const double *sl = S0 + (kk > 0 ? kk : 0) * MSLOT;
+            o.ah = lds_pair(sl + oAH), o.cp = lds_pair(sl + oCol), o.rp = lds_pair(sl + oRow), o.Br = sl[oB], o.At = sl[oAT], o.Bc = sl[oBc];
         };
-        fetch(N - 1);
-        for (int kk = N - 1; kk >= 0; --kk) {
-            const double Am = nah.x, CH = nah.y, Br = nBr;
-            const double Wb = c < 2 ? ncp.x : 0.0, CZc = c < 2 ? ncp.y : 0.0, CB = nrp.x, CZr = r == 0 ? nrp.y : 0.0;
-            fetch(kk > 0 ? kk - 1 : 0);
-            const double X1 = mfma4(Pm, Am, 0.0);
-            const double Y = mfma4(Pm, Wb, pcol);
-            const double Qt = mfma4(Am, X1, CH);
+        double sAcl = 0.0, sV1 = 0.0, sV2 = 0.0, sV3 = 0.0;   // results of a step
+        // the arithmetic of one step.  PIN: the step of stage 0 in Q-mode (u_0 pinned: K_0 = 0, kff_0 = 0, P_0 = Q)
+        auto head = [&](const MxOps &o, double &Y, double &X1) {
+            Y = mfma4(Pm, o.cp.x, pcol);          // column 3 of W is never read: bb there as well (no select)
+            X1 = mfma4(Pm, o.ah.x, 0.0);
+        };
+        auto tail = [&](const MxOps &o, double Y, double X1, bool pin) {
+            const double Am = o.ah.x, CZc = c < 2 ? o.cp.y : 0.0;
+            const double Yb = quad_bcast<0>(Y);
             const double Zc = mfma4(Am, Y, CZc);
-            const double Zr = mfma4(Y, Am, CZr);
-            const double Zb = mfma4(Br, Y, CB);
+            const double Zb = mfma4(o.Br, Y, o.rp.x);
+            const double Qt = mfma4(Am, X1, o.ah.y);
+            const double Zr = mfma4(Yb, Am, o.rp.y);            // every row = S'
             const double R = quad_bcast<0>(Zb), mvu = quad_bcast<1>(Zb), Sr = quad_bcast<0>(Zc);
-            const bool pin = kk == 0 && qmode;
-            ok = ok && (R > 0.0 || pin);
-            const double Rinv = fast_rcp(R);
-            const double Kr = pin ? 0.0 : Sr * Rinv, kf = pin ? 0.0 : mvu * Rinv;
-            const double pnew = fma(-Kr, mvu, Zc);   // meaningful in column 1
-            pcol = c == 1 ? pnew : 0.0;
-            const double Xb = r == 0 ? Zr : 0.0;
-            const double Xa = pin ? 0.0 : -Xb * Rinv;
-            Pm = mfma4(Xa, Xb, Qt);
-            wP[kk * sP] = Pm;
-            wM[kk * sM] = c == 0 ? Kr : (c == 1 ? pnew : (c == 2 ? kf : Rinv));
+            okacc = (R > 0.0 || pin) ? okacc : 0.0;
+            const double Rinv = pin ? 0.0 : fast_rcp(R);
+            const double Kr = Sr * Rinv;
+            Pm = fma(-Kr, Zr, Qt);                              // P_k = Q - K S'
+            const double t = fma(-Kr, Zb, Zc);                  // own column: p_k (c = 1), q_k (c = 2)
+            pcol = c == 1 ? t : 0.0;
+            const double kf = mvu * Rinv;
+            sAcl = fma(-o.Bc, Kr, o.At);                        // Acl(c, r) = A(c, r) - B[c] K[r]
+            const double dk = fma(-o.Br, kf, o.cp.x);           // c = 1: bb[r] - B[r] kff
+            sV1 = c == 0 ? Kr : (c == 1 ? dk : t);              // K[r] | d[r] | q[r]
+            sV2 = c == 0 ? Rinv : (c == 1 ? kf : Zb);           // 1/R | kff | beta
+            sV3 = t;
+        };
+        auto store = [&](int kk) {
+            wP[kk * sL] = Pm;
+            wA[kk * sL] = sAcl;
+            w1[kk * s1] = sV1;
+            w2[kk * s2] = sV2;
+            if constexpr (WANT_P) w3[kk * s3] = sV3;
+        };
+#if MPCRL_MX_TWOSETS
+        MxOps oa, ob;
+        double Y, X1;
+        load(oa, N - 1);
+        load(ob, N - 2);
+        head(oa, Y, X1);
+        __builtin_amdgcn_sched_barrier(0);
+        const MxOps o0 = oa;
+        load(oa, N - 3);
+        __builtin_amdgcn_sched_barrier(0);
+        tail(o0, Y, X1, false);
+        auto step = [&](MxOps &o, int kk, bool pin) {
+            head(o, Y, X1);
+            __builtin_amdgcn_sched_barrier(0);
+            store(kk + 1);
+            const MxOps oc = o;
+            load(o, kk - 2);
+            __builtin_amdgcn_sched_barrier(0);
+            tail(oc, Y, X1, pin);
+        };
+        int kk = N - 2;
+        for (; kk >= 2; kk -= 2) {
+            step(ob, kk, false);
+            step(oa, kk - 1, false);
         }
-        if (live && r == 0 && c == 0) ms[mxFlag + blk] = ok ? 1.0 : 0.0;
+        if (kk == 1) {
+            step(ob, 1, false);
+            step(oa, 0, qmode);
+        } else if (kk == 0)
+            step(ob, 0, qmode);
+        store(0);
+#else
+        // the operands of a stage do not depend on the recursion: those of stage kk - 1 are fetched while stage kk is computed
+        MxOps on;
+        load(on, N - 1);
+        for (int kk = N - 1; kk >= 0; --kk) {
+            const MxOps o = on;
+            load(on, kk - 1);
+            double Y, X1;
+            head(o, Y, X1);
+            tail(o, Y, X1, kk == 0 && qmode);
+            store(kk);
+        }
+#endif
+        if (live && r == 0 && c == 0) ms[mxFlag + blk] = okacc;
     }
-    // slot -> stage lane: the factors of this stage
-    MPCRL_DI bool mx_fetch(const double *g) {
+    // One affine chain over the horizon on the matrix cores, all four columns of a block carrying the same vector:
+    //   FWD   v_{k+1} = Acl_k v_k + d_k   (k = 0 .. N-1, v_0 = 0),    d_k at [35 + 4 r] of slot k, v_{k+1} -> [49 + 2 r] of slot k+1
+    //   !FWD  v_k = Acl_k' v_{k+1} + c_k  (k = N-1 .. 0, v_N = c_N),  c_k at [35 + 4 r] of slot k, v_k     -> [33 + 4 r] of slot k
+    // mfma(X, V, C) = X'V + C: the forward chain reads Acl transposed out of the slot, the backward chain as it lies.
+    template <bool FWD>
+    MPCRL_DI void mx_chain() {
+        const int l = threadIdx.x & 63, r = l >> 4, blk = (l >> 2) & 3, c = l & 3;
+        const int ipw = min(64 / lpi, M::MAX_IPW);
+        const bool live = blk < ipw;
+        const double *S0 = ms + (live ? blk : 0) * lpi * MSLOT;
+        const int oX = mxAH + (FWD ? 2 * (4 * c + r) : 2 * (4 * r + c)), oC = mxCol + 4 * r + 3;
+        const bool wr = live && c == 0;
+        double *const wO = wr ? ms + (S0 - ms) + (FWD ? mxRow + 2 * r + 1 : mxCol + 4 * r + 1) : ms + mxDump;
+        const int sO = wr ? MSLOT : 0;
+        double V = 0.0;
+        if constexpr (!FWD) {
+            V = S0[N * MSLOT + oC];
+            wO[N * sO] = V;   // p_N
+        }
+        // operands DEPTH steps ahead in a ring of register sets: a load issued in one step is first waited for DEPTH steps later, so
+        // the LDS round trip (longer than the MFMA's dependent latency) stays off the chain
+#ifndef MPCRL_CHAIN_DEPTH
+#define MPCRL_CHAIN_DEPTH 3   // measured: 3 beats 2 and 4 (4 costs registers the kernel does not have)
+#endif
+        constexpr int DEPTH = MPCRL_CHAIN_DEPTH;
+        auto slot_of = [&](int s_) { const int sc = s_ < N ? s_ : N - 1; return FWD ? sc : N - 1 - sc; };   // stage of chain step s_ (clamped)
+        double Xr[DEPTH], Cr[DEPTH];
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) Xr[j] = S0[slot_of(j) * MSLOT + oX], Cr[j] = S0[slot_of(j) * MSLOT + oC];
+        int s_ = 0;
+        for (; s_ + DEPTH <= N; s_ += DEPTH) {
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) {
+                V = mfma4(Xr[j], V, Cr[j]);
+                wO[(FWD ? slot_of(s_ + j) + 1 : slot_of(s_ + j)) * sO] = V;
+                Xr[j] = S0[slot_of(s_ + j + DEPTH) * MSLOT + oX], Cr[j] = S0[slot_of(s_ + j + DEPTH) * MSLOT + oC];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DEPTH - 1; ++j)
+            if (s_ + j < N) {
+                V = mfma4(Xr[j], V, Cr[j]);
+                wO[(FWD ? slot_of(s_ + j) + 1 : slot_of(s_ + j)) * sO] = V;
+            }
+    }
+    // Predictor / adjoint solve: publish, factor, forward chain; the stage lane gets Dx, Du (and with WANT_P the factors needed for
+    // Dnu, see mx_dnu).  Returns false where the factorisation met a non-positive pivot.
+    template <bool WANT_P, class HF>
+    MPCRL_DI bool mx_pred(HF Hs, const double *g, const double *bb) {
+        mx_publish(Hs, g, bb);
+        wave_lds_sync();
+        PHW(12);
+        mx_factor<WANT_P>();
+        wave_lds_sync();
+        PHW(13);
+        mx_chain<true>();
+        wave_lds_sync();
+        PHW(3);
         const double *sl = ms + (threadIdx.x & 63) * MSLOT;
+        const mx_d2 k01 = lds_pair(sl + mxK), k23 = lds_pair(sl + mxK + 2), rk = lds_pair(sl + mxMisc);
+        const double Kl[NX] = {k01.x, k01.y, k23.x, k23.y};
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Dx[i] = first ? 0.0 : sl[mxRow + 2 * i + 1];
+        double a = -rk.y;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) a = fma(-Kl[j], Dx[j], a);
+        Du[0] = term ? 0.0 : a;
+        PHW(14);
+        return ms[mxFlag + blkidx] != 0.0;
+    }
+    // Corrector: new right-hand side g (bb unchanged), same factorisation: backward chain, feed-forward terms, forward chain
+    MPCRL_DI void mx_corr(const double *g, const double *bb) {
+        double *sl = ms + (threadIdx.x & 63) * MSLOT;
+        const mx_d2 k01 = lds_pair(sl + mxK), k23 = lds_pair(sl + mxK + 2);
+        const double Kl[NX] = {k01.x, k01.y, k23.x, k23.y};
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const double q_ = sl[mxRow + 2 * i];
+            sl[mxCol + 4 * i + 3] = term ? g[NU + i] : fma(-Kl[i], g[0], q_ + g[NU + i]);   // c_k = q_k + g_x - K' g_u; c_N = g_x
+        }
+        wave_lds_sync();
+        PHW(5);
+        mx_chain<false>();
+        wave_lds_sync();
+        PHW(6);
+        // kff_k = (g_u + beta_k + B_k' p_{k+1}) / R_k,  d_k = bb_k - B_k kff_k   (stage-parallel: p_{k+1} is read out of the next slot)
+        const double *nx_ = (term || (threadIdx.x & 63) == 63) ? sl : sl + MSLOT;   // (lane 63 has no slot behind it)
+        const mx_d2 rk = lds_pair(sl + mxMisc);
+        double mvu = g[0] + sl[mxMisc + 2];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) mvu = fma(Bm[i], nx_[mxCol + 4 * i + 1], mvu);
+        const double kffc = mvu * rk.x;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) sl[mxCol + 4 * i + 3] = fma(-Bm[i], kffc, bb[i]);
+        wave_lds_sync();
+        PHW(2);
+        mx_chain<true>();
+        wave_lds_sync();
+        PHW(7);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Dx[i] = first ? 0.0 : sl[mxRow + 2 * i + 1];
+        double a = -kffc;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) a = fma(-Kl[j], Dx[j], a);
+        Du[0] = term ? 0.0 : a;
+        mx_dnu(g, false);
+        PHW(14);
+    }
+    // Dnu_k = P_k Dx_k + p_k (multipliers of the arriving dynamics).  own_p: the terminal lane's p_N is its own g_x (predictor /
+    // adjoint right-hand side, where the slots hold p_k for k < N only); after the backward chain p_N is in the slot as well
+    MPCRL_DI void mx_dnu(const double *g, bool own_p) {
+        const double *sl = ms + (threadIdx.x & 63) * MSLOT;
+        double Pl[NPK];
 #pragma unroll
         for (int i = 0; i < NX; ++i)
 #pragma unroll
-            for (int j = 0; j <= i; ++j) P[sym(i, j)] = sl[mxAH + 2 * (4 * i + j) + 1];
+            for (int j = 0; j <= i; ++j) Pl[sym(i, j)] = sl[mxAH + 2 * (4 * i + j) + 1];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) p[i] = term ? g[NU + i] : sl[mxp + i];
-        if (!term) {
+        for (int i = 0; i < NX; ++i) {
+            double a = (own_p && term) ? g[NU + i] : sl[mxCol + 4 * i + 1];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) K[i] = sl[mxK + i];
-            kff[0] = sl[mxkff], Li[0] = sl[mxLi];
+            for (int j = 0; j < NX; ++j) a = fma(Pl[sym(i, j)], Dx[j], a);
+            Dnu[i] = first ? 0.0 : a;
         }
-        return ms[mxFlag + blkidx] != 0.0;
     }
-    bool mx_dyn_dirty = true;   // A, B changed since they were last published (set by linearize)
-    template <class HF>
-    MPCRL_DI bool mx_backward(HF Hs, const double *g, const double *bb) {
-        mx_publish(Hs, g, bb, mx_dyn_dirty);
-        mx_dyn_dirty = false;
-        wave_lds_sync();
-        PHW(12);
-        mx_factor();
-        wave_lds_sync();
-        PHW(13);
-        const bool okf_ = mx_fetch(g);
-        PHW(14);
-        return okf_;
-    }
+    bool mx_dyn_dirty = true;   // (kept for the stage-layout path's linearize; the matrix-layout path republishes everything)
 
     // ---- backward sweep over the horizon (serial in k; the lanes of all instances in the wave step together).
     // (P, p) of stage k+1 arrive by a one-lane shift.  For the vector-only sweeps (corrector, extra right-hand sides) the
@@ -948,12 +1125,13 @@ struct SmallSolver {
             bool okf;
             PHW(1);
             if constexpr (MX)
-                okf = mx_backward(Hs, rt, rb);
-            else
+                okf = mx_pred<false>(Hs, rt, rb);
+            else {
                 okf = backward<true>(Hs, rt, rb);
-            PHW(2);
-            forward(rb);
-            PHW(3);
+                PHW(2);
+                forward(rb);
+                PHW(3);
+            }
             double okbad = okf ? 0.0 : 1.0;   // reduced together with the predictor's step length below
             double rmax = 1.0;                // rmax = 1 / (step to the boundary), at least 1
             // mu_aff(a) = sum (lam + a dlam)(t + a dt) = sum lam t + a c1 + a^2 c2: the two sums travel in the reduction tree of the step
@@ -998,11 +1176,15 @@ struct SmallSolver {
                 barrier_terms(i, v, 1, smu, dgi, ec);
                 rt[i] = rg[i] + ec;
             }
-            PHW(5);
-            backward<false>(Hs, rt, rb);
-            PHW(6);
-            forward(rb);
-            PHW(7);
+            if constexpr (MX)
+                mx_corr(rt, rb);
+            else {
+                PHW(5);
+                backward<false>(Hs, rt, rb);
+                PHW(6);
+                forward(rb);
+                PHW(7);
+            }
             rmax = 1.0;
             double d12[2] = {0.0, 0.0};   // sum lam t after the step = musum + alpha d12[0] + alpha^2 d12[1]
 #pragma unroll
@@ -1147,16 +1329,18 @@ struct SmallSolver {
         for (int iu = 0; iu < NU; ++iu) {
 #pragma unroll
             for (int i = 0; i < NW; ++i) rt[i] = (first && i == iu) ? -1.0 : 0.0;
-            if (iu == 0) {
-                bool okf;
-                if constexpr (MX)
-                    okf = mx_backward(Hs, rt, zero);
-                else
-                    okf = backward<true>(Hs, rt, zero);
+            if constexpr (MX) {   // NU = 1: one adjoint solve
+                const bool okf = mx_pred<true>(Hs, rt, zero);
+                mx_dnu(rt, true);
                 okall = seg_max<M::SEG_SKIP>(okf ? 0.0 : 1.0, k, lpi, base) < 0.5;
-            } else
-                backward<false>(Hs, rt, zero);
-            forward(zero);
+            } else {
+                if (iu == 0) {
+                    const bool okf = backward<true>(Hs, rt, zero);
+                    okall = seg_max<M::SEG_SKIP>(okf ? 0.0 : 1.0, k, lpi, base) < 0.5;
+                } else
+                    backward<false>(Hs, rt, zero);
+                forward(zero);
+            }
             double ynn[NX], yv[NW];
 #pragma unroll
             for (int i = 0; i < NX; ++i) ynn[i] = lane_dn(Dnu[i]);

@@ -1,5 +1,5 @@
 """Cycle breakdown of the cartpole solve kernel by phase (per wavefront).  Needs a library built with -DMPCRL_PROFILE_PHASES:
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DMPCRL_PROFILE_PHASES -Iinclude mpc4rl_amd/csrc/mpcrl_api.hip -o mpc4rl_amd/libmpcrl_hip.so
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -amdgpu-mfma-vgpr-form -DMPCRL_PROFILE_PHASES -Iinclude mpc4rl_amd/csrc/mpcrl_api.hip -o mpc4rl_amd/libmpcrl_hip.so
 """
 import ctypes as C, sys
 import numpy as np, torch
@@ -12,9 +12,9 @@ x0 = torch.as_tensor(x0, device='cuda')
 lib = _lib.load(); out = (C.c_ulonglong * 16)()
 mpc.solve(x0, cold=True); torch.cuda.synchronize(); lib.mpcrl_debug_phases(out, 1)
 r = mpc.solve(x0, cold=True); torch.cuda.synchronize(); lib.mpcrl_debug_phases(out, 1)
-names = ["0 residuals + stop test", "1 predictor barrier terms", "2 (factor: see 12-14)", "3 forward sweep (pred)",
-         "4 predictor rows, mu_aff", "5 corrector barrier terms", "6 backward vector sweep", "7 forward sweep (corr)",
-         "8 step length + update", "9 SQP: linearise + residuals", "10 SQP: step, tolerances", "11 QP setup", "12 factor: publish", "13 factor: MFMA sweep", "14 factor: fetch", "15"]
+names = ["0 residuals + stop test", "1 predictor barrier terms", "2 corrector: kff, d (stage lanes)", "3 forward chain (pred)",
+         "4 predictor rows, mu_aff", "5 corrector barrier terms, c", "6 backward chain", "7 forward chain (corr)",
+         "8 step length + update", "9 SQP: linearise + residuals", "10 SQP: step, tolerances", "11 QP setup", "12 factor: publish", "13 factor: MFMA sweep", "14 fetch Dx, Du (Dnu)", "15 (sliced: rotation)"]
 waves = (B + 2) // 3
 tot = sum(out[i] for i in range(16))
 print("IPM iterations mean %.1f, SQP mean %.1f" % (r.iters[:, 1].float().mean().item(), r.iters[:, 0].float().mean().item()))

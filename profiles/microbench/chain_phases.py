@@ -1,6 +1,6 @@
 """Phase breakdown of the chain kernel (one wavefront per instance): shader-clock ticks of lane 0 per phase, summed over the
 batch.  Needs a library built with -DMPCRL_PROFILE_PHASES, selected through MPCRL_LIB_PATH:
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DMPCRL_PROFILE_PHASES mpc4rl_amd/csrc/mpcrl_api.hip -o mpc4rl_amd/libmpcrl_prof.so
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -amdgpu-mfma-vgpr-form -DMPCRL_PROFILE_PHASES mpc4rl_amd/csrc/mpcrl_api.hip -o mpc4rl_amd/libmpcrl_prof.so
   MPCRL_LIB_PATH=mpc4rl_amd/libmpcrl_prof.so python profiles/microbench/chain_phases.py [n_mass]
 """
 import ctypes as C, numpy as np, torch, sys, time
