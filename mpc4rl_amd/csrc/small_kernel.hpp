@@ -83,6 +83,19 @@ MPCRL_DI double fast_rcp(double x) {
     return fma(fma(-x, r, 1.0), r, r);
 }
 
+// lane select by a compile-time lane mask (bit l = lane l takes `yes`): two v_cndmask_b32 as inline assembly, so that it STAYS a
+// select (a ternary on a lane-dependent condition with non-trivial arms may be turned into exec-mask branches)
+MPCRL_DI double lane_select(unsigned long long mask, double yes, double no) {
+    int yl = __double2loint(yes), yh = __double2hiint(yes), nl = __double2loint(no), nh = __double2hiint(no), rl, rh;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(rl) : "v"(nl), "v"(yl), "s"(mask));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(rh) : "v"(nh), "v"(yh), "s"(mask));
+    return __hiloint2double(rh, rl);
+}
+constexpr unsigned long long LANES_C0 = 0x1111111111111111ull, LANES_C1 = 0x2222222222222222ull, LANES_C01 = 0x3333333333333333ull;   // lane & 3 == 0 / == 1 / < 2
+#ifndef MPCRL_V_ASMSEL
+#define MPCRL_V_ASMSEL 1
+#endif
+
 #ifndef MPCRL_IPM_SCALE_RES
 #define MPCRL_IPM_SCALE_RES 1
 #endif
@@ -202,9 +215,16 @@ struct SmallSolver {
     MPCRL_DI double dvc(const double *ax, const double *au, int i) const {
         return i < NU ? (term ? 0.0 : au[i < NU ? i : 0]) : ax[i >= NU ? i - NU : 0];
     }
-    MPCRL_DI double Aget(int i) const { return A[i]; }
+    // A_k of the matrix-layout path (NX = 4, NU = 1) lives in the stage's LDS slot only — the linearisation writes it there, the
+    // sweeps and the few stage-lane uses (residuals of a QP's first iteration, NLP stationarity) read it there: 16 doubles per lane
+    // that the register allocator no longer carries through the whole interior-point loop
+    MPCRL_DI double Aget(int i) const {
+        if constexpr (NX == 4 && NU == 1) return ms[(threadIdx.x & 63) * 66 + 2 * i]; else return A[i];
+    }
     MPCRL_DI double Bget(int i) const { return Bm[i]; }
-    MPCRL_DI void Aset(int i, double v) { A[i] = v; }
+    MPCRL_DI void Aset(int i, double v) {
+        if constexpr (NX == 4 && NU == 1) ms[(threadIdx.x & 63) * 66 + 2 * i] = v; else A[i] = v;
+    }
     MPCRL_DI void Bset(int i, double v) { Bm[i] = v; }
     MPCRL_DI double BA(int m, int j) const { return j < NU ? Bget(m * NU + (j < NU ? j : 0)) : Aget(m * NX + (j >= NU ? j - NU : 0)); }
     // slack(v) of the bound row on side sd, coordinate i, at value v
@@ -495,11 +515,12 @@ struct SmallSolver {
     //   Q  = mfma(A, X1, Hxx + D)  = A' P A + Hxx + D_x       Zc = mfma(A, Y, [Hxu | g_x | 0 | 0]) = [S | mv_x | A' P bb | 0]  (columns)
     //   Zr = mfma(Y, A, [Hux; 0])  : row 0 = S'               Zb = mfma(BB, Y, [Huu + D_u | g_u | 0 | 0]): every row = [R, mv_u, beta, 0]
     //   K = S / R, kff = mv_u / R,  t = Zc - K Zb (own column): p_k in column 1, q_k = Acl_k' P_{k+1} bb_k in column 2,
-    //   P = mfma(-K' (row 0), S' (row 0), Q) = Q - K S',  Acl_k = A - B K (one FMA per element, stored over A),
+    //   P = Q - K S' (one fma per element: S' arrives broadcast over the rows from an MFMA on the column-0 broadcast of Y),
     //   d_k = bb - B kff.  7 MFMAs + ~50 VALU per step instead of ~300 VALU instructions.
     //
-    // Vector sweeps (round 3): with the closed-loop matrices Acl_k left in the slots by the factor sweep, both vector recursions
-    // are AFFINE CHAINS  v <- Acl v + c  on the matrix cores, one dependent MFMA per stage (mx_chain):
+    // Vector sweeps (round 3): on the closed-loop matrices Acl_k = A_k - B_k K_k (one fma per element out of A, B, K in the slot,
+    // off the chain) both vector recursions are AFFINE CHAINS  v <- Acl v + c  on the matrix cores, one dependent MFMA per stage
+    // (mx_chain):
     //   forward   Dx_{k+1} = Acl_k Dx_k + d_k,                 d_k = bb_k - B_k kff_k
     //   backward  p_k      = Acl_k' p_{k+1} + c_k,             c_k = q_k + g_x - K_k' g_u     (q_k does not depend on the right-hand side)
     // and everything off the chain is stage-parallel in the stage lanes: Du_k = -K_k Dx_k - kff_k, the corrector's
@@ -508,7 +529,8 @@ struct SmallSolver {
     static constexpr bool MX = (NX == 4 && NU == 1);
     // Slot of one stage (doubles; 16-byte aligned pairs so that one ds_read_b128 brings two operands — LDS instructions, not
     // bytes, are what the sweeps wait for).  Everything is (re)published by the stage lane before every factor sweep:
-    //   [0,32)   (A(r,c), Hxx(r,c) + D_x) pairs at 2 (4 r + c); the factor sweep overwrites them with (Acl_k(r,c), P_k(r,c))
+    //   [0,32)   (A(r,c), Hxx(r,c) + D_x) pairs at 2 (4 r + c); A is written by the linearisation and stays, the factor sweep
+    //            overwrites the second member with P_k(r,c)
     //   [32,48)  per row r: (B[r], Hxu[r]) at 32 + 4 r — the factor sweep / the backward chain leave p_k[r] in the second member;
     //            (bb[r], g_x[r]) at 34 + 4 r — second member: d_k[r] after the factor sweep, then c_k[r], then the corrector's d_k[r]
     //   [48,56)  per column c: ([Huu + D_u | g_u | 0 | 0][c], Hxu[c]) at 48 + 2 c — afterwards (q_k[c], Dx_k[c])
@@ -572,7 +594,7 @@ struct SmallSolver {
         *(mx_d2 *)__builtin_assume_aligned(q, 16) = v;
     }
 
-    // stage lane -> slot: the whole linearisation of the stage (the sweeps overwrite most of it), 28 ds_write_b128
+    // stage lane -> slot: everything of the stage but A_k (written by the linearisation, never overwritten); the sweeps overwrite most of it
     template <class HF>
     MPCRL_DI void mx_publish(HF Hs, const double *g, const double *bb) {
         double *sl = ms + (threadIdx.x & 63) * MSLOT;
@@ -580,8 +602,7 @@ struct SmallSolver {
         for (int i = 0; i < NX; ++i)
 #pragma unroll
             for (int j = 0; j < NX; ++j)
-                lds_pair_store(sl + mxAH + 2 * (4 * i + j), A[i * NX + j],
-                               fma(hscale, Hs(NU + (i > j ? i : j), NU + (i > j ? j : i)), i == j ? Dg[NU + i] : 0.0));
+                sl[mxAH + 2 * (4 * i + j) + 1] = fma(hscale, Hs(NU + (i > j ? i : j), NU + (i > j ? j : i)), i == j ? Dg[NU + i] : 0.0);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const double hxu = hscale * Hs(NU + i, 0);
@@ -596,25 +617,19 @@ struct SmallSolver {
     // broadcast of Y, so neither a seventh MFMA nor its operand selects sit on the chain.
     struct MxOps {
         mx_d2 ah, cp, rp;
-        double Br, At, Bc;
+        double Br;
     };
-#ifndef MPCRL_MX_TWOSETS
-#define MPCRL_MX_TWOSETS 0   // 1: two operand sets (loads two steps ahead, no register rotation) and stores deferred into the next step's
-                             //    MFMA shadow — measured slower while the kernel is short of registers (138 spilled registers, 300 B scratch)
-#endif
     template <bool WANT_P>
     MPCRL_DI void mx_factor() {
         const int l = threadIdx.x & 63, r = l >> 4, blk = (l >> 2) & 3, c = l & 3;
         const int ipw = min(64 / lpi, M::MAX_IPW);
         const bool live = blk < ipw;
         double *S0 = ms + (live ? blk : 0) * lpi * MSLOT;   // an idle block shadows block 0 and stores to the dump
-        const int oAH = mxAH + 2 * (4 * r + c), oAT = mxAH + 2 * (4 * c + r), oCol = mxCol + 4 * r + (c >= 1 ? 2 : 0), oB = mxCol + 4 * r,
-                  oBc = mxCol + 4 * c, oRow = mxRow + 2 * c;
+        const int oAH = mxAH + 2 * (4 * r + c), oCol = mxCol + 4 * r + (c >= 1 ? 2 : 0), oB = mxCol + 4 * r, oRow = mxRow + 2 * c;
         // store targets: slot-relative for lanes with something to store, else the dump pair (stride 0)
-        double *const dump = ms + mxDump;
+        double *const dump = ms + mxDump;   // (every lane its own dump word instead of one for all: measured, no difference)
         const bool has1 = live && c < 3, has2 = live && r == 0 && c < 3, has3 = live && c == 1;
         double *const wP = live ? S0 + oAH + 1 : dump;
-        double *const wA = live ? S0 + oAT : dump + 1;
         double *const w1 = has1 ? S0 + (c == 0 ? mxK + r : (c == 1 ? mxCol + 4 * r + 3 : mxRow + 2 * r)) : dump;   // K[r] | d[r] | q[r]
         double *const w2 = has2 ? S0 + mxMisc + c : dump + 1;                                                      // 1/R | kff | beta
         double *const w3 = has3 ? S0 + mxCol + 4 * r + 1 : dump;                                                   // p[r]
@@ -628,16 +643,20 @@ struct SmallSolver {
         double okacc = 1.0;             // > 0 while every pivot was positive
         auto load = [&](MxOps &o, int kk) {
             const double *sl = S0 + (kk > 0 ? kk : 0) * MSLOT;
-            o.ah = lds_pair(sl + oAH), o.cp = lds_pair(sl + oCol), o.rp = lds_pair(sl + oRow), o.Br = sl[oB], o.At = sl[oAT], o.Bc = sl[oBc];
+            o.ah = lds_pair(sl + oAH), o.cp = lds_pair(sl + oCol), o.rp = lds_pair(sl + oRow), o.Br = sl[oB];
         };
-        double sAcl = 0.0, sV1 = 0.0, sV2 = 0.0, sV3 = 0.0;   // results of a step
+        double sV1 = 0.0, sV2 = 0.0, sV3 = 0.0;   // results of a step
         // the arithmetic of one step.  PIN: the step of stage 0 in Q-mode (u_0 pinned: K_0 = 0, kff_0 = 0, P_0 = Q)
         auto head = [&](const MxOps &o, double &Y, double &X1) {
             Y = mfma4(Pm, o.cp.x, pcol);          // column 3 of W is never read: bb there as well (no select)
             X1 = mfma4(Pm, o.ah.x, 0.0);
         };
         auto tail = [&](const MxOps &o, double Y, double X1, bool pin) {
+#if MPCRL_V_ASMSEL
+            const double Am = o.ah.x, CZc = lane_select(LANES_C01, o.cp.y, 0.0);
+#else
             const double Am = o.ah.x, CZc = c < 2 ? o.cp.y : 0.0;
+#endif
             const double Yb = quad_bcast<0>(Y);
             const double Zc = mfma4(Am, Y, CZc);
             const double Zb = mfma4(o.Br, Y, o.rp.x);
@@ -649,53 +668,28 @@ struct SmallSolver {
             const double Kr = Sr * Rinv;
             Pm = fma(-Kr, Zr, Qt);                              // P_k = Q - K S'
             const double t = fma(-Kr, Zb, Zc);                  // own column: p_k (c = 1), q_k (c = 2)
+#if MPCRL_V_ASMSEL
+            pcol = lane_select(LANES_C1, t, 0.0);
+#else
             pcol = c == 1 ? t : 0.0;
+#endif
             const double kf = mvu * Rinv;
-            sAcl = fma(-o.Bc, Kr, o.At);                        // Acl(c, r) = A(c, r) - B[c] K[r]
             const double dk = fma(-o.Br, kf, o.cp.x);           // c = 1: bb[r] - B[r] kff
+#if MPCRL_V_ASMSEL
+            sV1 = lane_select(LANES_C0, Kr, lane_select(LANES_C1, dk, t));       // K[r] | d[r] | q[r]
+            sV2 = lane_select(LANES_C0, Rinv, lane_select(LANES_C1, kf, Zb));    // 1/R | kff | beta
+#else
             sV1 = c == 0 ? Kr : (c == 1 ? dk : t);              // K[r] | d[r] | q[r]
             sV2 = c == 0 ? Rinv : (c == 1 ? kf : Zb);           // 1/R | kff | beta
+#endif
             sV3 = t;
         };
         auto store = [&](int kk) {
             wP[kk * sL] = Pm;
-            wA[kk * sL] = sAcl;
             w1[kk * s1] = sV1;
             w2[kk * s2] = sV2;
             if constexpr (WANT_P) w3[kk * s3] = sV3;
         };
-#if MPCRL_MX_TWOSETS
-        MxOps oa, ob;
-        double Y, X1;
-        load(oa, N - 1);
-        load(ob, N - 2);
-        head(oa, Y, X1);
-        __builtin_amdgcn_sched_barrier(0);
-        const MxOps o0 = oa;
-        load(oa, N - 3);
-        __builtin_amdgcn_sched_barrier(0);
-        tail(o0, Y, X1, false);
-        auto step = [&](MxOps &o, int kk, bool pin) {
-            head(o, Y, X1);
-            __builtin_amdgcn_sched_barrier(0);
-            store(kk + 1);
-            const MxOps oc = o;
-            load(o, kk - 2);
-            __builtin_amdgcn_sched_barrier(0);
-            tail(oc, Y, X1, pin);
-        };
-        int kk = N - 2;
-        for (; kk >= 2; kk -= 2) {
-            step(ob, kk, false);
-            step(oa, kk - 1, false);
-        }
-        if (kk == 1) {
-            step(ob, 1, false);
-            step(oa, 0, qmode);
-        } else if (kk == 0)
-            step(ob, 0, qmode);
-        store(0);
-#else
         // the operands of a stage do not depend on the recursion: those of stage kk - 1 are fetched while stage kk is computed
         MxOps on;
         load(on, N - 1);
@@ -707,20 +701,21 @@ struct SmallSolver {
             tail(o, Y, X1, kk == 0 && qmode);
             store(kk);
         }
-#endif
         if (live && r == 0 && c == 0) ms[mxFlag + blk] = okacc;
     }
     // One affine chain over the horizon on the matrix cores, all four columns of a block carrying the same vector:
     //   FWD   v_{k+1} = Acl_k v_k + d_k   (k = 0 .. N-1, v_0 = 0),    d_k at [35 + 4 r] of slot k, v_{k+1} -> [49 + 2 r] of slot k+1
     //   !FWD  v_k = Acl_k' v_{k+1} + c_k  (k = N-1 .. 0, v_N = c_N),  c_k at [35 + 4 r] of slot k, v_k     -> [33 + 4 r] of slot k
-    // mfma(X, V, C) = X'V + C: the forward chain reads Acl transposed out of the slot, the backward chain as it lies.
+    // mfma(X, V, C) = X'V + C: the forward chain needs X(r,c) = Acl(c,r) = A(c,r) - B[c] K[r], the backward chain X(r,c) = Acl(r,c) =
+    // A(r,c) - B[r] K[c]; the operands of a step are fetched DEPTH steps ahead, so forming X is off the chain.
     template <bool FWD>
     MPCRL_DI void mx_chain() {
         const int l = threadIdx.x & 63, r = l >> 4, blk = (l >> 2) & 3, c = l & 3;
         const int ipw = min(64 / lpi, M::MAX_IPW);
         const bool live = blk < ipw;
         const double *S0 = ms + (live ? blk : 0) * lpi * MSLOT;
-        const int oX = mxAH + (FWD ? 2 * (4 * c + r) : 2 * (4 * r + c)), oC = mxCol + 4 * r + 3;
+        const int oA = mxAH + (FWD ? 2 * (4 * c + r) : 2 * (4 * r + c)), oBx = mxCol + 4 * (FWD ? c : r), oKx = mxK + (FWD ? r : c),
+                  oC = mxCol + 4 * r + 3;
         const bool wr = live && c == 0;
         double *const wO = wr ? ms + (S0 - ms) + (FWD ? mxRow + 2 * r + 1 : mxCol + 4 * r + 1) : ms + mxDump;
         const int sO = wr ? MSLOT : 0;
@@ -736,22 +731,26 @@ struct SmallSolver {
 #endif
         constexpr int DEPTH = MPCRL_CHAIN_DEPTH;
         auto slot_of = [&](int s_) { const int sc = s_ < N ? s_ : N - 1; return FWD ? sc : N - 1 - sc; };   // stage of chain step s_ (clamped)
-        double Xr[DEPTH], Cr[DEPTH];
+        double Ar[DEPTH], Br_[DEPTH], Kr_[DEPTH], Cr[DEPTH];
+        auto fetch = [&](int j, int s_) {
+            const double *sl = S0 + slot_of(s_) * MSLOT;
+            Ar[j] = sl[oA], Br_[j] = sl[oBx], Kr_[j] = sl[oKx], Cr[j] = sl[oC];
+        };
 #pragma unroll
-        for (int j = 0; j < DEPTH; ++j) Xr[j] = S0[slot_of(j) * MSLOT + oX], Cr[j] = S0[slot_of(j) * MSLOT + oC];
+        for (int j = 0; j < DEPTH; ++j) fetch(j, j);
         int s_ = 0;
         for (; s_ + DEPTH <= N; s_ += DEPTH) {
 #pragma unroll
             for (int j = 0; j < DEPTH; ++j) {
-                V = mfma4(Xr[j], V, Cr[j]);
+                V = mfma4(fma(-Br_[j], Kr_[j], Ar[j]), V, Cr[j]);
                 wO[(FWD ? slot_of(s_ + j) + 1 : slot_of(s_ + j)) * sO] = V;
-                Xr[j] = S0[slot_of(s_ + j + DEPTH) * MSLOT + oX], Cr[j] = S0[slot_of(s_ + j + DEPTH) * MSLOT + oC];
+                fetch(j, s_ + j + DEPTH);
             }
         }
 #pragma unroll
         for (int j = 0; j < DEPTH - 1; ++j)
             if (s_ + j < N) {
-                V = mfma4(Xr[j], V, Cr[j]);
+                V = mfma4(fma(-Br_[j], Kr_[j], Ar[j]), V, Cr[j]);
                 wO[(FWD ? slot_of(s_ + j) + 1 : slot_of(s_ + j)) * sO] = V;
             }
     }
