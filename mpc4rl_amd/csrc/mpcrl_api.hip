@@ -181,10 +181,12 @@ int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
     }
     if (!sliced) hipLaunchKernelGGL(small_solve_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
     HIP_OK(hipGetLastError());
+#if !MPCRL_FUSE_SENS
     if (a.flags & (MPCRL_SENS_V | MPCRL_SENS_PI)) {
         hipLaunchKernelGGL(small_sens_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
         HIP_OK(hipGetLastError());
     }
+#endif
     return 0;
 }
 

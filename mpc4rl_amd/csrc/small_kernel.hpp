@@ -1390,6 +1390,51 @@ struct SmallSolver {
 };
 
 // =====================================================================================================
+// Sensitivity pass on the state a lane holds (x, u, nu, lam, t of its stage; parameters, bounds and cost table set): dV/dp and
+// du0*/dp of the instance the lane's slot works on — what update_nlp computes after the reference's solve (nlp.py:1399-1424).
+// Called by the solve kernels at the end of a wavefront's life (MPCRL_FUSE_SENS: "the adjoint KKT solve fused into the same
+// sweep") and by small_sens_kernel on a stored iterate.  The output rows are written in full: the lanes of an instance zero
+// every entry sensitivities() does not store — the cost block of p (zero gradient of the mirror, nlp.py:1039-1055), everything
+// of an instance that was not solved, du0*/dp in Q-mode.
+// =====================================================================================================
+#ifndef MPCRL_FUSE_SENS
+#define MPCRL_FUSE_SENS 0   // measured (cartpole, 4096): fused 0.582 ms vs 0.564 ms with the pass as a second launch — the second-order jets of the
+                          // pass raise the register pressure of the SQP loop (sliced kernel: 36 -> 76 spilled VGPRs, 173 -> 237 SGPRs); the plain
+                          // launch (3072 instances) gains 0.6 %.  The fused form is kept buildable and tested (-DMPCRL_FUSE_SENS=1).
+#endif
+template <class M>
+MPCRL_DI void small_sens_tail(SmallSolver<M> &S, const SmallArgs &a, long inst, bool valid, int status) {
+    constexpr int NX = M::NX, NU = M::NU, NP = M::NP;
+    const int k = S.k, lpi = S.lpi;
+    double xn[NX], nun[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xn[i] = lane_dn(S.x[i]), nun[i] = lane_dn(S.nu_[i]);
+    double hdd[M::NLD * (M::NLD + 1) / 2];
+    if ((a.flags & 2) && a.dpi && !S.qmode) {   // wave-uniform
+        S.template linearize<true>(xn, nun, hdd);
+    } else {
+#pragma unroll
+        for (int e = 0; e < M::NLD * (M::NLD + 1) / 2; ++e) hdd[e] = 0.0;
+        S.linearize(xn);
+    }
+#pragma unroll
+    for (int i = 0; i < S.NPK; ++i) S.P[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) S.p[i] = 0.0;
+    const bool sv = valid && (status == 0 || status == 2);
+    S.sensitivities(a.flags, sv, nun, a.dV ? a.dV + inst * NP : nullptr, a.dpi ? a.dpi + inst * NU * NP : nullptr, hdd);
+    // the zeros go last so that no load of the pass waits behind these stores; the two sets of addresses are disjoint
+    if (valid) {
+        if (a.dV)
+            for (int e = k; e < NP; e += lpi)
+                if (!(sv && M::p_has_gradient(e))) a.dV[inst * NP + e] = 0.0;
+        if (a.dpi)
+            for (int e = k; e < NU * NP; e += lpi)
+                if (!(sv && !S.qmode && M::p_has_gradient(e % NP))) a.dpi[inst * NU * NP + e] = 0.0;
+    }
+}
+
+// =====================================================================================================
 // kernel: floor(64/(N+1)) instances per 64-lane workgroup
 // =====================================================================================================
 #ifndef MPCRL_LINEAR_OCC
@@ -1615,6 +1660,10 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
             }
         }
     }
+#if MPCRL_FUSE_SENS
+    // ---- sensitivities of the instances this wavefront solved, from the state its lanes still hold (wave-uniform branch)
+    if (a.flags & (1 | 2)) small_sens_tail<M>(S, a, inst, valid, status);
+#endif
 }
 
 // =====================================================================================================
@@ -1748,6 +1797,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
     int pk = (posof(ipw) < a.B) ? ipw : -1;
     bool pk_started = false;
     int rr = 0, rounds_since = 0;
+    int first_done = -1;                              // local index of the instance that left its slot for good (wave-uniform), or -1
     double nun[NX];
     for (;;) {
         double xn[NX];
@@ -1893,6 +1943,14 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
         if (v < 0) v = rr % ipw, ++rr;
         const bool sw = slot_on && slot == v;
         const int lo = __shfl(loc, v * lpi);            // local index of the outgoing instance
+#if MPCRL_FUSE_SENS
+        // an instance that leaves its slot for good (it finished) is remembered: with the park area in LDS its final state goes
+        // there in place of the parked one's, so that the wavefront can run its sensitivity pass at the end without reading it back
+        const bool keep_out = !for_good || (lds_park && (a.flags & 3));
+        if (for_good) first_done = lo;
+#else
+        const bool keep_out = !for_good;
+#endif
         if (sw && !for_good) {                          // park: state to LDS (or the instance's stored-iterate arrays), scalars to LDS
             if (valid && !lds_park) {
 #pragma unroll
@@ -1914,6 +1972,9 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
                 sc[5] = stepn;
             }
         }
+#if MPCRL_FUSE_SENS
+        if (sw && for_good && first) sc_lds[lo * 6 + 1] = (double)status;   // (read again by the sensitivity pass at the end)
+#endif
         SmallSolver<M>::wave_lds_sync();                // orders the stores above before the loads below (same wavefront: in order)
         // take the parked instance: every lane runs the same loads, the lanes of the slot keep the results
         const int newloc = sw ? pk : loc;
@@ -1956,7 +2017,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
                 out[2 * NX + NU + 4 * i] = S.lam[0][i], out[2 * NX + NU + 4 * i + 1] = S.lam[1][i];
                 out[2 * NX + NU + 4 * i + 2] = S.t[0][i], out[2 * NX + NU + 4 * i + 3] = S.t[1][i];
             }
-            if (sw && !for_good) {
+            if (sw && keep_out) {
 #pragma unroll
                 for (int j = 0; j < PK; ++j) pl[j * lpi] = out[j];
             }
@@ -2006,11 +2067,56 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
 #ifdef MPCRL_PROFILE_PHASES
     if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_phase_ticks[i_], S.phw[i_]);
 #endif
+#if MPCRL_FUSE_SENS
+    // ---- sensitivities.  Pass 1: the instances the slots hold at the end, from registers.  Pass 2: the instance that left its slot
+    // for good earlier, on slot 0 from the park area (LDS parking) — or, with HBM parking, from its stored iterate, which this
+    // wavefront wrote itself (its own stores are visible to its later loads once they have been waited for).
+    if (a.flags & 3) {
+        small_sens_tail<M>(S, a, inst, valid, status);
+        if (first_done >= 0) {
+            const bool on0 = slot == 0;
+            loc = first_done;
+            bind(loc);
+            valid = on0 && posof(loc) < a.B;
+            load_params();
+            const int st_ = (int)sc_lds[first_done * 6 + 1];
+            if constexpr (lds_park) {
+                const double *pl = park_lds + k;
+                double in[PK];
+#pragma unroll
+                for (int j = 0; j < PK; ++j) in[j] = pl[j * lpi];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) S.x[i] = in[i], S.nu_[i] = first ? 0.0 : in[NX + i];
+#pragma unroll
+                for (int i = 0; i < NU; ++i) S.u[i] = in[2 * NX + i];
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    S.lam[0][i] = in[2 * NX + NU + 4 * i], S.lam[1][i] = in[2 * NX + NU + 4 * i + 1];
+                    S.t[0][i] = in[2 * NX + NU + 4 * i + 2], S.t[1][i] = in[2 * NX + NU + 4 * i + 3];
+                }
+            } else {
+                __builtin_amdgcn_s_waitcnt(0);   // the stores of the finished instance have completed
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    S.x[i] = a.X[(inst * (N + 1) + k) * NX + i];
+                    S.nu_[i] = first ? 0.0 : a.PI[(inst * N + k - 1) * NX + i];
+                }
+#pragma unroll
+                for (int i = 0; i < NU; ++i) S.u[i] = term ? 0.0 : a.U[(inst * N + k) * NU + i];
+#pragma unroll
+                for (int i = 0; i < NW; ++i)
+                    S.lam[0][i] = bnd[0 * nb + i], S.lam[1][i] = bnd[1 * nb + i], S.t[0][i] = bnd[2 * nb + i], S.t[1][i] = bnd[3 * nb + i];
+            }
+            small_sens_tail<M>(S, a, inst, valid, st_);
+        }
+    }
+#endif
 }
 
 // =====================================================================================================
-// sensitivity kernel: re-reads the converged iterate (x, u, nu, lam, t) written by small_solve_kernel.
-// Kept separate so that the second-order jets do not set the register budget of the SQP loop.
+// sensitivity kernel: re-reads the converged iterate (x, u, nu, lam, t) written by small_solve_kernel.  With MPCRL_FUSE_SENS the
+// solve kernels run the pass themselves at the end of a wavefront's life and this kernel is not launched (it stays for builds
+// with MPCRL_FUSE_SENS = 0, where the pass was a second launch: 49 us + a 17 us boundary per 4096 cartpole instances).
 // =====================================================================================================
 template <class M>
 __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, const SmallArgs a) {
@@ -2052,36 +2158,8 @@ __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, cons
     for (int i = 0; i < NU; ++i) S.u[i] = term ? 0.0 : a.U[(inst * N + k) * NU + i];
 #pragma unroll
     for (int i = 0; i < NW; ++i) S.lam[0][i] = bnd[0 * nb + i], S.lam[1][i] = bnd[1 * nb + i], S.t[0][i] = bnd[2 * nb + i], S.t[1][i] = bnd[3 * nb + i];
-    // the dynamics Jacobians of the final iterate are needed by the adjoint Riccati sweep
-    double xn[NX], nun[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) xn[i] = lane_dn(S.x[i]), nun[i] = lane_dn(S.nu_[i]);
-    double hdd[M::NLD * (M::NLD + 1) / 2];
-    if ((a.flags & 2) && a.dpi && !S.qmode) {   // wave-uniform
-        S.template linearize<true>(xn, nun, hdd);
-    } else {
-#pragma unroll
-        for (int e = 0; e < M::NLD * (M::NLD + 1) / 2; ++e) hdd[e] = 0.0;
-        S.linearize(xn);
-    }
-#pragma unroll
-    for (int i = 0; i < S.NPK; ++i) S.P[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) S.p[i] = 0.0;
-    const int status = a.status[inst];
-    const bool sv = valid && (status == 0 || status == 2);
-    S.sensitivities(a.flags, sv, nun, a.dV ? a.dV + inst * NP : nullptr, a.dpi ? a.dpi + inst * NU * NP : nullptr, hdd);
-    // The output rows are written in full by this launch (no memset in front of it): the lanes of an instance zero every entry
-    // sensitivities() above does not store — the cost block of p (zero gradient of the mirror, nlp.py:1039-1055), everything of
-    // an instance that was not solved, du0*/dp in Q-mode.  The two sets of addresses are disjoint; the zeros go last so that no load of the pass waits behind these stores.
-    if (valid) {
-        if (a.dV)
-            for (int e = k; e < NP; e += lpi)
-                if (!(sv && M::p_has_gradient(e))) a.dV[inst * NP + e] = 0.0;
-        if (a.dpi)
-            for (int e = k; e < NU * NP; e += lpi)
-                if (!(sv && !S.qmode && M::p_has_gradient(e % NP))) a.dpi[inst * NU * NP + e] = 0.0;
-    }
+    // the dynamics Jacobians of the final iterate are needed by the adjoint Riccati sweep: linearised again inside the pass
+    small_sens_tail<M>(S, a, inst, valid, a.status[inst]);
 }
 
 }  // namespace mpcrl
