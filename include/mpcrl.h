@@ -100,6 +100,15 @@ int mpcrl_set_theta(mpcrl_handle h, const double *theta, int n_theta, int per_in
 int mpcrl_set_gamma(mpcrl_handle h, double gamma);
 int mpcrl_set_options(mpcrl_handle h, double tol, int max_iter);
 
+/* Opt-in divergence exit (not a reference behaviour: the reference runs full-step SQP without globalisation until
+ * nlp_solver_max_iter, config/cartpole.yaml:12-14, rlmpc/mpc/common/mpc.py:42,81-83 — one instance at a time, where a diverging
+ * solve costs only itself; in a batch the instances of a wavefront run in lock step and ONE diverging instance keeps its
+ * wavefront iterating to max_iter).  Every `window` SQP iterations of an instance the best NLP residual seen so far must have
+ * dropped below `factor` times its value at the previous check, else the instance ends with status 2 (as at max_iter) and its
+ * lanes are free.  window = 0 (default): off.  1 <= window <= 255, 0 < factor <= 1.  Instances that converge with the rule on
+ * return bit for bit what they return with it off.  cartpole / linear system only (MPCRL_E_MODEL for the chain of masses). */
+int mpcrl_set_exit_rule(mpcrl_handle h, int window, double factor);
+
 /* Scheduling hint (no effect on results): perm[B] int32 on the device, a permutation of 0..B-1 — slot i of a launch works on
  * instance perm[i], so that instances expected to need similar iteration counts share a wavefront. NULL = identity. */
 int mpcrl_set_order(mpcrl_handle h, const int32_t *perm, void *stream);

@@ -28,7 +28,7 @@ class ProblemSpec(C.Structure):
     ]
 
 
-EXPORTS = ["mpcrl_create", "mpcrl_destroy", "mpcrl_set_theta", "mpcrl_set_gamma", "mpcrl_set_options", "mpcrl_set_order", "mpcrl_set_bounds", "mpcrl_set_cold_mask", "mpcrl_reset",
+EXPORTS = ["mpcrl_create", "mpcrl_destroy", "mpcrl_set_theta", "mpcrl_set_gamma", "mpcrl_set_options", "mpcrl_set_exit_rule", "mpcrl_set_order", "mpcrl_set_bounds", "mpcrl_set_cold_mask", "mpcrl_reset",
            "mpcrl_solve", "mpcrl_get_iterate", "mpcrl_set_iterate", "mpcrl_get_lagrangian", "mpcrl_weighted_grad_sum", "mpcrl_env_cartpole_step", "mpcrl_env_cartpole_reset", "mpcrl_env_linear_step", "mpcrl_auto_order", "mpcrl_query_time_sliced", "mpcrl_workspace_bytes", "mpcrl_version"]
 
 _lib = None
@@ -50,6 +50,7 @@ def load():
     lib.mpcrl_set_theta.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     lib.mpcrl_set_gamma.argtypes = [vp, C.c_double]
     lib.mpcrl_set_options.argtypes = [vp, C.c_double, C.c_int]
+    lib.mpcrl_set_exit_rule.argtypes = [vp, C.c_int, C.c_double]
     lib.mpcrl_set_order.argtypes = [vp, vp, vp]
     lib.mpcrl_set_bounds.argtypes = [vp, C.c_int, _dp, _dp]
     lib.mpcrl_set_cold_mask.argtypes = [vp, vp, vp]

@@ -98,6 +98,12 @@ class MPCBatch:
     def set_options(self, tol: float = -1.0, max_iter: int = -1) -> None:
         self._check(self.lib.mpcrl_set_options(self._h, float(tol), int(max_iter)), "mpcrl_set_options")
 
+    def set_exit_rule(self, window: int = 10, factor: float = 0.1) -> None:
+        """Opt-in divergence exit (include/mpcrl.h mpcrl_set_exit_rule): every ``window`` SQP iterations the best NLP residual of an
+        instance must have dropped below ``factor`` x its value at the previous check, else it ends with status 2.  window = 0: off
+        (the reference's behaviour: full-step SQP to max_iter)."""
+        self._check(self.lib.mpcrl_set_exit_rule(self._h, int(window), float(factor)), "mpcrl_set_exit_rule")
+
     def set_bounds(self, which: int, lb, ub) -> None:
         """ocp_solver.constraints_set (mpc.py:72-73,87-88): which = _lib.BOUNDS_U0 (stage-0 controls, nu values), BOUNDS_STAGE
         (stages 1..N-1, v = [u; x], nu + nx values), BOUNDS_TERMINAL (stage N, nx values); |bound| >= 1e29 = absent."""

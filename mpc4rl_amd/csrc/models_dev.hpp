@@ -24,6 +24,8 @@ constexpr int SMALL_MAXC = 64;
 // constant below is a scalar (SGPR) operand in the kernel.
 struct SmallSpec {
     int N, np, cost_kind, rk_steps, max_iter;
+    int exit_window;      // mpcrl_set_exit_rule: check the progress every exit_window SQP iterations (0 = never: the reference's behaviour)
+    double exit_factor;   // ... the best NLP residual so far must be below exit_factor x its value at the previous check
     double dT, gamma, h, tol;
     double lb0[SMALL_MAXNW], ub0[SMALL_MAXNW];   // nu used
     double lb[SMALL_MAXNW], ub[SMALL_MAXNW];     // nu + nx used, v = [u; x]
@@ -37,7 +39,10 @@ struct CartpoleDev {
     static constexpr int NX = 4, NU = 1, NW = 5, NP = 83, NTD = 3, NTC = 0;
     static constexpr bool DISCRETE = false, HAS_SOFT = false;
     static constexpr int MAX_IPW = 4;   // instances per wavefront: the matrix-core factor sweep has four 4x4 blocks
-    static constexpr bool SEG_SKIP = false;   // segmented reductions: full trees (small_kernel.hpp, measured)
+#ifndef MPCRL_CARTPOLE_SEG_SKIP
+#define MPCRL_CARTPOLE_SEG_SKIP 0
+#endif
+    static constexpr bool SEG_SKIP = MPCRL_CARTPOLE_SEG_SKIP != 0;   // segmented reductions: full trees (small_kernel.hpp, measured)
     MPCRL_DI static int td_index(int i) { return i; }
     MPCRL_DI static int tc_index(int) { return 0; }
     MPCRL_DI static bool p_has_gradient(int e) { return e < NTD; }   // entries of p the sensitivity kernel computes; the rest are zeros

@@ -324,6 +324,13 @@ int mpcrl_set_options(mpcrl_handle h, double tol, int max_iter) {
     return 0;
 }
 
+int mpcrl_set_exit_rule(mpcrl_handle h, int window, double factor) {
+    if (!h || window < 0 || window > 255 || !(factor > 0.0 && factor <= 1.0)) return MPCRL_E_ARG;
+    if (h->is_large) return window == 0 ? 0 : MPCRL_E_MODEL;   // the chain kernel runs the reference's rule only
+    h->small.exit_window = window, h->small.exit_factor = factor;
+    return 0;
+}
+
 int mpcrl_set_order(mpcrl_handle h, const int32_t *perm, void *stream) {
     if (!h) return MPCRL_E_ARG;
     ON_DEVICE(h->device);

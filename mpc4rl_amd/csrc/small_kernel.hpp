@@ -1534,6 +1534,9 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
     const int max_iter = rti ? 1 : sp.max_iter;
     bool live = valid, last_tight = true;
     int status = 2, n_sqp = 0, n_ipm = 0;
+    // opt-in divergence exit (mpcrl_set_exit_rule): best residual so far, its value at the last check, iterations to the next check
+    double rbest = 1e300, rchk = 1e300;
+    int exit_cnt = sp.exit_window;
     // size of the perturbation the next QP sees (< 0: nothing to start from): change of the pinned x0 / u0 for a warm call
     double stepn = -1.0;
     if (!(a.flags & (8 | 16))) {   // MPCRL_COLD_DUAL: stored primal iterate, interior point from its default point
@@ -1578,6 +1581,15 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
                 status = 0, live = false;
             else if (it >= max_iter)
                 status = rmax < sp.tol ? 0 : 2, live = false;
+            else if (sp.exit_window > 0) {   // wave-uniform
+                rbest = fmin(rbest, rmax);
+                if (it == 0)
+                    rchk = rmax;
+                else if (--exit_cnt == 0) {
+                    if (rbest > sp.exit_factor * rchk) status = 2, live = false;   // no progress over the window: give the lanes back
+                    rchk = rbest, exit_cnt = sp.exit_window;
+                }
+            }
         }
         // QP tolerances of this iteration (per instance)
         const double rr_ = fmin(1.0, rmax), ad_ = (rmax < sp.tol || M::DISCRETE) ? 0.0 : IPM_ADAPT_C * rr_ * rr_;   // LQ model: first QP is the answer
@@ -1793,6 +1805,8 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
     bool live = valid, last_tight = true;
     int status = 2, iti = 0, n_ipm = 0;
     double stepn = -1.0;
+    double rbest = 1e300, rchk = 1e300;               // divergence exit (mpcrl_set_exit_rule), as in small_solve_kernel
+    int exit_cnt = sp.exit_window;
     // the parked instance (wave-uniform): local index or -1, and whether it has run at all
     int pk = (posof(ipw) < a.B) ? ipw : -1;
     bool pk_started = false;
@@ -1823,6 +1837,15 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
                 status = 0, live = false;
             else if (iti >= max_iter)
                 status = rmax < sp.tol ? 0 : 2, live = false;
+            else if (sp.exit_window > 0) {   // wave-uniform
+                rbest = fmin(rbest, rmax);
+                if (iti == 0)
+                    rchk = rmax;
+                else if (--exit_cnt == 0) {
+                    if (rbest > sp.exit_factor * rchk) status = 2, live = false;
+                    rchk = rbest, exit_cnt = sp.exit_window;
+                }
+            }
             fin_now = !live;
         }
         if (__any(fin_now)) {   // ---- results + iterate of the instances that finish here (wave-uniform branch: the reduction inside is safe)
@@ -1966,14 +1989,14 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
                 for (int i = 0; i < NW; ++i)
                     bnd[0 * nb + i] = S.lam[0][i], bnd[1 * nb + i] = S.lam[1][i], bnd[2 * nb + i] = S.t[0][i], bnd[3 * nb + i] = S.t[1][i];
             }
-            if (first) {
+            if (first) {   // the small integers share one word (exact in a double): live | tight | status (3 bits) | countdown (8) | iterations
                 double *sc = sc_lds + lo * 6;
-                sc[0] = live ? 1.0 : 0.0, sc[1] = (double)status, sc[2] = (double)iti, sc[3] = (double)n_ipm, sc[4] = last_tight ? 1.0 : 0.0,
-                sc[5] = stepn;
+                sc[0] = (double)((live ? 1 : 0) + (last_tight ? 2 : 0) + 4 * status + 32 * (exit_cnt & 255)) + 8192.0 * (double)iti;
+                sc[1] = (double)n_ipm, sc[2] = stepn, sc[3] = rbest, sc[4] = rchk;
             }
         }
 #if MPCRL_FUSE_SENS
-        if (sw && for_good && first) sc_lds[lo * 6 + 1] = (double)status;   // (read again by the sensitivity pass at the end)
+        if (sw && for_good && first) sc_lds[lo * 6 + 5] = (double)status;   // (read again by the sensitivity pass at the end)
 #endif
         SmallSolver<M>::wave_lds_sync();                // orders the stores above before the loads below (same wavefront: in order)
         // take the parked instance: every lane runs the same loads, the lanes of the slot keep the results
@@ -1983,14 +2006,18 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
         load_params();
         {
             const double *sc = sc_lds + pk * 6;
-            const double l_ = sc[0], st_ = sc[1], it_ = sc[2], ni_ = sc[3], lt_ = sc[4], sn_ = sc[5];
+            const double w_ = sc[0], ni_ = sc[1], sn_ = sc[2], rb_ = sc[3], rc_ = sc[4];
+            const int it_ = (int)(w_ * (1.0 / 8192.0)), lo_ = (int)(w_ - 8192.0 * (double)it_);   // iterations | the packed low bits
             if (sw) {
-                live = pk_started ? (l_ != 0.0) : valid;
-                status = pk_started ? (int)st_ : 2;
-                iti = pk_started ? (int)it_ : 0;
+                live = pk_started ? ((lo_ & 1) != 0) : valid;
+                last_tight = pk_started ? ((lo_ & 2) != 0) : true;
+                status = pk_started ? ((lo_ >> 2) & 7) : 2;
+                exit_cnt = pk_started ? ((lo_ >> 5) & 255) : sp.exit_window;
+                iti = pk_started ? it_ : 0;
                 n_ipm = pk_started ? (int)ni_ : 0;
-                last_tight = pk_started ? (lt_ != 0.0) : true;
                 stepn = pk_started ? sn_ : -1.0;
+                rbest = pk_started ? rb_ : 1e300;
+                rchk = pk_started ? rc_ : 1e300;
             }
         }
         if constexpr (lds_park) {
@@ -2079,7 +2106,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
             bind(loc);
             valid = on0 && posof(loc) < a.B;
             load_params();
-            const int st_ = (int)sc_lds[first_done * 6 + 1];
+            const int st_ = (int)sc_lds[first_done * 6 + 5];
             if constexpr (lds_park) {
                 const double *pl = park_lds + k;
                 double in[PK];

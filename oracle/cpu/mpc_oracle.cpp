@@ -486,8 +486,11 @@ struct Solver {
     }
 
     // ---- full-step SQP (oracle/sqp_dense.py:solve)
+    // stall > 0: the product's opt-in divergence exit (mpcrl_set_exit_rule): every `stall` SQP iterations the best NLP residual
+    // seen so far must have dropped below `stall_factor` times its value at the previous check, else the instance ends with
+    // status 2 (not a reference behaviour: the reference runs full-step SQP to max_iter, config/cartpole.yaml:12-14)
     int sqp(const double *x0, const double *u0fix, bool warm, int max_iter, double tol, double *res, int &n_sqp, int &n_ipm,
-            double &cost, bool rti = false) {
+            double &cost, bool rti = false, int stall = 0, double stall_factor = 0.1) {
         if (rti) max_iter = 1;
         setup_bounds(u0fix != nullptr);
         if (!warm) {
@@ -501,6 +504,7 @@ struct Solver {
         int status = 2;
         // size of the perturbation the next QP sees: change of the pinned initial state (warm call), then the last step
         bool last_tight = true;
+        double rbest = 1e300, rchk = 1e300;
         double stepn = -1.0;   // < 0: no previous QP to start from
         if (warm) {
             stepn = 0.0;
@@ -515,6 +519,12 @@ struct Solver {
             if (!std::isfinite(rmax) || !std::isfinite(cost)) return 1;   // std::max drops NaNs, the cost sum does not
             if (rmax < tol && last_tight && !(rti && n_sqp == 0)) return 0;
             if (n_sqp == max_iter) return rmax < tol ? 0 : 2;
+            rbest = std::min(rbest, rmax);
+            if (stall > 0 && n_sqp > 0 && n_sqp % stall == 0) {
+                if (rbest > stall_factor * rchk) return 2;
+                rchk = rbest;
+            }
+            if (n_sqp == 0) rchk = rmax;
             {   // QP tolerances for this iteration
                 // (a linear-quadratic OCP is solved by its first QP: no inexactness there)
                 const double rr = std::min(1.0, rmax), a = (rmax < tol || Mdl::DISCRETE || exact) ? 0.0 : IPM_ADAPT_C * rr * rr;
@@ -664,7 +674,7 @@ int run(const OracleSpec *sp, int Bn, const double *x0, const double *u0fix, con
         int ns = 0, ni = 0;
         S.exact = (flags & ORACLE_EXACT) != 0;
         const int st = S.sqp(x0 + (size_t)b * NX, u0fix ? u0fix + (size_t)b * NU : nullptr, warm, sp->max_iter, sp->tol, r4, ns, ni, cost,
-                             (flags & ORACLE_RTI) != 0);
+                             (flags & ORACLE_RTI) != 0, sp->exit_window, sp->exit_factor);
         if (status) status[b] = st;
         if (sqp_iter) sqp_iter[b] = ns;
         if (ipm_iter) ipm_iter[b] = ni;

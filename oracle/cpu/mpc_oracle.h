@@ -21,6 +21,7 @@ enum {
     ORACLE_RTI = 16 /* one SQP iteration from the given iterate (the product's MPCRL_RTI; not a reference mode) */
 };
 
+
 typedef struct {
     int model;          /* ORACLE_MODEL_* */
     int N, nx, nu, np;  /* horizon, dims, length of the full parameter vector p */
@@ -38,6 +39,10 @@ typedef struct {
     const double *zl, *zu;     /* nu + nx : L1 weights of the soft bounds */
     const double *consts;      /* model constants (see mpc_oracle.cpp, per model) */
     int n_consts;
+    /* the product's opt-in divergence exit (mpcrl_set_exit_rule): every exit_window SQP iterations the best NLP residual so far must
+     * be below exit_factor x its value at the previous check, else status 2; 0 = off (the reference's behaviour) */
+    int exit_window;
+    double exit_factor;
 } OracleSpec;
 
 /* Solves B independent OCPs.  All arrays are host, row-major, double.

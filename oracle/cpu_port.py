@@ -25,7 +25,7 @@ class OracleSpec(C.Structure):
         ("dT", C.c_double), ("gamma", C.c_double), ("h", C.c_double), ("rk_steps", C.c_int), ("tol", C.c_double),
         ("max_iter", C.c_int),
         ("lb0", _dp), ("ub0", _dp), ("lb", _dp), ("ub", _dp), ("lbe", _dp), ("ube", _dp), ("soft", _ip), ("zl", _dp), ("zu", _dp),
-        ("consts", _dp), ("n_consts", C.c_int),
+        ("consts", _dp), ("n_consts", C.c_int), ("exit_window", C.c_int), ("exit_factor", C.c_double),
     ]
 
 
@@ -93,8 +93,10 @@ class PortResult:
 
 
 def solve(P: Problem, x0, p=None, u0fix=None, gamma=None, flags=SENS_V | SENS_PI, warm: Optional[PortResult] = None,
-          max_iter=None, tol=None, nthreads=0, want_bnd=True, exact=False, rti=False) -> PortResult:
-    """exact=True: the frozen exact-QP mode (ORACLE_EXACT, oracle/cpu/mpc_oracle.h); rti=True: one SQP iteration from ``warm``."""
+          max_iter=None, tol=None, nthreads=0, want_bnd=True, exact=False, rti=False, exit_window=0, exit_factor=0.1) -> PortResult:
+    """exact=True: the frozen exact-QP mode (ORACLE_EXACT, oracle/cpu/mpc_oracle.h); rti=True: one SQP iteration from ``warm``;
+    exit_window > 0: the product's opt-in divergence exit (mpcrl_set_exit_rule: every exit_window SQP iterations the best residual
+    must have dropped below exit_factor x its value at the previous check, else status 2)."""
     x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, float)))
     B = x0.shape[0]
     nw = P.nu + P.nx
@@ -114,7 +116,7 @@ def solve(P: Problem, x0, p=None, u0fix=None, gamma=None, flags=SENS_V | SENS_PI
         gamma=P.gamma if gamma is None else gamma, h=h, rk_steps=rk, tol=P.tol if tol is None else tol,
         max_iter=P.max_iter if max_iter is None else max_iter,
         lb0=dptr(lb0), ub0=dptr(ub0), lb=dptr(lb), ub=dptr(ub), lbe=dptr(lbe), ube=dptr(ube), soft=soft.ctypes.data_as(_ip),
-        zl=dptr(zl), zu=dptr(zu), consts=dptr(consts), n_consts=len(consts))
+        zl=dptr(zl), zu=dptr(zu), consts=dptr(consts), n_consts=len(consts), exit_window=int(exit_window), exit_factor=float(exit_factor))
     flags |= (EXACT if exact else 0) | (RTI if rti else 0)
     if warm is not None:
         flags |= WARM

@@ -1,7 +1,8 @@
 """Lock-step tail: what a batch costs when part of it does not converge.  Full-step SQP without globalisation (what the reference
 runs, config/cartpole.yaml:8-14) fails on ~15 % of initial states drawn from the whole state box; such an instance keeps its
 wavefront iterating until max_iter (500 in the reference's yaml).  Times the bench distribution, the hard distribution at
-max_iter = 500 and at max_iter = 50, and closed-loop warm solves along a rollout.
+max_iter = 500 without and with the opt-in divergence exit (mpcrl_set_exit_rule) and at max_iter = 50, and closed-loop warm solves
+along a rollout.
     python profiles/microbench/hard_distribution.py
 """
 import sys, time
@@ -20,13 +21,20 @@ B = 4096
 rng = np.random.default_rng(7)
 xb = np.zeros((B, 4)); xb[:, 2] = np.random.default_rng(0).uniform(0.9 * np.pi, 1.1 * np.pi, B)
 xh = rng.uniform(-1, 1, (B, 4)) * np.array([2.0, 3.0, np.pi, 5.0])
-for name, x0, mi in (("bench distribution", xb, 500), ("hard distribution (whole box)", xh, 500), ("hard distribution, max_iter 50", xh, 50)):
+conv_off = None
+for name, x0, mi, rule in (("bench distribution", xb, 500, None), ("bench distribution, exit rule (10, 0.1)", xb, 500, (10, 0.1)),
+                           ("hard distribution (whole box)", xh, 500, None), ("hard distribution, exit rule (15, 0.1)", xh, 500, (15, 0.1)),
+                           ("hard distribution, exit rule (10, 0.1)", xh, 500, (10, 0.1)), ("hard distribution, exit rule (6, 0.3)", xh, 500, (6, 0.3)),
+                           ("hard distribution, max_iter 50", xh, 50, None)):
     mpc = MPCBatch(cartpole_ocp(max_iter=mi), B)
+    if rule: mpc.set_exit_rule(*rule)
     xt = torch.as_tensor(x0, device="cuda")
     ms, r = timed(lambda: mpc.solve(xt, sens_v=True, sens_pi=True, cold=True))
     st = r.status.cpu().numpy(); it = r.iters.cpu().numpy()
-    print("%-34s %8.2f ms per %d solves; converged %.3f, max-iter %.3f, QP-fail %.3f, NaN %.3f; SQP it mean %.1f max %d" % (
-        name, ms, B, (st == 0).mean(), (st == 2).mean(), (st == 4).mean(), (st == 1).mean(), it[:, 0].mean(), it[:, 0].max()))
+    if name.startswith("hard distribution (whole"): conv_off = st == 0
+    lost = "" if (conv_off is None or not name.startswith("hard") or rule is None) else "; lost %.1f %% of the rule-less run's converged" % (100.0 * (conv_off & (st != 0)).sum() / conv_off.sum())
+    print("%-42s %8.2f ms per %d solves; converged %.3f, max-iter %.3f, QP-fail %.3f, NaN %.3f; SQP it mean %.1f max %d%s" % (
+        name, ms, B, (st == 0).mean(), (st == 2).mean(), (st == 4).mean(), (st == 1).mean(), it[:, 0].mean(), it[:, 0].max(), lost))
 env = BatchedCartPoleSwingUpEnv(B, device="cuda", seed=0)
 obs = env.reset()
 mpc = MPCBatch(cartpole_ocp(), B)

@@ -285,3 +285,47 @@ def test_rccl_world1_allreduce_and_td3_step():
         assert any(float((p.detach() - q).abs().max()) > 0.0 for p, q in zip(agent.critic.parameters(), w0))     # the all-reduced gradient arrived
     finally:
         dist.destroy_process_group()
+
+
+def test_divergence_exit_rule(oracle_port, monkeypatch):
+    """mpcrl_set_exit_rule (opt-in; the reference has no such exit: full-step SQP to nlp_solver_max_iter, config/cartpole.yaml:12-14):
+    on 2048 states from the whole state box at max_iter = 500 the rule (window 10, factor 0.1) ends the non-converging instances
+    early with status 2, the same instances the oracle port ends under the same rule; every instance that still converges returns
+    bit for bit what it returns with the rule off; the plain and the time-sliced launch agree bit for bit under the rule."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    from oracle.problems import make_cartpole
+    rng = np.random.default_rng(7)
+    B = 2048
+    x0 = rng.uniform(-1, 1, (B, 4)) * np.array([2.0, 3.0, np.pi, 5.0])
+    xt = torch.as_tensor(x0, device="cuda")
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MPCRL_TIME_SLICE", mode)
+        off = MPCBatch(cartpole_ocp(max_iter=500), B)
+        r0 = off.solve(xt, sens_v=True, sens_pi=True, cold=True)
+        on = MPCBatch(cartpole_ocp(max_iter=500), B)
+        on.set_exit_rule(10, 0.1)
+        r1 = on.solve(xt, sens_v=True, sens_pi=True, cold=True)
+        out[mode] = (r0, r1)
+    (r0, r1), (s0, s1) = out["0"], out["1"]
+    for a, b in ((r0, s0), (r1, s1)):
+        for t1, t2 in ((a.u0, b.u0), (a.V, b.V), (a.status, b.status), (a.iters, b.iters), (a.dV_dp, b.dV_dp)):
+            assert torch.equal(t1, t2)
+    st0, st1 = r0.status.cpu().numpy(), r1.status.cpu().numpy()
+    it0, it1 = r0.iters.cpu().numpy(), r1.iters.cpu().numpy()
+    assert it0[:, 0].max() == 500 and it1[:, 0].max() <= 120, (it0[:, 0].max(), it1[:, 0].max())
+    conv1 = st1 == 0
+    assert np.all(st0[conv1] == 0) and conv1.sum() >= 0.9 * (st0 == 0).sum()      # nothing converges only BECAUSE of the rule; few are lost
+    for a, b in ((r0.u0, r1.u0), (r0.V, r1.V), (r0.dV_dp, r1.dV_dp), (r0.dpi_dp, r1.dpi_dp), (r0.iters, r1.iters)):
+        a, b = a.cpu().numpy()[conv1], b.cpu().numpy()[conv1]
+        assert np.array_equal(a, b, equal_nan=True)
+    ref = oracle_port.solve(make_cartpole(), x0, max_iter=500, exit_window=10, exit_factor=0.1)
+    same = st1 == ref.status
+    ok = conv1 & (ref.status == 0)
+    print(f"exit rule: converged off {(st0 == 0).mean():.4f} on {conv1.mean():.4f} (port {(ref.status == 0).mean():.4f}), status equal to port "
+          f"{same.mean():.4f}, SQP iterations max off {it0[:, 0].max()} on {it1[:, 0].max()} (port {ref.sqp_iter.max()}), "
+          f"sum off {it0[:, 0].sum()} on {it1[:, 0].sum()}")
+    assert same.mean() > 0.99 and (it1[ok, 0] == ref.sqp_iter[ok]).mean() > 0.97
+    assert rel_rows(r1.u0.cpu().numpy()[ok], ref.u0[ok]).max() < RTOL and rel_rows(r1.V.cpu().numpy()[ok], ref.V[ok]).max() < RTOL
+    # misuse
+    assert on.lib.mpcrl_set_exit_rule(on._h, 300, 0.1) < 0 and on.lib.mpcrl_set_exit_rule(on._h, 10, 0.0) < 0

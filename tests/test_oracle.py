@@ -277,3 +277,19 @@ def test_certification_worker_runs_in_a_process_pool(oracle_port):
         rows = pool.map(certify_job, jobs, chunksize=1)
     here = certify_job(jobs[0])
     assert np.array_equal(rows[0][0], here[0]) and np.abs(rows[1][0] - r.dV[1]).max() < 1e-8
+
+
+def test_port_divergence_exit_rule(oracle_port):
+    """The opt-in exit rule of the product (mpcrl_set_exit_rule) as the port restates it: bounded iteration counts on states from the
+    whole box, nothing converges only because of the rule, and what still converges is bitwise what the rule-less run returns."""
+    from oracle.problems import make_cartpole
+    P = make_cartpole()
+    rng = np.random.default_rng(7)
+    x0 = rng.uniform(-1, 1, (256, 4)) * np.array([2.0, 3.0, np.pi, 5.0])
+    r0 = oracle_port.solve(P, x0, flags=0, max_iter=300)
+    r1 = oracle_port.solve(P, x0, flags=0, max_iter=300, exit_window=10, exit_factor=0.1)
+    c1 = r1.status == 0
+    assert r0.sqp_iter.max() == 300 and r1.sqp_iter.max() < 120
+    assert np.all(r0.status[c1] == 0) and c1.sum() >= 0.9 * (r0.status == 0).sum()
+    assert np.array_equal(r0.u0[c1], r1.u0[c1]) and np.array_equal(r0.V[c1], r1.V[c1]) and np.array_equal(r0.sqp_iter[c1], r1.sqp_iter[c1])
+    assert set(np.unique(r1.status[~c1])) <= {2, 4}
