@@ -334,19 +334,24 @@ def td3_bench(args):
     env = BatchedCartPoleSwingUpEnv(E, device=dev, seed=rank)
     agent = BatchedTD3(cartpole_ocp(), env, batch_size=E, buffer_steps=64, policy_delay=2, lr_actor=1e-6, seed=0, device=dev)
     agent.collect(4)                       # something to sample from
+    if not args.no_graph:
+        agent.enable_graphs()              # fills the replay buffer, then captures the roll-out step and the update into HIP graphs
     for _ in range(args.warmup):
-        agent.collect(1), agent.train(1)
+        agent.collect(1, stats=False), agent.train(1, stats=False)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    agent.collect(0)                       # zero the roll-out statistics
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st = agent.collect(1)
-        tr = agent.train(1)
+    for _ in range(args.steps):            # no host synchronisation inside the timed region: statistics are read after it
+        agent.collect(1, stats=False)
+        agent.train(1, stats=False)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = job_aggregate(time.perf_counter() - t0, dist, dev)
+    st = agent.last_stats()
+    tr = {"critic_loss": float(agent._graphs["update"][True]["loss"].item())} if agent._graphs else agent.train(1)
     if rank == 0:
         # MPC solves per step and rank: E (roll-out, warm) + E (target actor, cold) + E / policy_delay (policy + sensitivities, cold)
         solves = world * args.steps * (E + E + E / agent.policy_delay)
@@ -356,7 +361,8 @@ def td3_bench(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"cartpole TD3 closed loop (BASELINE config 5): {E} environments/GPU, one environment step + one "
                                    f"TD3 update (batch {E}, policy_delay 2) per step; MPC solves per step and GPU: {E} warm (actor) "
-                                   f"+ {E} cold (target actor) + {E // 2} cold with du0*/dtheta (policy gradient)",
+                                   f"+ {E} cold (target actor) + {E // 2} cold with du0*/dtheta (policy gradient); "
+                                   + ("roll-out step and update replayed as HIP graphs" if not args.no_graph else "eager launches"),
                        "parallelism": f"environments sharded over {world} GPU(s); one all-reduce of the critic + theta gradients per update",
                        "mpc_solves_per_s": solves / elapsed, "converged_fraction": st["converged_fraction"],
                        "critic_loss": tr["critic_loss"]},
@@ -374,6 +380,7 @@ def main():
     ap.add_argument("--no-sens", action="store_true", help="forward solve only (BASELINE config 2)")
     ap.add_argument("--rti", action="store_true", help="one SQP iteration from the stored iterate (build-side mode)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="td3 workload: eager launches instead of replayed HIP graphs")
     ap.add_argument("--workload", default="cartpole", choices=["cartpole", "linear", "chain5", "chain7", "td3"],
                     help="cartpole = the headline metric (default); linear = the 2-state OCP of config 1 batched; chain5/chain7 = BASELINE "
                          "config 4; td3 = config 5 (none of these is the headline line)")

@@ -92,13 +92,28 @@ class DeviceReplayBuffer:
         self.rew = torch.zeros(capacity_steps, num_envs, **kw)
         self.done = torch.zeros(capacity_steps, num_envs, **kw)
         self.pos, self.full = 0, False
+        self.pos_t = torch.zeros(1, dtype=torch.int64, device=device)      # the write position as the device sees it (graph replays)
 
     def add(self, obs, next_obs, act, rew, done) -> None:
         i = self.pos
         self.obs[i], self.next_obs[i], self.act[i] = obs.to(self.obs.dtype), next_obs.to(self.obs.dtype), act.to(self.obs.dtype)
         self.rew[i], self.done[i] = rew.to(self.obs.dtype), done.to(self.obs.dtype)
-        self.pos = (i + 1) % self.cap
+        self._advance()
+
+    def _advance(self) -> None:
+        self.pos = (self.pos + 1) % self.cap
         self.full = self.full or self.pos == 0
+
+    def add_at_device_pos(self, obs, next_obs, act, rew, done) -> None:
+        """add() with the position read from ``pos_t`` on the device: the identical launches whatever the position, so that a captured
+        roll-out step can be replayed.  The host mirror (pos, full) is advanced by the caller once per replay (_advance)."""
+        dt = self.obs.dtype
+        self.obs.index_copy_(0, self.pos_t, obs.to(dt)[None])
+        self.next_obs.index_copy_(0, self.pos_t, next_obs.to(dt)[None])
+        self.act.index_copy_(0, self.pos_t, act.to(dt)[None])
+        self.rew.index_copy_(0, self.pos_t, rew.to(dt)[None])
+        self.done.index_copy_(0, self.pos_t, done.to(dt)[None])
+        self.pos_t.add_(1).remainder_(self.cap)
 
     def size(self) -> int:
         return (self.cap if self.full else self.pos) * self.E
@@ -155,7 +170,9 @@ class BatchedTD3:
         self.critic_target = ContinuousCritic(ocp.nx, ocp.nu, net_arch).to(dev)
         self.critic_target.load_state_dict(self.critic.state_dict())
         # fused / multi-tensor updates: the critic is 12 small tensors, one launch per tensor and operation is pure launch overhead
-        self.critic_opt = torch.optim.Adam(self.critic.parameters(), lr=lr_critic, **({"fused": True} if dev.type == "cuda" else {}))
+        # (capturable: the step counter lives on the device, so that the optimiser step can be part of a replayed HIP graph)
+        self.critic_opt = torch.optim.Adam(self.critic.parameters(), lr=lr_critic,
+                                           **({"fused": True, "capturable": True} if dev.type == "cuda" else {}))
         self.buffer = DeviceReplayBuffer(buffer_steps, self.E, ocp.nx, ocp.nu, dev)
         self.gamma, self.tau, self.policy_delay = gamma, tau, policy_delay
         self.action_noise, self.target_noise, self.noise_clip = action_noise, target_noise, noise_clip
@@ -165,39 +182,64 @@ class BatchedTD3:
         self.n_updates = 0
         self.obs = self.env.reset().to(dev)
         self._ended = None
+        self._stats = torch.zeros(3, dtype=torch.float64, device=dev)    # reward sum, converged solves, episodes ended (since the last read)
+        self._stats_steps = 0
+        self._graphs = None
         self.n_crit = sum(p.numel() for p in self.critic.parameters())
 
     # ------------------------------------------------------------------ roll-out
-    def collect(self, n_steps: int) -> dict:
-        """n_steps closed-loop steps of all E environments; returns roll-out statistics (device tensors -> python floats once)."""
-        rew_sum = torch.zeros((), dtype=torch.float64, device=self.device)
-        conv = torch.zeros((), dtype=torch.float64, device=self.device)
-        ended_total = torch.zeros((), dtype=torch.float64, device=self.device)
-        for _ in range(n_steps):
-            r = self.actor.mpc.solve(self.obs.to(torch.float64), cold_mask=self._ended)   # ONE launch for E policies
-            # a solve that ended with status 1 / 4 may hand back a non-finite u0: such an environment gets the zero action (a
-            # finite fallback; the reference raises instead, mpc.py:81-83).  The stored transition is the one that really happened
-            # (action 0 was applied), so no NaN ever reaches the environment, the replay buffer or the critic
-            u_ok = torch.isfinite(r.u0).all(dim=1) & ((r.status == 0) | (r.status == 2))
-            a = torch.where(u_ok[:, None], self.actor.scale_action(torch.nan_to_num(r.u0)), torch.zeros_like(r.u0)).to(torch.float32)
-            a = (a + self.action_noise * torch.randn(a.shape, device=self.device, generator=self.gen)).clamp(-1.0, 1.0)
-            nxt, rew, term, trunc = self.env.step(a.to(self.env.device))
-            nxt, rew = nxt.to(self.device), rew.to(self.device)
-            done = (term | trunc).to(self.device)
+    def _collect_step(self, static: bool = False):
+        """One closed-loop step of all E environments.  static: the form that can be captured into a HIP graph and replayed — the
+        replay write position is read on the device, the running observation / ended mask / statistics are updated in place."""
+        r = self.actor.mpc.solve(self.obs.to(torch.float64), cold_mask=self._ended)   # ONE launch for E policies
+        # a solve that ended with status 1 / 4 may hand back a non-finite u0: such an environment gets the zero action (a
+        # finite fallback; the reference raises instead, mpc.py:81-83).  The stored transition is the one that really happened
+        # (action 0 was applied), so no NaN ever reaches the environment, the replay buffer or the critic
+        u_ok = torch.isfinite(r.u0).all(dim=1) & ((r.status == 0) | (r.status == 2))
+        a = torch.where(u_ok[:, None], self.actor.scale_action(torch.nan_to_num(r.u0)), torch.zeros_like(r.u0)).to(torch.float32)
+        a = (a + self.action_noise * torch.randn(a.shape, device=self.device, generator=self.gen)).clamp(-1.0, 1.0)
+        nxt, rew, term, trunc = self.env.step(a.to(self.env.device))
+        nxt, rew = nxt.to(self.device), rew.to(self.device)
+        done = (term | trunc).to(self.device)
+        if static:
+            self.buffer.add_at_device_pos(self.obs, nxt, a, self.reward_scale * rew, term.to(self.device))
+        else:
             self.buffer.add(self.obs, nxt, a, self.reward_scale * rew, term.to(self.device))
-            rew_sum += rew.sum()
-            conv += (r.status == 0).sum()
-            ended_total += done.sum()
-            if hasattr(self.env, "reset_where"):
-                # no host synchronisation in a step: the masked reset and the per-instance cold mask run every step (empty masks are no-ops)
-                self.obs = self.env.reset_where(done.to(self.env.device)).to(self.device)
-                self._ended = done
+        self._stats[0] += rew.sum()
+        self._stats[1] += (r.status == 0).sum()
+        self._stats[2] += done.sum()
+        if hasattr(self.env, "reset_where"):
+            # no host synchronisation in a step: the masked reset and the per-instance cold mask run every step (empty masks are no-ops)
+            new_obs = self.env.reset_where(done.to(self.env.device)).to(self.device)
+            if static:
+                self.obs.copy_(new_obs)
+                self._ended.copy_(done)
             else:
-                any_done = bool(done.any())      # an episode end changes the control flow: one host synchronisation per step
-                self.obs = self.env.reset(done.to(self.env.device)).to(self.device) if any_done else nxt
-                self._ended = done if any_done else None
-        n = n_steps * self.E
-        return {"mean_reward": float(rew_sum.item()) / n, "converged_fraction": float(conv.item()) / n, "episodes_ended": int(ended_total.item())}
+                self.obs, self._ended = new_obs, done
+        else:
+            any_done = bool(done.any())      # an episode end changes the control flow: one host synchronisation per step
+            self.obs = self.env.reset(done.to(self.env.device)).to(self.device) if any_done else nxt
+            self._ended = done if any_done else None
+
+    def collect(self, n_steps: int, stats: bool = True) -> dict:
+        """n_steps closed-loop steps of all E environments; returns roll-out statistics (device tensors -> python floats once;
+        stats=False: no host synchronisation at all, read them later with last_stats())."""
+        if stats:
+            self._stats.zero_()
+            self._stats_steps = 0
+        for _ in range(n_steps):
+            if self._graphs is not None:
+                self._graphs["collect"].replay()
+                self.buffer._advance()
+            else:
+                self._collect_step()
+        self._stats_steps += n_steps
+        return self.last_stats() if stats else {}
+
+    def last_stats(self) -> dict:
+        n = max(1, self._stats_steps) * self.E
+        v = self._stats.tolist()
+        return {"mean_reward": v[0] / n, "converged_fraction": v[1] / n, "episodes_ended": int(v[2])}
 
     # ------------------------------------------------------------------ learning
     def _allreduce(self, flat: torch.Tensor) -> torch.Tensor:
@@ -206,65 +248,137 @@ class BatchedTD3:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
 
-    def train(self, n_updates: int) -> dict:
-        loss, step = None, None
+    def _world(self) -> int:
         import torch.distributed as dist
-        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def _update_pre(self, do_policy: bool):
+        """Everything of one update up to the message of the collective: sample, target actor's batched solve, critic loss and
+        gradients, (every policy_delay-th update) the policy's batched solve with du0*/dtheta and the theta-gradient sum.
+        Returns (flat message, loss)."""
+        world, n_theta = self._world(), self.theta.numel()
+        obs, nxt, act, rew, done = self.buffer.sample(self.B, self.gen)
+        with torch.no_grad():
+            noise = (self.target_noise * torch.randn(act.shape, device=self.device, generator=self.gen)).clamp(-self.noise_clip, self.noise_clip)
+            rt = self.target_mpc.mpc.solve(nxt.to(torch.float64), cold=True)               # actor_target(s'), one launch
+            # failed target solves are SELECTED out (a product with a 0 / 1 mask would keep their NaN: NaN * 0 = NaN), and so are
+            # transitions whose stored observations are not finite
+            ok_b = (rt.status == 0) & torch.isfinite(rt.u0).all(dim=1) & torch.isfinite(obs).all(dim=1) & torch.isfinite(nxt).all(dim=1) \
+                & torch.isfinite(act).all(dim=1) & torch.isfinite(rew)
+            u_next = torch.where(ok_b[:, None], torch.nan_to_num(rt.u0), torch.zeros_like(rt.u0))
+            a_next = (self.target_mpc.scale_action(u_next).to(torch.float32) + noise).clamp(-1.0, 1.0)
+            nxt_s, obs_s, act_s = (torch.where(ok_b[:, None], t, torch.zeros_like(t)) for t in (nxt, obs, act))
+            q_next = torch.min(*self.critic_target(nxt_s, a_next)).squeeze(1)
+            ok_t = ok_b.to(torch.float32)
+            y = torch.where(ok_b, rew + self.gamma * (1.0 - done) * q_next, torch.zeros_like(rew))
+        qs = self.critic(obs_s, act_s)
+        loss = sum((torch.where(ok_b, q.squeeze(1) - y, torch.zeros_like(y)) ** 2).sum() for q in qs) / ok_t.sum().clamp(min=1.0)
+        self.critic_opt.zero_grad(set_to_none=True)
+        loss.backward()
+        # one flat message: critic gradients (already the local mean) | theta-gradient sum | sample count
+        flat = torch.zeros(self.n_crit + n_theta + 1, dtype=torch.float64, device=self.device)
+        flat[: self.n_crit] = torch.cat([p.grad.reshape(-1) for p in self.critic.parameters()]).to(torch.float64) / world
+        if do_policy:
+            rp = self.pi_mpc.mpc.solve(obs.to(torch.float64), sens_pi=True, cold=True)   # pi(s_i), dpi/dtheta_i: one launch
+            okb = (rp.status == 0) & torch.isfinite(rp.u0).all(dim=1) & torch.isfinite(obs).all(dim=1)
+            u_pi = torch.where(okb[:, None], torch.nan_to_num(rp.u0), torch.zeros_like(rp.u0))
+            a_pi = self.pi_mpc.scale_action(u_pi).to(torch.float32).detach().requires_grad_(True)
+            (dq_da,) = torch.autograd.grad(self.critic.q1_forward(obs_s, a_pi).sum(), a_pi)
+            chain = (2.0 / (self.pi_mpc.high - self.pi_mpc.low)) if self.pi_mpc.scale else torch.ones_like(self.pi_mpc.low)
+            okp = okb.to(torch.float64)
+            g = torch.einsum("bu,bup->bp", torch.where(okb[:, None], dq_da.to(torch.float64) * chain, torch.zeros_like(chain)),
+                             torch.nan_to_num(rp.dpi_dp))
+            flat[self.n_crit: self.n_crit + n_theta] = g.sum(0)
+            flat[-1] = okp.sum()
+        return flat, loss.detach()
+
+    def _update_post(self, flat: torch.Tensor, do_policy: bool):
+        """After the collective: the averaged critic gradients into the optimiser step; the policy step and the Polyak updates.
+        All parameter tensors are updated IN PLACE (their addresses are what a captured graph and the solver handles hold)."""
         n_theta = self.theta.numel()
+        params = list(self.critic.parameters())
+        g32, off, views = flat[: self.n_crit].to(params[0].dtype), 0, []
+        for p in params:
+            views.append(g32[off: off + p.numel()].view(p.shape))
+            off += p.numel()
+        torch._foreach_copy_([p.grad for p in params], views)
+        self.critic_opt.step()
+        step = None
+        if do_policy:
+            step = self.lr_actor * self.learn_mask * flat[self.n_crit: self.n_crit + n_theta] / flat[-1].clamp(min=1.0)
+            self.theta.add_(step)
+            self.theta_target.mul_(1.0 - self.tau).add_(self.theta, alpha=self.tau)
+            for m, th in ((self.actor, self.theta), (self.pi_mpc, self.theta), (self.target_mpc, self.theta_target)):
+                m.theta = th
+                m.mpc.set_theta(th)
+            with torch.no_grad():
+                pts = list(self.critic_target.parameters())
+                torch._foreach_mul_(pts, 1.0 - self.tau)
+                torch._foreach_add_(pts, params, alpha=self.tau)
+        return step
+
+    def train(self, n_updates: int, stats: bool = True) -> dict:
+        loss, step = None, None
         for _ in range(n_updates):
             self.n_updates += 1
-            obs, nxt, act, rew, done = self.buffer.sample(self.B, self.gen)
-            with torch.no_grad():
-                noise = (self.target_noise * torch.randn(act.shape, device=self.device, generator=self.gen)).clamp(-self.noise_clip, self.noise_clip)
-                rt = self.target_mpc.mpc.solve(nxt.to(torch.float64), cold=True)               # actor_target(s'), one launch
-                # failed target solves are SELECTED out (a product with a 0 / 1 mask would keep their NaN: NaN * 0 = NaN), and so are
-                # transitions whose stored observations are not finite
-                ok_b = (rt.status == 0) & torch.isfinite(rt.u0).all(dim=1) & torch.isfinite(obs).all(dim=1) & torch.isfinite(nxt).all(dim=1) \
-                    & torch.isfinite(act).all(dim=1) & torch.isfinite(rew)
-                u_next = torch.where(ok_b[:, None], torch.nan_to_num(rt.u0), torch.zeros_like(rt.u0))
-                a_next = (self.target_mpc.scale_action(u_next).to(torch.float32) + noise).clamp(-1.0, 1.0)
-                nxt_s, obs_s, act_s = (torch.where(ok_b[:, None], t, torch.zeros_like(t)) for t in (nxt, obs, act))
-                q_next = torch.min(*self.critic_target(nxt_s, a_next)).squeeze(1)
-                ok_t = ok_b.to(torch.float32)
-                y = torch.where(ok_b, rew + self.gamma * (1.0 - done) * q_next, torch.zeros_like(rew))
-            qs = self.critic(obs_s, act_s)
-            loss = sum((torch.where(ok_b, q.squeeze(1) - y, torch.zeros_like(y)) ** 2).sum() for q in qs) / ok_t.sum().clamp(min=1.0)
-            self.critic_opt.zero_grad(set_to_none=True)
-            loss.backward()
             do_policy = self.n_updates % self.policy_delay == 0
-            # one flat message: critic gradients (already the local mean) | theta-gradient sum | sample count
-            flat = torch.zeros(self.n_crit + n_theta + 1, dtype=torch.float64, device=self.device)
-            flat[: self.n_crit] = torch.cat([p.grad.reshape(-1) for p in self.critic.parameters()]).to(torch.float64) / world
-            if do_policy:
-                rp = self.pi_mpc.mpc.solve(obs.to(torch.float64), sens_pi=True, cold=True)   # pi(s_i), dpi/dtheta_i: one launch
-                okb = (rp.status == 0) & torch.isfinite(rp.u0).all(dim=1) & torch.isfinite(obs).all(dim=1)
-                u_pi = torch.where(okb[:, None], torch.nan_to_num(rp.u0), torch.zeros_like(rp.u0))
-                a_pi = self.pi_mpc.scale_action(u_pi).to(torch.float32).detach().requires_grad_(True)
-                (dq_da,) = torch.autograd.grad(self.critic.q1_forward(obs_s, a_pi).sum(), a_pi)
-                chain = (2.0 / (self.pi_mpc.high - self.pi_mpc.low)) if self.pi_mpc.scale else torch.ones_like(self.pi_mpc.low)
-                okp = okb.to(torch.float64)
-                g = torch.einsum("bu,bup->bp", torch.where(okb[:, None], dq_da.to(torch.float64) * chain, torch.zeros_like(chain)),
-                                 torch.nan_to_num(rp.dpi_dp))
-                flat[self.n_crit: self.n_crit + n_theta] = g.sum(0)
-                flat[-1] = okp.sum()
-            flat = self._allreduce(flat)
-            params = list(self.critic.parameters())
-            g32, off, views = flat[: self.n_crit].to(params[0].dtype), 0, []
-            for p in params:
-                views.append(g32[off: off + p.numel()].view(p.shape))
-                off += p.numel()
-            torch._foreach_copy_([p.grad for p in params], views)
-            self.critic_opt.step()
-            if do_policy:
-                step = self.lr_actor * self.learn_mask * flat[self.n_crit: self.n_crit + n_theta] / flat[-1].clamp(min=1.0)
-                self.theta = self.theta + step
-                self.theta_target = (1.0 - self.tau) * self.theta_target + self.tau * self.theta
-                for m, th in ((self.actor, self.theta), (self.pi_mpc, self.theta), (self.target_mpc, self.theta_target)):
-                    m.theta = th
-                    m.mpc.set_theta(th)
-                with torch.no_grad():
-                    pts = list(self.critic_target.parameters())
-                    torch._foreach_mul_(pts, 1.0 - self.tau)
-                    torch._foreach_add_(pts, params, alpha=self.tau)
+            if self._graphs is not None:
+                gp = self._graphs["update"][do_policy]
+                gp["pre"].replay()
+                self._allreduce(gp["flat"])
+                gp["post"].replay()
+                loss, step = gp["loss"], gp["step"]
+            else:
+                flat, loss = self._update_pre(do_policy)
+                flat = self._allreduce(flat)
+                step = self._update_post(flat, do_policy)
+        if not stats:
+            return {}
         return {"critic_loss": float(loss.item()) if loss is not None else 0.0,
                 "theta_step_norm": float(step.norm().item()) if step is not None else 0.0}
+
+    # ------------------------------------------------------------------ HIP graphs
+    def enable_graphs(self) -> None:
+        """Captures the roll-out step and the two halves of an update (before / after the collective; with and without the policy
+        step) into HIP graphs and replays them from then on: a closed-loop step is ~190 small launches of which the three batched
+        solves are the only ones that take time — replayed as four graph launches the step is no longer bound by the host's launch
+        rate.  Every library call is capture-safe (no synchronisation, no allocation, fixed launch sequence: include/mpcrl.h).
+        Requirements: CUDA device, a native batched environment (reset_where), the replay buffer full (its sampling range is then a
+        constant; the missing steps are collected here).  The collective stays an eager call between the two halves."""
+        if self._graphs is not None:
+            return
+        if self.device.type != "cuda" or not hasattr(self.env, "reset_where"):
+            raise RuntimeError("enable_graphs needs a CUDA device and an environment with reset_where")
+        while not self.buffer.full:
+            self._collect_step()
+        if self._ended is None:
+            self._ended = torch.zeros(self.E, dtype=torch.bool, device=self.device)
+        self.buffer.pos_t.fill_(self.buffer.pos)
+        gens = [self.gen] + ([self.env.gen] if hasattr(self.env, "gen") else [])
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):                      # warm-up on the capture stream (allocator, lazy initialisations)
+            for dp in (False, True):
+                flat, _ = self._update_pre(dp)
+                self._update_post(self._allreduce(flat), dp)
+            self._collect_step(static=True)
+            self.buffer._advance()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+
+        def capture(fn):
+            g = torch.cuda.CUDAGraph()
+            for gen in gens:
+                g.register_generator_state(gen)
+            with torch.cuda.graph(g, stream=side):
+                out = fn()
+            return g, out
+
+        graphs = {"update": {}}
+        for dp in (False, True):
+            g_pre, (flat, loss) = capture(lambda: self._update_pre(dp))
+            g_post, step = capture(lambda: self._update_post(flat, dp))
+            graphs["update"][dp] = {"pre": g_pre, "post": g_post, "flat": flat, "loss": loss, "step": step}
+        graphs["collect"], _ = capture(lambda: self._collect_step(static=True))
+        torch.cuda.synchronize(self.device)
+        self._graphs = graphs

@@ -274,3 +274,41 @@ def test_per_instance_cold_mask(oracle_port):
     assert int(ra.iters[~mask][:, 0].max()) < int(ra.iters[mask][:, 0].min())        # warm starts need far fewer SQP iterations
     rb = a.solve(x1, reorder=False)                                                   # the mask was one-shot
     assert int(rb.iters[:, 0].max()) == 0
+
+
+def test_td3_graph_replay_mode():
+    """BatchedTD3.enable_graphs: the roll-out step and the two halves of an update captured into HIP graphs (the library calls are
+    capture-safe) and replayed.  The replays must do what the eager calls do: the replay buffer fills and wraps, the environments
+    move and reset, the critic changes at every update, theta and the Polyak target move at every policy_delay-th one, the solves of
+    the closed loop converge, and the roll-out statistics agree with the buffer's contents."""
+    from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedTD3, cartpole_ocp
+    E = 512
+    env = BatchedCartPoleSwingUpEnv(E, device="cuda", seed=3, max_episode_steps=12)      # short episodes: resets happen inside replays
+    agent = BatchedTD3(cartpole_ocp(), env, batch_size=E, buffer_steps=6, policy_delay=2, lr_actor=1e-3, seed=2)
+    agent.collect(2)
+    agent.enable_graphs()
+    assert agent.buffer.full and agent._graphs is not None
+    crit = lambda: torch.cat([p.detach().reshape(-1) for p in agent.critic.parameters()]).clone()
+    c_prev, th_prev, tt0, pos0, n0 = crit(), agent.theta.clone(), agent.theta_target.clone(), agent.buffer.pos, agent.n_updates
+    obs_prev = agent.obs.clone()
+    moved_theta = 0
+    agent.collect(0)
+    for i in range(8):
+        agent.collect(1, stats=False)
+        agent.train(1, stats=False)
+        torch.cuda.synchronize()
+        assert int(agent.buffer.pos_t.item()) == agent.buffer.pos == (pos0 + i + 1) % 6          # device and host positions in step
+        c = crit()
+        assert bool(torch.isfinite(c).all()) and float((c - c_prev).abs().max()) > 0.0               # every update moves the critic
+        assert not torch.equal(agent.obs, obs_prev)
+        moved_theta += int(float((agent.theta - th_prev).abs().max()) > 0.0)
+        c_prev, th_prev, obs_prev = c, agent.theta.clone(), agent.obs.clone()
+    st = agent.last_stats()
+    assert agent.n_updates == n0 + 8 and st["converged_fraction"] > 0.95 and st["episodes_ended"] >= E    # 12-step episodes: everyone ended once
+    assert bool(torch.isfinite(agent.theta).all()) and float((agent.theta_target - tt0).abs().max()) > 0.0
+    assert 1 <= moved_theta <= 4                                                                          # policy_delay = 2: at most every other update
+    # the handles hold the parameters the agent holds (set_theta replays as a captured device-to-device copy of the in-place tensor)
+    assert torch.equal(agent.actor.mpc.get_theta(), agent.theta) and torch.equal(agent.target_mpc.mpc.get_theta(), agent.theta_target)
+    # the newest replay row is the transition the last replayed step produced: its next_obs, un-reset, continues its obs
+    last = (agent.buffer.pos - 1) % 6
+    assert bool(torch.isfinite(agent.buffer.next_obs[last]).all()) and float(agent.buffer.act[last].abs().max()) <= 1.0
