@@ -296,9 +296,10 @@ struct HessConst {
                 }
     }
     template <class S_>
-    MPCRL_DI void rebind(const S_ &S) { th = S.th, sck = S.sCK(); }
+    MPCRL_DI void init(const S_ &S, unsigned) { th = S.th, sck = S.sCK(); }   // (factor() calls begin())
     MPCRL_DI void prefetch(int) {}
     MPCRL_DI void advance(int) {}
+    MPCRL_DI unsigned hex_offset() const { return 0u; }
     MPCRL_DI double tile(int k, int t, int r) const { return sck[k] * h[t][r]; }
     MPCRL_DI double term(int N, int i, int j) const { return sck[N] * M::Qs(th, i, j); }
 };
@@ -311,7 +312,7 @@ struct HessGlobal {
     double hn[NLT][4], hc[NLT][4];
     MPCRL_DI void begin(int lane) { lr = lane >> 4, lc = lane & 15; }
     template <class S_>
-    MPCRL_DI void rebind(const S_ &S) { S.uni(Hex); }
+    MPCRL_DI void init(const S_ &S, unsigned hex_off) { Hex = S.arr(hex_off); }
     MPCRL_DI void prefetch(int k) {
 #pragma unroll
         for (int tm = 0; tm < NT16; ++tm)
@@ -333,6 +334,7 @@ struct HessGlobal {
             for (int r = 0; r < 4; ++r) hc[t][r] = hn[t][r];
         if (k > 0) prefetch(k - 1);
     }
+    MPCRL_DI unsigned hex_offset() const { return Hex.off; }
     MPCRL_DI double tile(int, int t, int r) const { return hc[t][r]; }
     MPCRL_DI double term(int N, int i, int j) const { return Hex[N * NW * NW + (NU + i) * NW + NU + j]; }
 };
@@ -360,6 +362,7 @@ struct ChainSolver {
     int *sidx;
 
     MPCRL_DI ChainSolver(const LargeSpec &s, int lane_) : spp(&s), xs(s.consts), N(s.N), lane(lane_) {}
+    MPCRL_DI ChainSolver(const double *xs_, int N_, int lane_) : spp(nullptr), xs(xs_), N(N_), lane(lane_) {}   // inside a phase call: no set-up
 
 #ifdef MPCRL_PROFILE_PHASES
     // per-wavefront tick counters in LDS (no global traffic inside the timed regions), flushed once by ph_flush()
@@ -479,20 +482,10 @@ struct ChainSolver {
         }
     }
 
-    // ---- one-off set-up: constants into LDS, GEMM tile of this lane, list of bounded coordinates
-    MPCRL_DI void setup(double *lds_, int *sidx_) {
-        const LargeSpec &sp = *spp;
+    // ---- per-lane indices of the solver (a pure function of the lane and of the row counts the set-up left in LDS): what a phase
+    // call re-derives on entry instead of receiving it
+    MPCRL_DI void setup_lane(double *lds_, int *sidx_, bool read_counts) {
         lds = lds_, sidx = sidx_;
-        if (lane <= N) sCK()[lane] = ck_eval(lane);
-        if (lane == 0) {   // one lane, compile-time indices: the kernel arguments stay scalar operands
-#pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                sLB()[i] = sp.lb[i], sLB()[NW + i] = sp.ub[i];
-                sLB()[2 * NW + i] = i >= NU ? sp.lbe[i >= NU ? i - NU : 0] : -1e30, sLB()[3 * NW + i] = i >= NU ? sp.ube[i >= NU ? i - NU : 0] : 1e30;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sLB()[4 * NW + i] = sp.lb0[i], sLB()[4 * NW + 4 + i] = sp.ub0[i];
-        }
         {   // T tile: row-major tile index
             const int tr = lane / Cfg::NTC, tc = lane - tr * Cfg::NTC;
             t_live = lane < Cfg::NTT;
@@ -505,6 +498,25 @@ struct ChainSolver {
             m_live = lane < Cfg::NMM;
             m_i0 = m_live ? ti * TS : 0, m_j0 = m_live ? tj * TS : 0;
             m_diag = ti == tj;
+        }
+        if (read_counts) {
+            n0 = (int)rfl((unsigned)sidx[192]), nm = (int)rfl((unsigned)sidx[193]), ne = (int)rfl((unsigned)sidx[194]);
+            nrows = n0 + (N - 1) * nm + ne;
+        }
+    }
+    // ---- one-off set-up: constants into LDS, GEMM tile of this lane, list of bounded coordinates
+    MPCRL_DI void setup(double *lds_, int *sidx_) {
+        const LargeSpec &sp = *spp;
+        setup_lane(lds_, sidx_, false);
+        if (lane <= N) sCK()[lane] = ck_eval(lane);
+        if (lane == 0) {   // one lane, compile-time indices: the kernel arguments stay scalar operands
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                sLB()[i] = sp.lb[i], sLB()[NW + i] = sp.ub[i];
+                sLB()[2 * NW + i] = i >= NU ? sp.lbe[i >= NU ? i - NU : 0] : -1e30, sLB()[3 * NW + i] = i >= NU ? sp.ube[i >= NU ? i - NU : 0] : 1e30;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sLB()[4 * NW + i] = sp.lb0[i], sLB()[4 * NW + 4 + i] = sp.ub0[i];
         }
         wave_sync();
         if (lane == 0) {
@@ -1276,7 +1288,7 @@ struct ChainSolver {
             // along a direction that solves the Newton system takes them to (1 - alpha) times their value, exactly — they are
             // scaled at the end of the iteration instead of being re-evaluated (a sweep over all [B A]_k: 161 KB per instance at
             // n_mass 5, 10 % of the kernel).  Only the bound rows below depend on the step nonlinearly (complementarity).
-            if (!MPCRL_CHAIN_SCALE_RES || it == 0) rlin = wave_max(qp_residuals_call(*this));
+            if (!MPCRL_CHAIN_SCALE_RES || it == 0) rlin = wave_max(qp_residuals_call(ctx()));
             double rloc = rlin, muloc = 0.0;
             for (int r_ = lane; r_ < nrows; r_ += NT) {
                 int k, i;
@@ -1328,16 +1340,16 @@ struct ChainSolver {
                 wave_sync();
                 ph(1);
                 if (pass == 0) {
-                    if (!factor_call(*this, hs, rt, rb)) fail = true;
+                    if (!factor_call<HS>(ctx(), hs.hex_offset(), rt.off, rb.off)) fail = true;
                     ph(2);
                 } else {
-                    backward_vec_call(*this, rt);
+                    backward_vec_call(ctx(), rt.off);
                     ph(3);
                 }
                 if (pass == 1)   // the multiplier step is only needed with the final direction
-                    forward_call<true>(*this, rb);
+                    forward_call<true>(ctx(), rb.off);
                 else
-                    forward_call<false>(*this, rb);
+                    forward_call<false>(ctx(), rb.off);
                 ph(4);
                 double amax = 1.0, muaff = 0.0;
                 for (int r_ = lane; r_ < nrows; r_ += NT) {
@@ -1417,8 +1429,11 @@ struct ChainSolver {
     // ---- phase calls.  The big phases are real (non-inlined) functions: each gets a register allocation of its own, so the
     // operands of one phase are never spilled on behalf of another (inlined into one body, the interior-point loop carried
     // hundreds of hoisted loop invariants through every phase, and each reload from scratch is an s_waitcnt vmcnt(0) that also
-    // drains the streaming stores).  The solver travels by value; on entry the wave-uniform fields are made provably uniform
-    // again (scalar registers, scalar-base addressing) and the pointers get their address spaces back.
+    // drains the streaming stores).  What travels is a CONTEXT of 16 dwords (argument registers): workspace, parameters, iterate,
+    // LDS addresses, horizon.  Until round 3 the solver itself travelled by value — ~140 dwords per lane, i.e. 35 KB per wavefront
+    // written to and read back from scratch memory at every call (4.7 KB per lane of frame, a large part of the kernel's HBM
+    // traffic beyond its streamed factors); every field of it is a function of the context: the workspace arrays are offsets of one
+    // base (LargeLayout), the tile indices functions of the lane, the row counts three words the set-up left in LDS.
     MPCRL_DI static unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
     template <class T>
     MPCRL_DI static T *uni_global(T *ptr) {
@@ -1433,51 +1448,69 @@ struct ChainSolver {
         return (T *)(LT *)(unsigned long)rfl((unsigned)(unsigned long long)ptr);
     }
     MPCRL_DI void uni(WsArr &a_) const { a_.base = a_.base ? BA.base : nullptr, a_.off = rfl(a_.off); }
-    MPCRL_DI void uniformize() {
-        N = (int)rfl((unsigned)N), qmode = rfl(qmode ? 1u : 0u) != 0;
-        n0 = (int)rfl((unsigned)n0), nm = (int)rfl((unsigned)nm), ne = (int)rfl((unsigned)ne), nrows = (int)rfl((unsigned)nrows);
-        lane = threadIdx.x;
-        BA.base = uni_global(BA.base);
-        for (WsArr *a_ : {&BA, &r, &q, &dx, &du, &nuq, &Dx, &Du, &Dnu, &rg, &rb, &rt, &Dg, &lam, &t, &aff, &P, &p, &K, &L, &kff, &Acl, &hb, &ccv,
-                          &cvec, &state, &NUv})
-            uni(*a_);
-        X = uni_global(X), U = uni_global(U), th = uni_global(th), xs = uni_global(xs);
-        lds = uni_lds(lds), sidx = uni_lds(sidx);
+    struct Ctx {
+        double *w, *X, *U;
+        const double *th, *xs;
+        double *lds;
+        int *sidx;
+        int N, qmode;
 #ifdef MPCRL_PROFILE_PHASES
-        ph_lds = uni_lds(ph_lds);
+        unsigned long long *ph_lds;
 #endif
+    };
+    MPCRL_DI Ctx ctx() const {
+        Ctx c;
+        c.w = (double *)BA.base, c.X = X, c.U = U, c.th = th, c.xs = xs, c.lds = lds, c.sidx = sidx, c.N = N, c.qmode = qmode ? 1 : 0;
+#ifdef MPCRL_PROFILE_PHASES
+        c.ph_lds = ph_lds;
+#endif
+        return c;
     }
+    // the solver of a phase, rebuilt from the context; wave-uniform values end up in scalar registers (readfirstlane on entry,
+    // everything derived from them is scalar arithmetic), pointers get their address spaces back
+    MPCRL_DI static ChainSolver from_ctx(const Ctx &c) {
+        ChainSolver S(uni_global(c.xs), (int)rfl((unsigned)c.N), (int)threadIdx.x);
+        S.qmode = rfl((unsigned)c.qmode) != 0;
+        S.th = uni_global(c.th), S.X = uni_global(c.X), S.U = uni_global(c.U);
+        S.bind_workspace(uni_global(c.w), LargeLayout<M>(S.N));
+        S.setup_lane(uni_lds(c.lds), uni_lds(c.sidx), true);
+#ifdef MPCRL_PROFILE_PHASES
+        S.ph_lds = uni_lds(c.ph_lds);
+        S.ph_t = clock64();
+#endif
+        return S;
+    }
+    MPCRL_DI WsArr arr(unsigned off) const { return WsArr{BA.base, rfl(off)}; }
     struct RoundStart {
         double cost, res[4];
     };
-    __device__ __attribute__((noinline)) static RoundStart round_start_call(ChainSolver S, const double *x0, const double *u0f) {
-        S.uniformize();
+    __device__ __attribute__((noinline)) static RoundStart round_start_call(Ctx c, const double *x0, const double *u0f) {
+        ChainSolver S = from_ctx(c);
         x0 = uni_global(x0), u0f = u0f ? uni_global(u0f) : nullptr;
         RoundStart o;
         o.cost = S.round_start(x0, u0f, o.res);
         return o;
     }
-    __device__ __attribute__((noinline)) static double qp_residuals_call(ChainSolver S) {
-        S.uniformize();
+    __device__ __attribute__((noinline)) static double qp_residuals_call(Ctx c) {
+        ChainSolver S = from_ctx(c);
         return S.qp_residuals();
     }
+    // hex_off: workspace offset of the exact Hessian blocks (HessGlobal); the constant Hessian (HessConst) is rebuilt from theta
     template <class HS>
-    __device__ __attribute__((noinline)) static bool factor_call(ChainSolver S, HS hs, WsArr g, WsArr bb) {
-        S.uniformize();
-        S.uni(g), S.uni(bb);
-        hs.rebind(S);
-        return S.factor(hs, g, bb);
+    __device__ __attribute__((noinline)) static bool factor_call(Ctx c, unsigned hex_off, unsigned g_off, unsigned bb_off) {
+        ChainSolver S = from_ctx(c);
+        HS hs;
+        hs.init(S, hex_off);
+        return S.factor(hs, S.arr(g_off), S.arr(bb_off));
     }
-    __device__ __attribute__((noinline)) static void backward_vec_call(ChainSolver S, WsArr g) {
-        S.uniformize();
-        S.uni(g);
-        S.backward_vec(g);
+    __device__ __attribute__((noinline)) static void backward_vec_call(Ctx c, unsigned g_off) {
+        ChainSolver S = from_ctx(c);
+        S.backward_vec(S.arr(g_off));
     }
     template <bool want_nu>
-    __device__ __attribute__((noinline)) static void forward_call(ChainSolver S, WsArr bb) {
-        S.uniformize();
-        S.uni(bb);
-        S.template forward<want_nu>(bb);
+    __device__ __attribute__((noinline)) static void forward_call(Ctx c, unsigned bb_off) {
+        ChainSolver S = from_ctx(c);
+        S.template forward<want_nu>(S.arr(bb_off));
     }
 
     MPCRL_DI void bind_workspace(double *w, const LargeLayout<M> &lay) {
@@ -1743,7 +1776,7 @@ __global__ void __launch_bounds__(64, 1) chain_sqp_kernel(const LargeSpec sp, co
         S.ph(6);
         chain_dir_pass<M>(S.th, w, lds + Cfg::oBig, N, lane, sp.h, sp.rk_steps);
         S.ph(8);
-        const auto rs0 = ChainSolver<M>::round_start_call(S, x0, u0f);
+        const auto rs0 = ChainSolver<M>::round_start_call(S.ctx(), x0, u0f);
         cost = rs0.cost;
 #pragma unroll
         for (int j = 0; j < 4; ++j) res[j] = rs0.res[j];
@@ -2007,7 +2040,7 @@ __global__ void __launch_bounds__(64, 1) chain_sens_riccati_kernel(const LargeSp
         for (int e = lane; e < ne; e += NT) S.rt[e] = e == iu ? -1.0 : 0.0;
         wave_sync();
         if (iu == 0)
-            okall = ChainSolver<M>::factor_call(S, hs, S.rt, S.rb);
+            okall = ChainSolver<M>::template factor_call<HessGlobal<M>>(S.ctx(), hs.hex_offset(), S.rt.off, S.rb.off);
         else if (lane == 0) {
             // The right-hand side is -e_iu in the controls of stage 0 and zero elsewhere, and there is no dynamics offset: the backward
             // vector recursion is identically zero from the terminal stage down to stage 1 (p_k = 0 — what the factor sweep left for
@@ -2031,7 +2064,7 @@ __global__ void __launch_bounds__(64, 1) chain_sens_riccati_kernel(const LargeSp
             for (int i = 0; i < NU; ++i) S.kff[i] = z[i];
         }
         wave_sync();
-        ChainSolver<M>::template forward_call<true>(S, S.rb);
+        ChainSolver<M>::template forward_call<true>(S.ctx(), S.rb.off);
         for (int e = lane; e < (N + 1) * NX; e += NT) Ydx[iu * (N + 1) * NX + e] = S.Dx[e], Ydnu[iu * (N + 1) * NX + e] = S.Dnu[e];
         for (int e = lane; e < N * NU; e += NT) Ydu[iu * N * NU + e] = S.Du[e];
         wave_sync();
