@@ -67,6 +67,7 @@ struct CartpoleDev {
     // Structure of the discrete map: the cart position x0 does not enter the ODE and the cart velocity x1 enters it only through
     // d(x0)/dt = x1, so for RK4 with any step the columns of A for x0 and x1 are e_0 and [T, 1, 0, 0]' (T = step length) exactly.
     // Only u, theta, theta_dot are carried as jet directions.
+    __host__ __device__ static constexpr bool soft_coord(int) { return false; }
     static constexpr int NLD = 3;
     MPCRL_DI static constexpr int lin_coord(int d) { return d == 0 ? 0 : d + 2; }   // stage-vector coordinate (v = [u; x]) of direction d
     template <class F>
@@ -119,6 +120,7 @@ struct LinearDev {
     MPCRL_DI static int td_index(int i) { return i; }
     MPCRL_DI static int tc_index(int i) { return 8 + i; }   // V_0, f_0, f_1, f_2
     MPCRL_DI static bool p_has_gradient(int) { return true; }
+    __host__ __device__ static constexpr bool soft_coord(int i) { return i == NU; }   // idxsbx = [0]: the first state (linear_system/acados.py:73-131)
     static constexpr int NLD = NX + NU;
     MPCRL_DI static constexpr int lin_coord(int d) { return d; }
     template <class F>

@@ -250,6 +250,9 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
         default: rc = MPCRL_E_MODEL;
     }
     if (!rc) rc = h->is_large ? fill_large_spec(*spec, h->large) : fill_small_spec(*spec, h->small);
+    if (!rc && !h->is_large)   // L1-soft bounds only where the model's kernel carries slack state (models_dev.hpp soft_coord)
+        for (int i = 0; i < spec->nx + spec->nu; ++i)
+            if (h->small.soft[i] && !(spec->model == MPCRL_MODEL_LINEAR ? LinearDev::soft_coord(i) : CartpoleDev::soft_coord(i))) rc = MPCRL_E_MODEL;
     if (rc) {
         delete h;
         return rc;

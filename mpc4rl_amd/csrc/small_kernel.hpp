@@ -208,7 +208,9 @@ struct SmallSolver {
     MPCRL_DI double lbv(int i) const { return lbr[i]; }
     MPCRL_DI double ubv(int i) const { return ubr[i]; }
     MPCRL_DI bool has(int sd, int i) const { return (hasm >> (2 * i + sd)) & 1u; }
-    MPCRL_DI bool softc(int i) const { return SOFT && !first && !term && sp.soft[i] != 0; }
+    // (M::soft_coord: which coordinates of v = [u; x] the model's OCP can have L1-soft bounds on — a compile-time fact, so the
+    // slack state of the other coordinates never occupies registers; mpcrl_create rejects a spec that asks for more)
+    MPCRL_DI bool softc(int i) const { return SOFT && M::soft_coord(i) && !first && !term && sp.soft[i] != 0; }
     MPCRL_DI double zw(int sd, int i) const { return (sd ? sp.zu[i] : sp.zl[i]) * sp.dT * pow(sp.gamma, (double)k); }
     MPCRL_DI bool fixed(int i) const { return first && (i >= NU || qmode); }
     MPCRL_DI double vc(int i) const { return i < NU ? u[i < NU ? i : 0] : x[i >= NU ? i - NU : 0]; }
