@@ -104,6 +104,18 @@ class MPCBatch:
         (the reference's behaviour: full-step SQP to max_iter)."""
         self._check(self.lib.mpcrl_set_exit_rule(self._h, int(window), float(factor)), "mpcrl_set_exit_rule")
 
+    def set_launch_mode(self, mode: int = 0) -> None:
+        """0 = the library times the time-sliced and the plain launch of the solve kernel against each other on this handle's own
+        cold solves and uses the faster (default), 1 = time-sliced whenever legal, -1 = never (include/mpcrl.h mpcrl_set_launch_mode)."""
+        self._check(self.lib.mpcrl_set_launch_mode(self._h, int(mode)), "mpcrl_set_launch_mode")
+
+    def launch_times(self):
+        """(time-sliced ms, plain ms, preferred shape) of the launch tuner's last probes; -1 = not measured yet."""
+        a, b = C.c_double(-1.0), C.c_double(-1.0)
+        rc = self.lib.mpcrl_get_launch_times(self._h, C.byref(a), C.byref(b))
+        self._check(min(rc, 0), "mpcrl_get_launch_times")
+        return a.value, b.value, ("plain" if rc == 1 else "time-sliced")
+
     def set_bounds(self, which: int, lb, ub) -> None:
         """ocp_solver.constraints_set (mpc.py:72-73,87-88): which = _lib.BOUNDS_U0 (stage-0 controls, nu values), BOUNDS_STAGE
         (stages 1..N-1, v = [u; x], nu + nx values), BOUNDS_TERMINAL (stage N, nx values); |bound| >= 1e29 = absent."""

@@ -35,7 +35,14 @@ struct MpcrlSolver {
     double *X = nullptr, *U = nullptr, *PI = nullptr, *BND = nullptr, *RES = nullptr, *LAG = nullptr;
     int64_t bytes = 0;
     int n_simd = 1024;          // SIMDs of the device (one resident wavefront each for the small solve kernel)
-    int slice_mode = 0;         // MPCRL_TIME_SLICE: 0 = automatic, 1 = whenever legal, -1 = never (tests, profiling)
+    int slice_mode = 0;         // mpcrl_set_launch_mode / MPCRL_TIME_SLICE: 0 = automatic, 1 = whenever legal, -1 = never
+    // automatic mode: the two launch shapes of the small solve kernel are timed against each other on the caller's own batches
+    // (choose_launch below): [0] = time-sliced, [1] = plain
+    hipEvent_t tune_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    bool tune_pending[2] = {false, false};
+    float tune_ms[2] = {-1.f, -1.f};
+    unsigned tune_calls = 0;
+    int planned = -1;           // what mpcrl_query_time_sliced promised for the next solve (-1: nothing promised)
     bool have_iterate = false;
     bool dual_cold = false;   // the stored bound multipliers are placeholders (set_iterate without bnd): next solve = MPCRL_COLD_DUAL
 };
@@ -149,8 +156,17 @@ int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
 // 1 328 k cycles: write-outs inside the loop, 3 % for mixing QPs of instances one SQP iteration apart, and more register spill traffic
 // than the plain kernel) — so it pays only when it saves enough rounds of wavefronts on the chip's SIMDs: 4096 instances are 2 rounds
 // of 3-instance wavefronts or 1 round of 4-instance ones (5.44 -> 6.36 M solves/s); 32768 are 11 vs 8 rounds (plain wins).
+//
+// That rule counts wavefronts, not work.  A time-sliced wavefront lasts for the SUM of its instances' iterations and, at one round,
+// nothing evens the sums out between SIMDs; plain wavefronts last for the MAXIMUM over three neighbours of the packing order and the
+// dispatcher hands the second round to whichever SIMD frees up first.  On batches of one difficulty the sliced launch wins (cartpole
+// 4096 states of the benchmark box: 0.56 vs 0.60 ms); on replay samples along closed-loop swing-ups (SQP iterations 2..15) the plain
+// one does (0.47 vs 0.65 ms, profiles/r03_replay_cold_solve.txt).  Which of the two a caller's batches are cannot be read off the
+// flags, so in automatic mode a handle whose batch size passes the rule times the two shapes against each other on its own calls.
+enum { TUNE_PERIOD = 64, TUNE_SLICED = 0, TUNE_PLAIN = 1 };
+
 template <class M>
-bool plan_time_sliced(const MpcrlSolver *h, int flags, long *waves) {
+bool sliced_candidate(const MpcrlSolver *h, int flags, long *waves, bool *by_rule) {
     if constexpr (M::HAS_SOFT) {
         return false;
     } else {
@@ -160,8 +176,34 @@ bool plan_time_sliced(const MpcrlSolver *h, int flags, long *waves) {
         const long waves3 = (h->B + ipw - 1) / ipw, waves4 = (h->B + q - 1) / q;
         const long rounds3 = (waves3 + h->n_simd - 1) / h->n_simd, rounds4 = (waves4 + h->n_simd - 1) / h->n_simd;
         if (waves) *waves = waves4;
-        return legal && (h->slice_mode > 0 || (h->slice_mode == 0 && 162 * rounds4 <= 100 * rounds3));
+        if (by_rule) *by_rule = 162 * rounds4 <= 100 * rounds3;
+        return legal;
     }
+}
+
+// the shape the tuner currently prefers: plain only once both have been timed and the plain kernel was faster by more than 10 %.
+// The margin pays for the packing-order kernel the plain launch's callers put in front of it (16 us at 4096 instances) and is what
+// whole steps asked for: on the TD3 benchmark's replay rows the plain kernel probes 7 % faster (0.578 vs 0.624 ms) and the closed-loop
+// step is 1.5 % slower with it; on later-training replay rows it probes 27 % faster and the solve call is 25 % faster.
+constexpr float TUNE_MARGIN = 0.90f;
+inline int tuned_best(const MpcrlSolver *h) {
+    return (h->tune_ms[0] > 0.f && h->tune_ms[1] > 0.f && h->tune_ms[TUNE_PLAIN] < TUNE_MARGIN * h->tune_ms[TUNE_SLICED]) ? TUNE_PLAIN : TUNE_SLICED;
+}
+
+// shape of call number `call` of a tuned handle: calls 1 and 2 of every TUNE_PERIOD are the timed probes (call 0 of a fresh handle
+// pays module load and cold caches and is not timed)
+inline int tuned_shape(const MpcrlSolver *h, unsigned call, bool *timed) {
+    const unsigned ph = call % TUNE_PERIOD;
+    if (timed) *timed = ph == 1 || ph == 2;
+    return ph == 1 ? TUNE_SLICED : (ph == 2 ? TUNE_PLAIN : tuned_best(h));
+}
+
+template <class M>
+bool plan_time_sliced(const MpcrlSolver *h, int flags, long *waves) {
+    bool by_rule = false;
+    if (!sliced_candidate<M>(h, flags, waves, &by_rule)) return false;
+    if (h->slice_mode != 0) return h->slice_mode > 0;
+    return by_rule && tuned_shape(h, h->tune_calls, nullptr) == TUNE_SLICED;
 }
 
 template <class M>
@@ -169,9 +211,43 @@ int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
     const int lpi = h->N + 1, ipw = std::min(64 / lpi, M::MAX_IPW);
     const int blocks = (h->B + ipw - 1) / ipw;
     bool sliced = false;
+    int timed_shape = -1;
     if constexpr (!M::HAS_SOFT) {
         long waves4 = 0;
-        sliced = plan_time_sliced<M>(h, a.flags, &waves4);
+        bool by_rule = false;
+        if (sliced_candidate<M>(h, a.flags, &waves4, &by_rule)) {
+            if (h->slice_mode != 0) {
+                sliced = h->slice_mode > 0;
+            } else if (by_rule) {
+                // No event calls while the stream is being captured into a graph (they would end the capture): the graph gets the
+                // shape preferred so far, whatever the query promised.
+                hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+                const bool capturing = hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+                if (capturing) {
+                    sliced = tuned_best(h) == TUNE_SLICED;
+                } else {
+                    for (int m = 0; m < 2; ++m)
+                        if (h->tune_pending[m] && hipEventQuery(h->tune_ev[m][1]) == hipSuccess) {
+                            float ms = 0.f;
+                            if (hipEventElapsedTime(&ms, h->tune_ev[m][0], h->tune_ev[m][1]) == hipSuccess && ms > 0.f) h->tune_ms[m] = ms;
+                            h->tune_pending[m] = false;
+                        }
+                    bool timed = false;
+                    const int probe = tuned_shape(h, h->tune_calls, &timed);
+                    const int shape = h->planned >= 0 ? h->planned : probe;   // a promise made before the harvest above stands
+                    h->tune_calls++;
+                    sliced = shape == TUNE_SLICED;
+                    if (timed && shape == probe && !h->tune_pending[shape]) {
+                        if (!h->tune_ev[0][0])
+                            for (auto &pair : h->tune_ev)
+                                for (auto &e : pair) HIP_OK(hipEventCreate(&e));
+                        timed_shape = shape;
+                        HIP_OK(hipEventRecord(h->tune_ev[shape][0], st));
+                    }
+                }
+            }
+        }
+        h->planned = -1;
         if (sliced) {
             if (sliced_parks_in_lds<M>(h->N))
                 hipLaunchKernelGGL((small_solve_sliced_kernel<M, true>), dim3((unsigned)waves4), dim3(64), 0, st, h->small, a);
@@ -181,6 +257,10 @@ int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
     }
     if (!sliced) hipLaunchKernelGGL(small_solve_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
     HIP_OK(hipGetLastError());
+    if (timed_shape >= 0) {
+        HIP_OK(hipEventRecord(h->tune_ev[timed_shape][1], st));
+        h->tune_pending[timed_shape] = true;
+    }
 #if !MPCRL_FUSE_SENS
     if (a.flags & (MPCRL_SENS_V | MPCRL_SENS_PI)) {
         hipLaunchKernelGGL(small_sens_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
@@ -226,7 +306,7 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->n_simd = 4 * cus;
-        const char *e = std::getenv("MPCRL_TIME_SLICE");
+        const char *e = std::getenv("MPCRL_TIME_SLICE");   // tests, profiling: same as mpcrl_set_launch_mode
         if (e && *e) h->slice_mode = (*e == '0') ? -1 : 1;
     }
     int rc = 0;
@@ -299,6 +379,9 @@ int mpcrl_destroy(mpcrl_handle h) {
         if (p) hipFree(p);
     if (h->perm) hipFree(h->perm);
     if (h->cold_mask) hipFree(h->cold_mask);
+    for (auto &pair : h->tune_ev)
+        for (auto &e : pair)
+            if (e) hipEventDestroy(e);
     delete h;
     return 0;
 }
@@ -354,11 +437,39 @@ int mpcrl_query_time_sliced(mpcrl_handle h, int flags) {
     if (!h) return MPCRL_E_ARG;
     if (h->is_large) return 0;
     if (!h->have_iterate) flags |= MPCRL_COLD;
+    bool sliced = false, tuned = false, by_rule = false;
     switch (h->model) {
-        case MPCRL_MODEL_CARTPOLE: return plan_time_sliced<CartpoleDev>(h, flags, nullptr) ? 1 : 0;
-        case MPCRL_MODEL_LINEAR: return plan_time_sliced<LinearDev>(h, flags, nullptr) ? 1 : 0;
+        case MPCRL_MODEL_CARTPOLE:
+            sliced = plan_time_sliced<CartpoleDev>(h, flags, nullptr);
+            tuned = h->slice_mode == 0 && sliced_candidate<CartpoleDev>(h, flags, nullptr, &by_rule) && by_rule;
+            break;
+        case MPCRL_MODEL_LINEAR:
+            sliced = plan_time_sliced<LinearDev>(h, flags, nullptr);
+            tuned = h->slice_mode == 0 && sliced_candidate<LinearDev>(h, flags, nullptr, &by_rule) && by_rule;
+            break;
         default: return 0;
     }
+    h->planned = tuned ? (sliced ? TUNE_SLICED : TUNE_PLAIN) : -1;   // the next mpcrl_solve keeps this promise
+    return sliced ? 1 : 0;
+}
+
+int mpcrl_set_launch_mode(mpcrl_handle h, int mode) {
+    if (!h || mode < -1 || mode > 1) return MPCRL_E_ARG;
+    h->slice_mode = mode, h->planned = -1;
+    return 0;
+}
+
+int mpcrl_get_launch_times(mpcrl_handle h, double *sliced_ms, double *plain_ms) {
+    if (!h || !sliced_ms || !plain_ms) return MPCRL_E_ARG;
+    ON_DEVICE(h->device);
+    for (int m = 0; m < 2; ++m)   // harvest probes that have finished since the last solve (never waits)
+        if (h->tune_pending[m] && hipEventQuery(h->tune_ev[m][1]) == hipSuccess) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->tune_ev[m][0], h->tune_ev[m][1]) == hipSuccess && ms > 0.f) h->tune_ms[m] = ms;
+            h->tune_pending[m] = false;
+        }
+    *sliced_ms = h->tune_ms[TUNE_SLICED], *plain_ms = h->tune_ms[TUNE_PLAIN];
+    return tuned_best(h);
 }
 
 int mpcrl_auto_order(mpcrl_handle h, const double *x0, void *stream) {

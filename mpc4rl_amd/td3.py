@@ -354,6 +354,15 @@ class BatchedTD3:
         if self._ended is None:
             self._ended = torch.zeros(self.E, dtype=torch.bool, device=self.device)
         self.buffer.pos_t.fill_(self.buffer.pos)
+        # The replay solves' launch shape is chosen by timing (mpcrl_set_launch_mode) and a captured graph keeps the shape preferred
+        # at capture: let the two handles finish their probes on stored replay rows first (no random draws, no agent state touched).
+        rows = self.buffer.next_obs.reshape(-1, self.buffer.next_obs.shape[-1])
+        rows = rows[torch.arange(self.B, device=self.device) * (rows.shape[0] // self.B if rows.shape[0] >= self.B else 1) % rows.shape[0]]
+        rows = torch.where(torch.isfinite(rows), rows, torch.zeros_like(rows)).to(torch.float64).contiguous()
+        for _ in range(4):
+            self.target_mpc.mpc.solve(rows, cold=True)
+            self.pi_mpc.mpc.solve(rows, sens_pi=True, cold=True)
+            torch.cuda.synchronize(self.device)
         gens = [self.gen] + ([self.env.gen] if hasattr(self.env, "gen") else [])
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))

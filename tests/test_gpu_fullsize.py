@@ -329,3 +329,49 @@ def test_divergence_exit_rule(oracle_port, monkeypatch):
     assert rel_rows(r1.u0.cpu().numpy()[ok], ref.u0[ok]).max() < RTOL and rel_rows(r1.V.cpu().numpy()[ok], ref.V[ok]).max() < RTOL
     # misuse
     assert on.lib.mpcrl_set_exit_rule(on._h, 300, 0.1) < 0 and on.lib.mpcrl_set_exit_rule(on._h, 10, 0.0) < 0
+
+
+@pytest.mark.gpu
+def test_launch_shape_tuner(monkeypatch):
+    """mpcrl_set_launch_mode(0) (the default): a handle whose batch size makes the time-sliced launch a candidate (4096 cartpole
+    instances: one round of 4-instance wavefronts instead of two of 3-instance ones) probes both shapes on its own cold solves —
+    calls 1 and 2 of every 64 — and reads the times back without waiting.  The shapes return the same bits, so every call of the
+    sequence must return what the first one did, whatever shape it ran in; after the probes both times are known and the handle's
+    promise (mpcrl_query_time_sliced) is the shape the times prefer.  Forced modes override the tuner."""
+    monkeypatch.delenv("MPCRL_TIME_SLICE", raising=False)
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    from mpc4rl_amd import _lib
+    B = 4096
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(B, 4, generator=g, dtype=torch.float64) - 0.5) * torch.tensor([1.0, 1.0, 1.0, 1.0], dtype=torch.float64)
+    x[:, 1] += 3.14159
+    x = x.cuda()
+    mpc = MPCBatch(cartpole_ocp(), B)
+    assert mpc.launch_times()[:2] == (-1.0, -1.0)
+    first = mpc.solve(x, cold=True, sens_pi=True)
+    shapes = []
+    for _ in range(5):
+        shapes.append(mpc.lib.mpcrl_query_time_sliced(mpc._h, _lib.COLD | _lib.SENS_PI))
+        r = mpc.solve(x, cold=True, sens_pi=True)
+        torch.cuda.synchronize()
+        assert torch.equal(r.u0, first.u0) and torch.equal(r.V, first.V) and torch.equal(r.iters, first.iters)
+        assert torch.equal(torch.nan_to_num(r.dpi_dp), torch.nan_to_num(first.dpi_dp))
+    assert shapes[0] == 1 and shapes[1] == 0                       # the probes: call 1 time-sliced, call 2 plain
+    ts, tp, pref = mpc.launch_times()
+    assert ts > 0.0 and tp > 0.0 and pref == ("plain" if tp < 0.90 * ts else "time-sliced")
+    assert all(s == (0 if pref == "plain" else 1) for s in shapes[3:])
+    # warm solves and forced modes are not the tuner's business
+    assert mpc.lib.mpcrl_query_time_sliced(mpc._h, _lib.SENS_PI) == 0
+    mpc.set_launch_mode(-1)
+    assert mpc.lib.mpcrl_query_time_sliced(mpc._h, _lib.COLD) == 0
+    mpc.set_launch_mode(1)
+    assert mpc.lib.mpcrl_query_time_sliced(mpc._h, _lib.COLD) == 1
+    r = mpc.solve(x, cold=True, sens_pi=True)
+    assert torch.equal(r.u0, first.u0) and torch.equal(r.iters, first.iters)
+    assert mpc.lib.mpcrl_set_launch_mode(mpc._h, 2) < 0
+    # a batch the static rule already gives to the plain launch is never probed
+    small = MPCBatch(cartpole_ocp(), 96)
+    for _ in range(4):
+        small.solve(x[:96], cold=True)
+    torch.cuda.synchronize()
+    assert small.launch_times()[:2] == (-1.0, -1.0)
