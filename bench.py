@@ -365,7 +365,9 @@ def td3_bench(args):
                                    + ("roll-out step and update replayed as HIP graphs" if not args.no_graph else "eager launches"),
                        "parallelism": f"environments sharded over {world} GPU(s); one all-reduce of the critic + theta gradients per update",
                        "mpc_solves_per_s": solves / elapsed, "converged_fraction": st["converged_fraction"],
-                       "critic_loss": tr["critic_loss"]},
+                       "critic_loss": tr["critic_loss"],
+                       # launch shape of the replay solves (mpcrl_set_launch_mode 0): probe times in ms and the shape in use
+                       "replay_launch_shape": {"target_actor": list(agent.target_mpc.mpc.launch_times()), "policy": list(agent.pi_mpc.mpc.launch_times())}},
             **({"rccl_ranks": rccl_ranks} if rccl_ranks is not None else {})}), flush=True)
     if dist is not None:
         dist.destroy_process_group()

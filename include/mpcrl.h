@@ -124,7 +124,7 @@ int mpcrl_query_time_sliced(mpcrl_handle h, int flags);
 /* Launch shape of the cartpole / linear-system solve kernel for cold, non-RTI solves (no effect on results: the two shapes return
  * the same bits).  mode 0 (default) = automatic: where the batch size makes the time-sliced shape a candidate (it saves a round of
  * wavefronts on the device's SIMDs) the handle times the two shapes against each other on the caller's own batches — calls 1 and 2 of
- * every 64 are the probes, read back without waiting — and uses the plain one where its kernel is more than 10 % faster: time-sliced on batches of one difficulty, plain on
+ * every 64 are the probes, read back without waiting — and uses the plain one where its kernel is more than 20 % faster: time-sliced on batches of one difficulty, plain on
  * batches whose instances need very different iteration counts (replay samples).  Inside a stream capture nothing is timed and the
  * graph gets the shape preferred so far.  mode 1 = time-sliced whenever legal, mode -1 = never (what the environment variable
  * MPCRL_TIME_SLICE=1|0 sets at creation). */

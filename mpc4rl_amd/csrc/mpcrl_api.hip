@@ -181,11 +181,12 @@ bool sliced_candidate(const MpcrlSolver *h, int flags, long *waves, bool *by_rul
     }
 }
 
-// the shape the tuner currently prefers: plain only once both have been timed and the plain kernel was faster by more than 10 %.
-// The margin pays for the packing-order kernel the plain launch's callers put in front of it (16 us at 4096 instances) and is what
-// whole steps asked for: on the TD3 benchmark's replay rows the plain kernel probes 7 % faster (0.578 vs 0.624 ms) and the closed-loop
-// step is 1.5 % slower with it; on later-training replay rows it probes 27 % faster and the solve call is 25 % faster.
-constexpr float TUNE_MARGIN = 0.90f;
+// the shape the tuner currently prefers: plain only once both have been timed and the plain kernel was faster by more than 20 %.
+// The margin is what whole steps asked for.  The probes time the solve kernel alone; around it the plain launch carries the
+// packing-order kernel (16 us at 4096 instances) and, inside the TD3 loop's graphs, loses more than that: on the benchmark's early
+// replay rows the plain kernel probes 13 % faster (0.54 vs 0.63 ms) and the closed-loop step is 2 % SLOWER with it (2.06 vs 2.02 ms);
+// on later-training replay rows it probes 27 % faster and the whole solve call is 23 % faster (profiles/r03_replay_cold_solve.txt).
+constexpr float TUNE_MARGIN = 0.80f;
 inline int tuned_best(const MpcrlSolver *h) {
     return (h->tune_ms[0] > 0.f && h->tune_ms[1] > 0.f && h->tune_ms[TUNE_PLAIN] < TUNE_MARGIN * h->tune_ms[TUNE_SLICED]) ? TUNE_PLAIN : TUNE_SLICED;
 }
