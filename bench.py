@@ -367,7 +367,8 @@ def td3_bench(args):
                        "mpc_solves_per_s": solves / elapsed, "converged_fraction": st["converged_fraction"],
                        "critic_loss": tr["critic_loss"],
                        # launch shape of the replay solves (mpcrl_set_launch_mode 0): probe times in ms and the shape in use
-                       "replay_launch_shape": {"target_actor": list(agent.target_mpc.mpc.launch_times()), "policy": list(agent.pi_mpc.mpc.launch_times())}},
+                       "replay_launch_shape": {"target_actor": list(agent.target_mpc.mpc.launch_times()), "policy": list(agent.pi_mpc.mpc.launch_times()),
+                                               "rollout_warm": list(agent.actor.mpc.launch_times(warm=True))}},
             **({"rccl_ranks": rccl_ranks} if rccl_ranks is not None else {})}), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -121,17 +121,17 @@ int mpcrl_auto_order(mpcrl_handle h, const double *x0, void *stream);
 /* 1 if an mpcrl_solve with these flags would use the time-sliced launch (whose wavefronts take one instance from each quarter of the
  * batch: a packing order buys nothing there and the caller can skip building one), 0 if not, < 0 on misuse. */
 int mpcrl_query_time_sliced(mpcrl_handle h, int flags);
-/* Launch shape of the cartpole / linear-system solve kernel for cold, non-RTI solves (no effect on results: the two shapes return
- * the same bits).  mode 0 (default) = automatic: where the batch size makes the time-sliced shape a candidate (it saves a round of
- * wavefronts on the device's SIMDs) the handle times the two shapes against each other on the caller's own batches — calls 1 and 2 of
- * every 64 are the probes, read back without waiting — and uses the plain one where its kernel is more than 20 % faster: time-sliced on batches of one difficulty, plain on
- * batches whose instances need very different iteration counts (replay samples).  Inside a stream capture nothing is timed and the
- * graph gets the shape preferred so far.  mode 1 = time-sliced whenever legal, mode -1 = never (what the environment variable
- * MPCRL_TIME_SLICE=1|0 sets at creation). */
+/* Launch shape of the cartpole / linear-system solve kernel for non-RTI solves (no effect on results: the two shapes return the same
+ * bits).  mode 0 (default) = automatic: where the batch size makes the time-sliced shape a candidate (it saves a round of wavefronts
+ * on the device's SIMDs) the handle times the two shapes against each other on the caller's own batches — calls 1 and 2 of every 64
+ * are the probes, read back without waiting; cold calls and warm calls (stored iterates) are timed separately — and uses the plain
+ * one where its kernel is more than 20 % faster: time-sliced on batches of one difficulty, plain on batches whose instances need very
+ * different iteration counts (replay samples).  Inside a stream capture nothing is timed and the graph gets the shape preferred so
+ * far.  mode 1 = time-sliced whenever legal, mode -1 = never (what the environment variable MPCRL_TIME_SLICE=1|0 sets at creation). */
 int mpcrl_set_launch_mode(mpcrl_handle h, int mode);
-/* The tuner's last probe times in ms (-1 = not measured yet); returns 0 if it currently prefers the time-sliced shape, 1 if the
- * plain one, < 0 on misuse.  Never waits for the device. */
-int mpcrl_get_launch_times(mpcrl_handle h, double *sliced_ms, double *plain_ms);
+/* The tuner's last probe times in ms (-1 = not measured yet) for cold (warm = 0) or warm (warm = 1) calls; returns 0 if it currently
+ * prefers the time-sliced shape, 1 if the plain one, < 0 on misuse.  Never waits for the device. */
+int mpcrl_get_launch_times(mpcrl_handle h, int warm, double *sliced_ms, double *plain_ms);
 
 /* Box bounds after creation — ocp_solver.constraints_set(stage, "lbu"|"ubu"|"lbx"|"ubx", v) (rlmpc/mpc/common/mpc.py:72-73,87-88).
  * HOST pointers, stage-vector order v = [u; x]; |bound| >= 1e29 = absent.  which: U0 = controls of stage 0 (nu values),

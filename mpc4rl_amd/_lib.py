@@ -62,7 +62,7 @@ def load():
     lib.mpcrl_auto_order.argtypes = [vp, vp, vp]
     lib.mpcrl_query_time_sliced.argtypes = [vp, C.c_int]
     lib.mpcrl_set_launch_mode.argtypes = [vp, C.c_int]
-    lib.mpcrl_get_launch_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.mpcrl_get_launch_times.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.mpcrl_weighted_grad_sum.argtypes = [vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp]
     lib.mpcrl_env_cartpole_step.argtypes = [_dp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.mpcrl_env_cartpole_reset.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp]

@@ -106,13 +106,14 @@ class MPCBatch:
 
     def set_launch_mode(self, mode: int = 0) -> None:
         """0 = the library times the time-sliced and the plain launch of the solve kernel against each other on this handle's own
-        cold solves and uses the faster (default), 1 = time-sliced whenever legal, -1 = never (include/mpcrl.h mpcrl_set_launch_mode)."""
+        solves and uses the faster (default), 1 = time-sliced whenever legal, -1 = never (include/mpcrl.h mpcrl_set_launch_mode)."""
         self._check(self.lib.mpcrl_set_launch_mode(self._h, int(mode)), "mpcrl_set_launch_mode")
 
-    def launch_times(self):
-        """(time-sliced ms, plain ms, preferred shape) of the launch tuner's last probes; -1 = not measured yet."""
+    def launch_times(self, warm: bool = False):
+        """(time-sliced ms, plain ms, preferred shape) of the launch tuner's last probes on cold (default) or warm calls; -1 = not
+        measured yet."""
         a, b = C.c_double(-1.0), C.c_double(-1.0)
-        rc = self.lib.mpcrl_get_launch_times(self._h, C.byref(a), C.byref(b))
+        rc = self.lib.mpcrl_get_launch_times(self._h, int(warm), C.byref(a), C.byref(b))
         self._check(min(rc, 0), "mpcrl_get_launch_times")
         return a.value, b.value, ("plain" if rc == 1 else "time-sliced")
 

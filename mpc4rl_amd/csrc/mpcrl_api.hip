@@ -38,10 +38,12 @@ struct MpcrlSolver {
     int slice_mode = 0;         // mpcrl_set_launch_mode / MPCRL_TIME_SLICE: 0 = automatic, 1 = whenever legal, -1 = never
     // automatic mode: the two launch shapes of the small solve kernel are timed against each other on the caller's own batches
     // (choose_launch below): [0] = time-sliced, [1] = plain
-    hipEvent_t tune_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    bool tune_pending[2] = {false, false};
-    float tune_ms[2] = {-1.f, -1.f};
-    unsigned tune_calls = 0;
+    struct Tuner {
+        hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+        bool pending[2] = {false, false};
+        float ms[2] = {-1.f, -1.f};
+        unsigned calls = 0;
+    } tune[2];                  // [0] cold calls, [1] warm calls (different work per instance: timed separately)
     int planned = -1;           // what mpcrl_query_time_sliced promised for the next solve (-1: nothing promised)
     bool have_iterate = false;
     bool dual_cold = false;   // the stored bound multipliers are placeholders (set_iterate without bnd): next solve = MPCRL_COLD_DUAL
@@ -172,7 +174,7 @@ bool sliced_candidate(const MpcrlSolver *h, int flags, long *waves, bool *by_rul
     } else {
         const int lpi = h->N + 1, ipw = std::min(64 / lpi, M::MAX_IPW);
         const int ips = std::min(64 / lpi, M::MAX_IPW - 1), q = ips + 1;
-        const bool legal = ips >= 1 && 64 - ips * lpi >= 1 && (flags & MPCRL_COLD) && !(flags & MPCRL_RTI);
+        const bool legal = ips >= 1 && 64 - ips * lpi >= 1 && !(flags & MPCRL_RTI);
         const long waves3 = (h->B + ipw - 1) / ipw, waves4 = (h->B + q - 1) / q;
         const long rounds3 = (waves3 + h->n_simd - 1) / h->n_simd, rounds4 = (waves4 + h->n_simd - 1) / h->n_simd;
         if (waves) *waves = waves4;
@@ -187,16 +189,24 @@ bool sliced_candidate(const MpcrlSolver *h, int flags, long *waves, bool *by_rul
 // replay rows the plain kernel probes 13 % faster (0.54 vs 0.63 ms) and the closed-loop step is 2 % SLOWER with it (2.06 vs 2.02 ms);
 // on later-training replay rows it probes 27 % faster and the whole solve call is 23 % faster (profiles/r03_replay_cold_solve.txt).
 constexpr float TUNE_MARGIN = 0.80f;
-inline int tuned_best(const MpcrlSolver *h) {
-    return (h->tune_ms[0] > 0.f && h->tune_ms[1] > 0.f && h->tune_ms[TUNE_PLAIN] < TUNE_MARGIN * h->tune_ms[TUNE_SLICED]) ? TUNE_PLAIN : TUNE_SLICED;
+inline int tuned_best(const MpcrlSolver::Tuner &t) {
+    return (t.ms[0] > 0.f && t.ms[1] > 0.f && t.ms[TUNE_PLAIN] < TUNE_MARGIN * t.ms[TUNE_SLICED]) ? TUNE_PLAIN : TUNE_SLICED;
 }
 
 // shape of call number `call` of a tuned handle: calls 1 and 2 of every TUNE_PERIOD are the timed probes (call 0 of a fresh handle
 // pays module load and cold caches and is not timed)
-inline int tuned_shape(const MpcrlSolver *h, unsigned call, bool *timed) {
-    const unsigned ph = call % TUNE_PERIOD;
+inline int tuned_shape(const MpcrlSolver::Tuner &t, bool *timed) {
+    const unsigned ph = t.calls % TUNE_PERIOD;
     if (timed) *timed = ph == 1 || ph == 2;
-    return ph == 1 ? TUNE_SLICED : (ph == 2 ? TUNE_PLAIN : tuned_best(h));
+    return ph == 1 ? TUNE_SLICED : (ph == 2 ? TUNE_PLAIN : tuned_best(t));
+}
+inline void tuner_harvest(MpcrlSolver::Tuner &t) {   // probes that have finished since the last look (never waits)
+    for (int m = 0; m < 2; ++m)
+        if (t.pending[m] && hipEventQuery(t.ev[m][1]) == hipSuccess) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, t.ev[m][0], t.ev[m][1]) == hipSuccess && ms > 0.f) t.ms[m] = ms;
+            t.pending[m] = false;
+        }
 }
 
 template <class M>
@@ -204,7 +214,7 @@ bool plan_time_sliced(const MpcrlSolver *h, int flags, long *waves) {
     bool by_rule = false;
     if (!sliced_candidate<M>(h, flags, waves, &by_rule)) return false;
     if (h->slice_mode != 0) return h->slice_mode > 0;
-    return by_rule && tuned_shape(h, h->tune_calls, nullptr) == TUNE_SLICED;
+    return by_rule && tuned_shape(h->tune[(flags & MPCRL_COLD) ? 0 : 1], nullptr) == TUNE_SLICED;
 }
 
 template <class M>
@@ -224,43 +234,41 @@ int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
                 // shape preferred so far, whatever the query promised.
                 hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
                 const bool capturing = hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+                MpcrlSolver::Tuner &t = h->tune[(a.flags & MPCRL_COLD) ? 0 : 1];
                 if (capturing) {
-                    sliced = tuned_best(h) == TUNE_SLICED;
+                    sliced = tuned_best(t) == TUNE_SLICED;
                 } else {
-                    for (int m = 0; m < 2; ++m)
-                        if (h->tune_pending[m] && hipEventQuery(h->tune_ev[m][1]) == hipSuccess) {
-                            float ms = 0.f;
-                            if (hipEventElapsedTime(&ms, h->tune_ev[m][0], h->tune_ev[m][1]) == hipSuccess && ms > 0.f) h->tune_ms[m] = ms;
-                            h->tune_pending[m] = false;
-                        }
+                    tuner_harvest(t);
                     bool timed = false;
-                    const int probe = tuned_shape(h, h->tune_calls, &timed);
+                    const int probe = tuned_shape(t, &timed);
                     const int shape = h->planned >= 0 ? h->planned : probe;   // a promise made before the harvest above stands
-                    h->tune_calls++;
+                    t.calls++;
                     sliced = shape == TUNE_SLICED;
-                    if (timed && shape == probe && !h->tune_pending[shape]) {
-                        if (!h->tune_ev[0][0])
-                            for (auto &pair : h->tune_ev)
+                    if (timed && shape == probe && !t.pending[shape]) {
+                        if (!t.ev[0][0])
+                            for (auto &pair : t.ev)
                                 for (auto &e : pair) HIP_OK(hipEventCreate(&e));
                         timed_shape = shape;
-                        HIP_OK(hipEventRecord(h->tune_ev[shape][0], st));
+                        HIP_OK(hipEventRecord(t.ev[shape][0], st));
                     }
                 }
             }
         }
         h->planned = -1;
         if (sliced) {
-            if (sliced_parks_in_lds<M>(h->N))
-                hipLaunchKernelGGL((small_solve_sliced_kernel<M, true>), dim3((unsigned)waves4), dim3(64), 0, st, h->small, a);
-            else
-                hipLaunchKernelGGL((small_solve_sliced_kernel<M, false>), dim3((unsigned)waves4), dim3(64), 0, st, h->small, a);
+            const bool lds = sliced_parks_in_lds<M>(h->N), warm = !(a.flags & MPCRL_COLD);
+            if (lds && !warm) hipLaunchKernelGGL((small_solve_sliced_kernel<M, true, false>), dim3((unsigned)waves4), dim3(64), 0, st, h->small, a);
+            if (lds && warm) hipLaunchKernelGGL((small_solve_sliced_kernel<M, true, true>), dim3((unsigned)waves4), dim3(64), 0, st, h->small, a);
+            if (!lds && !warm) hipLaunchKernelGGL((small_solve_sliced_kernel<M, false, false>), dim3((unsigned)waves4), dim3(64), 0, st, h->small, a);
+            if (!lds && warm) hipLaunchKernelGGL((small_solve_sliced_kernel<M, false, true>), dim3((unsigned)waves4), dim3(64), 0, st, h->small, a);
         }
     }
     if (!sliced) hipLaunchKernelGGL(small_solve_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
     HIP_OK(hipGetLastError());
     if (timed_shape >= 0) {
-        HIP_OK(hipEventRecord(h->tune_ev[timed_shape][1], st));
-        h->tune_pending[timed_shape] = true;
+        MpcrlSolver::Tuner &t = h->tune[(a.flags & MPCRL_COLD) ? 0 : 1];
+        HIP_OK(hipEventRecord(t.ev[timed_shape][1], st));
+        t.pending[timed_shape] = true;
     }
 #if !MPCRL_FUSE_SENS
     if (a.flags & (MPCRL_SENS_V | MPCRL_SENS_PI)) {
@@ -380,9 +388,10 @@ int mpcrl_destroy(mpcrl_handle h) {
         if (p) hipFree(p);
     if (h->perm) hipFree(h->perm);
     if (h->cold_mask) hipFree(h->cold_mask);
-    for (auto &pair : h->tune_ev)
-        for (auto &e : pair)
-            if (e) hipEventDestroy(e);
+    for (auto &t : h->tune)
+        for (auto &pair : t.ev)
+            for (auto &e : pair)
+                if (e) (void)hipEventDestroy(e);
     delete h;
     return 0;
 }
@@ -460,17 +469,13 @@ int mpcrl_set_launch_mode(mpcrl_handle h, int mode) {
     return 0;
 }
 
-int mpcrl_get_launch_times(mpcrl_handle h, double *sliced_ms, double *plain_ms) {
+int mpcrl_get_launch_times(mpcrl_handle h, int warm, double *sliced_ms, double *plain_ms) {
     if (!h || !sliced_ms || !plain_ms) return MPCRL_E_ARG;
     ON_DEVICE(h->device);
-    for (int m = 0; m < 2; ++m)   // harvest probes that have finished since the last solve (never waits)
-        if (h->tune_pending[m] && hipEventQuery(h->tune_ev[m][1]) == hipSuccess) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, h->tune_ev[m][0], h->tune_ev[m][1]) == hipSuccess && ms > 0.f) h->tune_ms[m] = ms;
-            h->tune_pending[m] = false;
-        }
-    *sliced_ms = h->tune_ms[TUNE_SLICED], *plain_ms = h->tune_ms[TUNE_PLAIN];
-    return tuned_best(h);
+    MpcrlSolver::Tuner &t = h->tune[warm ? 1 : 0];
+    tuner_harvest(t);
+    *sliced_ms = t.ms[TUNE_SLICED], *plain_ms = t.ms[TUNE_PLAIN];
+    return tuned_best(t);
 }
 
 int mpcrl_auto_order(mpcrl_handle h, const double *x0, void *stream) {

@@ -1703,7 +1703,9 @@ constexpr int sliced_park_cap() { return (M::NX == 4 && M::NU == 1) ? 21 * slice
 template <class M>
 inline bool sliced_parks_in_lds(int N) { return (N + 1) * sliced_park_words<M>() <= sliced_park_cap<M>(); }
 
-template <class M, bool LDSPARK>
+// WARM: the instances start from their stored iterates (and the per-instance cold mask), as in small_solve_kernel — a separate
+// instantiation, so that the cold one keeps its register allocation.
+template <class M, bool LDSPARK, bool WARM = false>
 __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSpec sp, const SmallArgs a) {
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NP = M::NP, NTD = M::NTD, NTC = M::NTC;
     static_assert(!M::HAS_SOFT, "hard bounds only");
@@ -1785,13 +1787,48 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
         for (int i = 0; i < NTC; ++i) S.thc[i] = th_lds[loc * TH + NTD + i];
     };
     load_params();
-    // ---- cold start of the resident instances (MPC.reset, mpc.py:204-210)
+    // ---- cold start of the resident instances (MPC.reset, mpc.py:204-210), or their stored iterates
 #pragma unroll
     for (int i = 0; i < NX; ++i) S.x0r[i] = x0[i], S.x[i] = S.x0r[i], S.nu_[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < NU; ++i) S.u[i] = 0.0, S.u0r[i] = u0f[i];
 #pragma unroll
     for (int i = 0; i < NW; ++i) S.lam[0][i] = S.lam[1][i] = 0.0, S.t[0][i] = S.t[1][i] = 1.0, S.aff[0][i] = S.aff[1][i] = 0.0;
+    // stored state of the lane's current instance, with the per-instance cold mask applied by selects (small_solve_kernel's warm path)
+    auto load_stored = [&]() {
+        const bool cold = a.cold && a.cold[inst];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const double xs = a.X[(inst * (N + 1) + k) * NX + i], ns = a.PI[(inst * N + (first ? 0 : k - 1)) * NX + i];
+            S.x[i] = cold ? S.x0r[i] : xs;
+            S.nu_[i] = (first || cold) ? 0.0 : ns;
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const double us = a.U[(inst * N + (term ? 0 : k)) * NU + i];
+            S.u[i] = (term || cold) ? 0.0 : us;
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const double l0 = bnd[0 * nb + i], l1 = bnd[1 * nb + i], t0 = bnd[2 * nb + i], t1 = bnd[3 * nb + i];
+            S.lam[0][i] = cold ? 0.0 : l0, S.lam[1][i] = cold ? 0.0 : l1, S.t[0][i] = cold ? 1.0 : t0, S.t[1][i] = cold ? 1.0 : t1;
+        }
+    };
+    // change of the pinned x0 / u0 against the stored iterate: the perturbation a warm call's first QP sees (< 0: start cold)
+    auto warm_stepn = [&]() {
+        double sl = 0.0;
+        if (first) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) sl = fmax(sl, fabs(S.x0r[i] - S.x[i]));
+            if (S.qmode) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) sl = fmax(sl, fabs(S.u0r[i] - S.u[i]));
+            }
+        }
+        const double sn = seg_max<M::SEG_SKIP>(sl, k, lpi, base);
+        return ((a.flags & 16) || (a.cold && a.cold[inst])) ? -1.0 : sn;
+    };
+    if constexpr (WARM) load_stored();
 #pragma unroll
     for (int i = 0; i < S.NPK; ++i) S.P[i] = 0.0;
 #pragma unroll
@@ -1807,6 +1844,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
     bool live = valid, last_tight = true;
     int status = 2, iti = 0, n_ipm = 0;
     double stepn = -1.0;
+    if constexpr (WARM) stepn = warm_stepn();
     double rbest = 1e300, rchk = 1e300;               // divergence exit (mpcrl_set_exit_rule), as in small_solve_kernel
     int exit_cnt = sp.exit_window;
     // the parked instance (wave-uniform): local index or -1, and whether it has run at all
@@ -2062,25 +2100,47 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
                     S.t[0][i] = pk_started ? in[2 * NX + NU + 4 * i + 2] : 1.0, S.t[1][i] = pk_started ? in[2 * NX + NU + 4 * i + 3] : 1.0;
                 }
             }
+            if constexpr (WARM) {
+                if (!pk_started) {                    // (wave-uniform) first take of the parked instance: its stored iterate, once
+                    double kx[NX], kn[NX], ku[NU], kl[2][NW], kt[2][NW];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) kx[i] = S.x[i], kn[i] = S.nu_[i];
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) ku[i] = S.u[i];
+#pragma unroll
+                    for (int i = 0; i < NW; ++i) kl[0][i] = S.lam[0][i], kl[1][i] = S.lam[1][i], kt[0][i] = S.t[0][i], kt[1][i] = S.t[1][i];
+                    load_stored();
+                    if (!sw) {
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) S.x[i] = kx[i], S.nu_[i] = kn[i];
+#pragma unroll
+                        for (int i = 0; i < NU; ++i) S.u[i] = ku[i];
+#pragma unroll
+                        for (int i = 0; i < NW; ++i) S.lam[0][i] = kl[0][i], S.lam[1][i] = kl[1][i], S.t[0][i] = kt[0][i], S.t[1][i] = kt[1][i];
+                    }
+                }
+            }
         } else {
+            // the arrays hold the parked state — or, on a warm call's first take, the stored iterate the instance starts from
+            const bool from_arrays = pk_started || (WARM && !(a.cold && a.cold[inst]));
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 const double xs = a.X[(inst * (N + 1) + k) * NX + i], ns = a.PI[(inst * N + (first ? 0 : k - 1)) * NX + i];
                 const double x0n = x0[i];
-                S.x[i] = sw ? (pk_started ? xs : x0n) : S.x[i];
+                S.x[i] = sw ? (from_arrays ? xs : x0n) : S.x[i];
                 S.x0r[i] = sw ? x0n : S.x0r[i];
-                S.nu_[i] = sw ? ((first || !pk_started) ? 0.0 : ns) : S.nu_[i];
+                S.nu_[i] = sw ? ((first || !from_arrays) ? 0.0 : ns) : S.nu_[i];
             }
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
                 const double us = a.U[(inst * N + (term ? 0 : k)) * NU + i];
-                S.u[i] = sw ? ((term || !pk_started) ? 0.0 : us) : S.u[i];
+                S.u[i] = sw ? ((term || !from_arrays) ? 0.0 : us) : S.u[i];
             }
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 const double l0 = bnd[0 * nb + i], l1 = bnd[1 * nb + i], t0 = bnd[2 * nb + i], t1 = bnd[3 * nb + i];
-                S.lam[0][i] = sw ? (pk_started ? l0 : 0.0) : S.lam[0][i], S.lam[1][i] = sw ? (pk_started ? l1 : 0.0) : S.lam[1][i];
-                S.t[0][i] = sw ? (pk_started ? t0 : 1.0) : S.t[0][i], S.t[1][i] = sw ? (pk_started ? t1 : 1.0) : S.t[1][i];
+                S.lam[0][i] = sw ? (from_arrays ? l0 : 0.0) : S.lam[0][i], S.lam[1][i] = sw ? (from_arrays ? l1 : 0.0) : S.lam[1][i];
+                S.t[0][i] = sw ? (from_arrays ? t0 : 1.0) : S.t[0][i], S.t[1][i] = sw ? (from_arrays ? t1 : 1.0) : S.t[1][i];
             }
         }
         if (S.qmode) {   // the pinned u0 of the incoming instance (Q-mode only: one global read per rotation)
@@ -2088,6 +2148,12 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
             for (int i = 0; i < NU; ++i) {
                 const double un = u0f[i];
                 S.u0r[i] = sw ? un : S.u0r[i];
+            }
+        }
+        if constexpr (WARM) {
+            if (!pk_started) {   // (wave-uniform) the incoming instance's first QP: every lane takes part in the reduction, its slot keeps the result
+                const double sn = warm_stepn();
+                if (sw) stepn = sn;
             }
         }
         pk = for_good ? -1 : lo;

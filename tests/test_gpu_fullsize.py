@@ -360,8 +360,15 @@ def test_launch_shape_tuner(monkeypatch):
     ts, tp, pref = mpc.launch_times()
     assert ts > 0.0 and tp > 0.0 and pref == ("plain" if tp < 0.80 * ts else "time-sliced")
     assert all(s == (0 if pref == "plain" else 1) for s in shapes[3:])
-    # warm solves and forced modes are not the tuner's business
-    assert mpc.lib.mpcrl_query_time_sliced(mpc._h, _lib.SENS_PI) == 0
+    # warm calls are probed on their own (different work per instance): their first probe is still ahead
+    assert mpc.launch_times(warm=True)[:2] == (-1.0, -1.0) and mpc.lib.mpcrl_query_time_sliced(mpc._h, _lib.SENS_PI) == 1
+    w0 = mpc.solve(x, sens_pi=True)
+    for _ in range(4):
+        w = mpc.solve(x, sens_pi=True)
+        torch.cuda.synchronize()
+        assert torch.equal(w.u0, w0.u0) and torch.equal(w.V, w0.V)
+    tws, twp, _ = mpc.launch_times(warm=True)
+    assert tws > 0.0 and twp > 0.0 and (tws, twp) != (ts, tp)
     mpc.set_launch_mode(-1)
     assert mpc.lib.mpcrl_query_time_sliced(mpc._h, _lib.COLD) == 0
     mpc.set_launch_mode(1)

@@ -513,3 +513,46 @@ def test_sensitivity_rows_are_written_in_full():
                 assert torch.equal(st, ref.status)
                 assert torch.equal(dV, ref.dV_dp)
                 assert torch.equal(torch.nan_to_num(dpi, nan=7.0), torch.nan_to_num(ref.dpi_dp, nan=7.0))
+
+
+@pytest.mark.parametrize("N,tf,B", [(20, 2.0, 4096), (20, 2.0, 101), (30, 3.0, 203)])
+def test_time_sliced_launch_warm_calls(N, tf, B, monkeypatch):
+    """Warm calls through the time-sliced launch (small_solve_sliced_kernel<.., WARM>): the resident instances and, on its first take,
+    the parked one start from their stored iterates; the per-instance cold mask, the change of x0 that sizes the first QP's warm
+    start, the Q-mode's pinned u0 and a stored iterate without multipliers (MPCRL_COLD_DUAL) are handled as in small_solve_kernel.
+    A closed-loop sequence — cold solve, three warm solves at moved states (one with a cold mask, one in Q-mode), set_iterate without
+    multipliers, warm solve — must be bit-identical between the two launch shapes, parked state in LDS (N = 20) and in HBM (N = 30)."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    rng = np.random.default_rng(5)
+    x0 = cartpole_x0(B, seed=17)
+    steps = [torch.as_tensor(rng.normal(0.0, s, (B, 4)), device="cuda") for s in (0.02, 0.05, 0.01)]
+    mask = torch.as_tensor(rng.uniform(size=B) < 0.2, device="cuda")
+    u0 = torch.as_tensor(rng.uniform(-10.0, 10.0, (B, 1)), device="cuda")
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MPCRL_TIME_SLICE", mode)
+        mpc = MPCBatch(cartpole_ocp(N=N, tf=tf), B)
+        xs = torch.as_tensor(x0, device="cuda").clone()
+        seq = [mpc.solve(xs, cold=True)]
+        xs = xs + steps[0]
+        seq.append(mpc.solve(xs, sens_pi=True))                                   # warm
+        xs = xs + steps[1]
+        seq.append(mpc.solve(xs, sens_v=True, cold_mask=mask))                    # warm, a fifth of the instances reset
+        xs = xs + steps[2]
+        seq.append(mpc.solve(xs, u0, sens_v=True))                                # warm, Q-mode
+        x, u, pi, bnd, res = mpc.get_iterate()
+        mpc.set_iterate(x, u, pi)                                                 # primal iterate only: next solve = MPCRL_COLD_DUAL
+        seq.append(mpc.solve(xs))
+        out[mode] = (seq, mpc.get_iterate())
+    (sa, ia), (sb, ib) = out["0"], out["1"]
+    for n, (ra, rb) in enumerate(zip(sa, sb)):
+        assert int((ra.status == 0).sum()) > 0.8 * B, n
+        for f in ("u0", "V", "status", "iters", "dV_dp", "dpi_dp"):
+            t1, t2 = getattr(ra, f), getattr(rb, f)
+            assert (t1 is None and t2 is None) or torch.equal(torch.nan_to_num(t1), torch.nan_to_num(t2)), (n, f)
+    for t1, t2 in zip(ia, ib):
+        assert torch.equal(t1, t2)
+    ok = (sa[0].status == 0) & (sa[1].status == 0) & (sa[2].status == 0)
+    it = lambda r, m: float(r.iters[m][:, 0].double().mean())
+    assert it(sa[1], ok) < 0.9 * it(sa[0], ok)                      # a warm call is warm ...
+    assert it(sa[2], ok & mask) > 1.1 * it(sa[2], ok & ~mask)       # ... and an instance of the cold mask is not
