@@ -1796,7 +1796,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
     for (int i = 0; i < NW; ++i) S.lam[0][i] = S.lam[1][i] = 0.0, S.t[0][i] = S.t[1][i] = 1.0, S.aff[0][i] = S.aff[1][i] = 0.0;
     // stored state of the lane's current instance, with the per-instance cold mask applied by selects (small_solve_kernel's warm path)
     auto load_stored = [&]() {
-        const bool cold = a.cold && a.cold[inst];
+        const bool cold = (a.flags & 8) || (a.cold && a.cold[inst]);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const double xs = a.X[(inst * (N + 1) + k) * NX + i], ns = a.PI[(inst * N + (first ? 0 : k - 1)) * NX + i];
@@ -1826,7 +1826,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
             }
         }
         const double sn = seg_max<M::SEG_SKIP>(sl, k, lpi, base);
-        return ((a.flags & 16) || (a.cold && a.cold[inst])) ? -1.0 : sn;
+        return ((a.flags & (8 | 16)) || (a.cold && a.cold[inst])) ? -1.0 : sn;
     };
     if constexpr (WARM) load_stored();
 #pragma unroll
@@ -2122,7 +2122,7 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
             }
         } else {
             // the arrays hold the parked state — or, on a warm call's first take, the stored iterate the instance starts from
-            const bool from_arrays = pk_started || (WARM && !(a.cold && a.cold[inst]));
+            const bool from_arrays = pk_started || (WARM && !(a.flags & 8) && !(a.cold && a.cold[inst]));
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 const double xs = a.X[(inst * (N + 1) + k) * NX + i], ns = a.PI[(inst * N + (first ? 0 : k - 1)) * NX + i];
