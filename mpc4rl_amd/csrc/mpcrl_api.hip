@@ -385,9 +385,9 @@ int mpcrl_destroy(mpcrl_handle h) {
     if (!h) return MPCRL_E_ARG;
     DeviceGuard guard_(h->device);
     for (double *p : {h->X, h->U, h->PI, h->BND, h->RES, h->LAG, h->theta, h->ws, h->consts_dev})
-        if (p) hipFree(p);
-    if (h->perm) hipFree(h->perm);
-    if (h->cold_mask) hipFree(h->cold_mask);
+        if (p) (void)hipFree(p);
+    if (h->perm) (void)hipFree(h->perm);
+    if (h->cold_mask) (void)hipFree(h->cold_mask);
     for (auto &t : h->tune)
         for (auto &pair : t.ev)
             for (auto &e : pair)
