@@ -37,7 +37,7 @@ struct SmallSpec {
 
 struct CartpoleDev {
     static constexpr int NX = 4, NU = 1, NW = 5, NP = 83, NTD = 3, NTC = 0;
-    static constexpr bool DISCRETE = false, HAS_SOFT = false;
+    static constexpr bool DISCRETE = false, HAS_SOFT = false, SKIP_CORRECTOR = true;
     static constexpr int MAX_IPW = 4;   // instances per wavefront: the matrix-core factor sweep has four 4x4 blocks
 #ifndef MPCRL_CARTPOLE_SEG_SKIP
 #define MPCRL_CARTPOLE_SEG_SKIP 0
@@ -114,7 +114,7 @@ struct CartpoleDev {
 
 struct LinearDev {
     static constexpr int NX = 2, NU = 1, NW = 3, NP = 12, NTD = 8, NTC = 4;
-    static constexpr bool DISCRETE = true, HAS_SOFT = true;
+    static constexpr bool DISCRETE = true, HAS_SOFT = true, SKIP_CORRECTOR = false;
     static constexpr int MAX_IPW = 21;   // N >= 2
     static constexpr bool SEG_SKIP = true;
     MPCRL_DI static int td_index(int i) { return i; }

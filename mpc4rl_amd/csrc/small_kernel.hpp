@@ -43,6 +43,15 @@ constexpr double IPM_WARM_C = 1e-4, IPM_WARM_MIN = 1e-10, IPM_WARM_MAX = 3e-2;
 // inexact SQP: QP tolerances follow the NLP residual r (tol_res = clamp(C r^2, TOL_RES, CAP), tol_mu = clamp(C r^2 / 100, TOL_MU, CAP / 10));
 // convergence is only declared after a QP solved to the tight tolerances   
 constexpr double IPM_ADAPT_C = 1e1, IPM_ADAPT_CAP = 3e-2;
+// Where the predictor step alone cuts the complementarity by more than two orders of magnitude (sigma = (mu_aff / mu)^3 below this)
+// it is the Newton step of a QP that is all but solved: it is taken and the corrector's two vector sweeps are not run.  Models opt in
+// (M::SKIP_CORRECTOR: the cartpole — a third of its interior-point iterations, none more needed).
+constexpr double IPM_SKIP_SIGMA = 3e-6;
+// Adjoint (sensitivity) solve: the stiffness lam / t of an active bound row is capped.  A row whose slack the interior point took to
+// 1e-18 pins its coordinate either way (the answer moves by O(1 / stiffness)), but 1e19 on the diagonal of a STATE block costs the
+// Riccati recursion all sixteen digits of the entries next to it (against a dense pivoted solve on the hardest test instances:
+// cap 1e8 -> 2e-7, 1e9 -> 1e-7 (bias 1e-8), 1e10 -> 1e-6, 1e12 -> 9e-5, 1e14 -> 3e-2, none -> 5e-1).
+constexpr double SENS_W_MAX = 1e9;
 
 struct SmallArgs {
     int B;                 // instances
@@ -990,6 +999,7 @@ struct SmallSolver {
     // warm_mu > 0: start from the rows and multipliers of the previous QP, every complementarity product raised to >= warm_mu.
     MPCRL_DI bool qp_solve(bool act, const double *x0, const double *u0f, int &n_it, double warm_mu, double tol_res, double tol_mu) {
         auto Hs = [&](int i, int j) { return hess_of_stage(i, j); };
+        constexpr bool SKIPC = MX && M::SKIP_CORRECTOR;
         hscale = ck;
         const bool warm = warm_mu > 0.0;
         if (act) {
@@ -1126,7 +1136,7 @@ struct SmallSolver {
             bool okf;
             PHW(1);
             if constexpr (MX)
-                okf = mx_pred<false>(Hs, rt, rb);
+                okf = mx_pred<SKIPC>(Hs, rt, rb);   // (with the p_k of this right-hand side where the predictor step may be the step)
             else {
                 okf = backward<true>(Hs, rt, rb);
                 PHW(2);
@@ -1167,7 +1177,58 @@ struct SmallSolver {
             const double a_aff = fast_rcp(rmax);
             const double mu_aff = fma(a_aff, fma(a_aff, c12[1], c12[0]), musum) * inv_rows;
             const double ratio = mu > 0.0 ? mu_aff * fast_rcp(mu) : 0.0;
-            const double smu = ratio * ratio * ratio * mu;
+            const double sig3 = ratio * ratio * ratio;
+            const double smu = sig3 * mu;
+            const double frac = M::DISCRETE ? IPM_FRAC : fmax(IPM_FRAC, 1.0 - mu);   // fraction to the boundary -> 1 as mu -> 0 (LQ model: fixed)
+            // the step along (Dx, Du, Dnu) and the rows' directions of `pass`: rows of (i, sd) only read their own side's state, so they
+            // can be advanced in place; e12: sum lam t after the step = musum + alpha e12[0] + alpha^2 e12[1]
+            auto take_step = [&](int pass, double smu_, double alpha, const double *e12) {
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    if (term && i < NU) continue;
+                    const double v = vc(i) + dvc(dx, du, i), dv = dvc(Dx, Du, i);
+#pragma unroll
+                    for (int sd = 0; sd < 2; ++sd) {
+                        if (!has(sd, i)) continue;
+                        double dt1, dl1, dt2, dl2, dss, rat;
+                        row_steps(i, sd, v, dv, pass, smu_, dt1, dl1, dt2, dl2, dss, rat);
+                        lam[sd][i] = fma(alpha, dl1, lam[sd][i]);
+                        t[sd][i] = fma(alpha, dt1, t[sd][i]);
+                        if (SOFT && softc(i)) {
+                            const int ii = SOFT ? i : 0;
+                            lams[sd][ii] = fma(alpha, dl2, lams[sd][ii]);
+                            ts[sd][ii] = fma(alpha, dt2, ts[sd][ii]);
+                            s[sd][ii] = fma(alpha, dss, s[sd][ii]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NX; ++i) dx[i] = fma(alpha, Dx[i], dx[i]), nuq[i] = fma(alpha, Dnu[i], nuq[i]);
+#pragma unroll
+                for (int i = 0; i < NU; ++i) du[i] = fma(alpha, Du[i], du[i]);
+                if (MPCRL_IPM_SCALE_RES) {
+                    const double om = 1.0 - alpha;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) rb[i] *= om;
+#pragma unroll
+                    for (int i = 0; i < NW; ++i) rg[i] *= om;
+                    rinf_c = om * rinf;
+                    musum_c = fma(alpha, fma(alpha, e12[1], e12[0]), musum);
+                }
+            };
+            bool corr = qlive;
+            if constexpr (SKIPC) {
+                const bool skip = qlive && sig3 < IPM_SKIP_SIGMA;
+                if (__any(skip)) {   // (wave-uniform) the predictor step of these instances is their step
+                    mx_dnu(rt, true);
+                    if (skip) take_step(0, 0.0, fmin(1.0, frac * a_aff), c12);
+                }
+                corr = qlive && !skip;
+                if (!__any(corr)) {   // nobody left for the corrector
+                    PHW(8);
+                    continue;
+                }
+            }
             PHW(4);
             // ---- corrector (same factorisation, vector sweep only)
 #pragma unroll
@@ -1206,42 +1267,7 @@ struct SmallSolver {
                 }
             }
             seg_reduce<1, 2, M::SEG_SKIP>(&rmax, d12, k, lpi, base);
-            const double alpha = fmin(1.0, (M::DISCRETE ? IPM_FRAC : fmax(IPM_FRAC, 1.0 - mu)) * fast_rcp(rmax));   // fraction to the boundary -> 1 as mu -> 0 (LQ model: fixed)
-            if (qlive) {
-                // rows of (i, sd) only read their own side's state, so they can be advanced in place
-#pragma unroll
-                for (int i = 0; i < NW; ++i) {
-                    if (term && i < NU) continue;
-                    const double v = vc(i) + dvc(dx, du, i), dv = dvc(Dx, Du, i);
-#pragma unroll
-                    for (int sd = 0; sd < 2; ++sd) {
-                        if (!has(sd, i)) continue;
-                        double dt1, dl1, dt2, dl2, dss, rat;
-                        row_steps(i, sd, v, dv, 1, smu, dt1, dl1, dt2, dl2, dss, rat);
-                        lam[sd][i] = fma(alpha, dl1, lam[sd][i]);
-                        t[sd][i] = fma(alpha, dt1, t[sd][i]);
-                        if (SOFT && softc(i)) {
-                            const int ii = SOFT ? i : 0;
-                            lams[sd][ii] = fma(alpha, dl2, lams[sd][ii]);
-                            ts[sd][ii] = fma(alpha, dt2, ts[sd][ii]);
-                            s[sd][ii] = fma(alpha, dss, s[sd][ii]);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < NX; ++i) dx[i] = fma(alpha, Dx[i], dx[i]), nuq[i] = fma(alpha, Dnu[i], nuq[i]);
-#pragma unroll
-                for (int i = 0; i < NU; ++i) du[i] = fma(alpha, Du[i], du[i]);
-                if (MPCRL_IPM_SCALE_RES) {
-                    const double om = 1.0 - alpha;
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) rb[i] *= om;
-#pragma unroll
-                    for (int i = 0; i < NW; ++i) rg[i] *= om;
-                    rinf_c = om * rinf;
-                    musum_c = fma(alpha, fma(alpha, d12[1], d12[0]), musum);
-                }
-            }
+            if (corr) take_step(1, smu, fmin(1.0, frac * fast_rcp(rmax)), d12);
             PHW(8);
         }
         return ok;
@@ -1317,7 +1343,7 @@ struct SmallSolver {
             double d = 0.0;
 #pragma unroll
             for (int sd = 0; sd < 2; ++sd)
-                if (has(sd, i)) d += lam[sd][i] / t[sd][i];
+                if (has(sd, i)) d += fmin(lam[sd][i] / t[sd][i], SENS_W_MAX);
             Dg[i] = d;
         }
         auto Hs = [&](int i, int j) { return Hx[sym(i, j)]; };

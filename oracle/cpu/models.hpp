@@ -22,6 +22,12 @@ constexpr double IPM_WARM_C = 1e-4, IPM_WARM_MIN = 1e-10, IPM_WARM_MAX = 3e-2;  
 // inexact SQP: QP tolerances follow the NLP residual r: tol_res = clamp(C r^2, TOL_RES, CAP), tol_mu = clamp(C r^2 / 100, TOL_MU, CAP / 10);
 // convergence is only declared after a QP solved to the tight tolerances
 constexpr double IPM_ADAPT_C = 1e1, IPM_ADAPT_CAP = 3e-2;
+constexpr double IPM_SKIP_SIGMA = 3e-6;   // oracle/sqp_dense.py: the predictor step is taken where it alone cuts the complementarity this far
+// Adjoint (sensitivity) solve: the stiffness lam / t of an active bound row is capped.  A row whose slack the interior point took to
+// 1e-18 pins its coordinate either way (the answer moves by O(1 / stiffness)), but 1e19 on the diagonal of a STATE block costs the Riccati
+// recursion all sixteen digits of the entries next to it.  Measured against the dense solve of the mirror on the hardest instances of
+// tests/test_gpu_fullsize.py: cap 1e8 -> 2e-7, 1e9 -> 1e-7 (bias 1e-8), 1e10 -> 1e-6, 1e12 -> 9e-5, 1e14 -> 3e-2, none -> 5e-1.
+constexpr double SENS_W_MAX = 1e9;
 
 // ------------------------------------------------------------------------------------------------
 // forward-mode AD scalar, nestable
@@ -105,7 +111,7 @@ double val(const Dual<T, N> &a) { return val(a.v); }
 // ------------------------------------------------------------------------------------------------
 struct Cartpole {
     static constexpr int NX = 4, NU = 1, NP = 83, NTD = 3;
-    static constexpr bool DISCRETE = false;
+    static constexpr bool DISCRETE = false, SKIP_CORRECTOR = true;
     static int td_index(int i) { return i; }
     // cost block of the full parameter vector p (nlp.py:969-989, column-major): W_0 (5x5) at 3, W at 28, W_e (4x4) at 53, yref_0 at 69,
     // yref at 74, yref_e at 79.  The solver sees whatever set_parameter / cost_set wrote there (mpc.py:233-257); the mirror's cost
@@ -180,7 +186,7 @@ struct Cartpole {
 
 struct Linear {
     static constexpr int NX = 2, NU = 1, NP = 12, NTD = 8;
-    static constexpr bool DISCRETE = true;
+    static constexpr bool DISCRETE = true, SKIP_CORRECTOR = false;
     static int td_index(int i) { return i; }
     // consts: P (2x2 row-major) terminal DARE matrix
     template <class S>
@@ -245,7 +251,7 @@ struct Chain {
     static constexpr int OFF_M = 0, OFF_D = NL, OFF_L = 4 * NL, OFF_C = 7 * NL, OFF_Q = 10 * NL, OFF_R = OFF_Q + NX * NX,
                          OFF_W = OFF_R + NU * NU;
     static constexpr int NP = OFF_W + 3 * M, NTD = 10 * NL + 3 * M;
-    static constexpr bool DISCRETE = false;
+    static constexpr bool DISCRETE = false, SKIP_CORRECTOR = false;
     static int td_index(int i) { return i < 10 * NL ? i : OFF_W + (i - 10 * NL); }
     // consts: x_ss (NX)
     template <class S>

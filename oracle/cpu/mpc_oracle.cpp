@@ -468,6 +468,10 @@ struct Solver {
                             }
                     const double ratio = (sum / n_rows) / mu;
                     sigma = ratio * ratio * ratio;
+                    if (Mdl::SKIP_CORRECTOR && !exact && sigma < IPM_SKIP_SIGMA) {   // the predictor step is the step (sqp_dense.py IPM_SKIP_SIGMA)
+                        alpha = std::min(1.0, std::max(IPM_FRAC, 1.0 - mu) * amax);
+                        break;
+                    }
                 } else
                     alpha = std::min(1.0, ((Mdl::DISCRETE || exact) ? IPM_FRAC : std::max(IPM_FRAC, 1.0 - mu)) * amax);   // fraction to the boundary -> 1 as mu -> 0 (LQ model: fixed)
             }
@@ -601,7 +605,7 @@ struct Solver {
         for (int e = 0; e < n; ++e) {
             double d = 0;
             for (int sd = 0; sd < 2; ++sd)
-                if (has[sd][e]) d += lam[LB + sd][e] / t[LB + sd][e];
+                if (has[sd][e]) d += std::min(lam[LB + sd][e] / t[LB + sd][e], SENS_W_MAX);
             Dg[e] = d;
         }
         if (!riccati_factor(Hex.data(), Dg.data())) {

@@ -149,7 +149,7 @@ def make_cartpole(N: int = 20, tf: float = 2.0) -> Problem:
         lbu=np.array([-30.0]), ubu=np.array([30.0]),
         idxbx=np.arange(4), lbx=-xb, ubx=xb, idxbx_e=np.arange(4), lbx_e=-xb, ubx_e=xb,
         tol=1e-6, max_iter=500, x0_default=np.array([0.0, 0.0, 3.14, 0.0]),
-        extra={"h": h, "W": W, "W_e": W_e},
+        extra={"h": h, "W": W, "W_e": W_e, "skip_corrector": True},
     )
 
 

@@ -45,6 +45,12 @@ IPM_WARM_C, IPM_WARM_MIN, IPM_WARM_MAX = 1e-4, 1e-10, 3e-2
 # inexact SQP: the QP tolerances follow the NLP residual r, tol_res = clamp(C r^2, TOL_RES, CAP), tol_mu = clamp(C r^2 / 100, TOL_MU, CAP / 10);
 # convergence is only declared after a QP that was solved to the tight tolerances
 IPM_ADAPT_C, IPM_ADAPT_CAP = 1e1, 3e-2
+# Where the affine (predictor) step alone takes the complementarity down by more than two orders of magnitude — sigma = (mu_aff / mu)^3
+# below this — it IS the Newton step of a QP that is all but solved (the last iteration of a QP, the warm-started QPs near the SQP's
+# limit): the corrector solve is skipped and the predictor step taken.  Problems that opt in (Problem.extra["skip_corrector"]: the
+# cartpole — a third of its interior-point iterations, none more needed; not the LQ problem, where it never triggers, nor the chain of
+# masses, where iterations are lost), tuned mode only.
+IPM_SKIP_SIGMA = 3e-6
 
 
 @dataclass
@@ -179,7 +185,7 @@ class Linearizer:
         return val, g, H
 
 
-def ipm_dense(H, g, G, b, C, d, v0, warm=None, free=None, tol_res=IPM_TOL_RES, tol_mu=IPM_TOL_MU, lq=False):
+def ipm_dense(H, g, G, b, C, d, v0, warm=None, free=None, tol_res=IPM_TOL_RES, tol_mu=IPM_TOL_MU, lq=False, skip_corrector=False):
     """Mehrotra predictor-corrector on  min 1/2 v'Hv + g'v  s.t. Gv = b, Cv + t = d, t >= 0.
     warm = (mu_w, lam_prev, t_prev, pi_prev) or None.  free: mask of the variables that are not pinned by an equality
     row of their own (x_0, and u_0 in Q-mode); the stationarity rows of pinned variables only define the multiplier of
@@ -240,8 +246,11 @@ def ipm_dense(H, g, G, b, C, d, v0, warm=None, free=None, tol_res=IPM_TOL_RES, t
         a_aff = max_step(dlam, dt)
         mu_aff = float((lam + a_aff * dlam) @ (t + a_aff * dt)) / mi
         sigma = (mu_aff / mu) ** 3
-        dv, dpi, dlam, dt = solve(lam * t + dlam * dt - sigma * mu)
-        a = min(1.0, (IPM_FRAC if lq else max(IPM_FRAC, 1.0 - mu)) * max_step(dlam, dt))   # fraction to the boundary -> 1 as mu -> 0 (not for LQ problems)
+        if skip_corrector and sigma < IPM_SKIP_SIGMA:
+            a = min(1.0, max(IPM_FRAC, 1.0 - mu) * a_aff)
+        else:
+            dv, dpi, dlam, dt = solve(lam * t + dlam * dt - sigma * mu)
+            a = min(1.0, (IPM_FRAC if lq else max(IPM_FRAC, 1.0 - mu)) * max_step(dlam, dt))   # fraction to the boundary -> 1 as mu -> 0 (not for LQ problems)
         v = v + a * dv
         pi = pi + a * dpi
         lam = lam + a * dlam
@@ -400,7 +409,8 @@ def solve(prob: Problem, x0, p=None, u0fix=None, gamma=None, warm: Optional[Solu
         free[st.ix(0): st.ix(0) + nx] = False
         if u0fix is not None:
             free[:nu] = False
-        v, piq, lam, t, nit, ok = ipm_dense(H, g, G, b, C, d, v0, wrm, free, tol_res, tol_mu, lq=bool(P.extra.get("lq", False)) or exact)
+        v, piq, lam, t, nit, ok = ipm_dense(H, g, G, b, C, d, v0, wrm, free, tol_res, tol_mu, lq=bool(P.extra.get("lq", False)) or exact,
+                                              skip_corrector=bool(P.extra.get("skip_corrector", False)) and not exact)
         stepn = float(np.abs(v[: st.nw]).max())
         ipm_total += nit
         if not ok:
