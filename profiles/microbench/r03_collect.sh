@@ -1,7 +1,7 @@
 # usage (on the GPU box): bash profiles/microbench/r03_collect.sh   — everything the round's profiles/ files are made from
 set -x
 R=$GRAFT_REPO_ROOT; cd $R
-timeout 900 python -m pytest tests -m gpu -q --timeout 400 --timeout-method=thread 2>&1 | tail -5 > gpurun_out/r03_gputests.log
+timeout 900 python -m pytest tests -m gpu -q --timeout 400 --timeout-method=thread 2>&1 | grep -E "passed|failed|^FAILED|^ERROR" > gpurun_out/r03_gputests.log
 for w in cartpole linear chain5 chain7 td3; do
   extra=""; [ $w != cartpole ] && extra="--workload $w"
   steps="--steps 50 --warmup 10"; [ $w == chain5 ] && steps="--steps 10 --warmup 3"; [ $w == chain7 ] && steps="--steps 5 --warmup 2"; [ $w == td3 ] && steps="--steps 60 --warmup 10"
