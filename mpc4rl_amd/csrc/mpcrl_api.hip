@@ -29,6 +29,8 @@ struct MpcrlSolver {
     double *ws = nullptr, *consts_dev = nullptr;
     int *perm = nullptr, *cold_mask = nullptr;
     bool have_perm = false, have_cold_mask = false;
+    double *order_state = nullptr;   // order_kernel.hpp: {spread, minimum, coordinate} of the last from-scratch packing order
+    unsigned order_calls = 0;
     size_t ws_stride = 0;
     double *theta = nullptr;   // [np] or [B, np]
     int theta_stride = 0;
@@ -356,6 +358,7 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
     if (!rc) rc = dev_alloc(&h->theta, B * (size_t)spec->np, h->bytes);
     if (!rc) rc = dev_alloc(&h->perm, B, h->bytes);
     if (!rc) rc = dev_alloc(&h->cold_mask, B, h->bytes);
+    if (!rc) rc = dev_alloc(&h->order_state, 4, h->bytes);
     if (!rc && h->is_large) {
         h->ws_stride = h->n_mass == 3 ? LargeLayout<ChainDev<3>>(spec->N).total
                                       : (h->n_mass == 5 ? LargeLayout<ChainDev<5>>(spec->N).total : LargeLayout<ChainDev<7>>(spec->N).total);
@@ -388,6 +391,7 @@ int mpcrl_destroy(mpcrl_handle h) {
         if (p) (void)hipFree(p);
     if (h->perm) (void)hipFree(h->perm);
     if (h->cold_mask) (void)hipFree(h->cold_mask);
+    if (h->order_state) (void)hipFree(h->order_state);
     for (auto &t : h->tune)
         for (auto &pair : t.ev)
             for (auto &e : pair)
@@ -486,7 +490,13 @@ int mpcrl_auto_order(mpcrl_handle h, const double *x0, void *stream) {
         return 0;
     }
     ON_DEVICE(h->device);
-    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(ORDER_NT), 0, (hipStream_t)stream, x0, h->B, h->nx, h->perm);
+    // the coordinate and range the batch is bucketed along are found from scratch on the first call and every 32nd one (never inside a
+    // stream capture once they exist: a graph replays the cheap form)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+    const int refresh = (h->order_calls == 0 || (!capturing && h->order_calls % 32 == 0)) ? 1 : 0;
+    h->order_calls++;
+    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(ORDER_NT), 0, (hipStream_t)stream, x0, h->B, h->nx, h->perm, h->order_state, refresh);
     HIP_OK(hipGetLastError());
     h->have_perm = true;
     return 0;

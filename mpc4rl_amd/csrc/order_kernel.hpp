@@ -12,7 +12,11 @@ namespace mpcrl {
 
 constexpr int ORDER_NT = 1024, ORDER_MAX = 8192, ORDER_PER = ORDER_MAX / ORDER_NT, ORDER_BUCKET_MAX = 64;
 
-__global__ void __launch_bounds__(ORDER_NT) order_kernel(const double *x0, int B, int nx, int *perm) {
+// state[3] = {spread, minimum, coordinate} of the batch the order was last built from scratch for (refresh != 0): finding the
+// coordinate with the largest spread is four dependent passes over x0 — 7 of the kernel's 11 us — and consecutive batches of a
+// handle are alike, so in between the kernel buckets along the remembered coordinate and range (keys outside it land in the end
+// buckets; a batch that no longer spreads along it ends in one crowded bucket = the identity order below).
+__global__ void __launch_bounds__(ORDER_NT) order_kernel(const double *x0, int B, int nx, int *perm, double *state, int refresh) {
     __shared__ int cnt[ORDER_NT], off[ORDER_NT], wsum[ORDER_NT / 64], tmp[ORDER_MAX];
     __shared__ double red[2 * (ORDER_NT / 64)];
     __shared__ double best[3];   // spread, min, dim
@@ -20,20 +24,26 @@ __global__ void __launch_bounds__(ORDER_NT) order_kernel(const double *x0, int B
     if (tid == 0) best[0] = -1.0, best[1] = 0.0, best[2] = 0.0;
     cnt[tid] = 0;
     __syncthreads();
-    for (int d = 0; d < nx; ++d) {
-        double lo = 1e300, hi = -1e300;
-        for (int i = tid; i < B; i += ORDER_NT) {
-            const double v = x0[(size_t)i * nx + d];
-            if (v == v) lo = fmin(lo, v), hi = fmax(hi, v);   // NaN inputs do not take part
-        }
+    if (refresh) {
+        for (int d = 0; d < nx; ++d) {
+            double lo = 1e300, hi = -1e300;
+            for (int i = tid; i < B; i += ORDER_NT) {
+                const double v = x0[(size_t)i * nx + d];
+                if (v == v) lo = fmin(lo, v), hi = fmax(hi, v);   // NaN inputs do not take part
+            }
 #pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) lo = fmin(lo, __shfl_xor(lo, s)), hi = fmax(hi, __shfl_xor(hi, s));
-        if ((tid & 63) == 0) red[2 * (tid >> 6)] = lo, red[2 * (tid >> 6) + 1] = hi;
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < ORDER_NT / 64; ++w) lo = fmin(lo, red[2 * w]), hi = fmax(hi, red[2 * w + 1]);
-            if (hi - lo > best[0]) best[0] = hi - lo, best[1] = lo, best[2] = (double)d;
+            for (int s = 32; s >= 1; s >>= 1) lo = fmin(lo, __shfl_xor(lo, s)), hi = fmax(hi, __shfl_xor(hi, s));
+            if ((tid & 63) == 0) red[2 * (tid >> 6)] = lo, red[2 * (tid >> 6) + 1] = hi;
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < ORDER_NT / 64; ++w) lo = fmin(lo, red[2 * w]), hi = fmax(hi, red[2 * w + 1]);
+                if (hi - lo > best[0]) best[0] = hi - lo, best[1] = lo, best[2] = (double)d;
+            }
+            __syncthreads();
         }
+        if (tid == 0) state[0] = best[0], state[1] = best[1], state[2] = best[2];
+    } else {
+        if (tid == 0) best[0] = state[0], best[1] = state[1], best[2] = state[2];
         __syncthreads();
     }
     const int dim = (int)best[2];
