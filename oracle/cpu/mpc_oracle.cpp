@@ -533,7 +533,7 @@ struct Solver {
                 // (a linear-quadratic OCP is solved by its first QP: no inexactness there)
                 const double rr = std::min(1.0, rmax), a = (rmax < tol || Mdl::DISCRETE || exact) ? 0.0 : IPM_ADAPT_C * rr * rr;
                 qp_tol_res = std::min(IPM_ADAPT_CAP, std::max(IPM_TOL_RES, a));
-                qp_tol_mu = std::min(0.1 * IPM_ADAPT_CAP, std::max(IPM_TOL_MU, 1e-2 * a));
+                qp_tol_mu = std::min(Mdl::TOL_MU_FACTOR * IPM_ADAPT_CAP, std::max(IPM_TOL_MU, 1e-2 * a));
                 last_tight = qp_tol_res <= IPM_TOL_RES && qp_tol_mu <= IPM_TOL_MU;
             }
             bool ok;

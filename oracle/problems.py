@@ -307,7 +307,7 @@ def make_chain_mass(n_mass: int = 5, N: int = 40, Ts: float = 0.2) -> Problem:
         name=f"chain_mass_{n_mass}", nx=nx, nu=nu, N=N, dT=Ts, p0=p0, p_labels=labels,
         F=F, stage_cost=stage_cost, terminal_cost=terminal_cost, cost_kind="EXTERNAL",
         lbu=-np.ones(nu), ubu=np.ones(nu), gamma=1.0, tol=1e-5, max_iter=50, x0_default=x0,
-        extra={"x_ss": x_ss, "off": off, "n_mass": n_mass, "M": M},
+        extra={"x_ss": x_ss, "off": off, "n_mass": n_mass, "M": M, "tol_mu_factor": 1.0},
     )
 
 

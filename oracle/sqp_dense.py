@@ -362,7 +362,7 @@ def solve(prob: Problem, x0, p=None, u0fix=None, gamma=None, warm: Optional[Solu
         rr = min(1.0, float(res.max()))
         a_ = 0.0 if (res.max() < tol or P.extra.get("lq", False) or exact) else IPM_ADAPT_C * rr * rr   # an LQ problem is solved by its first QP
         tol_res = min(IPM_ADAPT_CAP, max(IPM_TOL_RES, a_))
-        tol_mu = min(0.1 * IPM_ADAPT_CAP, max(IPM_TOL_MU, 1e-2 * a_))
+        tol_mu = min(float(P.extra.get("tol_mu_factor", 0.1)) * IPM_ADAPT_CAP, max(IPM_TOL_MU, 1e-2 * a_))   # (chain of masses: factor 1)
         last_tight = tol_res <= IPM_TOL_RES and tol_mu <= IPM_TOL_MU
         # ---- QP in v = [du; dx; s]
         H = np.zeros((st.nv, st.nv))
