@@ -6,7 +6,8 @@ for w in cartpole linear chain5 chain7 td3; do
   extra=""; [ $w != cartpole ] && extra="--workload $w"
   steps="--steps 50 --warmup 10"; [ $w == chain5 ] && steps="--steps 10 --warmup 3"; [ $w == chain7 ] && steps="--steps 5 --warmup 2"; [ $w == td3 ] && steps="--steps 60 --warmup 10"
   python bench.py $extra $steps > gpurun_out/r03_final_${w}_bench.json 2>/dev/null
-  # (rocprofv3 around the TD3 loop did not return on two boxes late in round 3: its kernel stats are those of commit 8261478)
+  # (rocprofv3 around the graph-replayed TD3 loop did not return on two boxes in round 3: its kernel stats are taken from an eager run,
+  #  timeout 150 rocprofv3 --kernel-trace --stats ... -- python bench.py --workload td3 --no-graph --steps 20 --warmup 5)
   [ $w != td3 ] && timeout 300 bash profiles/microbench/kstats.sh r03_$w $extra $steps --no-cpu > /dev/null 2>&1
 done
 python bench.py --no-sens --no-cpu > gpurun_out/r03_final_cartpole_nosens_bench.json 2>/dev/null
