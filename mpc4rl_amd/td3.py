@@ -263,16 +263,19 @@ class BatchedTD3:
             rt = self.target_mpc.mpc.solve(nxt.to(torch.float64), cold=True)               # actor_target(s'), one launch
             # failed target solves are SELECTED out (a product with a 0 / 1 mask would keep their NaN: NaN * 0 = NaN), and so are
             # transitions whose stored observations are not finite
-            ok_b = (rt.status == 0) & torch.isfinite(rt.u0).all(dim=1) & torch.isfinite(obs).all(dim=1) & torch.isfinite(nxt).all(dim=1) \
-                & torch.isfinite(act).all(dim=1) & torch.isfinite(rew)
-            u_next = torch.where(ok_b[:, None], torch.nan_to_num(rt.u0), torch.zeros_like(rt.u0))
+            # (one finiteness test over the whole transition: every separate test, fill and select is a launch of its own)
+            row = torch.cat([obs, nxt, act, rew[:, None], rt.u0.to(obs.dtype)], dim=1)
+            ok_b = (rt.status == 0) & torch.isfinite(row).all(dim=1)
+            u_next = torch.where(ok_b[:, None], rt.u0, 0.0)
             a_next = (self.target_mpc.scale_action(u_next).to(torch.float32) + noise).clamp(-1.0, 1.0)
-            nxt_s, obs_s, act_s = (torch.where(ok_b[:, None], t, torch.zeros_like(t)) for t in (nxt, obs, act))
+            safe = torch.where(ok_b[:, None], row, 0.0)
+            nx_ = obs.shape[1]
+            obs_s, nxt_s, act_s = safe[:, :nx_], safe[:, nx_: 2 * nx_], safe[:, 2 * nx_: 2 * nx_ + act.shape[1]]
             q_next = torch.min(*self.critic_target(nxt_s, a_next)).squeeze(1)
             ok_t = ok_b.to(torch.float32)
-            y = torch.where(ok_b, rew + self.gamma * (1.0 - done) * q_next, torch.zeros_like(rew))
+            y = torch.where(ok_b, rew + self.gamma * (1.0 - done) * q_next, 0.0)
         qs = self.critic(obs_s, act_s)
-        loss = sum((torch.where(ok_b, q.squeeze(1) - y, torch.zeros_like(y)) ** 2).sum() for q in qs) / ok_t.sum().clamp(min=1.0)
+        loss = sum((torch.where(ok_b, q.squeeze(1) - y, 0.0) ** 2).sum() for q in qs) / ok_t.sum().clamp(min=1.0)
         self.critic_opt.zero_grad(set_to_none=True)
         loss.backward()
         # one flat message: critic gradients (already the local mean) | theta-gradient sum | sample count
@@ -280,14 +283,13 @@ class BatchedTD3:
         flat[: self.n_crit] = torch.cat([p.grad.reshape(-1) for p in self.critic.parameters()]).to(torch.float64) / world
         if do_policy:
             rp = self.pi_mpc.mpc.solve(obs.to(torch.float64), sens_pi=True, cold=True)   # pi(s_i), dpi/dtheta_i: one launch
-            okb = (rp.status == 0) & torch.isfinite(rp.u0).all(dim=1) & torch.isfinite(obs).all(dim=1)
-            u_pi = torch.where(okb[:, None], torch.nan_to_num(rp.u0), torch.zeros_like(rp.u0))
+            okb = (rp.status == 0) & torch.isfinite(torch.cat([rp.u0.to(obs.dtype), obs], dim=1)).all(dim=1)
+            u_pi = torch.where(okb[:, None], rp.u0, 0.0)
             a_pi = self.pi_mpc.scale_action(u_pi).to(torch.float32).detach().requires_grad_(True)
             (dq_da,) = torch.autograd.grad(self.critic.q1_forward(obs_s, a_pi).sum(), a_pi)
             chain = (2.0 / (self.pi_mpc.high - self.pi_mpc.low)) if self.pi_mpc.scale else torch.ones_like(self.pi_mpc.low)
             okp = okb.to(torch.float64)
-            g = torch.einsum("bu,bup->bp", torch.where(okb[:, None], dq_da.to(torch.float64) * chain, torch.zeros_like(chain)),
-                             torch.nan_to_num(rp.dpi_dp))
+            g = torch.einsum("bu,bup->bp", torch.where(okb[:, None], dq_da.to(torch.float64) * chain, 0.0), torch.nan_to_num(rp.dpi_dp))
             flat[self.n_crit: self.n_crit + n_theta] = g.sum(0)
             flat[-1] = okp.sum()
         return flat, loss.detach()
