@@ -195,85 +195,115 @@ def job_aggregate(elapsed_local, dist_mod, device):
     return float(tt.item())
 
 
-def dryrun(args):
-    """Launcher / rank plumbing without a GPU (tests/test_bench_ranks.py): gloo rendezvous, barrier-bracketed timed region,
-    MAX over ranks, one JSON line from rank 0.  The step is a no-op, so the line is marked and carries no throughput."""
-    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
-        dist.barrier()
-    n_ranks = count_ranks(dist, torch.device("cpu"))
+DRY = bool(os.environ.get("MPCRL_BENCH_DRYRUN"))
+
+
+def timed_steps(step, args, dist_mod, dev, rank=0):
+    """The driver's contract for every workload: W untimed warm-up steps, then EXACTLY K steps bracketed by a barrier + device
+    synchronisation on both sides; the job time is the MAX over ranks.  Returns (job seconds, mean HIP-event ms per step or None,
+    result of the last step).  Under MPCRL_BENCH_DRYRUN (tests/test_bench_ranks.py: launcher and rank plumbing on CPU, gloo) the
+    step is replaced by an uneven sleep, so that the line must carry the slowest rank's time."""
+    cuda = dev.type == "cuda"
+    sync = (lambda: torch.cuda.synchronize(dev)) if cuda else (lambda: None)
+    if DRY:
+        step = lambda: time.sleep(1e-3 * (rank + 1))
+    r = None
+    for _ in range(args.warmup):
+        r = step()
+    sync()
+    if dist_mod is not None:
+        dist_mod.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if cuda else None
+    sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        time.sleep(1e-3 * (rank + 1))        # uneven ranks: the job time must be the slowest rank's
-    if dist is not None:
-        dist.barrier()
-    elapsed = job_aggregate(time.perf_counter() - t0, dist, torch.device("cpu"))
-    if rank == 0:
-        print(json.dumps({"metric": "dryrun", "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": 1e3 * elapsed / args.steps, "dryrun": True,
-                          **({"rccl_ranks": n_ranks} if n_ranks is not None else {})}), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    for i in range(args.steps):
+        if ev:
+            ev[i][0].record()
+        r = step()
+        if ev:
+            ev[i][1].record()
+    sync()
+    if dist_mod is not None:
+        dist_mod.barrier()
+    elapsed = job_aggregate(time.perf_counter() - t0, dist_mod, dev)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
+    return elapsed, kern_ms, r
+
+
+def dry_line(args, world, rccl_ranks, elapsed, metric):
+    """What a dry run prints instead of the bench line: the plumbing's figures, no throughput."""
+    print(json.dumps({"metric": metric, "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": 1e3 * elapsed / args.steps, "dryrun": True, "workload": args.workload,
+                      **({"rccl_ranks": rccl_ranks} if rccl_ranks is not None else {})}), flush=True)
 
 
 def chain_bench(args):
-    """BASELINE config 4: chain_mass n_mass = 5 (nx=21) / 7 (nx=33), N=40, batch 1024, GN-SQP tol 1e-5 + sensitivities.
-    x0 = masses on the x axis (examples/chain_mass.py:17-25) + N(0, 1e-2) velocity perturbation, seed 0."""
-    from mpc4rl_amd import MPCBatch, chain_mass_ocp
+    """BASELINE config 4: chain_mass n_mass = 5 (nx=21) / 7 (nx=33), N=40, batch 1024 PER GPU, GN-SQP tol 1e-5 + sensitivities, "1 -> 8
+    GPU scaling".  x0 = masses on the x axis (examples/chain_mass.py:17-25) + N(0, 1e-2) velocity perturbation, seed = rank
+    (SURVEY.md §8d).  The instances are independent per parameter point (examples/chain_mass.py:133-174): every rank solves its own
+    1024, and a step ends with the ONE all-reduce of the 499- / 1173-dim theta-gradient sum a data-parallel update needs (§8e)."""
+    world, rank, local, dist, dev = init_ranks(args)
+    rccl_ranks = count_ranks(dist, dev)
     n_mass = 5 if args.workload == "chain5" else 7
-    ocp = chain_mass_ocp(n_mass=n_mass)
     B = args.batch if args.batch != B_PER_GPU else 1024
-    dev = torch.device("cuda", 0)
-    rng = np.random.default_rng(0)
+    sens = not args.no_sens
+    metric = f"MPC+KKT-sens solves/sec, chain_mass n_mass={n_mass} N=40 batch={B}"
+    if DRY:
+        elapsed, _, _ = timed_steps(None, args, dist, dev, rank)
+        if rank == 0:
+            dry_line(args, world, rccl_ranks, elapsed, metric)
+        return finish_ranks(dist)
+    from mpc4rl_amd import MPCBatch, chain_mass_ocp
+    from mpc4rl_amd.distributed import allreduce_weighted_grad
+    ocp = chain_mass_ocp(n_mass=n_mass)
+    rng = np.random.default_rng(rank)
     x0 = np.tile(ocp.x0, (B, 1))
     M = n_mass - 2
     x0[:, 3 * (M + 1):] += rng.normal(0.0, 1e-2, (B, 3 * M))
     mpc = MPCBatch(ocp, B, device=dev)
     x0t = torch.as_tensor(x0, device=dev)
-    sens = not args.no_sens
-    for _ in range(args.warmup):
+
+    def step():
         r = mpc.solve(x0t, sens_v=sens, sens_pi=sens, cold=True)
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        r = mpc.solve(x0t, sens_v=sens, sens_pi=sens, cold=True)
-        ev[i][1].record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        if dist is not None and sens:
+            allreduce_weighted_grad(r.dV_dp, r.V)     # local reduction kernel + one all_reduce of n_p + 2 doubles
+        return r
+
+    elapsed, kern_ms, r = timed_steps(step, args, dist, dev, rank)
     it = r.iters.cpu().numpy()
-    # SURVEY.md §8d: iterate + outputs, plus the streamed stage factors of every Riccati sweep
-    nx, nu, N, n_th = ocp.nx, ocp.nu, ocp.N, ocp.n_p
-    b_alg = algorithmic_bytes_per_solve(N, nx, nu, n_th, sens)
-    b_sweep = 2 * 8 * N * ((nx + nu) ** 2 + (nx + nu))
-    sweeps = float(it[:, 1].mean()) + (1 + nu if sens else 0)
-    achieved = (b_alg + sweeps * b_sweep) * B / (kern_ms * 1e-3) / 1e9
-    fp64 = sweeps * riccati_sweep_flops(N, nx, nu) * B / (kern_ms * 1e-3) / 1e12
-    traffic, traffic_src = measured_traffic(args.workload, B, sens, False)
-    peak_meas = measured_hbm_peak(dev)
-    out = {"metric": f"MPC+KKT-sens solves/sec, chain_mass n_mass={n_mass} N=40 batch={B}", "value": B * args.steps / elapsed,
-           "unit": "solves/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": f"chain_mass n_mass={n_mass} nx={nx} nu={nu} N={N}, {B} instances, cold-start GN-SQP tol 1e-5"
-                                  + (f" + dV/dp + du0*/dp ({n_th}-dim p)" if sens else ""),
-                      "converged_fraction": float((r.status == 0).float().mean().item()), "sqp_iters_mean": float(it[:, 0].mean()),
-                      "ipm_iters_mean": float(it[:, 1].mean())},
-           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "peak_measured": peak_meas, "frac_of_measured": (achieved / peak_meas) if peak_meas else None,
-                        "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms,
-                        "algorithmic_bytes_per_solve": b_alg + sweeps * b_sweep, "sweeps_per_solve": sweeps,
-                        "fp64": {"achieved": fp64, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp64 / FP64_MFMA_PEAK_TFLOPS,
-                                 "note": "SURVEY.md 8d: sweeps/s x F_sweep, sweeps = interior-point iterations + 1 + nu"}}}
-    if not args.no_cpu:
-        from oracle.problems import make_chain_mass
-        out["cpu_baseline"] = cpu_baseline_guarded(make_chain_mass(n_mass=n_mass), x0, sens, label=f"chain_mass n_mass={n_mass}: ")
-    print(json.dumps(out), flush=True)
+    conv = float((r.status == 0).float().mean().item())
+    if rank == 0:
+        # SURVEY.md §8d: iterate + outputs, plus the streamed stage factors of every Riccati sweep
+        nx, nu, N, n_th = ocp.nx, ocp.nu, ocp.N, ocp.n_p
+        b_alg = algorithmic_bytes_per_solve(N, nx, nu, n_th, sens)
+        b_sweep = 2 * 8 * N * ((nx + nu) ** 2 + (nx + nu))
+        sweeps = float(it[:, 1].mean()) + (1 + nu if sens else 0)
+        achieved = (b_alg + sweeps * b_sweep) * B / (kern_ms * 1e-3) / 1e9
+        fp64 = sweeps * riccati_sweep_flops(N, nx, nu) * B / (kern_ms * 1e-3) / 1e12
+        traffic, traffic_src = measured_traffic(args.workload, B, sens, False)
+        peak_meas = measured_hbm_peak(dev)
+        out = {"metric": metric, "value": world * B * args.steps / elapsed,
+               "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"chain_mass n_mass={n_mass} nx={nx} nu={nu} N={N}, {B} instances/GPU, cold-start GN-SQP tol 1e-5"
+                                      + (f" + dV/dp + du0*/dp ({n_th}-dim p)" if sens else ""),
+                          "batch_per_gpu": B, "parallelism": f"instances sharded over {world} GPU(s)"
+                          + (f"; one all-reduce of the {n_th}-dim theta-gradient per step" if world > 1 and sens else ""),
+                          "converged_fraction": conv, "sqp_iters_mean": float(it[:, 0].mean()),
+                          "ipm_iters_mean": float(it[:, 1].mean())},
+               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                            "peak_measured": peak_meas, "frac_of_measured": (achieved / peak_meas) if peak_meas else None,
+                            "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms,
+                            "algorithmic_bytes_per_solve": b_alg + sweeps * b_sweep, "sweeps_per_solve": sweeps,
+                            "fp64": {"achieved": fp64, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp64 / FP64_MFMA_PEAK_TFLOPS,
+                                     "note": "SURVEY.md 8d: sweeps/s x F_sweep, sweeps = interior-point iterations + 1 + nu"}}}
+        if rccl_ranks is not None:
+            out["rccl_ranks"] = rccl_ranks
+        if world == 1 and not args.no_cpu:
+            from oracle.problems import make_chain_mass
+            out["cpu_baseline"] = cpu_baseline_guarded(make_chain_mass(n_mass=n_mass), x0, sens, label=f"chain_mass n_mass={n_mass}: ")
+        print(json.dumps(out), flush=True)
+    finish_ranks(dist)
 
 
 class _StdoutToStderr:
@@ -292,12 +322,20 @@ class _StdoutToStderr:
 
 
 def init_ranks(args):
-    """(world, rank, local, dist module or None, device): one process per GPU, RCCL ("nccl") when there is more than one rank."""
+    """(world, rank, local, dist module or None, device): one process per GPU, RCCL ("nccl") when there is more than one rank.
+    Dry run (no GPU): the same rendezvous over gloo, device = cpu."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != max(1, args.gpus) and not os.environ.get("MPCRL_BENCH_FORCE_DIST"):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    if DRY:
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+            dist.barrier()
+        return world, rank, local, dist, torch.device("cpu")
     if world > 1 or os.environ.get("MPCRL_BENCH_FORCE_DIST"):   # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -311,6 +349,11 @@ def init_ranks(args):
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     return world, rank, local, dist, dev
+
+
+def finish_ranks(dist_mod):
+    if dist_mod is not None:
+        dist_mod.destroy_process_group()
 
 
 def count_ranks(dist_mod, dev):
@@ -329,6 +372,11 @@ def td3_bench(args):
     per update.  A step = one environment step of all environments + one TD3 update (batch 4096 per rank)."""
     world, rank, local, dist, dev = init_ranks(args)
     rccl_ranks = count_ranks(dist, dev)
+    if DRY:
+        elapsed, _, _ = timed_steps(None, args, dist, dev, rank)
+        if rank == 0:
+            dry_line(args, world, rccl_ranks, elapsed, "closed-loop environment steps/sec, cartpole TD3 with the MPC as actor")
+        return finish_ranks(dist)
     from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedTD3, cartpole_ocp
     E = args.batch
     env = BatchedCartPoleSwingUpEnv(E, device=dev, seed=rank)
@@ -336,20 +384,17 @@ def td3_bench(args):
     agent.collect(4)                       # something to sample from
     if not args.no_graph:
         agent.enable_graphs()              # fills the replay buffer, then captures the roll-out step and the update into HIP graphs
-    for _ in range(args.warmup):
-        agent.collect(1, stats=False), agent.train(1, stats=False)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    agent.collect(0)                       # zero the roll-out statistics
-    t0 = time.perf_counter()
-    for _ in range(args.steps):            # no host synchronisation inside the timed region: statistics are read after it
+
+    def step():                            # no host synchronisation inside the timed region: statistics are read after it
         agent.collect(1, stats=False)
         agent.train(1, stats=False)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = job_aggregate(time.perf_counter() - t0, dist, dev)
+
+    # the warm-up steps run here: the roll-out statistics are zeroed where the timed region starts
+    wa = argparse.Namespace(steps=args.steps, warmup=0)
+    for _ in range(args.warmup):
+        step()
+    agent.collect(0)                       # zero the roll-out statistics
+    elapsed, _, _ = timed_steps(step, wa, dist, dev, rank)
     st = agent.last_stats()
     tr = {"critic_loss": float(agent._graphs["update"][True]["loss"].item())} if agent._graphs else agent.train(1)
     if rank == 0:
@@ -370,8 +415,7 @@ def td3_bench(args):
                        "replay_launch_shape": {"target_actor": list(agent.target_mpc.mpc.launch_times()), "policy": list(agent.pi_mpc.mpc.launch_times()),
                                                "rollout_warm": list(agent.actor.mpc.launch_times(warm=True))}},
             **({"rccl_ranks": rccl_ranks} if rccl_ranks is not None else {})}), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    finish_ranks(dist)
 
 
 def main():
@@ -391,8 +435,6 @@ def main():
     rc = maybe_spawn(args, sys.argv[1:])
     if rc is not None:
         sys.exit(rc)
-    if os.environ.get("MPCRL_BENCH_DRYRUN"):
-        return dryrun(args)
     if args.workload == "td3":
         return td3_bench(args)
     if args.workload in ("chain5", "chain7"):
@@ -402,12 +444,19 @@ def main():
     world, rank, local, dist, dev = init_ranks(args)
     rccl_ranks = count_ranks(dist, dev)
 
-    from mpc4rl_amd import MPCBatch, cartpole_ocp, linear_system_ocp
-    from mpc4rl_amd.distributed import allreduce_weighted_grad
-    ocp = linear_system_ocp(discount_factor=0.99) if linear else cartpole_ocp()
     n_theta = 12 if linear else N_THETA
     B = args.batch
     sens = not args.no_sens
+    metric = ("MPC+KKT-sens solves/sec, %s batch=%d" if sens else "MPC solves/sec, %s batch=%d") % (
+        "linear_system N=40" if linear else "cartpole N=20", B)
+    if DRY:
+        elapsed, _, _ = timed_steps(None, args, dist, dev, rank)
+        if rank == 0:
+            dry_line(args, world, rccl_ranks, elapsed, metric)
+        return finish_ranks(dist)
+    from mpc4rl_amd import MPCBatch, cartpole_ocp, linear_system_ocp
+    from mpc4rl_amd.distributed import allreduce_weighted_grad
+    ocp = linear_system_ocp(discount_factor=0.99) if linear else cartpole_ocp()
     mpc = MPCBatch(ocp, B, device=dev)
     if linear:   # the state box of the linear-system environment (linear_system/environment.py: x in [0, 1] x [-1, 1]), interior part
         rng = np.random.default_rng(rank)
@@ -426,24 +475,7 @@ def main():
 
     if args.rti:
         mpc.solve(x0, cold=True)            # converge once; RTI steps then start from that iterate
-    for _ in range(args.warmup):
-        r = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        r = step()
-        ev[i][1].record()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = job_aggregate(elapsed, dist, dev)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    elapsed, kern_ms, r = timed_steps(step, args, dist, dev, rank)
 
     status = r.status.cpu().numpy()
     iters = r.iters.cpu().numpy()
@@ -451,8 +483,8 @@ def main():
         solves = B * world * args.steps
         bytes_per = algorithmic_bytes_per_solve(ocp.N, ocp.nx, ocp.nu, n_theta, sens)
         achieved = bytes_per * B / (kern_ms * 1e-3) / 1e9
-        # matrix-core work of the factor sweep: 7 v_mfma_f64_4x4x4 block-products (128 flop each) per stage step and instance
-        mfma_tflops = 0.0 if linear else float(iters[:, 1].sum()) * ocp.N * 7 * 128 / (kern_ms * 1e-3) / 1e12
+        # matrix-core work of the factor sweep: 6 v_mfma_f64_4x4x4 block-products (128 flop each) per stage step and instance
+        mfma_tflops = 0.0 if linear else float(iters[:, 1].sum()) * ocp.N * 6 * 128 / (kern_ms * 1e-3) / 1e12
         # algorithmic flops = Riccati sweeps x F_sweep, sweeps per solve = interior-point iterations (+ 1 sensitivity
         # factorisation + nu adjoint solves)
         sweeps = float(iters[:, 1].mean()) + (1 + ocp.nu if sens else 0)
@@ -461,8 +493,7 @@ def main():
         peak_meas = measured_hbm_peak(dev)
         name = "linear system N=40 nx=2 nu=1" if linear else "cartpole N=20 nx=4 nu=1"
         out = {
-            "metric": ("MPC+KKT-sens solves/sec, %s batch=%d" if sens else "MPC solves/sec, %s batch=%d") % (
-                "linear_system N=40" if linear else "cartpole N=20", B),
+            "metric": metric,
             "value": solves / elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
@@ -485,7 +516,7 @@ def main():
                                           "iterations + 1 + nu; the path is a serial dependency chain, not flop-bound"},
                          "mfma_f64_hw": {"achieved": mfma_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": mfma_tflops / FP64_MFMA_PEAK_TFLOPS,
-                                         "note": "hardware flops of the 7 v_mfma_f64_4x4x4 per factor-sweep stage step (padded 4x4x4 "
+                                         "note": "hardware flops of the 6 v_mfma_f64_4x4x4 per factor-sweep stage step (padded 4x4x4 "
                                                  "products; vector sweeps excluded): the MFMAs of the recursion wait on each other"}},
         }
         if rccl_ranks is not None:
@@ -494,8 +525,7 @@ def main():
             from oracle.problems import make_cartpole, make_linear_system
             out["cpu_baseline"] = cpu_baseline_guarded(make_linear_system(gamma=0.99) if linear else make_cartpole(), x0_np, sens)
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    finish_ranks(dist)
 
 
 if __name__ == "__main__":

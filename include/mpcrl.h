@@ -119,8 +119,10 @@ int mpcrl_set_order(mpcrl_handle h, const int32_t *perm, void *stream);
  * clears the order where every instance has a wavefront to itself (chain of masses; horizons of more than 31 stages). */
 int mpcrl_auto_order(mpcrl_handle h, const double *x0, void *stream);
 /* 1 if an mpcrl_solve with these flags would use the time-sliced launch (whose wavefronts take one instance from each quarter of the
- * batch: a packing order buys nothing there and the caller can skip building one), 0 if not, < 0 on misuse. */
-int mpcrl_query_time_sliced(mpcrl_handle h, int flags);
+ * batch: a packing order buys nothing there and the caller can skip building one), 0 if not, < 0 on misuse.  stream = the stream the
+ * solve will be launched on: while it is being captured into a graph the answer is the shape such a launch takes (the one preferred
+ * so far — nothing is timed inside a capture), not the shape of a probe call. */
+int mpcrl_query_time_sliced(mpcrl_handle h, int flags, void *stream);
 /* Launch shape of the cartpole / linear-system solve kernel for non-RTI solves (no effect on results: the two shapes return the same
  * bits).  mode 0 (default) = automatic: where the batch size makes the time-sliced shape a candidate (it saves a round of wavefronts
  * on the device's SIMDs) the handle times the two shapes against each other on the caller's own batches — calls 1 and 2 of every 64
@@ -177,7 +179,8 @@ int mpcrl_get_lagrangian(mpcrl_handle h, double *L, void *stream);
 /* K5, the local half of the one collective on the path: out[j] = sum_i weight[i] * grad[i*ld + j] (j < n), out[n] = sum_i weight[i],
  * out[n+1] = rows.  Replaces the per-sample Python accumulation of rlmpc/examples/linear_system_mpc_qlearning.py:203
  * (np.mean(np.vstack([LR * td[i] * dQ_dp[i, :] ...]))); the n+2 doubles are then all-reduced over the ranks (RCCL).
- * Device pointers on the current device; weight may be NULL (= 1). */
+ * Device pointers; weight may be NULL (= 1).  No handle: the launch goes to the device that owns `out` (hipPointerGetAttributes),
+ * whatever device is current in the calling thread, which is restored on return; MPCRL_E_ARG if `out` is not device memory. */
 int mpcrl_weighted_grad_sum(const double *grad, int64_t ld, const double *weight, int rows, int n, double *out, void *stream);
 
 /* K4, the batched cartpole swing-up environment (rlmpc/gym/continuous_cartpole/environment.py): B environments, one launch per call.
@@ -187,16 +190,20 @@ int mpcrl_weighted_grad_sum(const double *grad, int64_t ld, const double *weight
  *         x^2 + theta^2 of the new state (:193-194), terminated [B] uint8 = the terminal box (:136-146), truncated [B] uint8 =
  *         steps >= max_episode_steps (gymnasium TimeLimit).
  * reset — environments with mask[i] != 0 (mask NULL: all) restart at (0, 0, (0.9 + 0.2 u01[i]) pi, 0) (:178-180), steps = 0;
- *         u01 [B] uniform [0, 1) numbers drawn by the caller; obs [B, 4] (may be NULL) = the state of EVERY environment after it. */
-int mpcrl_env_cartpole_step(const double *par, int B, double *state, int64_t *steps, const double *action, double *obs, double *reward,
-                            uint8_t *terminated, uint8_t *truncated, void *stream);
-int mpcrl_env_cartpole_reset(int B, double *state, int64_t *steps, const uint8_t *mask, const double *u01, double *obs, void *stream);
+ *         u01 [B] uniform [0, 1) numbers drawn by the caller; obs [B, 4] (may be NULL) = the state of EVERY environment after it.
+ * obs_f32 != 0: obs is float (what the reference's gymnasium environments return, environment.py:166,186), else double; the state
+ * is always double (the reference's numpy state).  No handle: the three environment calls launch on the device that owns `state`
+ * (hipPointerGetAttributes), whatever device is current in the calling thread; MPCRL_E_ARG if it is not device memory. */
+int mpcrl_env_cartpole_step(const double *par, int B, double *state, int64_t *steps, const double *action, void *obs, int obs_f32,
+                            double *reward, uint8_t *terminated, uint8_t *truncated, void *stream);
+int mpcrl_env_cartpole_reset(int B, double *state, int64_t *steps, const uint8_t *mask, const double *u01, void *obs, int obs_f32,
+                             void *stream);
 /* The linear-system environment (rlmpc/gym/linear_system/environment.py:28-58), B environments in one launch:
  *   par [12] HOST: A (row-major 2x2), B (2), lb_noise, ub_noise, min_observation (2), max_observation (2)
  *   state [B, 2] (device, updated in place): s+ = A s + B a + [lb_noise + (ub_noise - lb_noise) u01, 0]; action [B]; u01 [B] uniform
  *   numbers of the caller; obs [B, 2] (may be NULL) = new state; cost [B] = 1/2 s's + 1/2 a'a + 100 per violated side of the box. */
-int mpcrl_env_linear_step(const double *par, int B, double *state, const double *action, const double *u01, double *obs, double *cost,
-                          void *stream);
+int mpcrl_env_linear_step(const double *par, int B, double *state, const double *action, const double *u01, void *obs, int obs_f32,
+                          double *cost, void *stream);
 
 /* Bytes of device memory held by the handle; library version. */
 int64_t mpcrl_workspace_bytes(mpcrl_handle h);

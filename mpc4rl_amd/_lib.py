@@ -60,13 +60,13 @@ def load():
     lib.mpcrl_set_iterate.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.mpcrl_get_lagrangian.argtypes = [vp, vp, vp]
     lib.mpcrl_auto_order.argtypes = [vp, vp, vp]
-    lib.mpcrl_query_time_sliced.argtypes = [vp, C.c_int]
+    lib.mpcrl_query_time_sliced.argtypes = [vp, C.c_int, vp]
     lib.mpcrl_set_launch_mode.argtypes = [vp, C.c_int]
     lib.mpcrl_get_launch_times.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.mpcrl_weighted_grad_sum.argtypes = [vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp]
-    lib.mpcrl_env_cartpole_step.argtypes = [_dp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
-    lib.mpcrl_env_cartpole_reset.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp]
-    lib.mpcrl_env_linear_step.argtypes = [_dp, C.c_int, vp, vp, vp, vp, vp, vp]
+    lib.mpcrl_env_cartpole_step.argtypes = [_dp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
+    lib.mpcrl_env_cartpole_reset.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_int, vp]
+    lib.mpcrl_env_linear_step.argtypes = [_dp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp]
     lib.mpcrl_workspace_bytes.argtypes = [vp]
     lib.mpcrl_workspace_bytes.restype = C.c_int64
     for name in EXPORTS:

@@ -164,7 +164,7 @@ class MPCBatch:
         flags = (_lib.SENS_V if sens_v else 0) | (_lib.SENS_PI if sens_pi else 0) | (_lib.RTI if rti else 0) | \
             (_lib.COLD if cold else 0)
         if reorder:
-            if self.lib.mpcrl_query_time_sliced(self._h, flags) == 1:
+            if self.lib.mpcrl_query_time_sliced(self._h, flags, self._stream()) == 1:
                 # the time-sliced launch deals the batch out in quarters: no packing order needed (and none left over from before)
                 self._check(self.lib.mpcrl_set_order(self._h, None, self._stream()), "mpcrl_set_order")
             else:

@@ -14,8 +14,20 @@ struct CartpoleEnvPar {
     long max_episode_steps;
 };
 
+// OBS: the type observations are stored in — double, or float as the reference's gymnasium environments return them
+// (np.array(self.state, dtype=np.float32), environment.py:166,186): the state itself stays fp64 like the reference's numpy state
+template <class OBS>
+__device__ __forceinline__ void store_obs4(OBS *obs, int i, double a, double b, double c, double d) {
+    if constexpr (sizeof(OBS) == 8) {
+        reinterpret_cast<double2 *>(obs)[2 * i] = make_double2(a, b);
+        reinterpret_cast<double2 *>(obs)[2 * i + 1] = make_double2(c, d);
+    } else
+        reinterpret_cast<float4 *>(obs)[i] = make_float4((float)a, (float)b, (float)c, (float)d);
+}
+
+template <class OBS>
 __global__ void __launch_bounds__(256) env_cartpole_step_kernel(const CartpoleEnvPar p, int B, double *state, int64_t *steps, const double *action,
-                                                                double *obs, double *reward, uint8_t *terminated, uint8_t *truncated) {
+                                                                OBS *obs, double *reward, uint8_t *terminated, uint8_t *truncated) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B) return;
     const double2 s01 = reinterpret_cast<const double2 *>(state)[2 * i], s23 = reinterpret_cast<const double2 *>(state)[2 * i + 1];
@@ -29,10 +41,7 @@ __global__ void __launch_bounds__(256) env_cartpole_step_kernel(const CartpoleEn
     const double nx = x + p.tau * xd, nxd = xd + p.tau * xacc, nth = th + p.tau * thd, nthd = thd + p.tau * thacc;
     reinterpret_cast<double2 *>(state)[2 * i] = make_double2(nx, nxd);
     reinterpret_cast<double2 *>(state)[2 * i + 1] = make_double2(nth, nthd);
-    if (obs) {
-        reinterpret_cast<double2 *>(obs)[2 * i] = make_double2(nx, nxd);
-        reinterpret_cast<double2 *>(obs)[2 * i + 1] = make_double2(nth, nthd);
-    }
+    if (obs) store_obs4(obs, i, nx, nxd, nth, nthd);
     const int64_t n = steps[i] + 1;
     steps[i] = n;
     reward[i] = nx * nx + nth * nth;
@@ -40,7 +49,8 @@ __global__ void __launch_bounds__(256) env_cartpole_step_kernel(const CartpoleEn
     truncated[i] = n >= p.max_episode_steps;
 }
 
-__global__ void __launch_bounds__(256) env_cartpole_reset_kernel(int B, double *state, int64_t *steps, const uint8_t *mask, const double *u01, double *obs) {
+template <class OBS>
+__global__ void __launch_bounds__(256) env_cartpole_reset_kernel(int B, double *state, int64_t *steps, const uint8_t *mask, const double *u01, OBS *obs) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B) return;
     if (!mask || mask[i]) {
@@ -49,8 +59,8 @@ __global__ void __launch_bounds__(256) env_cartpole_reset_kernel(int B, double *
         steps[i] = 0;
     }
     if (obs) {
-        reinterpret_cast<double2 *>(obs)[2 * i] = reinterpret_cast<const double2 *>(state)[2 * i];
-        reinterpret_cast<double2 *>(obs)[2 * i + 1] = reinterpret_cast<const double2 *>(state)[2 * i + 1];
+        const double2 a = reinterpret_cast<const double2 *>(state)[2 * i], b = reinterpret_cast<const double2 *>(state)[2 * i + 1];
+        store_obs4(obs, i, a.x, a.y, b.x, b.y);
     }
 }
 
@@ -61,8 +71,9 @@ struct LinearEnvPar {
     double A[4], B[2], lb_noise, ub_noise, low[2], high[2];
 };
 
+template <class OBS>
 __global__ void __launch_bounds__(256) env_linear_step_kernel(const LinearEnvPar p, int B, double *state, const double *action, const double *u01,
-                                                              double *obs, double *cost) {
+                                                              OBS *obs, double *cost) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B) return;
     const double2 s = reinterpret_cast<const double2 *>(state)[i];
@@ -71,7 +82,12 @@ __global__ void __launch_bounds__(256) env_linear_step_kernel(const LinearEnvPar
     const double s0 = (s.x * p.A[0] + s.y * p.A[1]) + a * p.B[0] + n0;
     const double s1 = (s.x * p.A[2] + s.y * p.A[3]) + a * p.B[1];
     reinterpret_cast<double2 *>(state)[i] = make_double2(s0, s1);
-    if (obs) reinterpret_cast<double2 *>(obs)[i] = make_double2(s0, s1);
+    if (obs) {
+        if constexpr (sizeof(OBS) == 8)
+            reinterpret_cast<double2 *>(obs)[i] = make_double2(s0, s1);
+        else
+            reinterpret_cast<float2 *>(obs)[i] = make_float2((float)s0, (float)s1);
+    }
     const double lower = (p.low[0] - s0 > 0.0 || p.low[1] - s1 > 0.0) ? 1e2 : 0.0;
     const double upper = (s0 - p.high[0] > 0.0 || s1 - p.high[1] > 0.0) ? 1e2 : 0.0;
     cost[i] = 0.5 * (s0 * s0 + s1 * s1) + 0.5 * (a * a) + lower + upper;

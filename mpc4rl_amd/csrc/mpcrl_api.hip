@@ -79,6 +79,21 @@ struct DeviceGuard {
     DeviceGuard guard_((dev));    \
     if (!guard_.ok) return MPCRL_E_HIP
 
+// the handle-less library kernels (reduction, environments) launch on the device that OWNS the memory they are given, whatever device
+// is current in the calling thread; -1 if the pointer is not device memory
+int device_of(const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return at.type == hipMemoryTypeDevice ? at.device : -1;
+}
+#define ON_DEVICE_OF(ptr)                       \
+    const int dev_of_ = device_of((ptr));       \
+    if (dev_of_ < 0) return MPCRL_E_ARG;        \
+    ON_DEVICE(dev_of_)
+
 template <class T>
 int dev_alloc(T **p, size_t n, int64_t &bytes) {
     hipError_t e = hipMalloc((void **)p, n * sizeof(T));
@@ -374,6 +389,11 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
     if (!rc && hipMemset(h->theta, 0, B * (size_t)spec->np * sizeof(double)) != hipSuccess) rc = MPCRL_E_HIP;
     if (!rc && hipMemset(h->RES, 0, B * 4 * sizeof(double)) != hipSuccess) rc = MPCRL_E_HIP;
     if (!rc && hipMemset(h->LAG, 0, B * sizeof(double)) != hipSuccess) rc = MPCRL_E_HIP;
+    if (!rc) {   // "no spread known": a cheap-form order launch that runs before any refresh (a captured first call that was never
+                 // replayed) then finds one crowded bucket = the identity order, never garbage
+        const double os0[4] = {-1.0, 0.0, 0.0, 0.0};
+        if (hipMemcpy(h->order_state, os0, sizeof(os0), hipMemcpyHostToDevice) != hipSuccess) rc = MPCRL_E_HIP;
+    }
     if (!rc) rc = fill_cold_iterate(h, nullptr, true, nullptr);
     if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) rc = MPCRL_E_HIP;
     if (rc) {
@@ -447,10 +467,22 @@ int mpcrl_set_cold_mask(mpcrl_handle h, const int32_t *mask, void *stream) {
     return 0;
 }
 
-int mpcrl_query_time_sliced(mpcrl_handle h, int flags) {
+int mpcrl_query_time_sliced(mpcrl_handle h, int flags, void *stream) {
     if (!h) return MPCRL_E_ARG;
     if (h->is_large) return 0;
     if (!h->have_iterate) flags |= MPCRL_COLD;
+    {   // a solve launched into a stream capture times nothing and takes the shape preferred so far (launch_small): answer with that
+        // shape, not with the probe shape the call counter would select, and promise nothing
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+        if (capturing && h->slice_mode == 0) {
+            bool by_rule = false, cand = false;
+            if (h->model == MPCRL_MODEL_CARTPOLE) cand = sliced_candidate<CartpoleDev>(h, flags, nullptr, &by_rule);
+            if (h->model == MPCRL_MODEL_LINEAR) cand = sliced_candidate<LinearDev>(h, flags, nullptr, &by_rule);
+            h->planned = -1;
+            return (cand && by_rule && tuned_best(h->tune[(flags & MPCRL_COLD) ? 0 : 1]) == TUNE_SLICED) ? 1 : 0;
+        }
+    }
     bool sliced = false, tuned = false, by_rule = false;
     switch (h->model) {
         case MPCRL_MODEL_CARTPOLE:
@@ -494,8 +526,10 @@ int mpcrl_auto_order(mpcrl_handle h, const double *x0, void *stream) {
     // stream capture once they exist: a graph replays the cheap form)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+    // (a first call inside a capture refreshes as well — the graph then always does — but does not count: the state is only known to
+    // be valid once a refresh launch was issued for real)
     const int refresh = (h->order_calls == 0 || (!capturing && h->order_calls % 32 == 0)) ? 1 : 0;
-    h->order_calls++;
+    if (!(capturing && h->order_calls == 0)) h->order_calls++;
     hipLaunchKernelGGL(order_kernel, dim3(1), dim3(ORDER_NT), 0, (hipStream_t)stream, x0, h->B, h->nx, h->perm, h->order_state, refresh);
     HIP_OK(hipGetLastError());
     h->have_perm = true;
@@ -572,6 +606,7 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
 
 int mpcrl_weighted_grad_sum(const double *grad, int64_t ld, const double *weight, int rows, int n, double *out, void *stream) {
     if (!grad || !out || rows < 0 || n < 1 || ld < n) return MPCRL_E_ARG;
+    ON_DEVICE_OF(out);
     hipStream_t st = (hipStream_t)stream;
     HIP_OK(hipMemsetAsync(out, 0, (size_t)(n + 2) * sizeof(double), st));
     if (rows == 0) return 0;
@@ -586,36 +621,50 @@ int mpcrl_weighted_grad_sum(const double *grad, int64_t ld, const double *weight
     return 0;
 }
 
-int mpcrl_env_cartpole_step(const double *par, int B, double *state, int64_t *steps, const double *action, double *obs, double *reward,
-                            uint8_t *terminated, uint8_t *truncated, void *stream) {
+int mpcrl_env_cartpole_step(const double *par, int B, double *state, int64_t *steps, const double *action, void *obs, int obs_f32,
+                            double *reward, uint8_t *terminated, uint8_t *truncated, void *stream) {
     if (!par || B < 0 || !state || !steps || !action || !reward || !terminated || !truncated) return MPCRL_E_ARG;
     if (B == 0) return 0;
+    ON_DEVICE_OF(state);
     CartpoleEnvPar p;
     p.gravity = par[0], p.masscart = par[1], p.masspole = par[2], p.length = par[3], p.force_mag = par[4], p.tau = par[5];
     p.x_threshold = par[6], p.theta_threshold = par[7], p.max_episode_steps = (long)par[8];
-    hipLaunchKernelGGL(env_cartpole_step_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, B, state, steps, action, obs, reward,
-                       terminated, truncated);
+    if (obs_f32)
+        hipLaunchKernelGGL(env_cartpole_step_kernel<float>, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, B, state, steps, action,
+                           (float *)obs, reward, terminated, truncated);
+    else
+        hipLaunchKernelGGL(env_cartpole_step_kernel<double>, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, B, state, steps, action,
+                           (double *)obs, reward, terminated, truncated);
     HIP_OK(hipGetLastError());
     return 0;
 }
 
-int mpcrl_env_linear_step(const double *par, int B, double *state, const double *action, const double *u01, double *obs, double *cost,
-                          void *stream) {
+int mpcrl_env_linear_step(const double *par, int B, double *state, const double *action, const double *u01, void *obs, int obs_f32,
+                          double *cost, void *stream) {
     if (!par || B < 0 || !state || !action || !u01 || !cost) return MPCRL_E_ARG;
     if (B == 0) return 0;
+    ON_DEVICE_OF(state);
     LinearEnvPar p;
     for (int i = 0; i < 4; ++i) p.A[i] = par[i];
     p.B[0] = par[4], p.B[1] = par[5], p.lb_noise = par[6], p.ub_noise = par[7];
     p.low[0] = par[8], p.low[1] = par[9], p.high[0] = par[10], p.high[1] = par[11];
-    hipLaunchKernelGGL(env_linear_step_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, B, state, action, u01, obs, cost);
+    if (obs_f32)
+        hipLaunchKernelGGL(env_linear_step_kernel<float>, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, B, state, action, u01, (float *)obs, cost);
+    else
+        hipLaunchKernelGGL(env_linear_step_kernel<double>, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, B, state, action, u01, (double *)obs, cost);
     HIP_OK(hipGetLastError());
     return 0;
 }
 
-int mpcrl_env_cartpole_reset(int B, double *state, int64_t *steps, const uint8_t *mask, const double *u01, double *obs, void *stream) {
+int mpcrl_env_cartpole_reset(int B, double *state, int64_t *steps, const uint8_t *mask, const double *u01, void *obs, int obs_f32,
+                             void *stream) {
     if (B < 0 || !state || !steps || !u01) return MPCRL_E_ARG;
     if (B == 0) return 0;
-    hipLaunchKernelGGL(env_cartpole_reset_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, state, steps, mask, u01, obs);
+    ON_DEVICE_OF(state);
+    if (obs_f32)
+        hipLaunchKernelGGL(env_cartpole_reset_kernel<float>, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, state, steps, mask, u01, (float *)obs);
+    else
+        hipLaunchKernelGGL(env_cartpole_reset_kernel<double>, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, state, steps, mask, u01, (double *)obs);
     HIP_OK(hipGetLastError());
     return 0;
 }

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(ORDER_NT) order_kernel(const double *x0, int B
         if (tid == 0) best[0] = state[0], best[1] = state[1], best[2] = state[2];
         __syncthreads();
     }
-    const int dim = (int)best[2];
+    const int dim = min(max((int)best[2], 0), nx - 1);   // (a state nobody refreshed holds {-1, 0, 0}: one crowded bucket, identity order)
     const double lo = best[1], scale = best[0] > 0.0 ? (double)ORDER_NT / best[0] : 0.0;
     int bkt[ORDER_PER], rnk[ORDER_PER];
 #pragma unroll

@@ -40,10 +40,10 @@ def allreduce_weighted_grad(grad: torch.Tensor, weight: torch.Tensor, group: Opt
         import ctypes as C
         from . import _lib
         w = w.contiguous()
-        with torch.cuda.device(g.device):
-            rc = _lib.load().mpcrl_weighted_grad_sum(C.c_void_p(g.data_ptr()), int(g.stride(0)), C.c_void_p(w.data_ptr()), int(g.shape[0]),
-                                                     int(n_theta), C.c_void_p(buf.data_ptr()),
-                                                     C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream))
+        # (the library launches on the device that owns `buf`, whatever device is current here)
+        rc = _lib.load().mpcrl_weighted_grad_sum(C.c_void_p(g.data_ptr()), int(g.stride(0)), C.c_void_p(w.data_ptr()), int(g.shape[0]),
+                                                 int(n_theta), C.c_void_p(buf.data_ptr()),
+                                                 C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream))
         if rc != 0:
             raise RuntimeError(f"mpcrl_weighted_grad_sum failed with {rc}")
     else:   # CPU tensors (gloo tests), and the deterministic path: the reduction kernel combines its per-wave partial sums with

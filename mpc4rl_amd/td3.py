@@ -286,7 +286,10 @@ class BatchedTD3:
             okb = (rp.status == 0) & torch.isfinite(torch.cat([rp.u0.to(obs.dtype), obs], dim=1)).all(dim=1)
             u_pi = torch.where(okb[:, None], rp.u0, 0.0)
             a_pi = self.pi_mpc.scale_action(u_pi).to(torch.float32).detach().requires_grad_(True)
-            (dq_da,) = torch.autograd.grad(self.critic.q1_forward(obs_s, a_pi).sum(), a_pi)
+            # the policy branch has its own mask: obs_s above is zeroed where the TARGET solve failed, and dQ/da at obs = 0 paired
+            # with pi(s) and dpi/dtheta of the real obs would bias the step for rows whose policy solve succeeded
+            obs_p = torch.where(okb[:, None], obs, 0.0)
+            (dq_da,) = torch.autograd.grad(self.critic.q1_forward(obs_p, a_pi).sum(), a_pi)
             chain = (2.0 / (self.pi_mpc.high - self.pi_mpc.low)) if self.pi_mpc.scale else torch.ones_like(self.pi_mpc.low)
             okp = okb.to(torch.float64)
             g = torch.einsum("bu,bup->bp", torch.where(okb[:, None], dq_da.to(torch.float64) * chain, 0.0), torch.nan_to_num(rp.dpi_dp))
@@ -351,6 +354,9 @@ class BatchedTD3:
             return
         if self.device.type != "cuda" or not hasattr(self.env, "reset_where"):
             raise RuntimeError("enable_graphs needs a CUDA device and an environment with reset_where")
+        if hasattr(self.env, "_native") and not self.env._native():
+            # a replayed step must update the environment's own state tensors in place (the library's environment kernels do)
+            raise RuntimeError("enable_graphs needs the environment on the GPU (its state is updated in place by the library kernels)")
         while not self.buffer.full:
             self._collect_step()
         if self._ended is None:
@@ -367,14 +373,49 @@ class BatchedTD3:
             torch.cuda.synchronize(self.device)
         gens = [self.gen] + ([self.env.gen] if hasattr(self.env, "gen") else [])
         side = torch.cuda.Stream(device=self.device)
+        # The warm-up on the capture stream (allocator, lazy initialisations) runs both kinds of update and one roll-out step for real.
+        # Everything it touches is put back afterwards — critics, optimiser state, theta / theta', generators, environment, replay
+        # buffer, running observation, statistics — so that enabling graphs neither perturbs the training trajectory nor shifts the
+        # policy_delay phase relative to eager mode.
+        import copy
+        snap = {"critic": copy.deepcopy(self.critic.state_dict()), "critic_target": copy.deepcopy(self.critic_target.state_dict()),
+                "opt": copy.deepcopy(self.critic_opt.state_dict()), "theta": self.theta.clone(), "theta_target": self.theta_target.clone(),
+                "gens": [g.get_state() for g in gens], "obs": self.obs.clone(), "ended": self._ended.clone(), "stats": self._stats.clone(),
+                "env": (self.env.state.clone(), self.env.steps.clone()) if hasattr(self.env, "steps") else None,
+                "buf": [t.clone() for t in (self.buffer.obs, self.buffer.next_obs, self.buffer.act, self.buffer.rew, self.buffer.done)],
+                "pos": (self.buffer.pos, self.buffer.full), "iter": self.actor.mpc.get_iterate() if hasattr(self.actor.mpc, "get_iterate") else None}
         side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):                      # warm-up on the capture stream (allocator, lazy initialisations)
+        with torch.cuda.stream(side):
             for dp in (False, True):
                 flat, _ = self._update_pre(dp)
                 self._update_post(self._allreduce(flat), dp)
             self._collect_step(static=True)
             self.buffer._advance()
         torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        with torch.no_grad():
+            self.critic.load_state_dict(snap["critic"]), self.critic_target.load_state_dict(snap["critic_target"])
+            # in place: the optimiser's state tensors (device step counter included) are what a captured update replays on
+            st_now, st_old = self.critic_opt.state_dict()["state"], snap["opt"]["state"]
+            for k, d in st_now.items():
+                for name, v in d.items():
+                    if torch.is_tensor(v):
+                        v.copy_(st_old[k][name]) if k in st_old else v.zero_()
+            self.theta.copy_(snap["theta"]), self.theta_target.copy_(snap["theta_target"])
+            for m, th in ((self.actor, self.theta), (self.pi_mpc, self.theta), (self.target_mpc, self.theta_target)):
+                m.mpc.set_theta(th)
+            for g, stt in zip(gens, snap["gens"]):
+                g.set_state(stt)
+            self.obs.copy_(snap["obs"]), self._ended.copy_(snap["ended"]), self._stats.copy_(snap["stats"])
+            if snap["env"] is not None:
+                self.env.state.copy_(snap["env"][0]), self.env.steps.copy_(snap["env"][1])
+            for t, old in zip((self.buffer.obs, self.buffer.next_obs, self.buffer.act, self.buffer.rew, self.buffer.done), snap["buf"]):
+                t.copy_(old)
+            self.buffer.pos, self.buffer.full = snap["pos"]
+            self.buffer.pos_t.fill_(self.buffer.pos)
+            if snap["iter"] is not None:
+                x_, u_, pi_, bnd_, _ = snap["iter"]
+                self.actor.mpc.set_iterate(x_, u_, pi_, bnd_)
         torch.cuda.synchronize(self.device)
 
         def capture(fn):

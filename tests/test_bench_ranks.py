@@ -9,11 +9,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(gpus, extra_env=None):
+def _run(gpus, extra_env=None, workload=None):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["MPCRL_BENCH_DRYRUN"] = "1"
     env.update(extra_env or {})
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "5", "--warmup", "1"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "5", "--warmup", "1"]
+                         + (["--workload", workload] if workload else []),
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -26,6 +27,17 @@ def test_gpus_2_spawns_two_ranks_and_reports_the_slowest():
     assert line["n_gpus"] == 2 and line["steps"] == 5 and line["dryrun"] is True
     assert line["ms_per_step"] >= 2.0          # rank 1 sleeps 2 ms per step: MAX over ranks, not rank 0's 1 ms
     assert line["rccl_ranks"] == 2             # the collective's own count of the ranks that joined (all-reduce of ones)
+
+
+def test_every_workload_is_rank_aware():
+    """BASELINE config 4 is "chain_mass ... 1 -> 8 GPU scaling" and config 5 shards its environments over 8 GPUs: `--workload chain5 |
+    chain7 | td3 | linear --gpus 2` must go through the same launcher, rendezvous, barrier-bracketed MAX-over-ranks region and print
+    ONE line with n_gpus = 2 (round 3's chain bench pinned cuda:0 and printed one line per rank)."""
+    for wl in ("chain5", "td3", "linear"):
+        line = _run(2, workload=wl)
+        assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["workload"] == wl, line
+        assert line["ms_per_step"] >= 2.0
+        assert ("chain_mass n_mass=5" in line["metric"]) == (wl == "chain5")
 
 
 def test_gpus_1_stays_in_process():

@@ -351,7 +351,7 @@ def test_launch_shape_tuner(monkeypatch):
     first = mpc.solve(x, cold=True, sens_pi=True)
     shapes = []
     for _ in range(5):
-        shapes.append(mpc.lib.mpcrl_query_time_sliced(mpc._h, _lib.COLD | _lib.SENS_PI))
+        shapes.append(mpc.lib.mpcrl_query_time_sliced(mpc._h, _lib.COLD | _lib.SENS_PI, None))
         r = mpc.solve(x, cold=True, sens_pi=True)
         torch.cuda.synchronize()
         assert torch.equal(r.u0, first.u0) and torch.equal(r.V, first.V) and torch.equal(r.iters, first.iters)
@@ -361,7 +361,7 @@ def test_launch_shape_tuner(monkeypatch):
     assert ts > 0.0 and tp > 0.0 and pref == ("plain" if tp < 0.80 * ts else "time-sliced")
     assert all(s == (0 if pref == "plain" else 1) for s in shapes[3:])
     # warm calls are probed on their own (different work per instance): their first probe is still ahead
-    assert mpc.launch_times(warm=True)[:2] == (-1.0, -1.0) and mpc.lib.mpcrl_query_time_sliced(mpc._h, _lib.SENS_PI) == 1
+    assert mpc.launch_times(warm=True)[:2] == (-1.0, -1.0) and mpc.lib.mpcrl_query_time_sliced(mpc._h, _lib.SENS_PI, None) == 1
     w0 = mpc.solve(x, sens_pi=True)
     for _ in range(4):
         w = mpc.solve(x, sens_pi=True)
@@ -370,9 +370,9 @@ def test_launch_shape_tuner(monkeypatch):
     tws, twp, _ = mpc.launch_times(warm=True)
     assert tws > 0.0 and twp > 0.0 and (tws, twp) != (ts, tp)
     mpc.set_launch_mode(-1)
-    assert mpc.lib.mpcrl_query_time_sliced(mpc._h, _lib.COLD) == 0
+    assert mpc.lib.mpcrl_query_time_sliced(mpc._h, _lib.COLD, None) == 0
     mpc.set_launch_mode(1)
-    assert mpc.lib.mpcrl_query_time_sliced(mpc._h, _lib.COLD) == 1
+    assert mpc.lib.mpcrl_query_time_sliced(mpc._h, _lib.COLD, None) == 1
     r = mpc.solve(x, cold=True, sens_pi=True)
     assert torch.equal(r.u0, first.u0) and torch.equal(r.iters, first.iters)
     assert mpc.lib.mpcrl_set_launch_mode(mpc._h, 2) < 0

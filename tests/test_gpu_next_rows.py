@@ -1,4 +1,6 @@
 """GPU tests of the callers of the hot path: batched Q-learning, the TD3/DPG actor, iterate store/load, RTI closed loop."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -312,3 +314,121 @@ def test_td3_graph_replay_mode():
     # the newest replay row is the transition the last replayed step produced: its next_obs, un-reset, continues its obs
     last = (agent.buffer.pos - 1) % 6
     assert bool(torch.isfinite(agent.buffer.next_obs[last]).all()) and float(agent.buffer.act[last].abs().max()) <= 1.0
+
+
+def test_float32_observations_through_the_native_env_kernels():
+    """dtype=torch.float32 (what the reference's gymnasium envs return, continuous_cartpole/environment.py:166,186): the state stays
+    fp64 (the reference's numpy state), the observation is stored as float by the SAME library kernels — one device path."""
+    from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedLinearSystemEnv
+    B = 1024
+    e32, e64 = (BatchedCartPoleSwingUpEnv(B, device="cuda", seed=4, dtype=dt) for dt in (torch.float32, torch.float64))
+    assert e32._native() and e32.state.dtype == torch.float64
+    o32, o64 = e32.reset(), e64.reset()
+    assert o32.dtype == torch.float32 and torch.equal(o32, o64.float()) and torch.equal(e32.state, e64.state)
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        a = torch.as_tensor(rng.uniform(-1, 1, (B, 1)), device="cuda")
+        sp = e32.state.data_ptr()
+        o32, r32, t32, _ = e32.step(a.float())
+        o64, r64, t64, _ = e64.step(a.float())
+        assert e32.state.data_ptr() == sp                                       # updated in place: a captured step keeps working
+        assert o32.dtype == torch.float32 and torch.equal(o32, o64.float()) and torch.equal(e32.state, e64.state)
+        assert torch.equal(r32, r64) and torch.equal(t32, t64)
+    mask = torch.arange(B, device="cuda") % 2 == 0
+    assert torch.equal(e32.reset_where(mask), e64.reset_where(mask).float())
+    l32 = BatchedLinearSystemEnv(B, device="cuda", seed=2, dtype=torch.float32)
+    l64 = BatchedLinearSystemEnv(B, device="cuda", seed=2)
+    l32.reset(), l64.reset()
+    a = torch.as_tensor(rng.uniform(-1, 1, (B, 1)), device="cuda")
+    o32, c32, _, _ = l32.step(a)
+    o64, c64, _, _ = l64.step(a)
+    assert o32.dtype == torch.float32 and torch.equal(o32, o64.float()) and torch.equal(c32, c64)
+
+
+def test_handleless_kernels_refuse_host_memory():
+    """mpcrl_weighted_grad_sum / mpcrl_env_* carry no handle: they launch on the device that owns the memory they are given and
+    return MPCRL_E_ARG for anything that is not device memory (instead of launching on whatever device happens to be current)."""
+    import ctypes as C
+    from mpc4rl_amd import _lib
+    lib = _lib.load()
+    host = (C.c_double * 16)()
+    dev = torch.zeros(16, dtype=torch.float64, device="cuda")
+    assert lib.mpcrl_weighted_grad_sum(C.c_void_p(dev.data_ptr()), 4, None, 4, 2, C.cast(host, C.c_void_p), None) == -1
+    assert lib.mpcrl_weighted_grad_sum(C.c_void_p(dev.data_ptr()), 4, None, 4, 2, C.c_void_p(dev.data_ptr() + 64), None) == 0
+    par = (C.c_double * 9)(9.8, 1.0, 0.1, 0.5, 30.0, 0.02, 0.1, 0.03, 500.0)
+    assert lib.mpcrl_env_cartpole_step(par, 2, C.cast(host, C.c_void_p), C.c_void_p(dev.data_ptr()), C.c_void_p(dev.data_ptr()), None, 0,
+                                       C.c_void_p(dev.data_ptr()), C.c_void_p(dev.data_ptr()), C.c_void_p(dev.data_ptr()), None) == -1
+
+
+def test_enable_graphs_leaves_the_training_trajectory_alone():
+    """enable_graphs warms the capture stream up with two real updates and one real roll-out step; everything they touched is put
+    back (critics, optimiser state, theta / theta', generators, environments, replay buffer, warm-start iterates), so that an agent
+    that enables graphs continues exactly where it was — and then follows the eager agent's trajectory (same kernels, same random
+    numbers: the generators are registered with the graphs)."""
+    from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedTD3, cartpole_ocp
+    E = 256
+
+    def make():
+        env = BatchedCartPoleSwingUpEnv(E, device="cuda", seed=11, max_episode_steps=9)
+        ag = BatchedTD3(cartpole_ocp(), env, batch_size=E, buffer_steps=4, policy_delay=2, lr_actor=1e-3, seed=5)
+        ag.collect(4)                       # the buffer is full: enable_graphs collects nothing on its own
+        ag.train(1)                         # n_updates = 1: the next update is a policy update
+        return ag
+
+    flat = lambda ag: torch.cat([p.detach().reshape(-1).double() for p in ag.critic.parameters()] + [ag.theta, ag.theta_target,
+                                 ag.env.state.reshape(-1), ag.obs.reshape(-1).double(), ag.buffer.obs.reshape(-1).double()])
+    a, b = make(), make()
+    assert torch.equal(flat(a), flat(b))
+    before, pos, nup = flat(b).clone(), (b.buffer.pos, b.buffer.full), b.n_updates
+    b.enable_graphs()
+    torch.cuda.synchronize()
+    assert torch.equal(flat(b), before) and (b.buffer.pos, b.buffer.full) == pos and b.n_updates == nup
+    assert int(b.buffer.pos_t.item()) == b.buffer.pos
+    for _ in range(3):
+        for ag in (a, b):
+            ag.collect(1, stats=False)
+            ag.train(1, stats=False)
+    torch.cuda.synchronize()
+    fa, fb = flat(a), flat(b)
+    assert bool(torch.isfinite(fb).all())
+    assert float((fa - fb).abs().max() / fa.abs().max()) < 1e-6, float((fa - fb).abs().max())
+    with pytest.raises(RuntimeError):       # a CPU environment cannot be replayed (its state would be frozen at the captured address)
+        BatchedTD3(cartpole_ocp(), BatchedCartPoleSwingUpEnv(E, device="cpu"), batch_size=E, buffer_steps=2, device="cuda").enable_graphs()
+
+
+def test_td3_config5_full_size_on_one_gpu():
+    """BASELINE config 5 at its full size — 32 768 cartpole environments — on ONE GPU (the 8-GPU job gives each rank 4096 of them):
+    two closed-loop steps + two TD3 updates on batches of 32 768 through the `nccl` (= RCCL) process group at world size 1, ONE
+    collective per update (scripts/cartpole_mpc_as_td3_agent_closed_loop.py:40-67 is the loop this batches)."""
+    import socket
+    import torch.distributed as dist
+    from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedTD3, cartpole_ocp
+    E = 32768
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    calls = []
+    real = dist.all_reduce
+    try:
+        env = BatchedCartPoleSwingUpEnv(E, device=dev, seed=0)
+        agent = BatchedTD3(cartpole_ocp(), env, batch_size=E, buffer_steps=4, policy_delay=1, lr_actor=1e-6, seed=0, device=dev)
+        agent._world = lambda: 2            # take the collective's path although the group has one rank
+        agent._allreduce = lambda flat: (calls.append(int(flat.numel())), real(flat, group=agent.group), flat.mul_(2.0))[-1]
+        th0 = agent.theta.clone()
+        st = agent.collect(2)
+        assert agent.buffer.size() == 2 * E and st["converged_fraction"] > 0.999 and np.isfinite(st["mean_reward"])
+        for _ in range(2):
+            tr = agent.train(1)
+        torch.cuda.synchronize()
+        n_crit = sum(p.numel() for p in agent.critic.parameters())
+        assert calls == [n_crit + agent.theta.numel() + 1] * 2                  # ONE message per update: critic + theta gradients + count
+        assert np.isfinite(tr["critic_loss"]) and bool(torch.isfinite(agent.theta).all()) and bool(torch.isfinite(agent.theta_target).all())
+        assert torch.equal(agent.theta[3:], th0[3:])                            # only the model block is learned
+        r = agent.pi_mpc.mpc.solve(agent.buffer.obs[0].double(), sens_pi=True, cold=True)
+        assert float((r.status == 0).double().mean()) > 0.999 and bool(torch.isfinite(r.dpi_dp).all())
+    finally:
+        dist.destroy_process_group()
