@@ -66,7 +66,7 @@ def load():
     lib.mpcrl_weighted_grad_sum.argtypes = [vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp]
     lib.mpcrl_env_cartpole_step.argtypes = [_dp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
     lib.mpcrl_env_cartpole_reset.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_int, vp]
-    lib.mpcrl_env_linear_step.argtypes = [_dp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp]
+    lib.mpcrl_env_linear_step.argtypes = [_dp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]
     lib.mpcrl_workspace_bytes.argtypes = [vp]
     lib.mpcrl_workspace_bytes.restype = C.c_int64
     for name in EXPORTS:
