@@ -44,6 +44,16 @@ constexpr double CHAIN_TOL_MU_FACTOR = 1.0;
 #define MPCRL_CHAIN_SCALE_RES 1
 #endif
 
+// Round 4: the three Riccati sweeps (factor, backward vector sweep, forward sweep) as register-resident MFMA pipelines in the
+// "Omega" coordinates of OmCfg below (no LDS in the sweeps, operands straight from HBM in their register layout).  0 = the round-3
+// sweeps (operands staged through LDS), kept for A/B measurements.
+#ifndef MPCRL_CHAIN_V2
+#define MPCRL_CHAIN_V2 1
+#endif
+#ifndef MPCRL_CHAIN_V2_MAXNX
+#define MPCRL_CHAIN_V2_MAXNX 21   // largest state dimension that runs the round-4 sweeps
+#endif
+
 struct LargeSpec {
     int N, np, cost_kind, rk_steps, max_iter;
     double dT, gamma, h, tol;
@@ -71,22 +81,53 @@ struct ChainCfgStride {   // stage strides of the streamed blocks (ChainCfg belo
     static constexpr int PST = 128 * (((NX * (NX + 1) / 2 + 1) / 2 + 63) / 64);   // P_k in HBM: packed lower triangle
 };
 
+// ---- Omega coordinates of the register-resident sweeps (round 4).
+// v_mfma_f64_16x16x4 wants A(i, k) and B(k, j) at lane 16 k + (i | j) and returns register r = rows 4 r + lane / 16, column lane % 16:
+// the RESULT layout of a matrix (row group of 4 on lane / 16, column on lane % 16) is at the same time its layout as a B operand
+// (contraction over its rows) and, transposed, as an A operand — so a chain of products can stay in registers as long as every
+// matrix of the recursion is indexed by ONE index set on both sides.  That set is Omega = 0 .. NW - 1, NW = NX + NU slots:
+//     slot e <  Q           : state x_e                    Q = 4 floor(NX / 4)
+//     slot Q + l, l < NU    : control u_l  as a COLUMN index (stage vector), a zero pad row as a ROW index (next state)
+//     slot e >= Q + NU      : state x_{e - NU}
+// i.e. the stage vector [x; u] with the controls moved into one aligned group of four slots (one register, lanes lr = 0 .. NU - 1),
+// and column NW (= VC) next to it carries the VECTORS of the recursion through the same products:
+//     W  = [A B | b]   (rows: next state, pad rows 0)       T = P W = [P A, P B | P b (+ p)]
+//     M  = H + D + W' T   ->  column VC = g + W'(P b + p),  rows Q.. = [S | R | mv_u]
+//     K  = R^-1 [S | R | mv_u] (one MFMA per column tile, R^-1 from a Cholesky every lane runs on broadcast values)
+//     P' = M - S' K    ->  x / x block = P_k, column VC = p_k          G = W - B K with K written into the pad rows
+// Per stage the factor sweep streams G_k (closed loop: x rows [Acl | B], pad rows [-K | 0]) and P_k to HBM in this register
+// layout (64 lanes x 8 bytes per register: every access a full 512-byte burst), and the two vector sweeps are MFMA chains whose
+// operand vector IS the previous stage's result registers:
+//     backward  [p_k; mv_u] = g~ + G' [p_{k+1} + P_{k+1} b; g~_u]          forward  [dx_{k+1}; du_k] = [b; -kff] + G [dx_k; -kff]
+template <class M>
+struct OmCfg {
+    static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU;
+    static constexpr int Q = 4 * (NX / 4), VC = NW, RG = (NW + 3) / 4, NT = (NW + 16) / 16, NTR = (RG + 3) / 4;
+    static constexpr int GQ = Q / 4, TQ = Q / 16, RQ = GQ % 4, LQ = Q % 16, TV = VC / 16, LV = VC % 16;
+    static constexpr int GSZ = RG * NT * 64;        // doubles of one streamed stage block (RG x NT registers of 64 lanes)
+    static constexpr int HBS = 4 * RG;               // stride of the per-stage Omega vectors
+    static_assert(NU <= 4 && LQ + NU <= 16 && NTR <= NT, "the control group sits in one register, inside one column tile");
+    // slot -> index in the stage vector [u; x] (e < NW) / index of the state (-1: none)
+    MPCRL_DI static constexpr int nat(int e) { return e < Q ? NU + e : (e < Q + NU ? e - Q : e); }
+    MPCRL_DI static constexpr int xrow(int e) { return e < Q ? e : (e < Q + NU ? -1 : (e < NW ? e - NU : -1)); }
+};
+
 // per-instance workspace layout (doubles)
 template <class M>
 struct LargeLayout {
     static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD;
     size_t BA, r, q, dx, du, nuq, Dx, Du, Dnu, rg, rb, rt, Dg, lamw, tw, aff, P, p, K, L, kff, Acl, hb, ccv, cvec, Hex, term, ynu, state, Ydx, Ydu, Ydnu,
-        term2, ptab, gtab, total;
+        term2, ptab, gtab, G2, P2, hb2, minv2, mvu2, total;
     __host__ __device__ explicit LargeLayout(int N) {
         size_t o = 0;
         auto take = [&](size_t n) { size_t s = o; o += (n + 1) & ~(size_t)1; return s; };   // every array 16-byte aligned
         BA = take((size_t)N * NX * NW), r = take((size_t)N * NX), q = take((size_t)(N + 1) * NW);
         dx = take((size_t)(N + 1) * NX), du = take((size_t)N * NU), nuq = take((size_t)(N + 1) * NX);
-        Dx = take((size_t)(N + 1) * NX), Du = take((size_t)N * NU), Dnu = take((size_t)(N + 1) * NX);
+        Dx = take((size_t)(N + 1) * NX + 2), Du = take((size_t)N * NU + 2), Dnu = take((size_t)(N + 1) * NX + 2);
         rg = take((size_t)(N + 1) * NW), rb = take((size_t)N * NX), rt = take((size_t)(N + 1) * NW), Dg = take((size_t)(N + 1) * NW);
         lamw = take((size_t)2 * (N + 1) * NW), tw = take((size_t)2 * (N + 1) * NW), aff = take((size_t)2 * (N + 1) * NW);
-        P = take((size_t)(N + 1) * ChainCfgStride<NX, NW>::PST), p = take((size_t)(N + 1) * NX), K = take((size_t)N * NU * NX), L = take((size_t)N * NU * NU);
-        kff = take((size_t)N * NU);
+        P = take((size_t)(N + 1) * ChainCfgStride<NX, NW>::PST), p = take((size_t)(N + 1) * NX + 2), K = take((size_t)N * NU * NX), L = take((size_t)N * NU * NU);
+        kff = take((size_t)N * NU + 2);   // (+ a dump slot each: masked lanes of the round-4 sweeps store there)
         Acl = take((size_t)N * ChainCfgStride<NX, NW>::BST), hb = take((size_t)N * NX), ccv = take((size_t)N * NX), cvec = take((size_t)N * NX);
         Hex = take((size_t)(N + 1) * NW * NW), term = take((size_t)N * NTD), ynu = take((size_t)(N + 1) * NX);
         state = take(16);   // ST_* below: the SQP loop's per-instance state between launches
@@ -94,6 +135,9 @@ struct LargeLayout {
         term2 = take((size_t)NU * N * NTD);
         // per stage: coefficients of the 8 evaluation points of the RK4 map (chain_point_kernel), and the link Hessians of the adjoint
         ptab = take((size_t)N * 8 * M::NL * M::TAB2), gtab = take((size_t)N * 8 * M::NL * 6);
+        // round-4 sweeps: closed-loop blocks G_k, cost-to-go P_k (Omega register layout), hb_k = P_{k+1} b_k, R_k^-1, mv_u of the corrector
+        G2 = take((size_t)N * OmCfg<M>::GSZ), P2 = take((size_t)(N + 1) * OmCfg<M>::GSZ + 64 * OmCfg<M>::NT * 4);
+        hb2 = take((size_t)N * OmCfg<M>::HBS), minv2 = take((size_t)N * 16), mvu2 = take((size_t)N * 4);
         total = (o + 7) & ~(size_t)7;
     }
 };
@@ -342,11 +386,80 @@ struct HessGlobal {
     MPCRL_DI double term(int N, int i, int j) const { return Hex[N * NW * NW + (NU + i) * NW + NU + j]; }
 };
 
+// The same two Hessian sources in Omega coordinates (OmCfg): register (rg, tj) of a lane holds entry (slot 4 rg + lane / 16,
+// slot 16 tj + lane % 16); slots past NW (and the vector column) are zero.
+template <class M>
+struct HessConst2 {
+    using O = OmCfg<M>;
+    double h[O::RG][O::NT];     // unscaled
+    const double *th;
+    const double *sck;
+    MPCRL_DI void begin(int lane) {
+        const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+        for (int rg = 0; rg < O::RG; ++rg)
+#pragma unroll
+            for (int tj = 0; tj < O::NT; ++tj) {
+                const int e = 4 * rg + lr, c = 16 * tj + lc;
+                const bool in = e < O::NW && c < O::NW;
+                h[rg][tj] = in ? M::hess(false, O::nat(in ? e : 0), O::nat(in ? c : 0), th) : 0.0;
+            }
+    }
+    template <class S_>
+    MPCRL_DI void init(const S_ &S, unsigned) { th = S.th, sck = S.sCK(); }
+    MPCRL_DI void prefetch(int) {}
+    MPCRL_DI void advance(int) {}
+    MPCRL_DI double tile(int k, int rg, int tj) const { return sck[k] * h[rg][tj]; }
+    MPCRL_DI double term(int N, int i, int j) const { return sck[N] * M::Qs(th, i, j); }
+};
+template <class M>
+struct HessGlobal2 {
+    using O = OmCfg<M>;
+    static constexpr int NW = O::NW, NU = O::NU;
+    WsArr Hex;                      // [(N+1), NW, NW], stage-vector order [u; x]
+    int lr, lc;
+    double hn[O::RG][O::NT], hc[O::RG][O::NT];
+    MPCRL_DI void begin(int lane) { lr = lane >> 4, lc = lane & 15; }
+    template <class S_>
+    MPCRL_DI void init(const S_ &S, unsigned hex_off) { Hex = S.arr(hex_off); }
+    MPCRL_DI void prefetch(int k) {
+#pragma unroll
+        for (int rg = 0; rg < O::RG; ++rg)
+#pragma unroll
+            for (int tj = 0; tj < O::NT; ++tj) {
+                const int e = 4 * rg + lr, c = 16 * tj + lc;
+                const bool in = e < NW && c < NW;
+                const double v = Hex[k * NW * NW + (in ? O::nat(e) * NW + O::nat(c) : 0)];
+                hn[rg][tj] = in ? v : 0.0;
+            }
+    }
+    MPCRL_DI void advance(int k) {
+#pragma unroll
+        for (int rg = 0; rg < O::RG; ++rg)
+#pragma unroll
+            for (int tj = 0; tj < O::NT; ++tj) hc[rg][tj] = hn[rg][tj];
+        if (k > 0) prefetch(k - 1);
+    }
+    MPCRL_DI double tile(int, int rg, int tj) const { return hc[rg][tj]; }
+    MPCRL_DI double term(int N, int i, int j) const { return Hex[N * NW * NW + (NU + i) * NW + NU + j]; }
+};
+template <class HS>
+struct HessV2;
+template <class M>
+struct HessV2<HessConst<M>> {
+    using type = HessConst2<M>;
+};
+template <class M>
+struct HessV2<HessGlobal<M>> {
+    using type = HessGlobal2<M>;
+};
+
 template <class M>
 struct ChainSolver {
     using Cfg = ChainCfg<M>;
     static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD, NP = M::NP, NT = 64;
     static constexpr int TI = Cfg::TI, TJ = Cfg::TJ, TS = Cfg::TS;
+    static constexpr bool USE_V2 = MPCRL_CHAIN_V2 != 0 && NX <= MPCRL_CHAIN_V2_MAXNX;
     const LargeSpec *spp;   // kernel-argument copy of the problem (set-up only)
     const double *xs;       // x_ss (device)
     int N, lane;
@@ -356,6 +469,7 @@ struct ChainSolver {
     double *X, *U;
     WsArr NUv;             // NUv[k]: multiplier arriving at stage k, [(N+1)*NX] (index 0 unused)
     WsArr BA, r, q, dx, du, nuq, Dx, Du, Dnu, rg, rb, rt, Dg, lam, t, aff, P, p, K, L, kff, Acl, hb, ccv, cvec, state;
+    WsArr G2, P2, hb2, minv2, mvu2;
     double *lds;
     // GEMM tiles of this lane
     int t_i0, t_j0, m_i0, m_j0;
@@ -1248,6 +1362,507 @@ struct ChainSolver {
         wave_sync();
     }
 
+    // =====================================================================================================================
+    // Round-4 sweeps: register-resident MFMA pipelines in Omega coordinates (OmCfg above).  Same contract as factor / backward_vec /
+    // forward — workspace in, workspace out (natural-order p, kff, Dx, Du, Dnu for the row phases) — without touching LDS:
+    // the round-3 sweeps spent most of a stage waiting for LDS round trips (69 s_waitcnt per factor stage for 49 MFMAs).
+    // =====================================================================================================================
+    typedef double d4_t __attribute__((ext_vector_type(4)));
+    template <int SRC>
+    MPCRL_DI static double bcast_lane(double v) {   // the value lane SRC holds, in every lane (two v_readlane_b32)
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, SRC), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), SRC);
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    // state index of row slot 4 rg + lr of a register (pad rows of the control group: some valid address, the value is masked)
+    template <int RG_>
+    MPCRL_DI static int om_xr(int lr) { return 4 * RG_ + lr - (RG_ >= OmCfg<M>::GQ ? NU : 0); }
+    // stage-vector index [u; x] of slot 4 rg + lr
+    template <int RG_>
+    MPCRL_DI static int om_nat(int lr) {
+        using O = OmCfg<M>;
+        if constexpr (RG_ < O::GQ) return NU + 4 * RG_ + lr;
+        if constexpr (RG_ > O::GQ) return 4 * RG_ + lr;
+        return lr < NU ? lr : O::Q + lr;
+    }
+
+    // ---- factor sweep (see OmCfg): P_{k+1} stays in registers in the result layout, which is its operand layout for T = P W.
+    template <class HS>
+    MPCRL_DI bool factor2(HS &hs, const WsArr g, const WsArr bb) {
+        using O = OmCfg<M>;
+        constexpr int RG = O::RG, NT = O::NT, NTR = O::NTR, GQ = O::GQ, TQ = O::TQ, RQ = O::RQ, LQ = O::LQ, TV = O::TV, LV = O::LV, FD = 2;
+        constexpr bool RAGGED = 4 * RG > NW;     // the last row group runs past NW
+        const int lr = lane >> 4, lc = lane & 15;
+        hs.begin(lane);
+        bool ok = true;
+        int colnat[NT];
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+            const int c = 16 * tj + lc;
+            colnat[tj] = c < NW ? O::nat(c < NW ? c : 0) : 0;
+        }
+        const bool vcl = lc == LV, wcl = lc < LV, padl = lr < NU, ucl = lc >= LQ && lc < LQ + NU;
+        const double vcm = vcl ? 1.0 : 0.0;
+        const int rbase = lr * NW;
+        int btoff[NTR];
+        bool btok[NTR];
+#pragma unroll
+        for (int ti = 0; ti < NTR; ++ti) {
+            const int e = 16 * ti + lc, xr = O::xrow(e < NW ? e : 0);
+            btok[ti] = e < NW && xr >= 0 && lr < NU;
+            btoff[ti] = (btok[ti] ? xr : 0) * NW + (lr < NU ? lr : 0);
+        }
+        const unsigned gbase = (unsigned)lane;
+        // ---- terminal stage: P_N = c_N hess l_N + D_N, p_N = g_N
+        d4_t Pt[NTR][NT];
+        static_for<NTR>([&](auto ti_) {
+            static_for<4>([&](auto r_) {
+                constexpr int ti = decltype(ti_)::value, r = decltype(r_)::value, rg = 4 * ti + r;
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) {
+                    double v = 0.0;
+                    if constexpr (rg < RG) {
+                        const int e = 4 * rg + lr, c = 16 * tj + lc;
+                        const int xr = O::xrow(e < NW ? e : 0), xc = O::xrow(c < NW ? c : 0);
+                        const bool rok = e < NW && xr >= 0;
+                        if (rok && c < NW && xc >= 0) {
+                            v = hs.term(N, xr > xc ? xr : xc, xr > xc ? xc : xr);
+                            if (xr == xc) v += Dg[N * NW + NU + xr];
+                        } else if (rok && c == O::VC)
+                            v = g[N * NW + NU + xr];
+                        P2[N * O::GSZ + (rg * NT + tj) * 64 + gbase] = v;
+                        if (rok && c == O::VC) p[N * NX + xr] = v;
+                    }
+                    Pt[ti][tj][r] = v;
+                }
+            });
+        });
+        // per stage and lane: W (RG x NT registers; in the tile of the vector column the lane of that column fetches b instead),
+        // B' (NTR), and ONE register per row group for the right-hand side and the barrier diagonal (the lane of the vector column
+        // fetches g, the diagonal lane D: they are different lanes for every valid row)
+        double nW[FD][RG][NT], nBt[FD][NTR], ngd[FD][RG];
+        const unsigned bbrel = bb.off - BA.off, grel = g.off - BA.off, dgrel = Dg.off - BA.off;
+        hs.prefetch(N - 1);
+        staged_loop<FD>(
+            N,
+            [&](int idx, auto sl) {
+                constexpr int d = decltype(sl)::value;
+                const int k = N - 1 - idx;
+                const WsArr Bk = BA + k * NX * NW;
+                static_for<RG>([&](auto rg_) {
+                    constexpr int rg = decltype(rg_)::value;
+                    const int xr = om_xr<rg>(lr), nt = om_nat<rg>(lr);
+#pragma unroll
+                    for (int tj = 0; tj < NT; ++tj) {
+                        const int ow = k * NX * NW + rbase + colnat[tj] + (4 * rg - (rg >= GQ ? NU : 0)) * NW;
+                        nW[d][rg][tj] = BA[(tj == TV && vcl) ? (int)bbrel + k * NX + xr : ow];
+                    }
+                    const bool rok = !RAGGED || rg < RG - 1 || 4 * rg + lr < NW;
+                    ngd[d][rg] = BA[(int)(vcl ? grel : dgrel) + k * NW + (rok ? nt : 0)];
+                });
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti) nBt[d][ti] = Bk[btoff[ti]];
+            },
+            [&](int idx, auto sl, auto refill) {
+                constexpr int d = decltype(sl)::value;
+                const int k = N - 1 - idx;
+                const bool pin = k == 0 && qmode;
+                hs.advance(k);
+                // ---- the stage operands out of their prefetch slot: W = [A B | b] with its pad rows, B' as an A operand
+                d4_t Wt[NTR][NT];
+                double gd[RG], Bt[NTR];
+                static_for<NTR>([&](auto ti_) {
+                    static_for<4>([&](auto r_) {
+                        constexpr int ti = decltype(ti_)::value, r = decltype(r_)::value, rg = 4 * ti + r;
+#pragma unroll
+                        for (int tj = 0; tj < NT; ++tj) {
+                            double v = 0.0;
+                            if constexpr (rg < RG) {
+                                v = nW[d][rg][tj];
+                                if (tj == TV) v = lc <= LV ? v : 0.0;
+                                if constexpr (rg == GQ) v = padl ? 0.0 : v;
+                                if constexpr (RAGGED && rg == RG - 1) v = 4 * rg + lr < NW ? v : 0.0;
+                            }
+                            Wt[ti][tj][r] = v;
+                        }
+                        if constexpr (rg < RG) {
+                            const bool rok = !RAGGED || rg < RG - 1 || 4 * rg + lr < NW;
+                            gd[rg] = rok ? ngd[d][rg] : 0.0;
+                        }
+                    });
+                });
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti) Bt[ti] = btok[ti] ? nBt[d][ti] : 0.0;
+                refill();
+                // ---- T = P W, row tile by row tile (the column tile of P it read is dead afterwards)
+                d4_t Tt[NTR][NT];
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < NT; ++tj) {
+                        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int ks = 0; ks < RG; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pt[ks / 4][ti][ks % 4], Wt[ks / 4][tj][ks % 4], acc, 0, 0, 0);
+                        Tt[ti][tj] = acc;
+                    }
+                ph(10);
+                // its vector column is P b (kept: hb, stored below), then + p
+                double hbv[RG];
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * ti + r < RG) {
+                            hbv[4 * ti + r] = Tt[ti][TV][r];
+                            Tt[ti][TV][r] = fma(Pt[ti][TV][r], vcm, Tt[ti][TV][r]);
+                        }
+                // ---- M = H + D + W' T, vector column g + W' (P b + p); column tile by column tile (T's is dead afterwards)
+                d4_t Mt[NTR][NT];
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj)
+                    static_for<NTR>([&](auto tm_) {
+                        constexpr int tm = decltype(tm_)::value;
+                        d4_t acc;
+                        static_for<4>([&](auto r_) {
+                            constexpr int r = decltype(r_)::value, rg = 4 * tm + r;
+                            double c = 0.0;
+                            if constexpr (rg < RG) {
+                                c = hs.tile(k, rg, tj);
+                                if (tj == tm) c += (lc == 4 * r + lr) ? gd[rg] : 0.0;
+                                if (tj == TV) c += vcl ? gd[rg] : 0.0;
+                            }
+                            acc[r] = c;
+                        });
+#pragma unroll
+                        for (int ks = 0; ks < RG; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wt[ks / 4][tm][ks % 4], Tt[ks / 4][tj][ks % 4], acc, 0, 0, 0);
+                        Mt[tm][tj] = acc;
+                    });
+                ph(11);
+                // ---- Cholesky of the control block on broadcast values (every lane, redundantly), then its inverse
+                double Minv[NU][NU];
+                {
+                    const double src = Mt[TQ][TQ][RQ];
+                    double a_[NU][NU], Lc[NU][NU], Li[NU][NU];
+                    static_for<NU>([&](auto i_) {
+                        static_for<NU>([&](auto j_) {
+                            constexpr int i = decltype(i_)::value, j = decltype(j_)::value;
+                            if constexpr (j <= i) a_[i][j] = bcast_lane<16 * i + LQ + j>(src);
+                        });
+                    });
+                    bool okc = true;
+#pragma unroll
+                    for (int i = 0; i < NU; ++i)
+#pragma unroll
+                        for (int j = 0; j <= i; ++j) {
+                            double a = a_[i][j];
+#pragma unroll
+                            for (int m = 0; m < j; ++m) a -= Lc[i][m] * Lc[j][m];
+                            if (i == j) {
+                                okc = okc && (a > 0.0);
+                                Lc[i][i] = 1.0 / sqrt(a);
+                            } else
+                                Lc[i][j] = a * Lc[j][j];
+                        }
+                    ok = ok && (okc || pin);
+                    // Li = L^-1 (lower; Lc carries the inverted diagonal), Minv = Li' Li
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) {
+                        Li[j][j] = Lc[j][j];
+#pragma unroll
+                        for (int i = j + 1; i < NU; ++i) {
+                            double a = 0.0;
+#pragma unroll
+                            for (int m = j; m < i; ++m) a -= Lc[i][m] * Li[m][j];
+                            Li[i][j] = a * Lc[i][i];
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NU; ++i)
+#pragma unroll
+                        for (int j = 0; j <= i; ++j) {
+                            double a = 0.0;
+#pragma unroll
+                            for (int m = i; m < NU; ++m) a = fma(Li[m][i], Li[m][j], a);
+                            Minv[i][j] = a, Minv[j][i] = a;
+                        }
+                }
+                double minvop = 0.0;     // A operand of K = R^-1 [S | R | mv_u]: R^-1(i, l) at lane (lr = l, lc = i)
+#pragma unroll
+                for (int i = 0; i < NU; ++i)
+#pragma unroll
+                    for (int l = 0; l < NU; ++l) minvop = (lc == i && lr == l) ? Minv[i][l] : minvop;
+                if (pin) minvop = 0.0;
+                ph(12);
+                // ---- K (register 0 of one MFMA per column tile), the rank-NU update P' = M - S' K, G = W - B K with -K in the pad rows
+                double nK[NT], nKz[NT], Sr[NTR];
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) {
+                    const d4_t z4 = {0.0, 0.0, 0.0, 0.0};
+                    const d4_t kt = __builtin_amdgcn_mfma_f64_16x16x4f64(minvop, Mt[TQ][tj][RQ], z4, 0, 0, 0);
+                    nK[tj] = -kt[0];
+                    nKz[tj] = (tj == TQ && ucl) ? 0.0 : nK[tj];
+                }
+#pragma unroll
+                for (int ta = 0; ta < NTR; ++ta) Sr[ta] = Mt[TQ][ta][RQ];
+#pragma unroll
+                for (int ta = 0; ta < NTR; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < NT; ++tb) Mt[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Sr[ta], nK[tb], Mt[ta][tb], 0, 0, 0);
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < NT; ++tj) Wt[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bt[ti], nKz[tj], Wt[ti][tj], 0, 0, 0);
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) Wt[TQ][tj][RQ] = padl ? nKz[tj] : Wt[TQ][tj][RQ];
+                // ---- out: G_k and P_k in the register layout (full 512-byte bursts); from the lanes of the vector column hb_k, and
+                // p_k, kff_k in natural order for the other phases; R^-1 from the lanes that hold its entries
+                static_for<RG>([&](auto rg_) {
+                    constexpr int rg = decltype(rg_)::value;
+#pragma unroll
+                    for (int tj = 0; tj < NT; ++tj) {
+                        G2[k * O::GSZ + (rg * NT + tj) * 64 + gbase] = Wt[rg / 4][tj][rg % 4];
+                        P2[k * O::GSZ + (rg * NT + tj) * 64 + gbase] = Mt[rg / 4][tj][rg % 4];
+                    }
+                });
+                if (vcl) {
+                    static_for<RG>([&](auto rg_) {
+                        constexpr int rg = decltype(rg_)::value;
+                        hb2[k * O::HBS + 4 * rg + lr] = hbv[rg];
+                        // natural p: the pad rows (and rows past NW) go to a dump slot behind the array of stage N
+                        const bool rok = (rg != GQ || !padl) && (!RAGGED || rg < RG - 1 || 4 * rg + lr < NW);
+                        p[rok ? k * NX + om_xr<rg>(lr) : (N + 1) * NX] = Mt[rg / 4][TV][rg % 4];
+                    });
+                    kff[padl ? k * NU + lr : N * NU] = -nK[TV];
+                }
+                if (lc < NU && lr < NU) minv2[k * 16 + 4 * lc + lr] = minvop;
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < NT; ++tj) Pt[ti][tj] = Mt[ti][tj];
+                ph(13);
+            });
+        return ok;
+    }
+
+    // ---- backward vector sweep for a new right-hand side g on the stored G_k: [p_k; mv_u] = g + G_k' [p_{k+1} + hb_k; g_u],
+    // a chain of MFMAs whose B operand is the previous result (column 0 of the lanes carries the vector), then kff = R^-1 mv_u.
+    MPCRL_DI void backward_vec2(const WsArr g) {
+        using O = OmCfg<M>;
+        constexpr int RG = O::RG, NT = O::NT, NTR = O::NTR, GQ = O::GQ, TQ = O::TQ, RQ = O::RQ, D = 2;
+        constexpr bool RAGGED = 4 * RG > NW;
+        const int lr = lane >> 4, lc = lane & 15;
+        const bool padl = lr < NU;
+        const unsigned gbase = (unsigned)lane;
+        d4_t R[NTR];
+        static_for<NTR>([&](auto ti_) {
+            static_for<4>([&](auto r_) {
+                constexpr int ti = decltype(ti_)::value, r = decltype(r_)::value, rg = 4 * ti + r;
+                double v = 0.0;
+                if constexpr (rg < RG) {
+                    const bool rok = (rg != GQ || !padl) && (!RAGGED || rg < RG - 1 || 4 * rg + lr < NW);
+                    const int xr = om_xr<rg>(lr);
+                    const double t_ = g[N * NW + NU + (rok ? xr : 0)];
+                    v = rok ? t_ : 0.0;
+                    if (rok && lc == 0) p[N * NX + xr] = v;
+                }
+                R[ti][r] = v;
+            });
+        });
+        double nG[D][RG][NTR], nhb[D][RG], ngt[D][RG];
+        staged_loop<D>(
+            N,
+            [&](int idx, auto sl) {
+                constexpr int d = decltype(sl)::value;
+                const int k = N - 1 - idx;
+                static_for<RG>([&](auto rg_) {
+                    constexpr int rg = decltype(rg_)::value;
+#pragma unroll
+                    for (int ti = 0; ti < NTR; ++ti) nG[d][rg][ti] = G2[k * O::GSZ + (rg * NT + ti) * 64 + gbase];
+                    const bool rok = !RAGGED || rg < RG - 1 || 4 * rg + lr < NW;
+                    nhb[d][rg] = hb2[k * O::HBS + 4 * rg + lr];
+                    const double t_ = g[k * NW + (rok ? om_nat<rg>(lr) : 0)];
+                    ngt[d][rg] = rok ? t_ : 0.0;
+                });
+            },
+            [&](int idx, auto sl, auto refill) {
+                constexpr int d = decltype(sl)::value;
+                const int k = N - 1 - idx;
+                double vop[RG];
+                static_for<RG>([&](auto rg_) {
+                    constexpr int rg = decltype(rg_)::value;
+                    double v = R[rg / 4][rg % 4] + nhb[d][rg];
+                    if constexpr (rg == GQ) v = padl ? ngt[d][rg] : v;
+                    vop[rg] = v;
+                });
+                d4_t acc[NTR];
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[ti][r] = 4 * ti + r < RG ? ngt[d][4 * ti + r < RG ? 4 * ti + r : 0] : 0.0;
+                double Gk[RG][NTR];
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                    for (int ti = 0; ti < NTR; ++ti) Gk[rg][ti] = nG[d][rg][ti];
+                refill();
+#pragma unroll
+                for (int ks = 0; ks < RG; ++ks)
+#pragma unroll
+                    for (int ti = 0; ti < NTR; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gk[ks][ti], vop[ks], acc[ti], 0, 0, 0);
+                if (lc == 0)
+                    static_for<RG>([&](auto rg_) {
+                        constexpr int rg = decltype(rg_)::value;
+                        const double v = acc[rg / 4][rg % 4];
+                        const bool rok = (rg != GQ || !padl) && (!RAGGED || rg < RG - 1 || 4 * rg + lr < NW);
+                        p[rok ? k * NX + om_xr<rg>(lr) : (N + 1) * NX] = v;
+                        if constexpr (rg == GQ) mvu2[k * 4 + lr] = v;      // (lane lr = 3 of the group: a state row, never read)
+                    });
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti) R[ti] = acc[ti];
+            });
+        wave_sync();
+        // feed-forward kff_k = R_k^-1 mv_u, one stage per lane
+        for (int k = lane; k < N; k += NT) {
+            double mv[NU];
+#pragma unroll
+            for (int m = 0; m < NU; ++m) mv[m] = mvu2[k * 4 + m];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                double a = 0.0;
+#pragma unroll
+                for (int m = 0; m < NU; ++m) a = fma(minv2[k * 16 + 4 * i + m], mv[m], a);
+                kff[k * NU + i] = a;     // (R^-1 is stored as zero at a pinned stage 0)
+            }
+        }
+        wave_sync();
+    }
+
+    // ---- forward sweep: [dx_{k+1}; du_k] = [b_k; -kff_k] + G_k [dx_k; -kff_k] (the control slots of the operand carry -kff: the
+    // x rows of G hold [Acl | B], its pad rows [-K | 0]), with want_nu also Dnu_k = p_k + P_k dx_k on the same operand.
+    // G_k is wanted as an A operand (contraction over its COLUMNS): the transposed access pattern of the streamed block.
+    template <bool want_nu>
+    MPCRL_DI void forward2(const WsArr bb) {
+        using O = OmCfg<M>;
+        constexpr int RG = O::RG, NT = O::NT, NTR = O::NTR, GQ = O::GQ, D = 2;
+        constexpr bool RAGGED = 4 * RG > NW;
+        const int lr = lane >> 4, lc = lane & 15;
+        const bool padl = lr < NU;
+        const unsigned gbase = (unsigned)lane;
+        // element (row a, column b) of a block sits at ((a / 4) NT + b / 16) 64 + (a % 4) 16 + b % 16; this lane wants a = 16 ti + lc,
+        // b = 4 ks + lr
+        const unsigned tbase = (unsigned)((lc >> 2) * NT * 64 + (lc & 3) * 16 + lr);
+        if (lane < NX) Dx[lane] = 0.0, Dnu[lane] = 0.0;
+        double w[RG];
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) w[rg] = 0.0;
+        // per stage and lane: G as an A operand (NTR x RG), the constant [b; kff] (one register per row group: the lanes of the control
+        // group fetch kff, the others b), with want_nu P_k (RG x NTR, natural) and p_k
+        double nGt[D][NTR][RG], nbk[D][RG], nP[D][want_nu ? RG : 1][want_nu ? NTR : 1], npv[D][want_nu ? RG : 1];
+        const unsigned kfrel = kff.off - bb.off;
+        staged_loop<D>(
+            N,
+            [&](int k, auto sl) {
+                constexpr int d = decltype(sl)::value;
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti)
+#pragma unroll
+                    for (int ks = 0; ks < RG; ++ks) nGt[d][ti][ks] = G2[k * O::GSZ + tbase + (4 * ti * NT + ks / 4) * 64 + 4 * (ks % 4)];
+                static_for<RG>([&](auto rg_) {
+                    constexpr int rg = decltype(rg_)::value;
+                    const bool rok = !RAGGED || rg < RG - 1 || 4 * rg + lr < NW;
+                    const int xr = rok ? om_xr<rg>(lr) : 0;
+                    nbk[d][rg] = bb[(rg == GQ && padl) ? (int)kfrel + k * NU + lr : k * NX + xr];
+                    if constexpr (want_nu) {
+#pragma unroll
+                        for (int ti = 0; ti < NTR; ++ti) nP[d][rg][ti] = P2[k * O::GSZ + (rg * NT + ti) * 64 + gbase];
+                        npv[d][rg] = p[k * NX + xr];
+                    }
+                });
+            },
+            [&](int k, auto sl, auto refill) {
+                constexpr int d = decltype(sl)::value;
+                d4_t acc[NTR], acc2[NTR];
+                static_for<NTR>([&](auto ti_) {
+                    static_for<4>([&](auto r_) {
+                        constexpr int ti = decltype(ti_)::value, r = decltype(r_)::value, rg = 4 * ti + r;
+                        double c = 0.0, c2 = 0.0;
+                        if constexpr (rg < RG) {
+                            const bool rok = !RAGGED || rg < RG - 1 || 4 * rg + lr < NW;
+                            c = rok ? nbk[d][rg] : 0.0;
+                            if constexpr (rg == GQ) c = padl ? -c : c;       // -kff in the control slots
+                            if constexpr (want_nu) {
+                                c2 = rok ? npv[d][rg] : 0.0;
+                                if constexpr (rg == GQ) c2 = padl ? 0.0 : c2;
+                            }
+                        }
+                        acc[ti][r] = c, acc2[ti][r] = c2;
+                    });
+                });
+                w[GQ] = padl ? acc[GQ / 4][GQ % 4] : w[GQ];                   // operand: -kff_k in the control slots as well
+                double Gk[NTR][RG], Pk[want_nu ? RG : 1][want_nu ? NTR : 1];
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti)
+#pragma unroll
+                    for (int ks = 0; ks < RG; ++ks) Gk[ti][ks] = nGt[d][ti][ks];
+                if constexpr (want_nu) {
+#pragma unroll
+                    for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                        for (int ti = 0; ti < NTR; ++ti) Pk[rg][ti] = nP[d][rg][ti];
+                }
+                refill();
+#pragma unroll
+                for (int ks = 0; ks < RG; ++ks)
+#pragma unroll
+                    for (int ti = 0; ti < NTR; ++ti) {
+                        acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gk[ti][ks], w[ks], acc[ti], 0, 0, 0);
+                        if constexpr (want_nu) acc2[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pk[ks][ti], w[ks], acc2[ti], 0, 0, 0);
+                    }
+                if (lc == 0)      // the vector sits in column 0: rows past NW and (for Dnu) the control slots go to the dump slots
+                    static_for<RG>([&](auto rg_) {
+                        constexpr int rg = decltype(rg_)::value;
+                        const double v = acc[rg / 4][rg % 4];
+                        const bool rok = (rg != GQ || !padl) && (!RAGGED || rg < RG - 1 || 4 * rg + lr < NW);
+                        if constexpr (rg == GQ)
+                            Dx[padl ? (int)(Du.off - Dx.off) + k * NU + lr : (k + 1) * NX + om_xr<rg>(lr)] = v;     // du_k / dx_{k+1}
+                        else
+                            Dx[rok ? (k + 1) * NX + om_xr<rg>(lr) : (N + 1) * NX] = v;
+                        if constexpr (want_nu) Dnu[(rok && k > 0) ? k * NX + om_xr<rg>(lr) : (N + 1) * NX] = acc2[rg / 4][rg % 4];
+                    });
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg) w[rg] = acc[rg / 4][rg % 4];
+            });
+        if constexpr (want_nu) {   // terminal multiplier step: Dnu_N = p_N + P_N dx_N
+            d4_t acc2[NTR];
+            double Pk[RG][NTR];
+            static_for<RG>([&](auto rg_) {
+                constexpr int rg = decltype(rg_)::value;
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti) Pk[rg][ti] = P2[N * O::GSZ + (rg * NT + ti) * 64 + gbase];
+                const bool rok = (rg != GQ || !padl) && (!RAGGED || rg < RG - 1 || 4 * rg + lr < NW);
+                const double t_ = p[N * NX + (rok ? om_xr<rg>(lr) : 0)];
+                acc2[rg / 4][rg % 4] = rok ? t_ : 0.0;
+            });
+#pragma unroll
+            for (int ti = 0; ti < NTR; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * ti + r >= RG) acc2[ti][r] = 0.0;
+            w[GQ] = padl ? 0.0 : w[GQ];
+#pragma unroll
+            for (int ks = 0; ks < RG; ++ks)
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti) acc2[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pk[ks][ti], w[ks], acc2[ti], 0, 0, 0);
+            if (lc == 0)
+                static_for<RG>([&](auto rg_) {
+                    constexpr int rg = decltype(rg_)::value;
+                    const bool rok = (rg != GQ || !padl) && (!RAGGED || rg < RG - 1 || 4 * rg + lr < NW);
+                    Dnu[rok ? N * NX + om_xr<rg>(lr) : (N + 1) * NX] = acc2[rg / 4][rg % 4];
+                });
+        }
+        wave_sync();
+    }
+
     // ---- Mehrotra predictor-corrector on the QP of the current linearisation (hard bounds) --------------------
     template <class HS>
     MPCRL_DI bool qp_solve(HS &hs, const double *x0, const double *u0f, int &n_it, double warm_mu, double tol_res, double tol_mu) {
@@ -1502,18 +2117,30 @@ struct ChainSolver {
     template <class HS>
     __device__ __attribute__((noinline)) static bool factor_call(Ctx c, unsigned hex_off, unsigned g_off, unsigned bb_off) {
         ChainSolver S = from_ctx(c);
-        HS hs;
-        hs.init(S, hex_off);
-        return S.factor(hs, S.arr(g_off), S.arr(bb_off));
+        if constexpr (USE_V2) {
+            typename HessV2<HS>::type hs;
+            hs.init(S, hex_off);
+            return S.factor2(hs, S.arr(g_off), S.arr(bb_off));
+        } else {
+            HS hs;
+            hs.init(S, hex_off);
+            return S.factor(hs, S.arr(g_off), S.arr(bb_off));
+        }
     }
     __device__ __attribute__((noinline)) static void backward_vec_call(Ctx c, unsigned g_off) {
         ChainSolver S = from_ctx(c);
-        S.backward_vec(S.arr(g_off));
+        if constexpr (USE_V2)
+            S.backward_vec2(S.arr(g_off));
+        else
+            S.backward_vec(S.arr(g_off));
     }
     template <bool want_nu>
     __device__ __attribute__((noinline)) static void forward_call(Ctx c, unsigned bb_off) {
         ChainSolver S = from_ctx(c);
-        S.template forward<want_nu>(S.arr(bb_off));
+        if constexpr (USE_V2)
+            S.template forward2<want_nu>(S.arr(bb_off));
+        else
+            S.template forward<want_nu>(S.arr(bb_off));
     }
 
     MPCRL_DI void bind_workspace(double *w, const LargeLayout<M> &lay) {
@@ -1522,6 +2149,7 @@ struct ChainSolver {
         Dx = at(lay.Dx), Du = at(lay.Du), Dnu = at(lay.Dnu), rg = at(lay.rg), rb = at(lay.rb), rt = at(lay.rt), Dg = at(lay.Dg);
         lam = at(lay.lamw), t = at(lay.tw), aff = at(lay.aff), P = at(lay.P), p = at(lay.p), K = at(lay.K), L = at(lay.L);
         kff = at(lay.kff), Acl = at(lay.Acl), hb = at(lay.hb), ccv = at(lay.ccv), cvec = at(lay.cvec), NUv = at(lay.ynu), state = at(lay.state);
+        G2 = at(lay.G2), P2 = at(lay.P2), hb2 = at(lay.hb2), minv2 = at(lay.minv2), mvu2 = at(lay.mvu2);
     }
 };
 
@@ -2048,23 +2676,28 @@ __global__ void __launch_bounds__(64, 1) chain_sens_riccati_kernel(const LargeSp
             // The right-hand side is -e_iu in the controls of stage 0 and zero elsewhere, and there is no dynamics offset: the backward
             // vector recursion is identically zero from the terminal stage down to stage 1 (p_k = 0 — what the factor sweep left for
             // iu = 0 as well), and at stage 0 only the feed-forward changes: kff_0 = (L_0 L_0')^{-1} (-e_iu).  No sweep.
-            double y[NU], z[NU];
+            if constexpr (ChainSolver<M>::USE_V2) {
 #pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                double a_ = i == iu ? -1.0 : 0.0;
+                for (int i = 0; i < NU; ++i) S.kff[i] = -S.minv2[4 * i + iu];
+            } else {
+                double y[NU], z[NU];
 #pragma unroll
-                for (int m = 0; m < i; ++m) a_ -= S.L[i * NU + m] * y[m];
-                y[i] = a_ * S.L[i * NU + i];
+                for (int i = 0; i < NU; ++i) {
+                    double a_ = i == iu ? -1.0 : 0.0;
+#pragma unroll
+                    for (int m = 0; m < i; ++m) a_ -= S.L[i * NU + m] * y[m];
+                    y[i] = a_ * S.L[i * NU + i];
+                }
+#pragma unroll
+                for (int i = NU - 1; i >= 0; --i) {
+                    double a_ = y[i];
+#pragma unroll
+                    for (int m = i + 1; m < NU; ++m) a_ -= S.L[m * NU + i] * z[m];
+                    z[i] = a_ * S.L[i * NU + i];
+                }
+#pragma unroll
+                for (int i = 0; i < NU; ++i) S.kff[i] = z[i];
             }
-#pragma unroll
-            for (int i = NU - 1; i >= 0; --i) {
-                double a_ = y[i];
-#pragma unroll
-                for (int m = i + 1; m < NU; ++m) a_ -= S.L[m * NU + i] * z[m];
-                z[i] = a_ * S.L[i * NU + i];
-            }
-#pragma unroll
-            for (int i = 0; i < NU; ++i) S.kff[i] = z[i];
         }
         wave_sync();
         ChainSolver<M>::template forward_call<true>(S.ctx(), S.rb.off);

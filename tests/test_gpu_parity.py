@@ -232,6 +232,29 @@ def test_golden_cartpole_and_linear_on_gpu():
         assert rel_err(r.dpi_dp.cpu().numpy()[strict], g["dpi"][strict]) < RTOL
 
 
+def test_hip_vs_third_party_solver():
+    """G6 (tests/golden/make_thirdparty.py): u0* and V of KKT points found and certified by scipy.optimize (SLSQP on the cartpole
+    NLP from the cold iterate, trust-constr on the linear-system QP) — a solver the build did not write.  The HIP path, through
+    the C ABI, at the solver default tolerance and at 1e-8, against it at the north_star bar."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp, linear_system_ocp
+    g6 = np.load(os.path.join(GOLD, "g6_thirdparty.npz"))
+    B = len(g6["cp_x0"])
+    ocp = cartpole_ocp()
+    theta = np.tile(ocp.p0, (B, 1))
+    theta[:, :3] = g6["cp_theta_model"]
+    for tol, bar in ((1e-8, RTOL), (None, 1e-5)):     # a run stopped at 1e-6 is within ~1e-6 x conditioning of the KKT point
+        mpc = MPCBatch(cartpole_ocp() if tol is None else cartpole_ocp(tol=tol), B)
+        mpc.set_theta(torch.as_tensor(theta))
+        r = mpc.solve(g6["cp_x0"], cold=True)
+        assert np.all(r.status.cpu().numpy() == 0)
+        assert rel_err(r.u0.cpu().numpy(), g6["cp_u0"]) < bar and rel_err(r.V.cpu().numpy(), g6["cp_V"]) < RTOL
+    for tag, gamma in (("g099", 0.99), ("g09", 0.9)):
+        mpc = MPCBatch(linear_system_ocp(discount_factor=gamma), len(g6[f"lin_{tag}_x0"]))
+        r = mpc.solve(g6[f"lin_{tag}_x0"], cold=True)
+        assert np.all(r.status.cpu().numpy() == 0)
+        assert rel_err(r.u0.cpu().numpy(), g6[f"lin_{tag}_u0"]) < RTOL and rel_err(r.V.cpu().numpy(), g6[f"lin_{tag}_V"]) < RTOL
+
+
 def test_chain_mass_n7_vs_oracle_and_full_size_properties(oracle_port):
     """BASELINE config 4 at its perf dimension (n_mass = 7, nx = 33, N = 40): parity with the oracle port on 8 instances, then the
     full batch of 1024 through size-independent properties (all converge, KKT residuals below tol, bounds respected, a second

@@ -293,3 +293,32 @@ def test_port_divergence_exit_rule(oracle_port):
     assert np.all(r0.status[c1] == 0) and c1.sum() >= 0.9 * (r0.status == 0).sum()
     assert np.array_equal(r0.u0[c1], r1.u0[c1]) and np.array_equal(r0.V[c1], r1.V[c1]) and np.array_equal(r0.sqp_iter[c1], r1.sqp_iter[c1])
     assert set(np.unique(r1.status[~c1])) <= {2, 4}
+
+
+def test_third_party_solver_agrees_with_the_goldens_and_the_port(oracle_port):
+    """G6 (tests/golden/make_thirdparty.py): KKT points found by scipy.optimize — SLSQP on the cartpole NLP from the reference's cold
+    iterate, trust-constr on the linear-system QP — and certified there without any of this repo's solvers (stationarity below
+    1e-13 / 1e-5, feasibility 1e-15).  Every other vector of tests/golden/ comes from the build's own dense oracle; this one removes
+    "same author on both sides": the dense oracle's goldens AND the C++ port must reproduce u0* and V of a solver nobody here wrote,
+    at the north_star bar 1e-6 (measured: cartpole <= 3e-9 in u0*, 7e-13 in V; linear <= 2.3e-8, 3.2e-9)."""
+    from oracle.problems import make_cartpole, make_linear_system
+    g6 = np.load(os.path.join(GOLD, "g6_thirdparty.npz"))
+    assert g6["cp_kkt"][:, 0].max() < 1e-12 and g6["cp_kkt"][:, 1].max() < 1e-12 and g6["cp_kkt"][:, 2].min() >= 0.0
+    assert bool(g6["cp_same_minimum"].all())          # SLSQP from the cold iterate ends in the minimum the full-step SQP finds
+    rel = lambda a, b: float((np.abs(np.asarray(a).reshape(len(b), -1) - np.asarray(b).reshape(len(b), -1)) /
+                              np.maximum(np.abs(np.asarray(b).reshape(len(b), -1)), 1.0)).max())
+    g3 = np.load(os.path.join(GOLD, "g3_cartpole.npz"))
+    rows = g6["cp_g3_row"]
+    assert np.array_equal(g3["x0"][rows], g6["cp_x0"])
+    assert rel(g3["u0"][rows], g6["cp_u0"]) < 1e-6 and rel(g3["V"][rows], g6["cp_V"]) < 1e-6
+    P = make_cartpole()
+    theta = np.tile(P.p0, (len(rows), 1))
+    theta[:, :3] = g6["cp_theta_model"]
+    r = oracle_port.solve(P, g6["cp_x0"], p=theta, tol=1e-8)
+    assert np.all(r.status == 0) and rel(r.u0, g6["cp_u0"]) < 1e-6 and rel(r.V, g6["cp_V"]) < 1e-6
+    for tag, gamma in (("g099", 0.99), ("g09", 0.9)):
+        g2 = np.load(os.path.join(GOLD, f"g2_linear_{tag}.npz"))
+        assert g6[f"lin_{tag}_kkt"][:, 0].max() < 1e-5 and g6[f"lin_{tag}_kkt"][:, 1].max() < 1e-12
+        assert rel(g2["u0"], g6[f"lin_{tag}_u0"]) < 1e-6 and rel(g2["V"], g6[f"lin_{tag}_V"]) < 1e-6
+        r = oracle_port.solve(make_linear_system(gamma=gamma), g6[f"lin_{tag}_x0"])
+        assert np.all(r.status == 0) and rel(r.u0, g6[f"lin_{tag}_u0"]) < 1e-6 and rel(r.V, g6[f"lin_{tag}_V"]) < 1e-6
