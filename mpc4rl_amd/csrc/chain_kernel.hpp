@@ -104,8 +104,14 @@ struct OmCfg {
     static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU;
     static constexpr int Q = 4 * (NX / 4), VC = NW, RG = (NW + 3) / 4, NT = (NW + 16) / 16, NTR = (RG + 3) / 4;
     static constexpr int GQ = Q / 4, TQ = Q / 16, RQ = GQ % 4, LQ = Q % 16, TV = VC / 16, LV = VC % 16;
-    static constexpr int GSZ = RG * NT * 64;        // doubles of one streamed stage block (RG x NT registers of 64 lanes)
+    // streamed stage block: per row group the full column tiles (64 lanes each), then the columns < NW of the last tile compactly
+    // (4 x LV doubles, lane lr LV + lc): exactly the NW x NW entries the vector sweeps read when NW is a multiple of 4
+    static constexpr int CT = 4 * LV, GSZ = RG * (TV * 64 + CT);
     static constexpr int HBS = 4 * RG;               // stride of the per-stage Omega vectors
+    MPCRL_DI static unsigned goff(int rg, int tj, int lr, int lc) {   // register (rg, tj) of lane (lr, lc) inside a block
+        if (tj < TV) return (unsigned)((rg * TV + tj) * 64 + lr * 16 + lc);
+        return (unsigned)(RG * TV * 64 + rg * CT + lr * LV + (lc < LV ? lc : (LV > 0 ? LV - 1 : 0)));
+    }
     static_assert(NU <= 4 && LQ + NU <= 16 && NTR <= NT, "the control group sits in one register, inside one column tile");
     // slot -> index in the stage vector [u; x] (e < NW) / index of the state (-1: none)
     MPCRL_DI static constexpr int nat(int e) { return e < Q ? NU + e : (e < Q + NU ? e - Q : e); }
@@ -136,7 +142,7 @@ struct LargeLayout {
         // per stage: coefficients of the 8 evaluation points of the RK4 map (chain_point_kernel), and the link Hessians of the adjoint
         ptab = take((size_t)N * 8 * M::NL * M::TAB2), gtab = take((size_t)N * 8 * M::NL * 6);
         // round-4 sweeps: closed-loop blocks G_k, cost-to-go P_k (Omega register layout), hb_k = P_{k+1} b_k, R_k^-1, mv_u of the corrector
-        G2 = take((size_t)N * OmCfg<M>::GSZ), P2 = take((size_t)(N + 1) * OmCfg<M>::GSZ + 64 * OmCfg<M>::NT * 4);
+        G2 = take((size_t)N * OmCfg<M>::GSZ), P2 = take((size_t)(N + 1) * OmCfg<M>::GSZ + 64);
         hb2 = take((size_t)N * OmCfg<M>::HBS), minv2 = take((size_t)N * 16), mvu2 = take((size_t)N * 4);
         total = (o + 7) & ~(size_t)7;
     }
@@ -146,6 +152,10 @@ enum { ST_ACTIVE = 0, ST_IT = 1, ST_NIPM = 2, ST_TIGHT = 3, ST_STEPN = 4, ST_COS
 
 template <class M, bool SECOND>
 __device__ void chain_point_pass(const double *X, const double *U, const double *th, double *w, int N, int k, double h, int steps);
+
+// The phase functions of the chain solver are real calls (register allocations of their own; the scratch they report is the
+// save / restore of callee-saved registers in their prologue and epilogue, not traffic inside their loops).
+#define MPCRL_PHASE_FN __attribute__((noinline))
 
 // An array inside the instance's workspace: one base pointer for all of them (scalar registers) plus a 32-bit offset, so that
 // every access is `global_load/store v, voffset, s[base]` — no 64-bit per-lane address arithmetic to keep live.
@@ -314,7 +324,11 @@ struct ChainCfg {
     static constexpr int ASP = ev(NX * (NW + 1)) + 2;         // [B A]-shaped block published with the odd row stride NW + 1 (+ a dump slot)
     static constexpr int oA = oBig, oPk = oBig + (BST > ASP ? BST : ASP), oQ = oBig, oX = oBig + NW * NW, oU = oX + 64 * NX;
     static constexpr int BIG_F = NW * NW + 2 * NX * NW, BIG_R = NW * NW + 64 * NW;
-    static constexpr int LDS_TOTAL = oBig + (BIG_F > BIG_R ? BIG_F : BIG_R);
+    // round-4 sweeps: the Hessian table of the factor sweep, or two vectors of the whole horizon (up to 64 stages) in Omega order
+    static constexpr bool V2 = MPCRL_CHAIN_V2 != 0 && NX <= MPCRL_CHAIN_V2_MAXNX;
+    static constexpr int BIG_V = V2 ? (OmCfg<M>::RG * OmCfg<M>::NT * 64 > 128 * OmCfg<M>::HBS ? OmCfg<M>::RG * OmCfg<M>::NT * 64 : 128 * OmCfg<M>::HBS) : 0;
+    static constexpr int BIG_O = BIG_F > BIG_R ? BIG_F : BIG_R;
+    static constexpr int LDS_TOTAL = oBig + (BIG_O > BIG_V ? BIG_O : BIG_V);
     static_assert(oBig % 2 == 0 && (BST > ASP ? BST : ASP) + AST <= BIG_F && NX * NX <= NW * NW, "aligned / overlays fit");
     static_assert(LDS_TOTAL * 8 <= 40 * 1024, "four wavefronts per CU");
 };
@@ -391,25 +405,27 @@ struct HessGlobal {
 template <class M>
 struct HessConst2 {
     using O = OmCfg<M>;
-    double h[O::RG][O::NT];     // unscaled
     const double *th;
     const double *sck;
+    double *tab;        // LDS, [RG * NT][64]: this lane's entries, unscaled (12 - 27 registers a lane would otherwise hold per sweep)
+    int lane_;
     MPCRL_DI void begin(int lane) {
         const int lr = lane >> 4, lc = lane & 15;
+        lane_ = lane;
 #pragma unroll
         for (int rg = 0; rg < O::RG; ++rg)
 #pragma unroll
             for (int tj = 0; tj < O::NT; ++tj) {
                 const int e = 4 * rg + lr, c = 16 * tj + lc;
                 const bool in = e < O::NW && c < O::NW;
-                h[rg][tj] = in ? M::hess(false, O::nat(in ? e : 0), O::nat(in ? c : 0), th) : 0.0;
+                tab[(rg * O::NT + tj) * 64 + lane] = in ? M::hess(false, O::nat(in ? e : 0), O::nat(in ? c : 0), th) : 0.0;
             }
     }
     template <class S_>
-    MPCRL_DI void init(const S_ &S, unsigned) { th = S.th, sck = S.sCK(); }
+    MPCRL_DI void init(const S_ &S, unsigned) { th = S.th, sck = S.sCK(), tab = S.lds + ChainCfg<M>::oBig; }
     MPCRL_DI void prefetch(int) {}
     MPCRL_DI void advance(int) {}
-    MPCRL_DI double tile(int k, int rg, int tj) const { return sck[k] * h[rg][tj]; }
+    MPCRL_DI double tile(int k, int rg, int tj) const { return sck[k] * tab[(rg * O::NT + tj) * 64 + lane_]; }
     MPCRL_DI double term(int N, int i, int j) const { return sck[N] * M::Qs(th, i, j); }
 };
 template <class M>
@@ -1412,7 +1428,7 @@ struct ChainSolver {
             btok[ti] = e < NW && xr >= 0 && lr < NU;
             btoff[ti] = (btok[ti] ? xr : 0) * NW + (lr < NU ? lr : 0);
         }
-        const unsigned gbase = (unsigned)lane;
+        const unsigned gbase = (unsigned)lane, cbase = (unsigned)(lr * LV + (lc < LV ? lc : 0));
         // ---- terminal stage: P_N = c_N hess l_N + D_N, p_N = g_N
         d4_t Pt[NTR][NT];
         static_for<NTR>([&](auto ti_) {
@@ -1430,7 +1446,7 @@ struct ChainSolver {
                             if (xr == xc) v += Dg[N * NW + NU + xr];
                         } else if (rok && c == O::VC)
                             v = g[N * NW + NU + xr];
-                        P2[N * O::GSZ + (rg * NT + tj) * 64 + gbase] = v;
+                        if (tj < TV || lc < LV) P2[N * O::GSZ + O::goff(rg, tj, lr, lc)] = v;
                         if (rok && c == O::VC) p[N * NX + xr] = v;
                     }
                     Pt[ti][tj][r] = v;
@@ -1619,11 +1635,17 @@ struct ChainSolver {
                 static_for<RG>([&](auto rg_) {
                     constexpr int rg = decltype(rg_)::value;
 #pragma unroll
-                    for (int tj = 0; tj < NT; ++tj) {
-                        G2[k * O::GSZ + (rg * NT + tj) * 64 + gbase] = Wt[rg / 4][tj][rg % 4];
-                        P2[k * O::GSZ + (rg * NT + tj) * 64 + gbase] = Mt[rg / 4][tj][rg % 4];
+                    for (int tj = 0; tj < TV; ++tj) {
+                        G2[k * O::GSZ + (rg * TV + tj) * 64 + gbase] = Wt[rg / 4][tj][rg % 4];
+                        P2[k * O::GSZ + (rg * TV + tj) * 64 + gbase] = Mt[rg / 4][tj][rg % 4];
                     }
                 });
+                if (wcl)      // the last column tile: its columns < NW, compactly
+                    static_for<RG>([&](auto rg_) {
+                        constexpr int rg = decltype(rg_)::value;
+                        G2[k * O::GSZ + RG * TV * 64 + rg * O::CT + cbase] = Wt[rg / 4][TV][rg % 4];
+                        P2[k * O::GSZ + RG * TV * 64 + rg * O::CT + cbase] = Mt[rg / 4][TV][rg % 4];
+                    });
                 if (vcl) {
                     static_for<RG>([&](auto rg_) {
                         constexpr int rg = decltype(rg_)::value;
@@ -1644,31 +1666,63 @@ struct ChainSolver {
         return ok;
     }
 
+    // One vector of the whole horizon from the workspace into LDS in Omega order, dst[k HBS + slot]: natural stage-vector arrays
+    // (stride NW: slot -> nat(slot)) or state arrays (stride NX: slot -> state index, control slots 0); kmax = last stage.
+    template <bool STATE>
+    MPCRL_DI void stage_vec_lds(double *dst, const WsArr src, int kmax) {
+        using O = OmCfg<M>;
+        const int n = (kmax + 1) * O::HBS;
+        batched_pass<4>(n, lane,
+                        [&](int e) {
+                            const int k = e / O::HBS, sl = e - k * O::HBS;
+                            if (STATE) {
+                                const int xr = O::xrow(sl < NW ? sl : 0);
+                                const double v = src[k * NX + (sl < NW && xr >= 0 ? xr : 0)];
+                                return (sl < NW && xr >= 0) ? v : 0.0;
+                            } else {
+                                const double v = src[k * NW + (sl < NW ? O::nat(sl) : 0)];
+                                return sl < NW ? v : 0.0;
+                            }
+                        },
+                        [&](int e, double v) { dst[e] = v; });
+    }
+
     // ---- backward vector sweep for a new right-hand side g on the stored G_k: [p_k; mv_u] = g + G_k' [p_{k+1} + hb_k; g_u],
     // a chain of MFMAs whose B operand is the previous result (column 0 of the lanes carries the vector), then kff = R^-1 mv_u.
+    // The two vectors of the horizon (g, hb) are staged in LDS in Omega order first: the stream of the G_k blocks is all that is
+    // left in the global-memory queue (the sweep is bound by HBM bandwidth: depth x block = bytes in flight).
     MPCRL_DI void backward_vec2(const WsArr g) {
         using O = OmCfg<M>;
-        constexpr int RG = O::RG, NT = O::NT, NTR = O::NTR, GQ = O::GQ, TQ = O::TQ, RQ = O::RQ, D = 2;
+        constexpr int RG = O::RG, NTR = O::NTR, GQ = O::GQ, TV = O::TV, D = 4;
         constexpr bool RAGGED = 4 * RG > NW;
         const int lr = lane >> 4, lc = lane & 15;
         const bool padl = lr < NU;
-        const unsigned gbase = (unsigned)lane;
+        double *const lg = lds + Cfg::oBig, *const lhb = lg + 64 * O::HBS;
+        stage_vec_lds<false>(lg, g, N);
+        batched_pass<4>(N * O::HBS, lane, [&](int e) { return hb2[e]; }, [&](int e, double v) { lhb[e] = v; });
+        wave_sync();
+        unsigned goffs[NTR];
+#pragma unroll
+        for (int ti = 0; ti < NTR; ++ti) goffs[ti] = O::goff(0, ti, lr, lc);
         d4_t R[NTR];
         static_for<NTR>([&](auto ti_) {
             static_for<4>([&](auto r_) {
                 constexpr int ti = decltype(ti_)::value, r = decltype(r_)::value, rg = 4 * ti + r;
                 double v = 0.0;
                 if constexpr (rg < RG) {
-                    const bool rok = (rg != GQ || !padl) && (!RAGGED || rg < RG - 1 || 4 * rg + lr < NW);
-                    const int xr = om_xr<rg>(lr);
-                    const double t_ = g[N * NW + NU + (rok ? xr : 0)];
-                    v = rok ? t_ : 0.0;
-                    if (rok && lc == 0) p[N * NX + xr] = v;
+                    v = lg[N * O::HBS + 4 * rg + lr];
+                    if constexpr (rg == GQ) v = padl ? 0.0 : v;
                 }
                 R[ti][r] = v;
             });
         });
-        double nG[D][RG][NTR], nhb[D][RG], ngt[D][RG];
+        if (lc == 0)
+            static_for<RG>([&](auto rg_) {
+                constexpr int rg = decltype(rg_)::value;
+                const bool rok = (rg != GQ || !padl) && (!RAGGED || rg < RG - 1 || 4 * rg + lr < NW);
+                p[rok ? N * NX + om_xr<rg>(lr) : (N + 1) * NX] = R[rg / 4][rg % 4];
+            });
+        double nG[D][RG][NTR];
         staged_loop<D>(
             N,
             [&](int idx, auto sl) {
@@ -1677,28 +1731,25 @@ struct ChainSolver {
                 static_for<RG>([&](auto rg_) {
                     constexpr int rg = decltype(rg_)::value;
 #pragma unroll
-                    for (int ti = 0; ti < NTR; ++ti) nG[d][rg][ti] = G2[k * O::GSZ + (rg * NT + ti) * 64 + gbase];
-                    const bool rok = !RAGGED || rg < RG - 1 || 4 * rg + lr < NW;
-                    nhb[d][rg] = hb2[k * O::HBS + 4 * rg + lr];
-                    const double t_ = g[k * NW + (rok ? om_nat<rg>(lr) : 0)];
-                    ngt[d][rg] = rok ? t_ : 0.0;
+                    for (int ti = 0; ti < NTR; ++ti) nG[d][rg][ti] = G2[k * O::GSZ + goffs[ti] + rg * (ti < TV ? TV * 64 : O::CT)];
                 });
             },
             [&](int idx, auto sl, auto refill) {
                 constexpr int d = decltype(sl)::value;
                 const int k = N - 1 - idx;
-                double vop[RG];
+                double vop[RG], gt[RG];
                 static_for<RG>([&](auto rg_) {
                     constexpr int rg = decltype(rg_)::value;
-                    double v = R[rg / 4][rg % 4] + nhb[d][rg];
-                    if constexpr (rg == GQ) v = padl ? ngt[d][rg] : v;
+                    gt[rg] = lg[k * O::HBS + 4 * rg + lr];
+                    double v = R[rg / 4][rg % 4] + lhb[k * O::HBS + 4 * rg + lr];
+                    if constexpr (rg == GQ) v = padl ? gt[rg] : v;
                     vop[rg] = v;
                 });
                 d4_t acc[NTR];
 #pragma unroll
                 for (int ti = 0; ti < NTR; ++ti)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[ti][r] = 4 * ti + r < RG ? ngt[d][4 * ti + r < RG ? 4 * ti + r : 0] : 0.0;
+                    for (int r = 0; r < 4; ++r) acc[ti][r] = 4 * ti + r < RG ? gt[4 * ti + r < RG ? 4 * ti + r : 0] : 0.0;
                 double Gk[RG][NTR];
 #pragma unroll
                 for (int rg = 0; rg < RG; ++rg)
@@ -1743,22 +1794,34 @@ struct ChainSolver {
     template <bool want_nu>
     MPCRL_DI void forward2(const WsArr bb) {
         using O = OmCfg<M>;
-        constexpr int RG = O::RG, NT = O::NT, NTR = O::NTR, GQ = O::GQ, D = 2;
+        constexpr int RG = O::RG, NTR = O::NTR, GQ = O::GQ, TV = O::TV, LV = O::LV, D = want_nu ? 3 : 4;
         constexpr bool RAGGED = 4 * RG > NW;
         const int lr = lane >> 4, lc = lane & 15;
         const bool padl = lr < NU;
-        const unsigned gbase = (unsigned)lane;
-        // element (row a, column b) of a block sits at ((a / 4) NT + b / 16) 64 + (a % 4) 16 + b % 16; this lane wants a = 16 ti + lc,
-        // b = 4 ks + lr
-        const unsigned tbase = (unsigned)((lc >> 2) * NT * 64 + (lc & 3) * 16 + lr);
+        // staged in LDS, Omega order: [b_k; kff_k] (control slots: kff), with want_nu p_k
+        double *const lbk = lds + Cfg::oBig, *const lp = lbk + 64 * O::HBS;
+        stage_vec_lds<true>(lbk, bb, N - 1);
+        if (want_nu) stage_vec_lds<true>(lp, p, N);
+        wave_sync();
+        for (int e = lane; e < N * NU; e += NT) {
+            const int k = e / NU;
+            lbk[k * O::HBS + O::Q + (e - k * NU)] = kff[e];
+        }
+        wave_sync();
+        // element (row a, column b) of a streamed block: this lane wants a = 16 ti + lc (rows past the block: its last row), b = 4 ks + lr
+        unsigned tfull[NTR], tcomp[NTR], poffs[NTR];
+#pragma unroll
+        for (int ti = 0; ti < NTR; ++ti) {
+            const int a_ = 16 * ti + lc, a = a_ < 4 * RG ? a_ : 4 * RG - 1;
+            tfull[ti] = (unsigned)((a >> 2) * TV * 64 + (a & 3) * 16 + lr);
+            tcomp[ti] = (unsigned)(RG * TV * 64 + (a >> 2) * O::CT + (a & 3) * LV + lr);
+            poffs[ti] = O::goff(0, ti, lr, lc);
+        }
         if (lane < NX) Dx[lane] = 0.0, Dnu[lane] = 0.0;
         double w[RG];
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg) w[rg] = 0.0;
-        // per stage and lane: G as an A operand (NTR x RG), the constant [b; kff] (one register per row group: the lanes of the control
-        // group fetch kff, the others b), with want_nu P_k (RG x NTR, natural) and p_k
-        double nGt[D][NTR][RG], nbk[D][RG], nP[D][want_nu ? RG : 1][want_nu ? NTR : 1], npv[D][want_nu ? RG : 1];
-        const unsigned kfrel = kff.off - bb.off;
+        double nGt[D][NTR][RG], nP[D][want_nu ? RG : 1][want_nu ? NTR : 1];
         staged_loop<D>(
             N,
             [&](int k, auto sl) {
@@ -1766,18 +1829,14 @@ struct ChainSolver {
 #pragma unroll
                 for (int ti = 0; ti < NTR; ++ti)
 #pragma unroll
-                    for (int ks = 0; ks < RG; ++ks) nGt[d][ti][ks] = G2[k * O::GSZ + tbase + (4 * ti * NT + ks / 4) * 64 + 4 * (ks % 4)];
-                static_for<RG>([&](auto rg_) {
-                    constexpr int rg = decltype(rg_)::value;
-                    const bool rok = !RAGGED || rg < RG - 1 || 4 * rg + lr < NW;
-                    const int xr = rok ? om_xr<rg>(lr) : 0;
-                    nbk[d][rg] = bb[(rg == GQ && padl) ? (int)kfrel + k * NU + lr : k * NX + xr];
-                    if constexpr (want_nu) {
+                    for (int ks = 0; ks < RG; ++ks)
+                        nGt[d][ti][ks] = G2[k * O::GSZ + (ks / 4 < TV ? tfull[ti] + (ks / 4) * 64 : tcomp[ti]) + 4 * (ks % 4)];
+                if constexpr (want_nu)
+                    static_for<RG>([&](auto rg_) {
+                        constexpr int rg = decltype(rg_)::value;
 #pragma unroll
-                        for (int ti = 0; ti < NTR; ++ti) nP[d][rg][ti] = P2[k * O::GSZ + (rg * NT + ti) * 64 + gbase];
-                        npv[d][rg] = p[k * NX + xr];
-                    }
-                });
+                        for (int ti = 0; ti < NTR; ++ti) nP[d][rg][ti] = P2[k * O::GSZ + poffs[ti] + rg * (ti < TV ? TV * 64 : O::CT)];
+                    });
             },
             [&](int k, auto sl, auto refill) {
                 constexpr int d = decltype(sl)::value;
@@ -1787,13 +1846,9 @@ struct ChainSolver {
                         constexpr int ti = decltype(ti_)::value, r = decltype(r_)::value, rg = 4 * ti + r;
                         double c = 0.0, c2 = 0.0;
                         if constexpr (rg < RG) {
-                            const bool rok = !RAGGED || rg < RG - 1 || 4 * rg + lr < NW;
-                            c = rok ? nbk[d][rg] : 0.0;
+                            c = lbk[k * O::HBS + 4 * rg + lr];
                             if constexpr (rg == GQ) c = padl ? -c : c;       // -kff in the control slots
-                            if constexpr (want_nu) {
-                                c2 = rok ? npv[d][rg] : 0.0;
-                                if constexpr (rg == GQ) c2 = padl ? 0.0 : c2;
-                            }
+                            if constexpr (want_nu) c2 = lp[k * O::HBS + 4 * rg + lr];
                         }
                         acc[ti][r] = c, acc2[ti][r] = c2;
                     });
@@ -1838,10 +1893,8 @@ struct ChainSolver {
             static_for<RG>([&](auto rg_) {
                 constexpr int rg = decltype(rg_)::value;
 #pragma unroll
-                for (int ti = 0; ti < NTR; ++ti) Pk[rg][ti] = P2[N * O::GSZ + (rg * NT + ti) * 64 + gbase];
-                const bool rok = (rg != GQ || !padl) && (!RAGGED || rg < RG - 1 || 4 * rg + lr < NW);
-                const double t_ = p[N * NX + (rok ? om_xr<rg>(lr) : 0)];
-                acc2[rg / 4][rg % 4] = rok ? t_ : 0.0;
+                for (int ti = 0; ti < NTR; ++ti) Pk[rg][ti] = P2[N * O::GSZ + poffs[ti] + rg * (ti < TV ? TV * 64 : O::CT)];
+                acc2[rg / 4][rg % 4] = lp[N * O::HBS + 4 * rg + lr];
             });
 #pragma unroll
             for (int ti = 0; ti < NTR; ++ti)
@@ -2102,20 +2155,20 @@ struct ChainSolver {
     struct RoundStart {
         double cost, res[4];
     };
-    __device__ __attribute__((noinline)) static RoundStart round_start_call(Ctx c, const double *x0, const double *u0f) {
+    __device__ MPCRL_PHASE_FN static RoundStart round_start_call(Ctx c, const double *x0, const double *u0f) {
         ChainSolver S = from_ctx(c);
         x0 = uni_global(x0), u0f = u0f ? uni_global(u0f) : nullptr;
         RoundStart o;
         o.cost = S.round_start(x0, u0f, o.res);
         return o;
     }
-    __device__ __attribute__((noinline)) static double qp_residuals_call(Ctx c) {
+    __device__ MPCRL_PHASE_FN static double qp_residuals_call(Ctx c) {
         ChainSolver S = from_ctx(c);
         return S.qp_residuals();
     }
     // hex_off: workspace offset of the exact Hessian blocks (HessGlobal); the constant Hessian (HessConst) is rebuilt from theta
     template <class HS>
-    __device__ __attribute__((noinline)) static bool factor_call(Ctx c, unsigned hex_off, unsigned g_off, unsigned bb_off) {
+    __device__ MPCRL_PHASE_FN static bool factor_call(Ctx c, unsigned hex_off, unsigned g_off, unsigned bb_off) {
         ChainSolver S = from_ctx(c);
         if constexpr (USE_V2) {
             typename HessV2<HS>::type hs;
@@ -2127,7 +2180,7 @@ struct ChainSolver {
             return S.factor(hs, S.arr(g_off), S.arr(bb_off));
         }
     }
-    __device__ __attribute__((noinline)) static void backward_vec_call(Ctx c, unsigned g_off) {
+    __device__ MPCRL_PHASE_FN static void backward_vec_call(Ctx c, unsigned g_off) {
         ChainSolver S = from_ctx(c);
         if constexpr (USE_V2)
             S.backward_vec2(S.arr(g_off));
@@ -2135,7 +2188,7 @@ struct ChainSolver {
             S.backward_vec(S.arr(g_off));
     }
     template <bool want_nu>
-    __device__ __attribute__((noinline)) static void forward_call(Ctx c, unsigned bb_off) {
+    __device__ MPCRL_PHASE_FN static void forward_call(Ctx c, unsigned bb_off) {
         ChainSolver S = from_ctx(c);
         if constexpr (USE_V2)
             S.template forward2<want_nu>(S.arr(bb_off));
@@ -2201,7 +2254,7 @@ __global__ void __launch_bounds__(64) chain_init_kernel(const LargeSpec sp, cons
 // the pass itself, for stage k of one instance (X, U, th: the instance's iterate and parameters, w: its workspace).  A real call: the
 // QP kernel runs it at the end of a round on N of its lanes, with a register allocation of its own.
 template <class M, bool SECOND>
-__device__ __attribute__((noinline)) void chain_point_pass(const double *X, const double *U, const double *th, double *w, int N, int k, double h, int steps) {
+__device__ MPCRL_PHASE_FN void chain_point_pass(const double *X, const double *U, const double *th, double *w, int N, int k, double h, int steps) {
     constexpr int NX = M::NX, NU = M::NU, NL = M::NL, TS = SECOND ? M::TAB2 : M::TAB;
     const LargeLayout<M> lay(N);
     double *tab = w + lay.ptab + (size_t)k * 8 * NL * M::TAB2;
@@ -2304,7 +2357,7 @@ struct DirCfg {
 };
 
 template <class M>
-__device__ __attribute__((noinline)) void chain_dir_pass(const double *th, double *w, double *tabl, int N, int lane, double h, int steps) {
+__device__ MPCRL_PHASE_FN void chain_dir_pass(const double *th, double *w, double *tabl, int N, int lane, double h, int steps) {
     using DC = DirCfg<M>;
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NL = M::NL, TAB = M::TAB, TSZ = DC::TSZ, STG = DC::EV * NL * M::TAB2;
     const LargeLayout<M> lay(N);
