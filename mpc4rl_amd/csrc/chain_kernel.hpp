@@ -1403,7 +1403,8 @@ struct ChainSolver {
     }
 
     // ---- factor sweep (see OmCfg): P_{k+1} stays in registers in the result layout, which is its operand layout for T = P W.
-    template <class HS>
+    // STORE_P: P_k goes to HBM as well (only the adjoint solves of the sensitivities multiply with it afterwards: forward2<true>).
+    template <class HS, bool STORE_P>
     MPCRL_DI bool factor2(HS &hs, const WsArr g, const WsArr bb) {
         using O = OmCfg<M>;
         constexpr int RG = O::RG, NT = O::NT, NTR = O::NTR, GQ = O::GQ, TQ = O::TQ, RQ = O::RQ, LQ = O::LQ, TV = O::TV, LV = O::LV, FD = 2;
@@ -1446,7 +1447,7 @@ struct ChainSolver {
                             if (xr == xc) v += Dg[N * NW + NU + xr];
                         } else if (rok && c == O::VC)
                             v = g[N * NW + NU + xr];
-                        if (tj < TV || lc < LV) P2[N * O::GSZ + O::goff(rg, tj, lr, lc)] = v;
+                        if (STORE_P && (tj < TV || lc < LV)) P2[N * O::GSZ + O::goff(rg, tj, lr, lc)] = v;
                         if (rok && c == O::VC) p[N * NX + xr] = v;
                     }
                     Pt[ti][tj][r] = v;
@@ -1637,14 +1638,14 @@ struct ChainSolver {
 #pragma unroll
                     for (int tj = 0; tj < TV; ++tj) {
                         G2[k * O::GSZ + (rg * TV + tj) * 64 + gbase] = Wt[rg / 4][tj][rg % 4];
-                        P2[k * O::GSZ + (rg * TV + tj) * 64 + gbase] = Mt[rg / 4][tj][rg % 4];
+                        if constexpr (STORE_P) P2[k * O::GSZ + (rg * TV + tj) * 64 + gbase] = Mt[rg / 4][tj][rg % 4];
                     }
                 });
                 if (wcl)      // the last column tile: its columns < NW, compactly
                     static_for<RG>([&](auto rg_) {
                         constexpr int rg = decltype(rg_)::value;
                         G2[k * O::GSZ + RG * TV * 64 + rg * O::CT + cbase] = Wt[rg / 4][TV][rg % 4];
-                        P2[k * O::GSZ + RG * TV * 64 + rg * O::CT + cbase] = Mt[rg / 4][TV][rg % 4];
+                        if constexpr (STORE_P) P2[k * O::GSZ + RG * TV * 64 + rg * O::CT + cbase] = Mt[rg / 4][TV][rg % 4];
                     });
                 if (vcl) {
                     static_for<RG>([&](auto rg_) {
@@ -1916,6 +1917,140 @@ struct ChainSolver {
         wave_sync();
     }
 
+    // ---- multipliers of the dynamics at the end of a QP, by ONE costate sweep instead of Dnu_k = p_k + P_k Dx_k in every
+    // interior-point iteration (which made the factor sweep stream P_k out and the corrector's forward sweep stream it back in: 9 KB
+    // of the 32 KB a stage moved per iteration at n_mass 5).  No step of the iteration uses nuq — the Riccati direction gives Dx, Du,
+    // and the bound rows give the step length — it is only an output, and the x rows of the QP's stationarity residual tie it to
+    // what the iteration does carry:
+    //     rg_x,k = q_x,k + (H dv_k)_x + A_k' nuq_{k+1} - nuq_k -+ lam_x,k        (rg: kept current by the (1 - alpha) scaling)
+    // so  nuq_k = [q + H dv -+ lam - rg]_x,k + A_k' nuq_{k+1},  nuq_N = [..]_x,N : the same numbers as the accumulated steps, to
+    // rounding.  H dv for all stages is three batches of MFMAs (16 stages per batch as the 16 columns of the B operand), the sweep a
+    // chain of MFMAs on [B A]_k as it lies in the workspace.
+    MPCRL_DI void costate_nu() {
+        using O = OmCfg<M>;
+        constexpr int RG = O::RG, NT_ = O::NT, NTR = O::NTR, GQ = O::GQ, D = 4;
+        constexpr bool RAGGED = 4 * RG > NW;
+        const int lr = lane >> 4, lc = lane & 15;
+        const bool padl = lr < NU;
+        const int ne = (N + 1) * NW;
+        double *const lc_ = lds + Cfg::oBig, *const ltab = lc_ + 64 * O::HBS;      // the stage vectors c_k (Omega order), the Hessian table
+        // Hessian table in the register layout (= its A-operand layout: H is symmetric)
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+            for (int tj = 0; tj < NTR; ++tj) {
+                const int e = 4 * rg + lr, c = 16 * tj + lc;
+                const bool in = e < NW && c < NW;
+                ltab[(rg * NTR + tj) * 64 + lane] = in ? M::hess(false, O::nat(in ? e : 0), O::nat(in ? c : 0), th) : 0.0;
+            }
+        wave_sync();
+        for (int b0 = 0; b0 <= N; b0 += 16) {
+            const int st = b0 + lc, stc = st <= N ? st : N;      // this lane's stage (column lc of the batch)
+            double op[RG];
+            static_for<RG>([&](auto rg_) {
+                constexpr int rg = decltype(rg_)::value;
+                const bool rok = !RAGGED || rg < RG - 1 || 4 * rg + lr < NW;
+                double v;
+                if constexpr (rg == GQ) {      // the control slots of the group take du (none at the terminal stage)
+                    const double t_ = WsArr{dx.base, padl ? du.off + (unsigned)((stc < N ? stc : N - 1) * NU + lr) : dx.off + (unsigned)(stc * NX + om_xr<rg>(lr))}[0];
+                    v = (padl && stc >= N) ? 0.0 : t_;
+                } else
+                    v = dx[stc * NX + (rok ? om_xr<rg>(lr) : 0)];
+                op[rg] = rok ? v : 0.0;
+            });
+            d4_t y[NTR];
+#pragma unroll
+            for (int ti = 0; ti < NTR; ++ti) {
+                d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < RG; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ltab[(ks * NTR + ti) * 64 + lane], op[ks], acc, 0, 0, 0);
+                y[ti] = acc;
+            }
+            const double cks = ck(stc);
+            static_for<RG>([&](auto rg_) {
+                constexpr int rg = decltype(rg_)::value;
+                const bool rok = (rg != GQ || !padl) && (!RAGGED || rg < RG - 1 || 4 * rg + lr < NW);
+                const int e = stc * NW + (rok ? om_nat<rg>(lr) : 0), i = rok ? om_nat<rg>(lr) : NU;
+                double v = fma(cks, y[rg / 4][rg % 4], q[e]) - this->rg[e];
+                if (has(0, stc, i)) v -= lam[e];
+                if (has(1, stc, i)) v += lam[ne + e];
+                if (st <= N) lc_[st * O::HBS + 4 * rg + lr] = rok ? v : 0.0;
+            });
+        }
+        wave_sync();
+        // the chain: nuq_k = c_k + A_k' nuq_{k+1}  (operand rows: next state, pad rows 0; columns: the state slots of stage k)
+        int colnat[NTR];
+#pragma unroll
+        for (int tj = 0; tj < NTR; ++tj) {
+            const int c = 16 * tj + lc;
+            colnat[tj] = c < NW ? O::nat(c < NW ? c : 0) : 0;
+        }
+        const int rbase = lr * NW;
+        d4_t R[NTR];
+        static_for<NTR>([&](auto ti_) {
+            static_for<4>([&](auto r_) {
+                constexpr int ti = decltype(ti_)::value, r = decltype(r_)::value, rg = 4 * ti + r;
+                double v = 0.0;
+                if constexpr (rg < RG) v = lc_[N * O::HBS + 4 * rg + lr];
+                R[ti][r] = v;
+            });
+        });
+        auto store_nu = [&](int k) {
+            if (lc == 0)
+                static_for<RG>([&](auto rg_) {
+                    constexpr int rg = decltype(rg_)::value;
+                    const bool rok = (rg != GQ || !padl) && (!RAGGED || rg < RG - 1 || 4 * rg + lr < NW);
+                    nuq[rok ? k * NX + om_xr<rg>(lr) : (N + 1) * NX] = R[rg / 4][rg % 4];
+                });
+        };
+        store_nu(N);
+        double nA[D][RG][NTR];
+        staged_loop<D>(
+            N - 1,     // stages N - 1 .. 1 (the multiplier of the initial condition is not an iterate)
+            [&](int idx, auto sl) {
+                constexpr int d = decltype(sl)::value;
+                const int k = N - 1 - idx;
+                static_for<RG>([&](auto rg_) {
+                    constexpr int rg = decltype(rg_)::value;
+#pragma unroll
+                    for (int tj = 0; tj < NTR; ++tj) nA[d][rg][tj] = BA[k * NX * NW + rbase + colnat[tj] + (4 * rg - (rg >= GQ ? NU : 0)) * NW];
+                });
+            },
+            [&](int idx, auto sl, auto refill) {
+                constexpr int d = decltype(sl)::value;
+                const int k = N - 1 - idx;
+                double Ak[RG][NTR], vop[RG];
+                static_for<RG>([&](auto rg_) {
+                    constexpr int rg = decltype(rg_)::value;
+#pragma unroll
+                    for (int tj = 0; tj < NTR; ++tj) {
+                        double v = nA[d][rg][tj];
+                        if constexpr (rg == GQ) v = padl ? 0.0 : v;
+                        if constexpr (RAGGED && rg == RG - 1) v = 4 * rg + lr < NW ? v : 0.0;
+                        Ak[rg][tj] = v;
+                    }
+                    vop[rg] = R[rg / 4][rg % 4];
+                });
+                d4_t acc[NTR];
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[ti][r] = 4 * ti + r < RG ? lc_[k * O::HBS + 4 * (4 * ti + r < RG ? 4 * ti + r : 0) + lr] : 0.0;
+                refill();
+#pragma unroll
+                for (int ks = 0; ks < RG; ++ks)
+#pragma unroll
+                    for (int ti = 0; ti < NTR; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[ks][ti], vop[ks], acc[ti], 0, 0, 0);
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti) R[ti] = acc[ti];
+                // the control slots of the result (B' nu) are not part of the vector: zero, so that the next operand's pad entries are
+                R[GQ / 4][GQ % 4] = padl ? 0.0 : R[GQ / 4][GQ % 4];
+                store_nu(k);
+            });
+        (void)NT_;
+        wave_sync();
+    }
+
     // ---- Mehrotra predictor-corrector on the QP of the current linearisation (hard bounds) --------------------
     template <class HS>
     MPCRL_DI bool qp_solve(HS &hs, const double *x0, const double *u0f, int &n_it, double warm_mu, double tol_res, double tol_mu) {
@@ -1951,7 +2086,7 @@ struct ChainSolver {
         }
         const double n_rows = wave_sum(cnt);
         wave_sync();
-        bool ok = false;
+        bool ok = false, stepped = false;
         double rlin = 0.0;
         for (int it = 0;; ++it) {
             ph(7);
@@ -2017,7 +2152,7 @@ struct ChainSolver {
                     backward_vec_call(ctx(), rt.off);
                     ph(3);
                 }
-                if (pass == 1)   // the multiplier step is only needed with the final direction
+                if (pass == 1 && !USE_V2)   // the multiplier step is only needed with the final direction (round 4: not at all, costate_nu)
                     forward_call<true>(ctx(), rb.off);
                 else
                     forward_call<false>(ctx(), rb.off);
@@ -2082,8 +2217,13 @@ struct ChainSolver {
                     }
             }
             wave_sync();
-            batched_pass<4>((N + 1) * NX, lane, [&](int e) { return Quad4{Dx[e], dx[e], Dnu[e], nuq[e]}; },
-                            [&](int e, const Quad4 &v) { dx[e] = fma(alpha, v.a, v.b), nuq[e] = fma(alpha, v.c, v.d); });
+            if constexpr (USE_V2)
+                batched_pass<8>((N + 1) * NX, lane, [&](int e) { return Pair2{Dx[e], dx[e]}; },
+                                [&](int e, const Pair2 &v) { dx[e] = fma(alpha, v.a, v.b); });
+            else
+                batched_pass<4>((N + 1) * NX, lane, [&](int e) { return Quad4{Dx[e], dx[e], Dnu[e], nuq[e]}; },
+                                [&](int e, const Quad4 &v) { dx[e] = fma(alpha, v.a, v.b), nuq[e] = fma(alpha, v.c, v.d); });
+            stepped = true;
             batched_pass<2>(N * NU, lane, [&](int e) { return Pair2{Du[e], du[e]}; },
                             [&](int e, const Pair2 &v) { du[e] = fma(alpha, v.a, v.b); });
             if (MPCRL_CHAIN_SCALE_RES) {
@@ -2094,6 +2234,8 @@ struct ChainSolver {
             }
             wave_sync();
         }
+        if constexpr (USE_V2)
+            if (stepped) costate_call(ctx());      // nuq of the point the iteration ended at (no iteration: the warm multipliers stand)
         return ok;
     }
 
@@ -2173,7 +2315,7 @@ struct ChainSolver {
         if constexpr (USE_V2) {
             typename HessV2<HS>::type hs;
             hs.init(S, hex_off);
-            return S.factor2(hs, S.arr(g_off), S.arr(bb_off));
+            return S.template factor2<typename HessV2<HS>::type, !std::is_same<HS, HessConst<M>>::value>(hs, S.arr(g_off), S.arr(bb_off));
         } else {
             HS hs;
             hs.init(S, hex_off);
@@ -2186,6 +2328,10 @@ struct ChainSolver {
             S.backward_vec2(S.arr(g_off));
         else
             S.backward_vec(S.arr(g_off));
+    }
+    __device__ MPCRL_PHASE_FN static void costate_call(Ctx c) {
+        ChainSolver S = from_ctx(c);
+        S.costate_nu();
     }
     template <bool want_nu>
     __device__ MPCRL_PHASE_FN static void forward_call(Ctx c, unsigned bb_off) {
