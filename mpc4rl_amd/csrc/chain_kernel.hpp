@@ -51,7 +51,10 @@ constexpr double CHAIN_TOL_MU_FACTOR = 1.0;
 #define MPCRL_CHAIN_V2 1
 #endif
 #ifndef MPCRL_CHAIN_V2_MAXNX
-#define MPCRL_CHAIN_V2_MAXNX 21   // largest state dimension that runs the round-4 sweeps
+#define MPCRL_CHAIN_V2_MAXNX 33   // largest state dimension that runs the round-4 sweeps
+#endif
+#ifndef MPCRL_CHAIN_V2_SENS_MAXNX
+#define MPCRL_CHAIN_V2_SENS_MAXNX 21   // ... in the adjoint solves of the sensitivities (exact Hessian from the workspace, P_k streamed)
 #endif
 
 struct LargeSpec {
@@ -324,12 +327,19 @@ struct ChainCfg {
     static constexpr int ASP = ev(NX * (NW + 1)) + 2;         // [B A]-shaped block published with the odd row stride NW + 1 (+ a dump slot)
     static constexpr int oA = oBig, oPk = oBig + (BST > ASP ? BST : ASP), oQ = oBig, oX = oBig + NW * NW, oU = oX + 64 * NX;
     static constexpr int BIG_F = NW * NW + 2 * NX * NW, BIG_R = NW * NW + 64 * NW;
-    // round-4 sweeps: the Hessian table of the factor sweep, or two vectors of the whole horizon (up to 64 stages) in Omega order
+    // round-4 sweeps: the Hessian table of the factor sweep, or two vectors of the whole horizon in Omega order (HBS doubles per
+    // stage) — which depends on the horizon, so the kernels that run the solver take their LDS as a launch argument (lds_doubles)
     static constexpr bool V2 = MPCRL_CHAIN_V2 != 0 && NX <= MPCRL_CHAIN_V2_MAXNX;
-    static constexpr int BIG_V = V2 ? (OmCfg<M>::RG * OmCfg<M>::NT * 64 > 128 * OmCfg<M>::HBS ? OmCfg<M>::RG * OmCfg<M>::NT * 64 : 128 * OmCfg<M>::HBS) : 0;
     static constexpr int BIG_O = BIG_F > BIG_R ? BIG_F : BIG_R;
-    static constexpr int LDS_TOTAL = oBig + (BIG_O > BIG_V ? BIG_O : BIG_V);
-    static_assert(oBig % 2 == 0 && (BST > ASP ? BST : ASP) + AST <= BIG_F && NX * NX <= NW * NW, "aligned / overlays fit");
+    static constexpr int LDS_TOTAL = oBig + BIG_O;      // without the round-4 staging (DirCfg: table budget of the direction pass)
+    __host__ __device__ static constexpr int lds_doubles(int N) {
+        int big = BIG_O;
+        if (V2) {
+            const int tab = OmCfg<M>::RG * OmCfg<M>::NT * 64, vec = 2 * (N + 1) * OmCfg<M>::HBS, cst = (N + 1) * OmCfg<M>::HBS + tab;
+            big = big > tab ? big : tab, big = big > vec ? big : vec, big = big > cst ? big : cst;
+        }
+        return oBig + big + (big & 1);
+    }
     static_assert(LDS_TOTAL * 8 <= 40 * 1024, "four wavefronts per CU");
 };
 
@@ -475,7 +485,7 @@ struct ChainSolver {
     using Cfg = ChainCfg<M>;
     static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD, NP = M::NP, NT = 64;
     static constexpr int TI = Cfg::TI, TJ = Cfg::TJ, TS = Cfg::TS;
-    static constexpr bool USE_V2 = MPCRL_CHAIN_V2 != 0 && NX <= MPCRL_CHAIN_V2_MAXNX;
+    static constexpr bool USE_V2 = MPCRL_CHAIN_V2 != 0 && NX <= MPCRL_CHAIN_V2_MAXNX, USE_V2_SENS = USE_V2 && NX <= MPCRL_CHAIN_V2_SENS_MAXNX;
     const LargeSpec *spp;   // kernel-argument copy of the problem (set-up only)
     const double *xs;       // x_ss (device)
     int N, lane;
@@ -1457,7 +1467,9 @@ struct ChainSolver {
         // per stage and lane: W (RG x NT registers; in the tile of the vector column the lane of that column fetches b instead),
         // B' (NTR), and ONE register per row group for the right-hand side and the barrier diagonal (the lane of the vector column
         // fetches g, the diagonal lane D: they are different lanes for every valid row)
-        double nW[FD][RG][NT], nBt[FD][NTR], ngd[FD][RG];
+        // (one lane is both: the diagonal lane of row 16 ti + LV in a tile ti != TV is the lane of the vector column — its D comes
+        // with a load of its own, ndx)
+        double nW[FD][RG][NT], nBt[FD][NTR], ngd[FD][RG], ndx[FD][NTR];
         const unsigned bbrel = bb.off - BA.off, grel = g.off - BA.off, dgrel = Dg.off - BA.off;
         hs.prefetch(N - 1);
         staged_loop<FD>(
@@ -1478,7 +1490,10 @@ struct ChainSolver {
                     ngd[d][rg] = BA[(int)(vcl ? grel : dgrel) + k * NW + (rok ? nt : 0)];
                 });
 #pragma unroll
-                for (int ti = 0; ti < NTR; ++ti) nBt[d][ti] = Bk[btoff[ti]];
+                for (int ti = 0; ti < NTR; ++ti) {
+                    nBt[d][ti] = Bk[btoff[ti]];
+                    ndx[d][ti] = (ti != TV && 16 * ti + LV < NW) ? Dg[k * NW + O::nat(16 * ti + LV < NW ? 16 * ti + LV : 0)] : 0.0;
+                }
             },
             [&](int idx, auto sl, auto refill) {
                 constexpr int d = decltype(sl)::value;
@@ -1487,7 +1502,9 @@ struct ChainSolver {
                 hs.advance(k);
                 // ---- the stage operands out of their prefetch slot: W = [A B | b] with its pad rows, B' as an A operand
                 d4_t Wt[NTR][NT];
-                double gd[RG], Bt[NTR];
+                double gd[RG], Bt[NTR], dgx[NTR];
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti) dgx[ti] = ndx[d][ti];
                 static_for<NTR>([&](auto ti_) {
                     static_for<4>([&](auto r_) {
                         constexpr int ti = decltype(ti_)::value, r = decltype(r_)::value, rg = 4 * ti + r;
@@ -1545,7 +1562,7 @@ struct ChainSolver {
                             double c = 0.0;
                             if constexpr (rg < RG) {
                                 c = hs.tile(k, rg, tj);
-                                if (tj == tm) c += (lc == 4 * r + lr) ? gd[rg] : 0.0;
+                                if (tj == tm) c += (lc == 4 * r + lr) ? ((tm != TV && r == LV / 4 && vcl) ? dgx[tm] : gd[rg]) : 0.0;
                                 if (tj == TV) c += vcl ? gd[rg] : 0.0;
                             }
                             acc[r] = c;
@@ -1694,11 +1711,11 @@ struct ChainSolver {
     // left in the global-memory queue (the sweep is bound by HBM bandwidth: depth x block = bytes in flight).
     MPCRL_DI void backward_vec2(const WsArr g) {
         using O = OmCfg<M>;
-        constexpr int RG = O::RG, NTR = O::NTR, GQ = O::GQ, TV = O::TV, D = 4;
+        constexpr int RG = O::RG, NTR = O::NTR, GQ = O::GQ, TV = O::TV, D = NTR <= 2 ? 4 : 2;   // (stages in flight: registers at n_mass 7)
         constexpr bool RAGGED = 4 * RG > NW;
         const int lr = lane >> 4, lc = lane & 15;
         const bool padl = lr < NU;
-        double *const lg = lds + Cfg::oBig, *const lhb = lg + 64 * O::HBS;
+        double *const lg = lds + Cfg::oBig, *const lhb = lg + (N + 1) * O::HBS;
         stage_vec_lds<false>(lg, g, N);
         batched_pass<4>(N * O::HBS, lane, [&](int e) { return hb2[e]; }, [&](int e, double v) { lhb[e] = v; });
         wave_sync();
@@ -1795,12 +1812,12 @@ struct ChainSolver {
     template <bool want_nu>
     MPCRL_DI void forward2(const WsArr bb) {
         using O = OmCfg<M>;
-        constexpr int RG = O::RG, NTR = O::NTR, GQ = O::GQ, TV = O::TV, LV = O::LV, D = want_nu ? 3 : 4;
+        constexpr int RG = O::RG, NTR = O::NTR, GQ = O::GQ, TV = O::TV, LV = O::LV, D = NTR <= 2 ? (want_nu ? 3 : 4) : (want_nu ? 1 : 2);
         constexpr bool RAGGED = 4 * RG > NW;
         const int lr = lane >> 4, lc = lane & 15;
         const bool padl = lr < NU;
         // staged in LDS, Omega order: [b_k; kff_k] (control slots: kff), with want_nu p_k
-        double *const lbk = lds + Cfg::oBig, *const lp = lbk + 64 * O::HBS;
+        double *const lbk = lds + Cfg::oBig, *const lp = lbk + (N + 1) * O::HBS;
         stage_vec_lds<true>(lbk, bb, N - 1);
         if (want_nu) stage_vec_lds<true>(lp, p, N);
         wave_sync();
@@ -1928,12 +1945,12 @@ struct ChainSolver {
     // chain of MFMAs on [B A]_k as it lies in the workspace.
     MPCRL_DI void costate_nu() {
         using O = OmCfg<M>;
-        constexpr int RG = O::RG, NT_ = O::NT, NTR = O::NTR, GQ = O::GQ, D = 4;
+        constexpr int RG = O::RG, NT_ = O::NT, NTR = O::NTR, GQ = O::GQ, D = NTR <= 2 ? 4 : 2;
         constexpr bool RAGGED = 4 * RG > NW;
         const int lr = lane >> 4, lc = lane & 15;
         const bool padl = lr < NU;
         const int ne = (N + 1) * NW;
-        double *const lc_ = lds + Cfg::oBig, *const ltab = lc_ + 64 * O::HBS;      // the stage vectors c_k (Omega order), the Hessian table
+        double *const lc_ = lds + Cfg::oBig, *const ltab = lc_ + (N + 1) * O::HBS;      // the stage vectors c_k (Omega order), the Hessian table
         // Hessian table in the register layout (= its A-operand layout: H is symmetric)
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg)
@@ -2312,7 +2329,7 @@ struct ChainSolver {
     template <class HS>
     __device__ MPCRL_PHASE_FN static bool factor_call(Ctx c, unsigned hex_off, unsigned g_off, unsigned bb_off) {
         ChainSolver S = from_ctx(c);
-        if constexpr (USE_V2) {
+        if constexpr (std::is_same<HS, HessConst<M>>::value ? USE_V2 : USE_V2_SENS) {
             typename HessV2<HS>::type hs;
             hs.init(S, hex_off);
             return S.template factor2<typename HessV2<HS>::type, !std::is_same<HS, HessConst<M>>::value>(hs, S.arr(g_off), S.arr(bb_off));
@@ -2336,7 +2353,7 @@ struct ChainSolver {
     template <bool want_nu>
     __device__ MPCRL_PHASE_FN static void forward_call(Ctx c, unsigned bb_off) {
         ChainSolver S = from_ctx(c);
-        if constexpr (USE_V2)
+        if constexpr (want_nu ? USE_V2_SENS : USE_V2)      // (with the multiplier step: only the sensitivities' adjoint solves)
             S.template forward2<want_nu>(S.arr(bb_off));
         else
             S.template forward<want_nu>(S.arr(bb_off));
@@ -2571,7 +2588,7 @@ template <class M>
 __global__ void __launch_bounds__(64, 1) chain_sqp_kernel(const LargeSpec sp, const LargeArgs a) {
     using Cfg = ChainCfg<M>;
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NT = 64;
-    __shared__ __attribute__((aligned(16))) double lds[Cfg::LDS_TOTAL];
+    extern __shared__ __attribute__((aligned(16))) double lds[];      // Cfg::lds_doubles(N) doubles (launch_large)
     __shared__ int sidx[196];
     const int lane = threadIdx.x, inst = blockIdx.x, N = sp.N;
     const LargeLayout<M> lay(N);
@@ -2833,7 +2850,7 @@ template <class M>
 __global__ void __launch_bounds__(64, 1) chain_sens_riccati_kernel(const LargeSpec sp, const LargeArgs a) {
     using Cfg = ChainCfg<M>;
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD, NP = M::NP, NT = 64;
-    __shared__ __attribute__((aligned(16))) double lds[Cfg::LDS_TOTAL];
+    extern __shared__ __attribute__((aligned(16))) double lds[];      // Cfg::lds_doubles(N) doubles (launch_large)
     __shared__ int sidx[196];
     const int lane = threadIdx.x, inst = blockIdx.x, N = sp.N;
     const int status = a.status[inst];
@@ -2875,7 +2892,7 @@ __global__ void __launch_bounds__(64, 1) chain_sens_riccati_kernel(const LargeSp
             // The right-hand side is -e_iu in the controls of stage 0 and zero elsewhere, and there is no dynamics offset: the backward
             // vector recursion is identically zero from the terminal stage down to stage 1 (p_k = 0 — what the factor sweep left for
             // iu = 0 as well), and at stage 0 only the feed-forward changes: kff_0 = (L_0 L_0')^{-1} (-e_iu).  No sweep.
-            if constexpr (ChainSolver<M>::USE_V2) {
+            if constexpr (ChainSolver<M>::USE_V2_SENS) {
 #pragma unroll
                 for (int i = 0; i < NU; ++i) S.kff[i] = -S.minv2[4 * i + iu];
             } else {

@@ -149,10 +149,12 @@ int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
     const int B = h->B, N = h->N, NW = M::NX + M::NU;
     const int max_iter = (a.flags & MPCRL_RTI) ? 1 : h->large.max_iter;
     auto blocks = [](long items) { return dim3((unsigned)((items + 255) / 256)); };
+    const unsigned lds_bytes = (unsigned)(ChainCfg<M>::lds_doubles(N) * sizeof(double));   // the solver kernels' LDS depends on the horizon
+    if (lds_bytes + 1024 > 64 * 1024) return MPCRL_E_ARG;
     hipLaunchKernelGGL(chain_init_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
     // the whole SQP loop of an instance runs inside one wavefront of one launch (linearisation, QP, step; chain_kernel.hpp)
     (void)max_iter, (void)blocks;
-    hipLaunchKernelGGL(chain_sqp_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
+    hipLaunchKernelGGL(chain_sqp_kernel<M>, dim3(B), dim3(64), lds_bytes, st, h->large, a);
     HIP_OK(hipGetLastError());
     if (a.flags & (MPCRL_SENS_V | MPCRL_SENS_PI)) {
         hipLaunchKernelGGL(chain_sens_th_kernel<M>, dim3((unsigned)(((long)B * N + 63) / 64)), dim3(64), 0, st, h->large, a);
@@ -160,7 +162,7 @@ int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
         if (want_pi) {
             hipLaunchKernelGGL((chain_point_kernel<M, true>), dim3((unsigned)(((long)B * N + 63) / 64)), dim3(64), 0, st, h->large, a);
             hipLaunchKernelGGL(chain_sens_ad_kernel<M>, dim3((unsigned)(B * N)), dim3(64), 0, st, h->large, a);
-            hipLaunchKernelGGL(chain_sens_riccati_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
+            hipLaunchKernelGGL(chain_sens_riccati_kernel<M>, dim3(B), dim3(64), lds_bytes, st, h->large, a);
             hipLaunchKernelGGL(chain_sens_mix_kernel<M>, blocks((long)B * N * M::NU), dim3(256), 0, st, h->large, a);
         }
         hipLaunchKernelGGL(chain_sens_out_kernel<M>, blocks((long)B * (M::NU + 1) * (M::NTD + M::NX * M::NX + M::NU * M::NU)), dim3(256), 0, st,
