@@ -53,6 +53,9 @@ constexpr double CHAIN_TOL_MU_FACTOR = 1.0;
 #ifndef MPCRL_CHAIN_V2_MAXNX
 #define MPCRL_CHAIN_V2_MAXNX 33   // largest state dimension that runs the round-4 sweeps
 #endif
+#ifndef MPCRL_CHAIN_V2_ROUNDSTART
+#define MPCRL_CHAIN_V2_ROUNDSTART 0
+#endif
 #ifndef MPCRL_CHAIN_V2_SENS_MAXNX
 #define MPCRL_CHAIN_V2_SENS_MAXNX 21   // ... in the adjoint solves of the sensitivities (exact Hessian from the workspace, P_k streamed)
 #endif
@@ -725,6 +728,21 @@ struct ChainSolver {
         });
         wave_sync();
         double rs = 0, re = 0, ri = 0, rc = 0;
+        if constexpr (USE_V2 && MPCRL_CHAIN_V2_ROUNDSTART) {   // (measured slower than the staged pass below: 77 vs 64 us per call at n_mass 5)
+            // [B A]_k' nu_{k+1} of all stages by the MFMA pass (the staged Q, X, U above are dead), then one pass over the entries
+            double *const lnu = lds + Cfg::oBig, *const ly = lnu + (N + 1) * OmCfg<M>::HBS;
+            wt_nu_pass(NUv, lnu, ly);
+            batched_pass<4>(ne, lane,
+                            [&](int e) {
+                                const int k = e / NW, i = e - k * NW;
+                                return Pair2{rg[e], (i >= NU && k > 0) ? NUv[k * NX + i - NU] : 0.0};
+                            },
+                            [&](int e, const Pair2 &v) {
+                                const int k = e / NW, i = e - k * NW;
+                                const double a = v.a - v.b + (k < N ? ly[k * OmCfg<M>::HBS + om_slot(i)] : 0.0);
+                                if (!fixedc(k, i) && !skipc(k, i)) rs = fmax(rs, fabs(a));
+                            });
+        } else
         {
             d2_t nB[Cfg::DEPTH][Cfg::NBA2];
             double ng[Cfg::DEPTH], nn[Cfg::DEPTH], no[Cfg::DEPTH];
@@ -1413,11 +1431,130 @@ struct ChainSolver {
     }
 
     // ---- factor sweep (see OmCfg): P_{k+1} stays in registers in the result layout, which is its operand layout for T = P W.
+    // slot of entry i of the stage vector [u; x]
+    MPCRL_DI static int om_slot(int i) { return i < NU ? OmCfg<M>::Q + i : (i - NU < OmCfg<M>::Q ? i - NU : i); }
+
+    // ---- y_k = [B A]_k' nu_{k+1}, k = 0 .. N - 1, for a multiplier array nu [(N+1) NX]: into ly (LDS, [k HBS + slot of the stage
+    // vector]); lnu (LDS) receives nu in Omega order.  Stage-parallel (no chain): [B A]_k as it lies in the workspace is the A
+    // operand, the vector the B operand, 4 stages of operands in flight.
+    MPCRL_DI void wt_nu_pass(const WsArr nu, double *lnu, double *ly) {
+        using O = OmCfg<M>;
+        constexpr int RG = O::RG, NTR = O::NTR, GQ = O::GQ, D = NTR <= 2 ? 4 : 2;
+        constexpr bool RAGGED = 4 * RG > NW;
+        const int lr = lane >> 4, lc = lane & 15;
+        const bool padl = lr < NU;
+        stage_vec_lds<true>(lnu, nu, N);
+        wave_sync();
+        int colnat[NTR];
+#pragma unroll
+        for (int tj = 0; tj < NTR; ++tj) {
+            const int c = 16 * tj + lc;
+            colnat[tj] = c < NW ? O::nat(c < NW ? c : 0) : 0;
+        }
+        const int rbase = lr * NW;
+        double nA[D][RG][NTR];
+        staged_loop<D>(
+            N,
+            [&](int k, auto sl) {
+                constexpr int d = decltype(sl)::value;
+                static_for<RG>([&](auto rg_) {
+                    constexpr int rg = decltype(rg_)::value;
+#pragma unroll
+                    for (int tj = 0; tj < NTR; ++tj) nA[d][rg][tj] = BA[k * NX * NW + rbase + colnat[tj] + (4 * rg - (rg >= GQ ? NU : 0)) * NW];
+                });
+            },
+            [&](int k, auto sl, auto refill) {
+                constexpr int d = decltype(sl)::value;
+                double Ak[RG][NTR], vop[RG];
+                static_for<RG>([&](auto rg_) {
+                    constexpr int rg = decltype(rg_)::value;
+#pragma unroll
+                    for (int tj = 0; tj < NTR; ++tj) {
+                        double v = nA[d][rg][tj];
+                        if constexpr (rg == GQ) v = padl ? 0.0 : v;
+                        if constexpr (RAGGED && rg == RG - 1) v = 4 * rg + lr < NW ? v : 0.0;
+                        Ak[rg][tj] = v;
+                    }
+                    vop[rg] = lnu[(k + 1) * O::HBS + 4 * rg + lr];
+                });
+                refill();
+                d4_t acc[NTR];
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti) acc[ti] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < RG; ++ks)
+#pragma unroll
+                    for (int ti = 0; ti < NTR; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[ks][ti], vop[ks], acc[ti], 0, 0, 0);
+                if (lc == 0)
+                    static_for<RG>([&](auto rg_) {
+                        constexpr int rg = decltype(rg_)::value;
+                        ly[k * O::HBS + 4 * rg + lr] = acc[rg / 4][rg % 4];
+                    });
+            });
+        wave_sync();
+    }
+
+    // ---- residuals of the QP at its START (what qp_solve asks for with the residual scaling on: later iterations scale them):
+    // there the direction of every stage but the first is zero — dx_0 = x0 - X_0 and a pinned du_0 are the only entries of (dx, du)
+    // the QP starts with — so  rb_k = r_k,  rg_k = q_k -+ lam + [B A]_k' nuq_{k+1} - [0; nuq_k], plus [B A]_0 dv_0 and c_0 H dv_0 at
+    // stage 0 where dv_0 != 0 (first QP of a warm solve from a new initial state).  One MFMA pass + one pass over the entries,
+    // against a stage-serial pass with [B A]_k staged through LDS (round 3: 7 % / 14 % of the kernel at n_mass 5 / 7).
+    MPCRL_DI double qp_residuals2() {
+        using O = OmCfg<M>;
+        const int ne = (N + 1) * NW;
+        double *const lnu = lds + Cfg::oBig, *const ly = lnu + (N + 1) * O::HBS;
+        wt_nu_pass(nuq, lnu, ly);
+        double rloc = 0.0;
+        batched_pass<4>(ne, lane,
+                        [&](int e) {
+                            const int k = e / NW, i = e - k * NW;
+                            return Quad4{q[e], lam[e], lam[ne + e], (i >= NU && k > 0) ? nuq[k * NX + i - NU] : 0.0};
+                        },
+                        [&](int e, const Quad4 &v) {
+                            const int k = e / NW, i = e - k * NW;
+                            double g = v.a;
+                            if (!skipc(k, i)) {
+                                if (has(0, k, i)) g -= v.b;
+                                if (has(1, k, i)) g += v.c;
+                            }
+                            g += (k < N ? ly[k * O::HBS + om_slot(i)] : 0.0) - v.d;
+                            if (fixedc(k, i) || skipc(k, i)) g = 0.0;
+                            rg[e] = g, rloc = fmax(rloc, fabs(g));
+                        });
+        batched_pass<8>(N * NX, lane, [&](int e) { return r[e]; }, [&](int e, double v) { rb[e] = v, rloc = fmax(rloc, fabs(v)); });
+        wave_sync();
+        // stage 0 with a non-zero direction: one row / column per lane
+        double d0 = 0.0;
+        if (lane < NX) d0 = fabs(dx[lane]);
+        if (lane < NU) d0 = fmax(d0, fabs(du[lane]));
+        if (wave_max(d0) > 0.0) {
+            double dv[NW];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) dv[j] = j < NU ? du[j < NU ? j : 0] : dx[j >= NU ? j - NU : 0];
+            if (lane < NX) {
+                double a = rb[lane];
+#pragma unroll 4
+                for (int j = 0; j < NW; ++j) a = fma(BA[lane * NW + j], dv[j], a);
+                rb[lane] = a, rloc = fmax(rloc, fabs(a));
+            }
+            if (lane < NW && !fixedc(0, lane)) {
+                double hd = 0.0;
+#pragma unroll 4
+                for (int j = 0; j < NW; ++j) hd = fma(M::hess(false, lane < NW ? lane : 0, j, th), dv[j], hd);
+                const double g = fma(ck(0), hd, rg[lane]);
+                rg[lane] = g, rloc = fmax(rloc, fabs(g));
+            }
+            wave_sync();
+        }
+        return rloc;
+    }
+
     // STORE_P: P_k goes to HBM as well (only the adjoint solves of the sensitivities multiply with it afterwards: forward2<true>).
     template <class HS, bool STORE_P>
     MPCRL_DI bool factor2(HS &hs, const WsArr g, const WsArr bb) {
         using O = OmCfg<M>;
-        constexpr int RG = O::RG, NT = O::NT, NTR = O::NTR, GQ = O::GQ, TQ = O::TQ, RQ = O::RQ, LQ = O::LQ, TV = O::TV, LV = O::LV, FD = 2;
+        constexpr int RG = O::RG, NT = O::NT, NTR = O::NTR, GQ = O::GQ, TQ = O::TQ, RQ = O::RQ, LQ = O::LQ, TV = O::TV, LV = O::LV;
+        constexpr int FD = NTR <= 2 ? 2 : 1;     // prefetch slots (a stage is 3 - 9 us of work: one stage ahead covers the HBM latency; registers at n_mass 7)
         constexpr bool RAGGED = 4 * RG > NW;     // the last row group runs past NW
         const int lr = lane >> 4, lc = lane & 15;
         hs.begin(lane);
@@ -2323,7 +2460,10 @@ struct ChainSolver {
     }
     __device__ MPCRL_PHASE_FN static double qp_residuals_call(Ctx c) {
         ChainSolver S = from_ctx(c);
-        return S.qp_residuals();
+        if constexpr (USE_V2 && MPCRL_CHAIN_SCALE_RES)
+            return S.qp_residuals2();
+        else
+            return S.qp_residuals();
     }
     // hex_off: workspace offset of the exact Hessian blocks (HessGlobal); the constant Hessian (HessConst) is rebuilt from theta
     template <class HS>
