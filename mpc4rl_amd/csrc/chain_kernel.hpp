@@ -57,7 +57,7 @@ constexpr double CHAIN_TOL_MU_FACTOR = 1.0;
 #define MPCRL_CHAIN_V2_ROUNDSTART 0
 #endif
 #ifndef MPCRL_CHAIN_V2_SENS_MAXNX
-#define MPCRL_CHAIN_V2_SENS_MAXNX 21   // ... in the adjoint solves of the sensitivities (exact Hessian from the workspace, P_k streamed)
+#define MPCRL_CHAIN_V2_SENS_MAXNX 33   // ... in the adjoint solves of the sensitivities (exact Hessian from the workspace, P_k streamed)
 #endif
 
 struct LargeSpec {
@@ -143,7 +143,7 @@ struct LargeLayout {
         Acl = take((size_t)N * ChainCfgStride<NX, NW>::BST), hb = take((size_t)N * NX), ccv = take((size_t)N * NX), cvec = take((size_t)N * NX);
         Hex = take((size_t)(N + 1) * NW * NW), term = take((size_t)N * NTD), ynu = take((size_t)(N + 1) * NX);
         state = take(16);   // ST_* below: the SQP loop's per-instance state between launches
-        Ydx = take((size_t)NU * (N + 1) * NX), Ydu = take((size_t)NU * N * NU), Ydnu = take((size_t)NU * (N + 1) * NX);   // adjoint solutions
+        Ydx = take((size_t)NU * (N + 1) * NX + 2), Ydu = take((size_t)NU * N * NU), Ydnu = take((size_t)NU * (N + 1) * NX + 2);   // adjoint solutions
         term2 = take((size_t)NU * N * NTD);
         // per stage: coefficients of the 8 evaluation points of the RK4 map (chain_point_kernel), and the link Hessians of the adjoint
         ptab = take((size_t)N * 8 * M::NL * M::TAB2), gtab = take((size_t)N * 8 * M::NL * 6);
@@ -2071,6 +2071,113 @@ struct ChainSolver {
         wave_sync();
     }
 
+    // ---- the NU adjoint solves of the sensitivities in ONE forward sweep: right-hand side -e_iu in the controls of stage 0, no
+    // dynamics offset, so p_k = 0 and kff_k = 0 for k >= 1 and kff_0 = -R_0^-1 e_iu; solve iu rides in column iu of the B operand
+    // (the 16 columns of the MFMA cost the same as one).  Out: Ydx / Ydu / Ydnu [iu][...] as chain_sens_mix / chain_sens_out read them.
+    MPCRL_DI void forward2_sens(const WsArr Ydx, const WsArr Ydu, const WsArr Ydnu) {
+        using O = OmCfg<M>;
+        constexpr int RG = O::RG, NTR = O::NTR, GQ = O::GQ, TV = O::TV, LV = O::LV, D = NTR <= 2 ? 3 : 1;
+        constexpr bool RAGGED = 4 * RG > NW;
+        const int lr = lane >> 4, lc = lane & 15;
+        const bool padl = lr < NU, col = lc < NU;
+        const int sx = (N + 1) * NX, su = N * NU, cj = col ? lc : 0;
+        unsigned tfull[NTR], tcomp[NTR], poffs[NTR];
+#pragma unroll
+        for (int ti = 0; ti < NTR; ++ti) {
+            const int a_ = 16 * ti + lc, a = a_ < 4 * RG ? a_ : 4 * RG - 1;
+            tfull[ti] = (unsigned)((a >> 2) * TV * 64 + (a & 3) * 16 + lr);
+            tcomp[ti] = (unsigned)(RG * TV * 64 + (a >> 2) * O::CT + (a & 3) * LV + lr);
+            poffs[ti] = O::goff(0, ti, lr, lc);
+        }
+        for (int e = lane; e < NU * NX; e += NT) {
+            const int j = e / NX;
+            Ydx[j * sx + (e - j * NX)] = 0.0, Ydnu[j * sx + (e - j * NX)] = 0.0;
+        }
+        // -kff_0 of solve lc: column lc of R_0^-1, in the control slots
+        const double k0 = (padl && col) ? minv2[4 * lr + cj] : 0.0;
+        double w[RG];
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) w[rg] = 0.0;
+        w[GQ] = k0;
+        double nGt[D][NTR][RG], nP[D][RG][NTR];
+        staged_loop<D>(
+            N,
+            [&](int k, auto sl) {
+                constexpr int d = decltype(sl)::value;
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti)
+#pragma unroll
+                    for (int ks = 0; ks < RG; ++ks)
+                        nGt[d][ti][ks] = G2[k * O::GSZ + (ks / 4 < TV ? tfull[ti] + (ks / 4) * 64 : tcomp[ti]) + 4 * (ks % 4)];
+                static_for<RG>([&](auto rg_) {
+                    constexpr int rg = decltype(rg_)::value;
+#pragma unroll
+                    for (int ti = 0; ti < NTR; ++ti) nP[d][rg][ti] = P2[k * O::GSZ + poffs[ti] + rg * (ti < TV ? TV * 64 : O::CT)];
+                });
+            },
+            [&](int k, auto sl, auto refill) {
+                constexpr int d = decltype(sl)::value;
+                d4_t acc[NTR], acc2[NTR];
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti) acc[ti] = d4_t{0.0, 0.0, 0.0, 0.0}, acc2[ti] = d4_t{0.0, 0.0, 0.0, 0.0};
+                acc[GQ / 4][GQ % 4] = k == 0 ? k0 : 0.0;          // [b; -kff]: only -kff_0
+                w[GQ] = padl ? acc[GQ / 4][GQ % 4] : w[GQ];
+                double Gk[NTR][RG], Pk[RG][NTR];
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti)
+#pragma unroll
+                    for (int ks = 0; ks < RG; ++ks) Gk[ti][ks] = nGt[d][ti][ks];
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                    for (int ti = 0; ti < NTR; ++ti) Pk[rg][ti] = nP[d][rg][ti];
+                refill();
+#pragma unroll
+                for (int ks = 0; ks < RG; ++ks)
+#pragma unroll
+                    for (int ti = 0; ti < NTR; ++ti) {
+                        acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gk[ti][ks], w[ks], acc[ti], 0, 0, 0);
+                        acc2[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pk[ks][ti], w[ks], acc2[ti], 0, 0, 0);
+                    }
+                if (col)
+                    static_for<RG>([&](auto rg_) {
+                        constexpr int rg = decltype(rg_)::value;
+                        const double v = acc[rg / 4][rg % 4];
+                        const bool rok = (rg != GQ || !padl) && (!RAGGED || rg < RG - 1 || 4 * rg + lr < NW);
+                        if constexpr (rg == GQ)
+                            Ydx[padl ? (int)(Ydu.off - Ydx.off) + cj * su + k * NU + lr : cj * sx + (k + 1) * NX + om_xr<rg>(lr)] = v;
+                        else
+                            Ydx[rok ? cj * sx + (k + 1) * NX + om_xr<rg>(lr) : NU * sx] = v;
+                        Ydnu[(rok && k > 0) ? cj * sx + k * NX + om_xr<rg>(lr) : NU * sx] = acc2[rg / 4][rg % 4];
+                    });
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg) w[rg] = acc[rg / 4][rg % 4];
+            });
+        {   // terminal multiplier step: Dnu_N = P_N dx_N
+            d4_t acc2[NTR];
+            double Pk[RG][NTR];
+            static_for<RG>([&](auto rg_) {
+                constexpr int rg = decltype(rg_)::value;
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti) Pk[rg][ti] = P2[N * O::GSZ + poffs[ti] + rg * (ti < TV ? TV * 64 : O::CT)];
+            });
+#pragma unroll
+            for (int ti = 0; ti < NTR; ++ti) acc2[ti] = d4_t{0.0, 0.0, 0.0, 0.0};
+            w[GQ] = padl ? 0.0 : w[GQ];
+#pragma unroll
+            for (int ks = 0; ks < RG; ++ks)
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti) acc2[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Pk[ks][ti], w[ks], acc2[ti], 0, 0, 0);
+            if (col)
+                static_for<RG>([&](auto rg_) {
+                    constexpr int rg = decltype(rg_)::value;
+                    const bool rok = (rg != GQ || !padl) && (!RAGGED || rg < RG - 1 || 4 * rg + lr < NW);
+                    Ydnu[rok ? cj * sx + N * NX + om_xr<rg>(lr) : NU * sx] = acc2[rg / 4][rg % 4];
+                });
+        }
+        wave_sync();
+    }
+
     // ---- multipliers of the dynamics at the end of a QP, by ONE costate sweep instead of Dnu_k = p_k + P_k Dx_k in every
     // interior-point iteration (which made the factor sweep stream P_k out and the corrector's forward sweep stream it back in: 9 KB
     // of the 32 KB a stage moved per iteration at n_mass 5).  No step of the iteration uses nuq — the Riccati direction gives Dx, Du,
@@ -2485,6 +2592,10 @@ struct ChainSolver {
             S.backward_vec2(S.arr(g_off));
         else
             S.backward_vec(S.arr(g_off));
+    }
+    __device__ MPCRL_PHASE_FN static void forward_sens_call(Ctx c, unsigned ydx, unsigned ydu, unsigned ydnu) {
+        ChainSolver S = from_ctx(c);
+        S.forward2_sens(S.arr(ydx), S.arr(ydu), S.arr(ydnu));
     }
     __device__ MPCRL_PHASE_FN static void costate_call(Ctx c) {
         ChainSolver S = from_ctx(c);
@@ -3023,6 +3134,12 @@ __global__ void __launch_bounds__(64, 1) chain_sens_riccati_kernel(const LargeSp
     for (int e = lane; e < N * NX; e += NT) S.rb[e] = 0.0;   // no dynamics offset in the adjoint systems
     const WsArr Ydx{(char *)w, (unsigned)lay.Ydx}, Ydu{(char *)w, (unsigned)lay.Ydu}, Ydnu{(char *)w, (unsigned)lay.Ydnu};
     bool okall = true;
+    if constexpr (ChainSolver<M>::USE_V2_SENS) {      // one factor sweep, ONE forward sweep for the NU adjoint solves
+        for (int e = lane; e < ne; e += NT) S.rt[e] = e == 0 ? -1.0 : 0.0;
+        wave_sync();
+        okall = ChainSolver<M>::template factor_call<HessGlobal<M>>(S.ctx(), hs.hex_offset(), S.rt.off, S.rb.off);
+        ChainSolver<M>::forward_sens_call(S.ctx(), Ydx.off, Ydu.off, Ydnu.off);
+    } else
     for (int iu = 0; iu < NU; ++iu) {
         for (int e = lane; e < ne; e += NT) S.rt[e] = e == iu ? -1.0 : 0.0;
         wave_sync();
