@@ -12,6 +12,7 @@ reference's NLP.
 """
 import multiprocessing as mp
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -147,7 +148,7 @@ def test_chain5_bench_size_vs_port(oracle_port):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # mirror certification of the HIP iterate
 # ---------------------------------------------------------------------------------------------------------------------------------
-def _certify_batch(name, kw, mpc, r, x0, theta=None, u0=None, gamma=None, idx=None):
+def _certify_batch(name, kw, mpc, r, x0, theta=None, u0=None, gamma=None, idx=None, procs=8):
     from oracle.from_iterate import certify_job      # the worker lives in an importable module (fresh interpreters unpickle it)
     x, u, pi, bnd, _ = [t.cpu().numpy() for t in mpc.get_iterate()]
     V = r.V.cpu().numpy()
@@ -159,7 +160,7 @@ def _certify_batch(name, kw, mpc, r, x0, theta=None, u0=None, gamma=None, idx=No
     saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
     os.environ.update({k: "1" for k in saved})
     try:
-        with mp.get_context("spawn").Pool(min(8, len(jobs))) as pool:
+        with mp.get_context("spawn").Pool(min(procs, len(jobs))) as pool:
             rows = pool.map(certify_job, jobs, chunksize=1)
     finally:
         for k, v in saved.items():
@@ -246,6 +247,63 @@ def test_mirror_certifies_the_hip_iterate_chain():
         dk = r.dpi_dp.cpu().numpy()
         assert (np.abs(dk - dpi).reshape(B, -1).max(1) / np.abs(dpi).reshape(B, -1).max(1)).max() < RTOL
         assert rel_rows(mpc.get_lagrangian().cpu().numpy(), L).max() < RTOL
+
+
+def _cores():
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def test_mirror_certifies_the_bench_inputs():
+    """The only reference-anchored check of the repo on the inputs the benchmark itself times.
+      * cartpole: 256 of the 4096 instances of `bench.py` (bench.make_inputs(4096, rank 0), every 16th): the reference's update_nlp
+        thresholds (nlp.py:1445-1537) hold at the HIP iterate and dL/dp, dz/dp[:nu] of the mirror (nlp.py:1401,1410-1424) equal the
+        kernel's dV/dp, du0*/dp at 1e-6;
+      * chain n_mass 5: 16 instances of `bench.py --workload chain5` at the REFERENCE'S OWN tolerance 1e-5 (ocp_utils.py:311-312) —
+        what tests/test_chain_mass.py really asserts through update_nlp: its thresholds at the iterate acados would hand over;
+      * linear system: initial states that move AWAY from the soft bound x[0] >= 0 (x[1] >= 0), where no row ends weakly active and
+        the slacks are zero: du0*/dp at 1e-6 (the bench box [0.15, 0.85] x [-0.5, 0.5] is held to 1e-5 above for that reason)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from mpc4rl_amd import MPCBatch, cartpole_ocp, chain_mass_ocp, linear_system_ocp
+    procs = max(2, min(16, _cores()))
+    x0 = bench.make_inputs(4096, 0)
+    mpc = MPCBatch(cartpole_ocp(), 4096)
+    r = mpc.solve(x0, sens_v=True, sens_pi=True, cold=True)
+    assert bool((r.status == 0).all())
+    idx = np.arange(0, 4096, 16)
+    out = _certify_batch("cartpole", {}, mpc, r, x0, idx=idx, procs=procs)
+    _check_certified(r, mpc.get_lagrangian(), out, idx)
+    # chain, at the reference's tolerance
+    ocp = chain_mass_ocp(n_mass=5)
+    B = 16
+    rng = np.random.default_rng(0)
+    xc = np.tile(ocp.x0, (B, 1))
+    xc[:, 12:] += rng.normal(0.0, 1e-2, (B, 9))
+    mc = MPCBatch(ocp, B)
+    rc = mc.solve(xc, sens_v=True, sens_pi=True, cold=True)
+    assert bool((rc.status == 0).all())
+    dL, dpi, L, sc, smax, stat = _certify_batch("chain", {"n_mass": 5}, mc, rc, xc, procs=min(procs, 8))
+    e_dpi = (np.abs(rc.dpi_dp.cpu().numpy() - dpi).reshape(B, -1).max(1) / np.abs(dpi).reshape(B, -1).max(1)).max()
+    print("chain5 at tol 1e-5: dV/dp", float(rel_rows(rc.dV_dp.cpu().numpy(), dL).max()), "du0/dp", float(e_dpi), "stationarity", float(stat.max()))
+    assert rel_rows(rc.dV_dp.cpu().numpy(), dL).max() < RTOL and rel_rows(mc.get_lagrangian().cpu().numpy(), L).max() < RTOL
+    assert e_dpi < 1e-5          # both linearise at the same iterate, which is itself 1e-5 from the KKT point
+    # linear system away from the soft bound
+    B = 32
+    rng = np.random.default_rng(21)
+    xl = np.column_stack([rng.uniform(0.3, 0.9, B), rng.uniform(0.0, 0.6, B)])
+    for gamma in (0.99, 0.9):
+        ml = MPCBatch(linear_system_ocp(discount_factor=gamma), B)
+        rl = ml.solve(xl, sens_v=True, sens_pi=True, cold=True)
+        assert bool((rl.status == 0).all())
+        out = _certify_batch("linear", {"gamma": gamma}, ml, rl, xl, gamma=gamma, procs=procs)
+        _check_certified(rl, ml.get_lagrangian(), out, range(B), soft=True, dpi_tol=RTOL)
 
 
 def test_rccl_world1_allreduce_and_td3_step():
