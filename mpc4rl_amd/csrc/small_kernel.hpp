@@ -105,6 +105,9 @@ constexpr unsigned long long LANES_C0 = 0x1111111111111111ull, LANES_C1 = 0x2222
 #define MPCRL_V_ASMSEL 1
 #endif
 
+#ifndef MPCRL_SMALL_SCAN
+#define MPCRL_SMALL_SCAN 1      // vector sweeps of the stage-per-lane layout as parallel scans (SmallSolver::SCAN)
+#endif
 #ifndef MPCRL_IPM_SCALE_RES
 #define MPCRL_IPM_SCALE_RES 1
 #endif
@@ -369,7 +372,9 @@ struct SmallSolver {
     // Hs(i,j): UNSCALED stage Hessian accessor, multiplied by hscale where it is used (keeping the product out of registers:
     // a per-lane scale times 15-25 kernel-argument constants would otherwise be hoisted and held live across the whole loop);
     // Dg: barrier diagonal, g: modified gradient, bb: dynamics offset.
-    template <bool FACTOR, class HF>
+    // VEC = false: the matrix part only (P_k, K_k, 1/R_k) — tried with the vector recursion as a scan after the factor sweep: slower
+    // (3.93 vs 4.51 M solves/s: the scan costs more than the ~20 instructions it takes out of a factor step)
+    template <bool FACTOR, class HF, bool VEC = true>
     MPCRL_DI bool riccati_stage(const double *Pn, const double *pn, HF Hs, const double *g, const double *bb) {
         bool ok = true;
         double cc[NX], mv[NW];
@@ -384,6 +389,7 @@ struct SmallSolver {
             for (int i = 0; i < NX; ++i) p[i] = g[NU + i];
             return true;
         }
+        if constexpr (VEC) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             double a = pn[i];
@@ -399,6 +405,7 @@ struct SmallSolver {
 #pragma unroll
             for (int m = 0; m < NX; ++m) a = fma(BA(m, i), cc[m], a);
             mv[i] = a;
+        }
         }
         double Mm[NW * (NW + 1) / 2];
         if constexpr (FACTOR) {
@@ -478,6 +485,7 @@ struct SmallSolver {
                     P[sym(i, j)] = a;
                 }
         }
+        if constexpr (!VEC) return ok;
         if (first && qmode) {
 #pragma unroll
             for (int i = 0; i < NU; ++i) kff[i] = 0.0;
@@ -891,6 +899,122 @@ struct SmallSolver {
         return ok;
     }
 
+    // =====================================================================================================================
+    // Vector sweeps of the stage-per-lane layout as PARALLEL SCANS (round 4; the linear-system model: NX = 2, NU = 1, 41 stage lanes).
+    // On stored factors both vector recursions are affine,
+    //     backward  p_k      = Acl_k' (p_{k+1} + hb_{k+1}) + c_k,   c_k = g_x - K_k' g_u,   hb_{k+1} = P_{k+1} bb_k
+    //     forward   Dx_{k+1} = Acl_k Dx_k + d_k,                     d_k = bb_k - B_k kff_k,  Acl_k = A_k - B_k K_k,
+    // and affine maps compose associatively: (M2, v2) o (M1, v1) = (M2 M1, M2 v1 + v2).  A Hillis-Steele scan over the lanes of an
+    // instance gives every stage its composed map in ceil(log2(N + 1)) = 6 steps of (6 doubles through ds_bpermute + 6 fma pairs)
+    // instead of N + 1 = 41 serial steps in which ONE lane of the wavefront works (round 3: the three vector sweeps of an
+    // interior-point iteration were 31 % of a wavefront's life).  Everything off the recursion (kff, Du, Dnu) is stage-local.
+    // Same numbers as the serial sweeps up to the association of the products (the port runs the serial order).
+    static constexpr bool SCAN = !MX && NU == 1 && MPCRL_SMALL_SCAN != 0;
+    MPCRL_DI void compose_from(double (&Mm)[NX * NX], double (&vv)[NX], int s, bool up, bool valid) {
+        // partner = lane -/+ s; this lane's map is applied AFTER (forward: partner covers earlier stages) / BEFORE ... in both sweeps
+        // the own map is the OUTER one: new = own o partner
+        double Mp[NX * NX], vp[NX];
+#pragma unroll
+        for (int i = 0; i < NX * NX; ++i) Mp[i] = up ? __shfl_up(Mm[i], s) : __shfl_down(Mm[i], s);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) vp[i] = up ? __shfl_up(vv[i], s) : __shfl_down(vv[i], s);
+        double Mn[NX * NX], vn[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double a = vv[i];
+#pragma unroll
+            for (int m = 0; m < NX; ++m) a = fma(Mm[i * NX + m], vp[m], a);
+            vn[i] = a;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                double b = 0.0;
+#pragma unroll
+                for (int m = 0; m < NX; ++m) b = fma(Mm[i * NX + m], Mp[m * NX + j], b);
+                Mn[i * NX + j] = b;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) vv[i] = valid ? vn[i] : vv[i];
+#pragma unroll
+        for (int i = 0; i < NX * NX; ++i) Mm[i] = valid ? Mn[i] : Mm[i];
+    }
+    // vector-only backward sweep (what backward<false> computes: p_k, kff_k on the stored K, Li, P)
+    MPCRL_DI void backward_scan(const double *g, const double *bb) {
+        double hb[NX], hbn[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) a = fma(P[sym(i, j)], lane_up(bb[j]), a);
+            hb[i] = a;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) hbn[i] = lane_dn(hb[i]);
+        double Mm[NX * NX], vv[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double c = g[NU + i];
+#pragma unroll
+            for (int u_ = 0; u_ < NU; ++u_) c = fma(-K[u_ * NX + i], g[u_], c);
+#pragma unroll
+            for (int m = 0; m < NX; ++m) {
+                double a = Aget(m * NX + i);
+#pragma unroll
+                for (int u_ = 0; u_ < NU; ++u_) a = fma(-Bget(m * NU + u_), K[u_ * NX + i], a);
+                Mm[i * NX + m] = term ? 0.0 : a;          // (Acl')(i, m); the terminal lane is the constant map p_N = g_x
+                c = term ? c : fma(a, hbn[m], c);
+            }
+            vv[i] = term ? g[NU + i] : c;
+        }
+        for (int s = 1; s <= N; s <<= 1) compose_from(Mm, vv, s, false, k + s <= N);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) p[i] = vv[i];
+        // feed-forward: kff = (g_u + B' (p_{k+1} + hb_{k+1})) / R
+        double mvu = g[0];
+#pragma unroll
+        for (int m = 0; m < NX; ++m) mvu = fma(Bget(m * NU), lane_dn(p[m] + hb[m]), mvu);
+        if (!term) kff[0] = (first && qmode) ? 0.0 : mvu * Li[0];
+    }
+    // forward sweep (what forward() computes: Dx, Du, Dnu)
+    MPCRL_DI void forward_scan(const double *bb) {
+        double Mm[NX * NX], vv[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double d = bb[i];
+#pragma unroll
+            for (int u_ = 0; u_ < NU; ++u_) d = fma(-Bget(i * NU + u_), kff[u_], d);
+            vv[i] = term ? 0.0 : d;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                double a = Aget(i * NX + j);
+#pragma unroll
+                for (int u_ = 0; u_ < NU; ++u_) a = fma(-Bget(i * NU + u_), K[u_ * NX + j], a);
+                Mm[i * NX + j] = term ? (i == j ? 1.0 : 0.0) : a;
+            }
+        }
+        for (int s = 1; s <= N; s <<= 1) compose_from(Mm, vv, s, true, k - s >= 0);
+        // lane k now holds Dx_{k+1} (its composed map applied to Dx_0 = 0)
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const double xin = lane_up(vv[i]);
+            Dx[i] = first ? 0.0 : xin;
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            double a = -kff[i];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) a = fma(-K[i * NX + j], Dx[j], a);
+            Du[i] = a;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double a = p[i];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) a = fma(P[sym(i, j)], Dx[j], a);
+            Dnu[i] = first ? 0.0 : a;
+        }
+    }
+
     // ---- forward sweep: Newton step (Dx, Du) and the multipliers Dnu of the arriving dynamics ------
     MPCRL_DI void forward(const double *bb) {
 #pragma unroll
@@ -1140,7 +1264,7 @@ struct SmallSolver {
             else {
                 okf = backward<true>(Hs, rt, rb);
                 PHW(2);
-                forward(rb);
+                if constexpr (SCAN) forward_scan(rb); else forward(rb);
                 PHW(3);
             }
             double okbad = okf ? 0.0 : 1.0;   // reduced together with the predictor's step length below
@@ -1242,9 +1366,9 @@ struct SmallSolver {
                 mx_corr(rt, rb);
             else {
                 PHW(5);
-                backward<false>(Hs, rt, rb);
+                if constexpr (SCAN) backward_scan(rt, rb); else backward<false>(Hs, rt, rb);
                 PHW(6);
-                forward(rb);
+                if constexpr (SCAN) forward_scan(rb); else forward(rb);
                 PHW(7);
             }
             rmax = 1.0;
@@ -1364,9 +1488,11 @@ struct SmallSolver {
                 if (iu == 0) {
                     const bool okf = backward<true>(Hs, rt, zero);
                     okall = seg_max<M::SEG_SKIP>(okf ? 0.0 : 1.0, k, lpi, base) < 0.5;
-                } else
+                } else if constexpr (SCAN)
+                    backward_scan(rt, zero);
+                else
                     backward<false>(Hs, rt, zero);
-                forward(zero);
+                if constexpr (SCAN) forward_scan(zero); else forward(zero);
             }
             double ynn[NX], yv[NW];
 #pragma unroll
