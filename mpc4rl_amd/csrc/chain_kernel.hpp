@@ -769,9 +769,15 @@ struct ChainSolver {
                     wave_sync();
                     a = lds_dot<NX>(lBA + lj, NW, lnu, a);
                     if (lane < NW && !fixedc(k, lane)) rs = fmax(rs, fabs(a));
+                    // the vector itself stays in rg: it IS the stationarity residual the next QP starts from (qp_start_residuals)
+                    if (USE_V2 && lane < NW) rg[k * NW + lane] = fixedc(k, lane) ? 0.0 : a;
                     wave_sync();
                 });
-            if (lane >= NU && lane < NW) rs = fmax(rs, fabs(rg[N * NW + lane] - NUv[N * NX + lane - NU]));
+            if (lane >= NU && lane < NW) {
+                const double a = rg[N * NW + lane] - NUv[N * NX + lane - NU];
+                rs = fmax(rs, fabs(a));
+                if (USE_V2) rg[N * NW + lane] = a;
+            }
         }
         for (int r_ = lane; r_ < nrows; r_ += NT) {
             int k, i;
@@ -1523,8 +1529,23 @@ struct ChainSolver {
                         });
         batched_pass<8>(N * NX, lane, [&](int e) { return r[e]; }, [&](int e, double v) { rb[e] = v, rloc = fmax(rloc, fabs(v)); });
         wave_sync();
-        // stage 0 with a non-zero direction: one row / column per lane
-        double d0 = 0.0;
+        rloc = fmax(rloc, stage0_direction_terms());
+        return rloc;
+    }
+
+    // ---- the same at no pass over the [B A]_k: round_start evaluated rg at the multipliers the QP starts from (qp_solve, rg_ready)
+    MPCRL_DI double qp_start_residuals() {
+        const int ne = (N + 1) * NW;
+        double rloc = 0.0;
+        batched_pass<8>(ne, lane, [&](int e) { return rg[e]; }, [&](int, double v) { rloc = fmax(rloc, fabs(v)); });
+        batched_pass<8>(N * NX, lane, [&](int e) { return r[e]; }, [&](int e, double v) { rb[e] = v, rloc = fmax(rloc, fabs(v)); });
+        wave_sync();
+        return fmax(rloc, stage0_direction_terms());
+    }
+    // stage 0 with a non-zero direction (dx_0 = x0 - X_0 of a warm solve from a new state, a pinned du_0): [B A]_0 dv_0 into rb_0,
+    // c_0 H dv_0 into rg_0; one row / column per lane.  Returns the largest entry it changed.
+    MPCRL_DI double stage0_direction_terms() {
+        double rloc = 0.0, d0 = 0.0;
         if (lane < NX) d0 = fabs(dx[lane]);
         if (lane < NU) d0 = fmax(d0, fabs(du[lane]));
         if (wave_max(d0) > 0.0) {
@@ -2314,7 +2335,9 @@ struct ChainSolver {
 
     // ---- Mehrotra predictor-corrector on the QP of the current linearisation (hard bounds) --------------------
     template <class HS>
-    MPCRL_DI bool qp_solve(HS &hs, const double *x0, const double *u0f, int &n_it, double warm_mu, double tol_res, double tol_mu) {
+    // rg_ready: rg holds q -+ lam + [B A]' NUv - [0; NUv] of this linearisation (round_start left it there) and the QP starts from
+    // nuq = NUv (warm) or from NUv = 0 (cold): its starting residual needs no pass over the [B A]_k
+    MPCRL_DI bool qp_solve(HS &hs, const double *x0, const double *u0f, int &n_it, double warm_mu, double tol_res, double tol_mu, bool rg_ready = false) {
         const bool warm = warm_mu > 0.0;
         const int ne = (N + 1) * NW;
         for (int e = lane; e < (N + 1) * NX; e += NT) dx[e] = e < NX ? x0[e] - X[e] : 0.0, nuq[e] = warm ? NUv[e] : 0.0;
@@ -2326,11 +2349,14 @@ struct ChainSolver {
             row_of(r_, k, i);
             const int e = k * NW + i;
             const double v = vc(k, i) + dvc(dx, du, k, i);
+            double drg = 0.0;      // the multipliers of this row change: so does its entry of the stationarity residual
             for (int sd = 0; sd < 2; ++sd)
                 if (has(sd, k, i)) {
                     cnt += 1.0;
+                    const double l_old = LAM(sd, e);
+                    double l_new;
                     if (warm) {
-                        double l = LAM(sd, e), tt = fmax(bslack(sd, k, i, v), TT(sd, e));
+                        double l = l_old, tt = fmax(bslack(sd, k, i, v), TT(sd, e));
                         if (l * tt < warm_mu) {
                             if (l >= tt)
                                 tt = warm_mu / l;
@@ -2338,12 +2364,16 @@ struct ChainSolver {
                                 l = warm_mu / tt;
                         }
                         LAM(sd, e) = l, TT(sd, e) = tt;
+                        l_new = l;
                     } else {
                         const double tt = fmax(bslack(sd, k, i, v), IPM_T_MIN);
                         TT(sd, e) = tt;
-                        LAM(sd, e) = IPM_MU0 / tt;
+                        l_new = IPM_MU0 / tt;
+                        LAM(sd, e) = l_new;
                     }
+                    drg += sd ? l_new - l_old : l_old - l_new;
                 }
+            if (rg_ready && !skipc(k, i) && !fixedc(k, i)) rg[e] += drg;
         }
         const double n_rows = wave_sum(cnt);
         wave_sync();
@@ -2355,7 +2385,7 @@ struct ChainSolver {
             // along a direction that solves the Newton system takes them to (1 - alpha) times their value, exactly — they are
             // scaled at the end of the iteration instead of being re-evaluated (a sweep over all [B A]_k: 161 KB per instance at
             // n_mass 5, 10 % of the kernel).  Only the bound rows below depend on the step nonlinearly (complementarity).
-            if (!MPCRL_CHAIN_SCALE_RES || it == 0) rlin = wave_max(qp_residuals_call(ctx()));
+            if (!MPCRL_CHAIN_SCALE_RES || it == 0) rlin = wave_max((rg_ready && it == 0) ? qp_start_residuals() : qp_residuals_call(ctx()));
             double rloc = rlin, muloc = 0.0;
             for (int r_ = lane; r_ < nrows; r_ += NT) {
                 int k, i;
@@ -2895,7 +2925,9 @@ __global__ void __launch_bounds__(64, 1) chain_sqp_kernel(const LargeSpec sp, co
         // the SQP Hessian: this lane's tiles of (R, Q) without c_k, in registers
         HessConst<M> hs;
         hs.th = S.th, hs.sck = S.sCK();
-        if (!S.qp_solve(hs, x0, u0f, n_ipm, warm_mu, tol_res, tol_mu)) {
+        // (MPCRL_COLD_DUAL keeps the stored multipliers of the dynamics while the QP starts from zero ones: not the same residual)
+        const bool rg_ready = ChainSolver<M>::USE_V2 && MPCRL_CHAIN_SCALE_RES && (stepn >= 0.0 || !(a.flags & 16));
+        if (!S.qp_solve(hs, x0, u0f, n_ipm, warm_mu, tol_res, tol_mu, rg_ready)) {
             status = 4;
             break;
         }
