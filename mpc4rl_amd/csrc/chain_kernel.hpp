@@ -3243,60 +3243,73 @@ __global__ void __launch_bounds__(256) chain_sens_mix_kernel(const LargeSpec sp,
 // One output element per lane: slot 0 = dV/dp (with MPCRL_SENS_V), slots 1..NU = rows of du0*/dp (with MPCRL_SENS_PI).
 // Each element is a sum over the stages of per-stage terms left in the workspace, or of closed forms in (X, U, adjoint solution).
 template <class M>
-__global__ void __launch_bounds__(256) chain_sens_out_kernel(const LargeSpec sp, const LargeArgs a) {
+__global__ void __launch_bounds__(1024) chain_sens_out_kernel(const LargeSpec sp, const LargeArgs a) {
     constexpr int NX = M::NX, NU = M::NU, NTD = M::NTD, NP = M::NP;
     constexpr int NE = NTD + NX * NX + NU * NU;   // elements per slot: dynamics parameters, Q (column-major), R
+    constexpr int PER = (NU + 1) * NE;
     const int N = sp.N;
-    // stage weights c_k once per workgroup (a pow() per stage and lane was most of this kernel's time)
-    __shared__ double cks[64];   // N + 1 <= 64 (mpcrl_create)
-    for (int k = threadIdx.x; k <= N; k += 256) {
+    // One workgroup of 1024 lanes per INSTANCE.  The Q / R outputs are sums over the stages of products of two trajectory entries:
+    // the trajectories (X - x_ss, U, the NU adjoint solutions: 32 KB at n_mass 5) are staged in LDS once, coalesced, and every lane
+    // then takes outputs rem = lane, lane + 1024, ...  (Round 3 ran one lane per output on 256-lane workgroups that each went to
+    // global memory with 64 different addresses per load instruction: 0.22 ms; staged per 256 outputs: 0.20 ms — the staging latency
+    // of 8 workgroups per instance, 6 rounds of them on the chip, was the time.)
+    extern __shared__ double sm[];
+    double *cks = sm, *lX = sm + 64, *lU = lX + (N + 1) * NX, *lY = lU + N * NU;   // lY: [NU][(N+1) NX + N NU]
+    const int inst = blockIdx.x, tid = threadIdx.x;
+    const int status = a.status[inst];
+    if (!(status == 0 || status == 2)) return;
+    const bool want_v = (a.flags & 1) && a.dV, want_pi = (a.flags & 2) && a.dpi && !a.u0fix;
+    const LargeLayout<M> lay(N);
+    const double *w = a.ws + (size_t)inst * a.ws_stride;
+    const double *X = a.X + (size_t)inst * (N + 1) * NX, *U = a.U + (size_t)inst * N * NU, *xs = sp.consts;
+    const int ny = (N + 1) * NX + N * NU;
+    for (int k = tid; k <= N; k += 1024) {
         double c = k == N ? 1.0 : sp.dT;
         if (sp.cost_kind != 0) c = k == 0 ? sp.dT : (k == N ? pow(sp.gamma, (double)N) : pow(sp.gamma, (double)k) * sp.dT);
         cks[k] = c;
     }
+    for (int e = tid; e < (N + 1) * NX; e += 1024) lX[e] = X[e] - xs[e % NX];
+    for (int e = tid; e < N * NU; e += 1024) lU[e] = U[e];
+    if (want_pi)
+        for (int e = tid; e < NU * ny; e += 1024) {
+            const int iu = e / ny, o = e - iu * ny;
+            lY[e] = o < (N + 1) * NX ? w[lay.Ydx + (size_t)iu * (N + 1) * NX + o] : w[lay.Ydu + (size_t)iu * N * NU + (o - (N + 1) * NX)];
+        }
     __syncthreads();
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const int per = (NU + 1) * NE;
-    const int inst = (int)(gid / per);
-    if (inst >= a.B) return;
-    const int status = a.status[inst];
-    if (!(status == 0 || status == 2)) return;
-    const int rem = (int)(gid - (long)inst * per), slot = rem / NE, e0 = rem - slot * NE;
-    const bool want_v = (a.flags & 1) && a.dV, want_pi = (a.flags & 2) && a.dpi && !a.u0fix;
-    if (slot == 0 ? !want_v : !want_pi) return;
-    const LargeLayout<M> lay(N);
-    const double *w = a.ws + (size_t)inst * a.ws_stride;
-    const double *X = a.X + (size_t)inst * (N + 1) * NX, *U = a.U + (size_t)inst * N * NU, *xs = sp.consts;
-    auto ck = [&](int k) { return cks[k]; };
-    const int iu = slot - 1;
-    const double *tm = slot == 0 ? w + lay.term : w + lay.term2 + (size_t)iu * N * NTD;
-    const double *Dx = w + lay.Ydx + (size_t)(iu < 0 ? 0 : iu) * (N + 1) * NX, *Du = w + lay.Ydu + (size_t)(iu < 0 ? 0 : iu) * N * NU;
-    double acc = 0.0;
-    int pidx;
-    if (e0 < NTD) {
-        for (int k = 0; k < N; ++k) acc += tm[k * NTD + e0];
-        pidx = M::td_index(e0);
-    } else if (e0 < NTD + NX * NX) {
-        const int e = e0 - NTD, j = e / NX, i = e - j * NX;   // column-major position of Q(i, j)
-        if (slot == 0) {   // d/dQ_ij of sum_k c_k l_k (ocp_utils.py:276-277)
-            for (int k = 0; k <= N; ++k) acc = fma(0.5 * ck(k) * (X[k * NX + i] - xs[i]), X[k * NX + j] - xs[j], acc);
-        } else {           // y' d2 l / dv dQ_ij = 1/2 (y_i e_j + y_j e_i)
-            for (int k = 0; k <= N; ++k) acc += 0.5 * ck(k) * (Dx[k * NX + i] * (X[k * NX + j] - xs[j]) + Dx[k * NX + j] * (X[k * NX + i] - xs[i]));
-        }
-        pidx = M::OFF_Q + e;
-    } else {
-        const int ee = e0 - NTD - NX * NX, j = ee / NU, i = ee - j * NU;
-        if (slot == 0) {
-            for (int k = 0; k < N; ++k) acc = fma(0.5 * ck(k) * U[k * NU + i], U[k * NU + j], acc);
+    const bool sens_ok = w[lay.state + ST_STATUS] == 0.0;
+    for (int rem = tid; rem < PER; rem += 1024) {
+        const int slot = rem / NE, e0 = rem - slot * NE;
+        if (slot == 0 ? !want_v : !want_pi) continue;
+        const int iu = slot - 1;
+        const double *tm = slot == 0 ? w + lay.term : w + lay.term2 + (size_t)iu * N * NTD;
+        const double *Dx = lY + (iu < 0 ? 0 : iu) * ny, *Du = Dx + (N + 1) * NX;
+        double acc = 0.0;
+        int pidx;
+        if (e0 < NTD) {
+            for (int k = 0; k < N; ++k) acc += tm[k * NTD + e0];
+            pidx = M::td_index(e0);
+        } else if (e0 < NTD + NX * NX) {
+            const int e = e0 - NTD, j = e / NX, i = e - j * NX;   // column-major position of Q(i, j)
+            if (slot == 0) {   // d/dQ_ij of sum_k c_k l_k (ocp_utils.py:276-277)
+                for (int k = 0; k <= N; ++k) acc = fma(0.5 * cks[k] * lX[k * NX + i], lX[k * NX + j], acc);
+            } else {           // y' d2 l / dv dQ_ij = 1/2 (y_i e_j + y_j e_i)
+                for (int k = 0; k <= N; ++k) acc += 0.5 * cks[k] * (Dx[k * NX + i] * lX[k * NX + j] + Dx[k * NX + j] * lX[k * NX + i]);
+            }
+            pidx = M::OFF_Q + e;
         } else {
-            for (int k = 0; k < N; ++k) acc += 0.5 * ck(k) * (Du[k * NU + i] * U[k * NU + j] + Du[k * NU + j] * U[k * NU + i]);
+            const int ee = e0 - NTD - NX * NX, j = ee / NU, i = ee - j * NU;
+            if (slot == 0) {
+                for (int k = 0; k < N; ++k) acc = fma(0.5 * cks[k] * lU[k * NU + i], lU[k * NU + j], acc);
+            } else {
+                for (int k = 0; k < N; ++k) acc += 0.5 * cks[k] * (Du[k * NU + i] * lU[k * NU + j] + Du[k * NU + j] * lU[k * NU + i]);
+            }
+            pidx = M::OFF_R + ee;
         }
-        pidx = M::OFF_R + ee;
+        if (slot == 0)
+            a.dV[(size_t)inst * NP + pidx] = acc;
+        else
+            a.dpi[((size_t)inst * NU + iu) * NP + pidx] = sens_ok ? -acc : NAN;
     }
-    if (slot == 0)
-        a.dV[(size_t)inst * NP + pidx] = acc;
-    else
-        a.dpi[((size_t)inst * NU + iu) * NP + pidx] = (w[lay.state + ST_STATUS] == 0.0) ? -acc : NAN;
 }
 
 }  // namespace mpcrl

@@ -165,8 +165,10 @@ int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
             hipLaunchKernelGGL(chain_sens_riccati_kernel<M>, dim3(B), dim3(64), lds_bytes, st, h->large, a);
             hipLaunchKernelGGL(chain_sens_mix_kernel<M>, blocks((long)B * N * M::NU), dim3(256), 0, st, h->large, a);
         }
-        hipLaunchKernelGGL(chain_sens_out_kernel<M>, blocks((long)B * (M::NU + 1) * (M::NTD + M::NX * M::NX + M::NU * M::NU)), dim3(256), 0, st,
-                           h->large, a);
+        {   // one workgroup of 1024 lanes per instance; its trajectories staged in LDS (chain_sens_out_kernel)
+            const unsigned smem = (unsigned)((64 + (1 + M::NU) * ((N + 1) * M::NX + N * M::NU)) * sizeof(double));
+            hipLaunchKernelGGL(chain_sens_out_kernel<M>, dim3((unsigned)B), dim3(1024), smem, st, h->large, a);
+        }
         HIP_OK(hipGetLastError());
     }
     return 0;
