@@ -53,6 +53,9 @@ constexpr double CHAIN_TOL_MU_FACTOR = 1.0;
 #ifndef MPCRL_CHAIN_V2_MAXNX
 #define MPCRL_CHAIN_V2_MAXNX 33   // largest state dimension that runs the round-4 sweeps
 #endif
+#ifndef MPCRL_CHAIN_ROWS_IN_REGS
+#define MPCRL_CHAIN_ROWS_IN_REGS 1     // qp_solve_rows: the bound rows of a QP in registers (at most 128 rows)
+#endif
 #ifndef MPCRL_CHAIN_V2_ROUNDSTART
 #define MPCRL_CHAIN_V2_ROUNDSTART 0
 #endif
@@ -2333,11 +2336,240 @@ struct ChainSolver {
         wave_sync();
     }
 
-    // ---- Mehrotra predictor-corrector on the QP of the current linearisation (hard bounds) --------------------
+    // ---- the interior-point iteration of qp_solve (below) with the BOUND ROWS IN REGISTERS (round 4; at most 128 rows: two per lane — the chain
+    // problems bound the controls only, 3 x 40 rows).  Every row phase of qp_solve below is a pass over the rows through the
+    // workspace: multipliers, slacks, the row's entry of the iterate and of the direction — a global-memory round trip (~2 us with
+    // the chip streaming) per phase, ~27 of them per iteration, one lane-pass each.  Here a lane keeps its rows' (lam, t, aff, value,
+    // residual entry) for the whole QP; what the sweeps need (barrier diagonal, modified gradient at the rows) is stored, the
+    // direction at the rows is the one load per sweep, and the dense vector updates of an iteration are one fused pass.
     template <class HS>
+    MPCRL_DI bool qp_solve_rows(HS &hs, const double *x0, const double *u0f, int &n_it, double warm_mu, double tol_res, double tol_mu, bool rg_ready) {
+        const bool warm = warm_mu > 0.0;
+        const int ne = (N + 1) * NW;
+        for (int e = lane; e < (N + 1) * NX; e += NT) dx[e] = e < NX ? x0[e] - X[e] : 0.0, nuq[e] = warm ? NUv[e] : 0.0;
+        for (int e = lane; e < N * NU; e += NT) du[e] = (qmode && e < NU) ? u0f[e] - U[e] : 0.0;
+        wave_sync();
+        // ---- this lane's rows
+        bool on[2], hs_[2][2];
+        int re_[2];
+        unsigned doff[2], Doff[2];      // where the row's entry of (dx | du) and (Dx | Du) sits, relative to dx / Dx
+        double lb_[2], ub_[2], v0[2], dvq[2], rgr[2], lm[2][2], tt_[2][2], af[2][2];
+        double cnt = 0.0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r_ = lane + 64 * j;
+            on[j] = r_ < nrows;
+            int k = 0, i = 0;
+            if (on[j]) row_of(r_, k, i);
+            re_[j] = k * NW + i;
+            lb_[j] = lbv(k, i), ub_[j] = ubv(k, i);
+            hs_[j][0] = on[j] && has(0, k, i), hs_[j][1] = on[j] && has(1, k, i);
+            const bool isu = i < NU;
+            doff[j] = isu ? (du.off - dx.off) + (unsigned)((k < N ? k : 0) * NU + i) : (unsigned)(k * NX + i - NU);
+            Doff[j] = isu ? (Du.off - Dx.off) + (unsigned)((k < N ? k : 0) * NU + i) : (unsigned)(k * NX + i - NU);
+            v0[j] = on[j] ? vc(k, i) : 0.0;
+            dvq[j] = on[j] ? dx[(int)doff[j]] : 0.0;
+            rgr[j] = on[j] ? rg[re_[j]] : 0.0;
+            const double v = v0[j] + dvq[j];
+            double drg = 0.0;
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd) {
+                lm[j][sd] = 0.0, tt_[j][sd] = 1.0, af[j][sd] = 0.0;
+                if (hs_[j][sd]) {
+                    cnt += 1.0;
+                    const double l_old = LAM(sd, re_[j]), sl = sd ? ub_[j] - v : v - lb_[j];
+                    double l, t1;
+                    if (warm) {
+                        l = l_old, t1 = fmax(sl, TT(sd, re_[j]));
+                        if (l * t1 < warm_mu) {
+                            if (l >= t1)
+                                t1 = warm_mu / l;
+                            else
+                                l = warm_mu / t1;
+                        }
+                    } else {
+                        t1 = fmax(sl, IPM_T_MIN);
+                        l = IPM_MU0 / t1;
+                    }
+                    lm[j][sd] = l, tt_[j][sd] = t1;
+                    drg += sd ? l - l_old : l_old - l;
+                }
+            }
+            if (rg_ready && on[j] && !skipc(k, i) && !fixedc(k, i)) {
+                rgr[j] += drg;
+                rg[re_[j]] = rgr[j];
+            }
+        }
+        auto store_rows = [&]() {      // multipliers and slacks back to the workspace (next QP's warm start, the kernel's write-out)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int sd = 0; sd < 2; ++sd)
+                    if (hs_[j][sd]) LAM(sd, re_[j]) = lm[j][sd], TT(sd, re_[j]) = tt_[j][sd];
+        };
+        const double n_rows = wave_sum(cnt);
+        if (!rg_ready) store_rows();      // (qp_residuals reads lam from the workspace)
+        wave_sync();
+        bool ok = false, stepped = false;
+        double rlin = wave_max(rg_ready ? qp_start_residuals() : qp_residuals_call(ctx()));
+        if (!rg_ready) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rgr[j] = on[j] ? rg[re_[j]] : 0.0;
+        } else {      // the stage-0 terms of a warm solve from a new state may have touched this lane's entries
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rgr[j] = (on[j] && re_[j] < NW) ? rg[re_[j]] : rgr[j];
+        }
+        // rt = rg, Dg = 0 once: the rows rewrite their own entries in every pass, the other entries of rt follow rg in the fused update
+        batched_pass<8>(ne, lane, [&](int e) { return rg[e]; }, [&](int e, double v) { rt[e] = v, Dg[e] = 0.0; });
+        wave_sync();
+        for (int it = 0;; ++it) {
+            ph(7);
+            double rloc = rlin, muloc = 0.0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const double v = v0[j] + dvq[j];
+#pragma unroll
+                for (int sd = 0; sd < 2; ++sd)
+                    if (hs_[j][sd]) {
+                        rloc = fmax(rloc, fabs(tt_[j][sd] - (sd ? ub_[j] - v : v - lb_[j])));
+                        muloc = fma(lm[j][sd], tt_[j][sd], muloc);
+                    }
+            }
+            const double rinf = wave_max(rloc);
+            const double mu = n_rows > 0.0 ? wave_sum(muloc) / n_rows : 0.0;
+            if (rinf <= tol_res && mu <= tol_mu) {
+                ok = true;
+                break;
+            }
+            if (it >= IPM_MAX_ITER || !(rinf < 1e300)) break;
+            ++n_it;
+            ph(0);
+            double sigma_mu = 0.0, alpha = 1.0, dvr[2] = {0.0, 0.0};
+            bool fail = false;
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    double dg = 0.0, er = 0.0;
+                    const double v = v0[j] + dvq[j];
+#pragma unroll
+                    for (int sd = 0; sd < 2; ++sd)
+                        if (hs_[j][sd]) {
+                            const double l1 = lm[j][sd], t1 = tt_[j][sd];
+                            const double rd1 = t1 - (sd ? ub_[j] - v : v - lb_[j]);
+                            const double rm = fma(l1, t1, pass ? af[j][sd] - sigma_mu : 0.0);
+                            dg += l1 / t1;
+                            er += (sd ? -1.0 : 1.0) * (rm - l1 * rd1) / t1;
+                        }
+                    if (on[j]) {
+                        if (pass == 0) Dg[re_[j]] = dg;
+                        rt[re_[j]] = rgr[j] + er;
+                    }
+                }
+                wave_sync();
+                ph(1);
+                if (pass == 0) {
+                    if (!factor_call<HS>(ctx(), hs.hex_offset(), rt.off, rb.off)) fail = true;
+                    ph(2);
+                } else {
+                    backward_vec_call(ctx(), rt.off);
+                    ph(3);
+                }
+                forward_call<false>(ctx(), rb.off);
+                ph(4);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) dvr[j] = on[j] ? Dx[(int)Doff[j]] : 0.0;      // the direction at the rows: the one load of the pass
+                double amax = 1.0, muaff = 0.0;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const double v = v0[j] + dvq[j], dv = dvr[j];
+#pragma unroll
+                    for (int sd = 0; sd < 2; ++sd)
+                        if (hs_[j][sd]) {
+                            const double l1 = lm[j][sd], t1 = tt_[j][sd];
+                            const double rd1 = t1 - (sd ? ub_[j] - v : v - lb_[j]);
+                            const double rm = fma(l1, t1, pass ? af[j][sd] - sigma_mu : 0.0);
+                            const double dt1 = -rd1 + (sd ? -dv : dv);
+                            const double dl1 = (-rm - l1 * dt1) / t1;
+                            if (dl1 < 0.0) amax = fmin(amax, -l1 / dl1);
+                            if (dt1 < 0.0) amax = fmin(amax, -t1 / dt1);
+                        }
+                }
+                amax = -wave_max(-amax);
+                if (pass == 0) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const double v = v0[j] + dvq[j], dv = dvr[j];
+#pragma unroll
+                        for (int sd = 0; sd < 2; ++sd)
+                            if (hs_[j][sd]) {
+                                const double l1 = lm[j][sd], t1 = tt_[j][sd];
+                                const double rd1 = t1 - (sd ? ub_[j] - v : v - lb_[j]);
+                                const double dt1 = -rd1 + (sd ? -dv : dv);
+                                const double dl1 = (-l1 * t1 - l1 * dt1) / t1;
+                                muaff = fma(fma(amax, dl1, l1), fma(amax, dt1, t1), muaff);
+                                af[j][sd] = dl1 * dt1;
+                            }
+                    }
+                    const double mu_aff = n_rows > 0.0 ? wave_sum(muaff) / n_rows : 0.0;
+                    const double ratio = mu > 0.0 ? mu_aff / mu : 0.0;
+                    sigma_mu = ratio * ratio * ratio * mu;
+                } else
+                    alpha = fmin(1.0, fmax(IPM_FRAC, 1.0 - mu) * amax);   // fraction to the boundary -> 1 as mu -> 0
+            }
+            ph(5);
+            if (fail) break;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const double v = v0[j] + dvq[j], dv = dvr[j];
+#pragma unroll
+                for (int sd = 0; sd < 2; ++sd)
+                    if (hs_[j][sd]) {
+                        const double l1 = lm[j][sd], t1 = tt_[j][sd];
+                        const double rd1 = t1 - (sd ? ub_[j] - v : v - lb_[j]);
+                        const double rm = fma(l1, t1, af[j][sd] - sigma_mu);
+                        const double dt1 = -rd1 + (sd ? -dv : dv);
+                        const double dl1 = (-rm - l1 * dt1) / t1;
+                        lm[j][sd] = fma(alpha, dl1, l1);
+                        tt_[j][sd] = fma(alpha, dt1, t1);
+                    }
+                dvq[j] = fma(alpha, dvr[j], dvq[j]);      // (the same fma the dense update below applies to the entry)
+            }
+            // one fused pass: dx += alpha Dx, du += alpha Du, rg *= (1 - alpha) (and rt = rg), rb *= (1 - alpha)
+            const double om = 1.0 - alpha;
+            struct Upd {
+                double a, b, c, d, e, f;
+            };
+            batched_pass<4>(ne, lane,
+                            [&](int e) {
+                                const int ex = e < (N + 1) * NX ? e : 0, eu = e < N * NU ? e : 0, eb = e < N * NX ? e : 0;
+                                return Upd{rg[e], Dx[ex], dx[ex], Du[eu], du[eu], rb[eb]};
+                            },
+                            [&](int e, const Upd &v) {
+                                const double g = om * v.a;
+                                rg[e] = g, rt[e] = g;
+                                if (e < (N + 1) * NX) dx[e] = fma(alpha, v.b, v.c);
+                                if (e < N * NU) du[e] = fma(alpha, v.d, v.e);
+                                if (e < N * NX) rb[e] = om * v.f;
+                            });
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rgr[j] *= om;
+            rlin *= om;
+            stepped = true;
+            wave_sync();
+        }
+        store_rows();
+        wave_sync();
+        if (stepped) costate_call(ctx());      // nuq of the point the iteration ended at (no iteration: the warm multipliers stand)
+        return ok;
+    }
+
+    // ---- Mehrotra predictor-corrector on the QP of the current linearisation (hard bounds) --------------------
     // rg_ready: rg holds q -+ lam + [B A]' NUv - [0; NUv] of this linearisation (round_start left it there) and the QP starts from
     // nuq = NUv (warm) or from NUv = 0 (cold): its starting residual needs no pass over the [B A]_k
+    template <class HS>
     MPCRL_DI bool qp_solve(HS &hs, const double *x0, const double *u0f, int &n_it, double warm_mu, double tol_res, double tol_mu, bool rg_ready = false) {
+        if constexpr (USE_V2 && MPCRL_CHAIN_SCALE_RES && MPCRL_CHAIN_ROWS_IN_REGS)
+            if (nrows <= 128) return qp_solve_rows(hs, x0, u0f, n_it, warm_mu, tol_res, tol_mu, rg_ready);
         const bool warm = warm_mu > 0.0;
         const int ne = (N + 1) * NW;
         for (int e = lane; e < (N + 1) * NX; e += NT) dx[e] = e < NX ? x0[e] - X[e] : 0.0, nuq[e] = warm ? NUv[e] : 0.0;
