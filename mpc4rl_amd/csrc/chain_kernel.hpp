@@ -1711,12 +1711,14 @@ struct ChainSolver {
                             hbv[4 * ti + r] = Tt[ti][TV][r];
                             Tt[ti][TV][r] = fma(Pt[ti][TV][r], vcm, Tt[ti][TV][r]);
                         }
-                // ---- M = H + D + W' T, vector column g + W' (P b + p); column tile by column tile (T's is dead afterwards)
+                // ---- M = H + D + W' T, vector column g + W' (P b + p); column tile by column tile (T's is dead afterwards).  The column
+                // tile of the control group goes first: its diagonal tile feeds the Cholesky below, whose serial VALU chain (~1.5 k cycles)
+                // then runs in the shadow of the other column tiles' MFMAs
                 d4_t Mt[NTR][NT];
-#pragma unroll
-                for (int tj = 0; tj < NT; ++tj)
-                    static_for<NTR>([&](auto tm_) {
-                        constexpr int tm = decltype(tm_)::value;
+                auto m_column = [&](auto tj_) {
+                    constexpr int tj = decltype(tj_)::value;
+                    static_for<NTR>([&](auto tmo_) {
+                        constexpr int tmo = decltype(tmo_)::value, tm = tmo == 0 ? TQ : (tmo <= TQ ? tmo - 1 : tmo);     // row tile TQ first
                         d4_t acc;
                         static_for<4>([&](auto r_) {
                             constexpr int r = decltype(r_)::value, rg = 4 * tm + r;
@@ -1732,7 +1734,8 @@ struct ChainSolver {
                         for (int ks = 0; ks < RG; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wt[ks / 4][tm][ks % 4], Tt[ks / 4][tj][ks % 4], acc, 0, 0, 0);
                         Mt[tm][tj] = acc;
                     });
-                ph(11);
+                };
+                m_column(std::integral_constant<int, TQ>{});
                 // ---- Cholesky of the control block on broadcast values (every lane, redundantly), then its inverse
                 double Minv[NU][NU];
                 {
@@ -1754,7 +1757,12 @@ struct ChainSolver {
                             for (int m = 0; m < j; ++m) a -= Lc[i][m] * Lc[j][m];
                             if (i == j) {
                                 okc = okc && (a > 0.0);
-                                Lc[i][i] = 1.0 / sqrt(a);
+                                // 1 / sqrt(a) from the hardware seed + two Newton steps (~1 ulp): the pivot is a positive normal number
+                                // wherever the result is used, and an IEEE sqrt followed by an IEEE division is ~40 dependent
+                                // instructions on the critical path of every stage
+                                double y = __builtin_amdgcn_rsq(a);
+                                y = y * fma(-0.5 * a * y, y, 1.5);
+                                Lc[i][i] = y * fma(-0.5 * a * y, y, 1.5);
                             } else
                                 Lc[i][j] = a * Lc[j][j];
                         }
@@ -1781,6 +1789,10 @@ struct ChainSolver {
                             Minv[i][j] = a, Minv[j][i] = a;
                         }
                 }
+                static_for<NT>([&](auto tj_) {
+                    if constexpr (decltype(tj_)::value != TQ) m_column(tj_);
+                });
+                ph(11);
                 double minvop = 0.0;     // A operand of K = R^-1 [S | R | mv_u]: R^-1(i, l) at lane (lr = l, lc = i)
 #pragma unroll
                 for (int i = 0; i < NU; ++i)
