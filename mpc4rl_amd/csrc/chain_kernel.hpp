@@ -53,6 +53,9 @@ constexpr double CHAIN_TOL_MU_FACTOR = 1.0;
 #ifndef MPCRL_CHAIN_V2_MAXNX
 #define MPCRL_CHAIN_V2_MAXNX 33   // largest state dimension that runs the round-4 sweeps
 #endif
+#ifndef MPCRL_CHAIN_MIX2
+#define MPCRL_CHAIN_MIX2 1     // chain_sens_mix2_kernel (point tables) instead of chain_sens_mix_kernel (jets)
+#endif
 #ifndef MPCRL_CHAIN_ROWS_IN_REGS
 #define MPCRL_CHAIN_ROWS_IN_REGS 1     // qp_solve_rows: the bound rows of a QP in registers (at most 128 rows)
 #endif
@@ -132,7 +135,7 @@ template <class M>
 struct LargeLayout {
     static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD;
     size_t BA, r, q, dx, du, nuq, Dx, Du, Dnu, rg, rb, rt, Dg, lamw, tw, aff, P, p, K, L, kff, Acl, hb, ccv, cvec, Hex, term, ynu, state, Ydx, Ydu, Ydnu,
-        term2, ptab, gtab, G2, P2, hb2, minv2, mvu2, total;
+        term2, ptab, gtab, qvtab, G2, P2, hb2, minv2, mvu2, total;
     __host__ __device__ explicit LargeLayout(int N) {
         size_t o = 0;
         auto take = [&](size_t n) { size_t s = o; o += (n + 1) & ~(size_t)1; return s; };   // every array 16-byte aligned
@@ -150,6 +153,7 @@ struct LargeLayout {
         term2 = take((size_t)NU * N * NTD);
         // per stage: coefficients of the 8 evaluation points of the RK4 map (chain_point_kernel), and the link Hessians of the adjoint
         ptab = take((size_t)N * 8 * M::NL * M::TAB2), gtab = take((size_t)N * 8 * M::NL * 6);
+        qvtab = take((size_t)N * 8 * M::NL * 6);      // per evaluation point and link: force adjoint q (3), velocity difference dv (3) — chain_sens_mix2
         // round-4 sweeps: closed-loop blocks G_k, cost-to-go P_k (Omega register layout), hb_k = P_{k+1} b_k, R_k^-1, mv_u of the corrector
         G2 = take((size_t)N * OmCfg<M>::GSZ), P2 = take((size_t)(N + 1) * OmCfg<M>::GSZ + 64);
         hb2 = take((size_t)N * OmCfg<M>::HBS), minv2 = take((size_t)N * 16), mvu2 = take((size_t)N * 4);
@@ -2953,18 +2957,36 @@ __device__ MPCRL_PHASE_FN void chain_point_pass(const double *X, const double *U
         double xc[NX], acc[NX], kk[NX], xt[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) xc[i] = X[k * NX + i];
+        // (with SECOND also the velocity difference of every link at every evaluation point: the mixed term wants it, chain_sens_mix2)
+        auto store_dv = [&](const double *xs_, int e) {
+            if constexpr (SECOND) {
+                double *qv = w + lay.qvtab + ((size_t)k * 8 + e) * NL * 6;
+                constexpr int Mm = M::M;
+#pragma unroll
+                for (int i = 0; i < NL; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const double vr = i < Mm ? xs_[3 * (Mm + 1) + 3 * (i < Mm ? i : 0) + j] : u[j];
+                        qv[6 * i + 3 + j] = i ? vr - xs_[3 * (Mm + 1) + 3 * (i > 0 ? i - 1 : 0) + j] : vr;
+                    }
+            }
+        };
         for (int s = 0; s < steps; ++s) {
             double *tb = tab + (size_t)(4 * s) * NL * TS;
             M::template ode_coef<SECOND>(xc, u, th, kk, tb, true);
+            store_dv(xc, 4 * s);
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc[i] = kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
             M::template ode_coef<SECOND>(xt, u, th, kk, tb + NL * TS, true);
+            store_dv(xt, 4 * s + 1);
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
             M::template ode_coef<SECOND>(xt, u, th, kk, tb + 2 * NL * TS, true);
+            store_dv(xt, 4 * s + 2);
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + h * kk[i];
             M::template ode_coef<SECOND>(xt, u, th, kk, tb + 3 * NL * TS, true);
+            store_dv(xt, 4 * s + 3);
 #pragma unroll
             for (int i = 0; i < NX; ++i) xc[i] = xc[i] + (h / 6.0) * (acc[i] + kk[i]);
         }
@@ -2986,8 +3008,13 @@ __device__ MPCRL_PHASE_FN void chain_point_pass(const double *X, const double *U
 #pragma unroll
                 for (int i = 0; i < NX; ++i) Xb[i] = 0.0;
                 M::template ode_tan_T<TS>(tb, th, kb, Xb, q);
+                double *qv = w + lay.qvtab + ((size_t)k * 8 + e) * NL * 6;
 #pragma unroll
-                for (int i = 0; i < NL; ++i) M::link_hessian(tb + i * TS, q + 3 * i, Gt + ((size_t)e * NL + i) * 6);
+                for (int i = 0; i < NL; ++i) {
+                    M::link_hessian(tb + i * TS, q + 3 * i, Gt + ((size_t)e * NL + i) * 6);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) qv[6 * i + j] = q[3 * i + j];
+                }
             };
 #pragma unroll
             for (int i = 0; i < NX; ++i) kb[i] = (h / 6.0) * lb[i];
@@ -3482,6 +3509,148 @@ __global__ void __launch_bounds__(256) chain_sens_mix_kernel(const LargeSpec sp,
     disc_map_adj_p<M, true, Jet1<1>>(jx, ju, th, lm, xb, ub, tb, sp.h, sp.rk_steps);
     double *term2 = w + lay.term2 + ((size_t)iu * N + k) * NTD;
     for (int d = 0; d < NTD; ++d) term2[d] = tb[d].d[0];
+}
+
+// ---- the mixed term on the POINT TABLES (round 4; replaces chain_sens_mix_kernel, whose forward-over-reverse jet sweep of the whole
+// RK4 map kept four stage states, four adjoint vectors and the parameter adjoint live as jets: 1 076 spilled registers and 3.3 KB of
+// scratch per lane at n_mass 5, 1 696 / 6 KB at n_mass 7 — 0.43 / 1.85 ms for 12 k flops per lane).  Per (instance, stage, control)
+//     term2 = d/d eps  grad_theta [nu' F](v + eps y_v, nu + eps y_nu)
+// F is RK4 steps of an ODE whose only nonlinearity is the spring force of each link, so everything second order is local to a
+// (evaluation point e, link i): with the point tables of chain_point_pass<true> (dist, spring coefficients; G_{e,i}; the force
+// adjoint q_{e,i} and the velocity difference dv_{e,i}) the sweep is
+//   1. the tangent of the evaluation states along y_v: plain ode_tan on the tables (what the direction pass does), one RK4 step at a time;
+//   2. the tangent of the reverse sweep: the same linear recursion as the values (ode_tan_T) on the tangent adjoints, plus the source
+//      (d dist / dx)' G_{e,i} d dist_{e,i} at every evaluation point;
+//   3. at every (e, i) the tangent of the parameter adjoint of ode_adj_p, written out in the table quantities.
+// ~170 doubles of live state, no jets, no scratch.
+template <class M>
+__global__ void __launch_bounds__(64) chain_sens_mix2_kernel(const LargeSpec sp, const LargeArgs a) {
+    constexpr int NX = M::NX, NU = M::NU, NTD = M::NTD, NL = M::NL, TAB2 = M::TAB2, MM = M::M;
+    // per lane in LDS ([index][lane]: conflict-free): the NTD accumulators of the parameter-adjoint tangent and the start state of
+    // the second RK4 step — with the evaluation states recomputed where they are used, what stays in registers is one evaluation
+    // state, one ODE tangent and the four adjoint vectors
+    extern __shared__ double sm[];
+    const int N = sp.N, lane = threadIdx.x;
+    double *thd = sm + lane, *dx1 = sm + NTD * 64 + lane;
+    const long gid = (long)blockIdx.x * 64 + threadIdx.x;
+    const int per = N * NU;
+    const int inst = (int)(gid / per);
+    if (inst >= a.B) return;
+    const int status = a.status[inst];
+    if (!(status == 0 || status == 2)) return;
+    const int it = (int)(gid - (long)inst * per), iu = it / N, k = it - iu * N;
+    const LargeLayout<M> lay(N);
+    double *w = a.ws + (size_t)inst * a.ws_stride;
+    const double *th = a.theta + (size_t)inst * a.theta_stride;
+    const double *tab = w + lay.ptab + (size_t)k * 8 * NL * TAB2, *Gt = w + lay.gtab + (size_t)k * 8 * NL * 6, *qv = w + lay.qvtab + (size_t)k * 8 * NL * 6;
+    const double *Ydx = w + lay.Ydx + (size_t)iu * (N + 1) * NX + (size_t)k * NX, *Ydu = w + lay.Ydu + (size_t)iu * N * NU,
+                 *Ydnu = w + lay.Ydnu + (size_t)iu * (N + 1) * NX;
+    const double h = sp.h;
+    const int steps = sp.rk_steps;
+    const double *mp = th, *Dp = th + NL, *Lp = th + 4 * NL;
+    double du[NU], lbd[NX];
+#pragma unroll
+    for (int c = 0; c < NU; ++c) du[c] = Ydu[k * NU + c];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) lbd[c] = Ydnu[(k + 1) * NX + c];
+#pragma unroll
+    for (int d = 0; d < NTD; ++d) thd[d * 64] = 0.0;
+    auto dx0 = [&](int s, int i) { return s == 0 ? Ydx[i] : dx1[i * 64]; };      // start state of step s
+    // evaluation state n (0..3) of step s into dX.  Runtime loops on purpose (no unrolling over the evaluation points): straight-line
+    // code over the eight points lets the scheduler stretch live ranges over all of them, and the kernel is back in scratch
+    auto state_at = [&](int s, int n, double (&dX)[NX]) {
+        const double *tb = tab + (size_t)(4 * s) * NL * TAB2;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dX[i] = dx0(s, i);
+#pragma unroll 1
+        for (int m = 0; m < n; ++m) {
+            double dk[NX];
+            M::template ode_tan<TAB2, false>(tb + (size_t)m * NL * TAB2, th, dX, du, dk, nullptr);
+            const double c = m == 2 ? h : 0.5 * h;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) dX[i] = dx0(s, i) + c * dk[i];
+        }
+    };
+    if (steps > 1) {      // start state of the second step: one full RK4 step of the tangent
+        const double *tb = tab;
+        double dX[NX], acc[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dX[i] = dx0(0, i), acc[i] = 0.0;
+#pragma unroll 1
+        for (int m = 0; m < 4; ++m) {
+            double dk[NX];
+            M::template ode_tan<TAB2, false>(tb + (size_t)m * NL * TAB2, th, dX, du, dk, nullptr);
+            const double c = m == 2 ? h : 0.5 * h, wgt = (m == 0 || m == 3) ? 1.0 : 2.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = fma(wgt, dk[i], acc[i]), dX[i] = dx0(0, i) + c * dk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dx1[i * 64] = dx0(0, i) + (h / 6.0) * acc[i];
+    }
+#pragma unroll 1
+    for (int s = steps - 1; s >= 0; --s) {
+        double kbd[NX], Xbd[NX], accd[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) accd[i] = lbd[i], Xbd[i] = 0.0;
+#pragma unroll 1
+        for (int n = 3; n >= 0; --n) {      // evaluation point e = 4 s + n: Xbd = J' kbd + Hessian source; parameter-adjoint tangents
+            // weights of the reverse RK4 sweep: kb_3 = h/6 lb, kb_2 = h/3 lb + h Xb_3, kb_1 = h/3 lb + h/2 Xb_2, kb_0 = h/6 lb + h/2 Xb_1
+            const double ca = (n == 3 || n == 0) ? h / 6.0 : h / 3.0, cb = n == 3 ? 0.0 : (n == 2 ? h : 0.5 * h);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) kbd[i] = ca * lbd[i] + cb * Xbd[i];
+            const int e = 4 * s + n;
+            const double *tb = tab + (size_t)e * NL * TAB2;
+            double qd[3 * NL], dX[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) Xbd[i] = 0.0;
+            M::template ode_tan_T<TAB2>(tb, th, kbd, Xbd, qd);
+#pragma unroll
+            for (int i = 0; i < 3 * MM; ++i) thd[(10 * NL + i) * 64] += kbd[3 * (MM + 1) + i];        // w enters the accelerations directly
+            state_at(s, n, dX);
+            const double *dpos = dX, *dvel = dX + 3 * (MM + 1);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const double *t = tb + i * TAB2, *G = Gt + ((size_t)e * NL + i) * 6, *q = qv + ((size_t)e * NL + i) * 6, *dv = q + 3;
+                double dd[3], ddv[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    dd[j] = i ? dpos[3 * i + j] - dpos[3 * (i > 0 ? i - 1 : 0) + j] : dpos[j];
+                    const double dvr = i < MM ? dvel[3 * (i < MM ? i : 0) + j] : du[j];
+                    ddv[j] = i ? dvr - dvel[3 * (i > 0 ? i - 1 : 0) + j] : dvr;
+                }
+                const double w0 = G[0] * dd[0] + G[1] * dd[1] + G[3] * dd[2], w1 = G[1] * dd[0] + G[2] * dd[1] + G[4] * dd[2],
+                             w2 = G[3] * dd[0] + G[4] * dd[1] + G[5] * dd[2];
+                const double wv[3] = {w0, w1, w2};
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    Xbd[3 * i + j] += wv[j];
+                    if (i > 0) Xbd[3 * (i > 0 ? i - 1 : 0) + j] -= wv[j];
+                }
+                const double inrm = sqrt(t[12] * (1.0 / 3.0)), sdot = t[0] * dd[0] + t[1] * dd[1] + t[2] * dd[2];
+                const double dinrm = -(inrm * inrm * inrm) * sdot, im = 1.0 / mp[i];
+                double thm = 0.0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double Lj = Lp[3 * i + j], dm = Dp[3 * i + j] * im;
+                    const double g = 1.0 - Lj * inrm, dg = -Lj * dinrm;
+                    const double fd = q[j] * t[j], dfd = qd[3 * i + j] * t[j] + q[j] * dd[j];
+                    const double dgd = im * (dfd * g + fd * dg);
+                    thd[(7 * NL + 3 * i + j) * 64] += qd[3 * i + j] * dv[j] + q[j] * ddv[j];
+                    thd[(NL + 3 * i + j) * 64] += dgd;
+                    thm -= dm * dgd;
+                    thd[(4 * NL + 3 * i + j) * 64] -= dm * (dfd * inrm + fd * dinrm);
+                }
+                thd[i * 64] += thm;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) accd[i] += Xbd[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) lbd[i] = accd[i];
+    }
+    double *term2 = w + lay.term2 + ((size_t)iu * N + k) * NTD;
+#pragma unroll
+    for (int d = 0; d < NTD; ++d) term2[d] = thd[d * 64];
 }
 
 // One output element per lane: slot 0 = dV/dp (with MPCRL_SENS_V), slots 1..NU = rows of du0*/dp (with MPCRL_SENS_PI).

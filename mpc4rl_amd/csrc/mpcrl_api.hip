@@ -163,7 +163,11 @@ int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
             hipLaunchKernelGGL((chain_point_kernel<M, true>), dim3((unsigned)(((long)B * N + 63) / 64)), dim3(64), 0, st, h->large, a);
             hipLaunchKernelGGL(chain_sens_ad_kernel<M>, dim3((unsigned)(B * N)), dim3(64), 0, st, h->large, a);
             hipLaunchKernelGGL(chain_sens_riccati_kernel<M>, dim3(B), dim3(64), lds_bytes, st, h->large, a);
-            hipLaunchKernelGGL(chain_sens_mix_kernel<M>, blocks((long)B * N * M::NU), dim3(256), 0, st, h->large, a);
+            if (MPCRL_CHAIN_MIX2)
+                hipLaunchKernelGGL(chain_sens_mix2_kernel<M>, dim3((unsigned)(((long)B * N * M::NU + 63) / 64)), dim3(64), (unsigned)((M::NTD + M::NX) * 64 * sizeof(double)), st,
+                                   h->large, a);
+            else
+                hipLaunchKernelGGL(chain_sens_mix_kernel<M>, blocks((long)B * N * M::NU), dim3(256), 0, st, h->large, a);
         }
         {   // one workgroup of 1024 lanes per instance; its trajectories staged in LDS (chain_sens_out_kernel)
             const unsigned smem = (unsigned)((64 + (1 + M::NU) * ((N + 1) * M::NX + N * M::NU)) * sizeof(double));
