@@ -59,6 +59,9 @@ constexpr double CHAIN_TOL_MU_FACTOR = 1.0;
 #ifndef MPCRL_CHAIN_ROWS_IN_REGS
 #define MPCRL_CHAIN_ROWS_IN_REGS 1     // qp_solve_rows: the bound rows of a QP in registers (at most 128 rows)
 #endif
+#ifndef MPCRL_CHAIN_FUSE_GT
+#define MPCRL_CHAIN_FUSE_GT 1   // [B A]_k' nu_{k+1} (stationarity residual) formed by the direction pass from the columns it holds; 0: a stage pass over [B A]
+#endif
 #ifndef MPCRL_CHAIN_V2_ROUNDSTART
 #define MPCRL_CHAIN_V2_ROUNDSTART 0
 #endif
@@ -163,8 +166,8 @@ struct LargeLayout {
 
 enum { ST_ACTIVE = 0, ST_IT = 1, ST_NIPM = 2, ST_TIGHT = 3, ST_STEPN = 4, ST_COST = 5, ST_RES = 6, ST_STATUS = 10 };
 
-template <class M, bool SECOND>
-__device__ void chain_point_pass(const double *X, const double *U, const double *th, double *w, int N, int k, double h, int steps);
+template <class M, bool SECOND, bool TH_LDS = false>
+__device__ void chain_point_pass(const double *X, const double *U, const double *th, double *w, int N, int k, double h, int steps, double *lacc = nullptr);
 
 // The phase functions of the chain solver are real calls (register allocations of their own; the scratch they report is the
 // save / restore of callee-saved registers in their prologue and epilogue, not traffic inside their loops).
@@ -185,6 +188,21 @@ struct WsArr {
 #ifdef MPCRL_PROFILE_PHASES
 __device__ unsigned long long g_phase_ticks[16];
 #endif
+
+// A pointer that arrives through a real call has lost its address space: every access through it is a FLAT instruction, which counts
+// on lgkmcnt as well as vmcnt — a wait for an LDS read then also waits for every global load in flight (the prefetches), and the
+// compiler can no longer order the two streams.  These give it back (the round trip through the address-space-qualified type is what
+// InferAddressSpaces follows).
+template <class T>
+MPCRL_DI T *as_global(T *ptr) {
+    typedef __attribute__((address_space(1))) T GT;
+    return (T *)(GT *)(unsigned long long)ptr;
+}
+template <class T>
+MPCRL_DI T *as_lds(T *ptr) {
+    typedef __attribute__((address_space(3))) T LT;
+    return (T *)(LT *)(unsigned long)(unsigned)(unsigned long long)ptr;
+}
 
 // Ordering between the lanes of ONE wavefront (LDS and global alike): memory operations of a wavefront are performed in order,
 // so only the compiler has to be kept from moving accesses across this point — no s_waitcnt is emitted.
@@ -298,6 +316,8 @@ struct Quad4 {
 
 // tile shapes of the two stage GEMMs: one tile per lane, at most 64 tiles
 template <class M>
+struct DirCfg;
+template <class M>
 struct ChainCfg {
     static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU;
     static constexpr int TI = NX <= 9 ? 2 : (NX <= 21 ? 3 : 4);   // T = P [B A]   : TI x TJ outputs per lane
@@ -307,8 +327,10 @@ struct ChainCfg {
     static constexpr int NTT = NTR * NTC, NMM = NMT * (NMT + 1) / 2;
     // the stage GEMMs on the matrix cores: 16-wide tiles of the [u; x] index (NT16 per side), of the state index (NTX), k-steps of 4
     static constexpr int NT16 = (NW + 15) / 16, NTX = (NX + 15) / 16, KS = (NX + 3) / 4;
-    static_assert(NTT <= 64 && NMM <= 64, "one GEMM tile per lane");
-    static_assert(NW % TJ == 0 && NW % TS == 0, "column tiles are full");
+    static constexpr bool V2_ = MPCRL_CHAIN_V2 != 0 && NX <= MPCRL_CHAIN_V2_MAXNX && NX <= MPCRL_CHAIN_V2_SENS_MAXNX;
+    // (tilings of the round-3 sweeps: only the odd chain sizes are laid out for them; the even ones exist on the round-4 sweeps only)
+    static_assert(V2_ || (NTT <= 64 && NMM <= 64), "one GEMM tile per lane");
+    static_assert(V2_ || (NW % TJ == 0 && NW % TS == 0), "column tiles are full");
     static constexpr int NBA2 = (NX * NW / 2 + 63) / 64;    // 16-byte pieces per lane of one [B A] block
     static constexpr int NAC2 = ((NX * NX + 1) / 2 + 63) / 64;   // ... of one nx x nx block
     // stage strides of the streamed blocks in the workspace: whole pieces, so that the block copies need no tail predicate
@@ -340,6 +362,10 @@ struct ChainCfg {
     // round-4 sweeps: the Hessian table of the factor sweep, or two vectors of the whole horizon in Omega order (HBS doubles per
     // stage) — which depends on the horizon, so the kernels that run the solver take their LDS as a launch argument (lds_doubles)
     static constexpr bool V2 = MPCRL_CHAIN_V2 != 0 && NX <= MPCRL_CHAIN_V2_MAXNX;
+    // [B A]_k' nu_{k+1} out of the direction pass (MPCRL_CHAIN_FUSE_GT).  Up to n_mass 5: at n_mass 7 the lane's four tangent arrays
+    // already overflow the vector registers and the extra dot product costs the direction pass more (+450 us per solve) than the
+    // stage pass it replaces (-380 us).
+    static constexpr bool FUSE_GT = MPCRL_CHAIN_FUSE_GT != 0 && NX <= 21;
     static constexpr int BIG_O = BIG_F > BIG_R ? BIG_F : BIG_R;
     static constexpr int LDS_TOTAL = oBig + BIG_O;      // without the round-4 staging (DirCfg: table budget of the direction pass)
     __host__ __device__ static constexpr int lds_doubles(int N) {
@@ -348,6 +374,10 @@ struct ChainCfg {
             const int tab = OmCfg<M>::RG * OmCfg<M>::NT * 64, vec = 2 * (N + 1) * OmCfg<M>::HBS, cst = (N + 1) * OmCfg<M>::HBS + tab;
             big = big > tab ? big : tab, big = big > vec ? big : vec, big = big > cst ? big : cst;
         }
+        // the direction pass: its tables, the compact parameter copy and the multipliers of the whole horizon
+        // (and the point pass's RK4 accumulators: NX per stage lane)
+        const int dir = DirCfg<M>::CO + M::NTD + (FUSE_GT ? (N + 1) * NX : 0) + N * NX;
+        big = big > dir ? big : dir;
         return oBig + big + (big & 1);
     }
     static_assert(LDS_TOTAL * 8 <= 40 * 1024, "four wavefronts per CU");
@@ -749,8 +779,23 @@ struct ChainSolver {
                                 const double a = v.a - v.b + (k < N ? ly[k * OmCfg<M>::HBS + om_slot(i)] : 0.0);
                                 if (!fixedc(k, i) && !skipc(k, i)) rs = fmax(rs, fabs(a));
                             });
-        } else
-        {
+        } else if constexpr (Cfg::FUSE_GT) {
+            // [B A]_k' nu_{k+1} arrives in rt from the direction pass of this round (chain_dir_pass): one pass over the entries
+            batched_pass<4>(ne, lane,
+                            [&](int e) {
+                                const int k = e / NW, i = e - k * NW;
+                                return Quad4{rg[e], (i >= NU && k > 0) ? NUv[k * NX + i - NU] : 0.0, k < N ? rt[e] : 0.0, 0.0};
+                            },
+                            [&](int e, const Quad4 &v) {
+                                const int k = e / NW, i = e - k * NW;
+                                if (k == N && i < NU) return;           // (no controls at the terminal stage)
+                                const double a = (v.a - v.b) + v.c;
+                                const bool fx = k < N && fixedc(k, i);
+                                if (!fx) rs = fmax(rs, fabs(a));
+                                // the vector itself stays in rg: it IS the stationarity residual the next QP starts from (qp_start_residuals)
+                                if (USE_V2) rg[e] = fx ? 0.0 : a;
+                            });
+        } else {
             d2_t nB[Cfg::DEPTH][Cfg::NBA2];
             double ng[Cfg::DEPTH], nn[Cfg::DEPTH], no[Cfg::DEPTH];
             double *lBA = sBA(), *lnu = sBB();
@@ -2945,16 +2990,36 @@ __global__ void __launch_bounds__(64) chain_init_kernel(const LargeSpec sp, cons
 // pass was repeated by every lane of a stage — 60 % of the linearisation's and half of the Hessian kernel's instructions.
 // the pass itself, for stage k of one instance (X, U, th: the instance's iterate and parameters, w: its workspace).  A real call: the
 // QP kernel runs it at the end of a round on N of its lanes, with a register allocation of its own.
-template <class M, bool SECOND>
-__device__ MPCRL_PHASE_FN void chain_point_pass(const double *X, const double *U, const double *th, double *w, int N, int k, double h, int steps) {
+// TH_LDS (the SQP kernel): th is the instance's COMPACT parameter copy in LDS (the NTD differentiable entries, staged by the caller) —
+// out of the parameter vector in global memory every evaluation point fetched its ~50-75 coefficients again, behind the table
+// stores of the point before.
+template <class M, bool SECOND, bool TH_LDS>
+__device__ MPCRL_PHASE_FN void chain_point_pass(const double *X_, const double *U_, const double *th_, double *w_, int N, int k, double h, int steps, double *lacc_) {
     constexpr int NX = M::NX, NU = M::NU, NL = M::NL, TS = SECOND ? M::TAB2 : M::TAB;
+    static_assert(!(TH_LDS && SECOND), "the second-order pass reads the full parameter vector");
+    const double *X = as_global(X_), *U = as_global(U_), *th = TH_LDS ? as_lds(th_) : as_global(th_);
+    double *w = as_global(w_);
     const LargeLayout<M> lay(N);
     double *tab = w + lay.ptab + (size_t)k * 8 * NL * M::TAB2;
     double u[NU];
 #pragma unroll
     for (int i = 0; i < NU; ++i) u[i] = U[k * NU + i];
     {
-        double xc[NX], acc[NX], kk[NX], xt[NX];
+        // (TH_LDS: the RK4 accumulator of the lane lives in LDS, entry i at lacc[i N + k].  With all four arrays in registers the
+        // compiler kept ~8 doubles of them in scratch, and every reload — an s_waitcnt vmcnt(0) — also waited for the table stores in
+        // flight, 40 scattered lines each: ~20 drains per RK4 step were most of this pass's time.)
+        struct AccReg {
+            double a[NX];
+            MPCRL_DI double &operator[](int i) { return a[i]; }
+        };
+        struct AccLds {
+            double *p;
+            int st;
+            MPCRL_DI double &operator[](int i) const { return p[i * st]; }
+        };
+        std::conditional_t<TH_LDS, AccLds, AccReg> acc;
+        if constexpr (TH_LDS) acc.p = as_lds(lacc_) + k, acc.st = N;
+        double xc[NX], kk[NX], xt[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) xc[i] = X[k * NX + i];
         // (with SECOND also the velocity difference of every link at every evaluation point: the mixed term wants it, chain_sens_mix2)
@@ -2973,19 +3038,19 @@ __device__ MPCRL_PHASE_FN void chain_point_pass(const double *X, const double *U
         };
         for (int s = 0; s < steps; ++s) {
             double *tb = tab + (size_t)(4 * s) * NL * TS;
-            M::template ode_coef<SECOND>(xc, u, th, kk, tb, true);
+            M::template ode_coef<SECOND, TH_LDS>(xc, u, th, kk, tb, true);
             store_dv(xc, 4 * s);
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc[i] = kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
-            M::template ode_coef<SECOND>(xt, u, th, kk, tb + NL * TS, true);
+            M::template ode_coef<SECOND, TH_LDS>(xt, u, th, kk, tb + NL * TS, true);
             store_dv(xt, 4 * s + 1);
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + (0.5 * h) * kk[i];
-            M::template ode_coef<SECOND>(xt, u, th, kk, tb + 2 * NL * TS, true);
+            M::template ode_coef<SECOND, TH_LDS>(xt, u, th, kk, tb + 2 * NL * TS, true);
             store_dv(xt, 4 * s + 2);
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * kk[i], xt[i] = xc[i] + h * kk[i];
-            M::template ode_coef<SECOND>(xt, u, th, kk, tb + 3 * NL * TS, true);
+            M::template ode_coef<SECOND, TH_LDS>(xt, u, th, kk, tb + 3 * NL * TS, true);
             store_dv(xt, 4 * s + 3);
 #pragma unroll
             for (int i = 0; i < NX; ++i) xc[i] = xc[i] + (h / 6.0) * (acc[i] + kk[i]);
@@ -3068,12 +3133,15 @@ struct DirCfg {
     static constexpr int BIG = ChainCfg<M>::LDS_TOTAL - ChainCfg<M>::oBig;
     static constexpr bool FITS = SPAN * TSZ <= BIG;                  // else whole stages per step
     static constexpr int LP = FITS ? 64 : (64 / NW) * NW;            // items per step
-    static_assert((FITS ? SPAN : 64 / NW) * TSZ <= BIG, "tables of a step fit the LDS region");
+    static constexpr int CO = (FITS ? SPAN : 64 / NW) * TSZ;         // after the tables: the instance's NTD differentiable parameters
+    static_assert(CO + M::NTD <= BIG, "tables of a step fit the LDS region");
 };
 
 template <class M>
-__device__ MPCRL_PHASE_FN void chain_dir_pass(const double *th, double *w, double *tabl, int N, int lane, double h, int steps) {
+__device__ MPCRL_PHASE_FN void chain_dir_pass(const double *th_, double *w_, double *tabl_, int N, int lane, double h, int steps) {
     using DC = DirCfg<M>;
+    const double *th = as_global(th_);
+    double *w = as_global(w_), *tabl = as_lds(tabl_);
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NL = M::NL, TAB = M::TAB, TSZ = DC::TSZ, STG = DC::EV * NL * M::TAB2;
     const LargeLayout<M> lay(N);
     const int items = N * NW;
@@ -3089,6 +3157,7 @@ __device__ MPCRL_PHASE_FN void chain_dir_pass(const double *th, double *w, doubl
         }
     };
     request(0);
+    const double *Cl = tabl + DC::CO + 7 * NL;       // damping coefficients of the compact parameter copy the caller staged
     for (int i0 = 0; i0 < items; i0 += DC::LP) {
         const int k_lo = i0 / NW, k_hi = min(N - 1, (i0 + DC::LP - 1) / NW);
 #pragma unroll
@@ -3107,18 +3176,48 @@ __device__ MPCRL_PHASE_FN void chain_dir_pass(const double *th, double *w, doubl
         for (int i = 0; i < NU; ++i) du[i] = d == i ? 1.0 : 0.0;
 #pragma unroll
         for (int i = 0; i < NX; ++i) dxc[i] = d == NU + i ? 1.0 : 0.0;
+        // The tangent of the ODE at an evaluation point, link by link, with the 9 coefficients of the NEXT link (the next evaluation
+        // point's first one after the last; and the link's damping coefficients) requested from LDS before the current link is computed: this wavefront is alone on its
+        // SIMD, so nothing else covers the LDS round trip, and with 4 NX doubles of tangents live the compiler placed every read
+        // right in front of its use (55 waits on an empty LDS queue per RK4 step: the pass ran on LDS latency).
+        constexpr int Mm = M::M;
+        double tq[2][12];
+        auto fetch = [&](const double *src, int link, double (&t)[12]) {   // 9 coefficients of the point + the link's damping
+#pragma unroll
+            for (int j = 0; j < 9; ++j) t[j] = src[j];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) t[9 + j] = Cl[3 * link + j];
+        };
+        auto eval = [&](const double *tb, const double *dxe, auto par0) {   // dk = (d f / d x) dxe + (d f / d u) du; par0: buffer of link 0
+#pragma unroll
+            for (int i = 0; i < 3 * Mm; ++i) dk[3 * (Mm + 1) + i] = 0.0;
+            static_for<NL>([&](auto i_) {
+                constexpr int i = decltype(i_)::value, cur = (decltype(par0)::value + i) & 1;
+                fetch(tb + (i + 1) * TAB, i + 1 < NL ? i + 1 : 0, tq[cur ^ 1]);   // (i + 1 = NL: link 0 of the next evaluation point, the tables are contiguous)
+                __builtin_amdgcn_sched_barrier(0);
+                M::template ode_tan_link<i>(tq[cur], dxe, du, dk + 3 * (Mm + 1));
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#pragma unroll
+            for (int i = 0; i < 3 * Mm; ++i) dk[i] = dxe[3 * (Mm + 1) + i];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dk[3 * Mm + j] = du[j];
+        };
+        constexpr int P1 = NL & 1, P2 = (2 * NL) & 1, P3 = (3 * NL) & 1;   // buffer parity at the start of the evaluation points
+        static_assert(((4 * NL) & 1) == 0, "an RK4 step ends on the buffer it started with");
+        fetch(mytab, 0, tq[0]);
         for (int s_ = 0; s_ < steps; ++s_) {
             const double *tb = mytab + (size_t)(4 * s_) * NL * TAB;
-            M::template ode_tan<TAB, false>(tb, th, dxc, du, dk, nullptr);
+            eval(tb, dxc, std::integral_constant<int, 0>{});
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc[i] = dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
-            M::template ode_tan<TAB, false>(tb + NL * TAB, th, dxt, du, dk, nullptr);
+            eval(tb + NL * TAB, dxt, std::integral_constant<int, P1>{});
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
-            M::template ode_tan<TAB, false>(tb + 2 * NL * TAB, th, dxt, du, dk, nullptr);
+            eval(tb + 2 * NL * TAB, dxt, std::integral_constant<int, P2>{});
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + h * dk[i];
-            M::template ode_tan<TAB, false>(tb + 3 * NL * TAB, th, dxt, du, dk, nullptr);
+            eval(tb + 3 * NL * TAB, dxt, std::integral_constant<int, P3>{});
 #pragma unroll
             for (int i = 0; i < NX; ++i) dxc[i] = dxc[i] + (h / 6.0) * (acc[i] + dk[i]);
         }
@@ -3126,6 +3225,17 @@ __device__ MPCRL_PHASE_FN void chain_dir_pass(const double *th, double *w, doubl
             double *BA = w + lay.BA + (size_t)k * NX * NW;
 #pragma unroll
             for (int i = 0; i < NX; ++i) BA[i * NW + d] = dxc[i];
+            if constexpr (ChainCfg<M>::FUSE_GT) {
+                // ([B A]_k' nu_{k+1})_d: this lane holds column d.  What the stationarity residual of the round wants (round_start) —
+                // as a stage pass over [B A] there it was 40 serial steps through LDS and one more read of the blocks.  Same
+                // association as lds_dot<NX> (four partial sums per chunk).
+                const double *nun = tabl + DC::CO + M::NTD + (size_t)(k + 1) * NX;
+                constexpr int CH = NX <= 12 ? NX : (NX % 12 == 0 ? 12 : (NX % 11 == 0 ? 11 : (NX % 8 == 0 ? 8 : (NX % 7 == 0 ? 7 : 3))));
+                double ac[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int i = 0; i < NX; ++i) ac[(i % CH) & 3] = fma(dxc[i], nun[i], ac[(i % CH) & 3]);
+                w[lay.rt + (size_t)k * NW + d] = (ac[0] + ac[1]) + (ac[2] + ac[3]);
+            }
         }
         wave_sync();                                 // the next step's tables overwrite these
     }
@@ -3170,7 +3280,13 @@ __global__ void __launch_bounds__(64, 1) chain_sqp_kernel(const LargeSpec sp, co
         const double stepn = S.state[ST_STEPN];
         // ---- linearisation at the current iterate
         wave_sync();
-        if (lane < N) chain_point_pass<M, false>(S.X, S.U, S.th, w, N, lane, sp.h, sp.rk_steps);
+        for (int e = lane; e < M::NTD; e += NT) lds[Cfg::oBig + DirCfg<M>::CO + e] = S.th[M::td_index(e)];   // (the QP phases reuse the region)
+        if constexpr (Cfg::FUSE_GT)
+            batched_pass<8>((N + 1) * NX, lane, [&](int e) { return S.NUv[e]; }, [&](int e, double v) { lds[Cfg::oBig + DirCfg<M>::CO + M::NTD + e] = v; });
+        wave_sync();
+        if (lane < N)
+            chain_point_pass<M, false, true>(S.X, S.U, lds + Cfg::oBig + DirCfg<M>::CO, w, N, lane, sp.h, sp.rk_steps,
+                                             lds + Cfg::oBig + DirCfg<M>::CO + M::NTD + (Cfg::FUSE_GT ? (N + 1) * NX : 0));
         wave_sync();
         S.ph(6);
         chain_dir_pass<M>(S.th, w, lds + Cfg::oBig, N, lane, sp.h, sp.rk_steps);
@@ -3299,16 +3415,23 @@ struct HexCfg {
                                                                 // of a 64-bit LDS read fall on disjoint bank sets
     static constexpr int oTab = 0, oG = oTab + EV * NL * TAB2, oY = (oG + EV * NL * 6 + 1) & ~1, oW = oY + RP * LD, TOTAL = oW + RP * LD;
     static_assert(NTI * 16 <= LD && NW <= 64, "one direction per lane, tiles inside the padded row");
+    // STAGES PER WAVEFRONT (round 4): the tangent propagation keeps NW of the 64 lanes busy and runs on LDS latency (this kernel is
+    // one wavefront per SIMD: 4 NX doubles of tangents per lane), so a wavefront takes GW-lane groups of consecutive stages — 2 at
+    // n_mass 4-6, 4 at n_mass 3: the same wavefront time for 2 (4) stages.  Each group has its own tables, Y / W and accumulators.
+    static constexpr int GW = NW <= 16 ? 16 : (NW <= 32 ? 32 : 64), SPW = 64 / GW;
+    __host__ __device__ static constexpr int groups(int N) { return (N + SPW - 1) / SPW; }
+    static_assert(SPW * TOTAL * 8 <= 40 * 1024, "four wavefronts per CU");
 };
 
 template <class M>
 __global__ void __launch_bounds__(64, 1) chain_sens_ad_kernel(const LargeSpec sp, const LargeArgs a) {
     using HC = HexCfg<M>;
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NL = M::NL, TAB2 = M::TAB2, LD = HC::LD, RP = HC::RP, NTI = HC::NTI;
+    constexpr int GW = HC::GW, SPW = HC::SPW, NTT = NTI * (NTI + 1) / 2;
     typedef double d4_t __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) double lds[HC::TOTAL];
-    const int N = sp.N, lane = threadIdx.x;
-    const int inst = blockIdx.x / N, k = blockIdx.x - inst * N;
+    __shared__ __attribute__((aligned(16))) double lds[SPW * HC::TOTAL];
+    const int N = sp.N, lane = threadIdx.x, NG = HC::groups(N);
+    const int inst = blockIdx.x / NG, k0 = (blockIdx.x - inst * NG) * SPW;
     const int status = a.status[inst];
     if (!(status == 0 || status == 2)) return;
     const LargeLayout<M> lay(N);
@@ -3316,87 +3439,132 @@ __global__ void __launch_bounds__(64, 1) chain_sens_ad_kernel(const LargeSpec sp
     const double *th = a.theta + (size_t)inst * a.theta_stride;
     const double h = sp.h;
     const int steps = sp.rk_steps;
-    double *tab = lds + HC::oTab, *Gt = lds + HC::oG, *Y = lds + HC::oY, *W = lds + HC::oW;
-    {   // 1. + 2. the point and the adjoint were done per stage by chain_point_kernel<M, true>: its tables -> LDS
+    const int sub = lane / GW, dl = lane - sub * GW;      // this lane's stage group and direction
+    double *const mine = lds + sub * HC::TOTAL;
+    const double *tab = mine + HC::oTab;
+    for (int s_ = 0; s_ < SPW; ++s_) {   // 1. + 2. the point and the adjoint were done per stage by chain_point_kernel<M, true>: its tables -> LDS
+        const int k = min(k0 + s_, N - 1);   // (a group past the horizon repeats the last stage and is not stored)
         const double *pt = w + lay.ptab + (size_t)k * HC::EV * NL * TAB2, *gt = w + lay.gtab + (size_t)k * HC::EV * NL * 6;
-        for (int e = lane; e < HC::EV * NL * TAB2; e += 64) tab[e] = pt[e];
-        for (int e = lane; e < HC::EV * NL * 6; e += 64) Gt[e] = gt[e];
+        double *tb_ = lds + s_ * HC::TOTAL;
+        for (int e = lane; e < HC::EV * NL * TAB2; e += 64) tb_[HC::oTab + e] = pt[e];
+        for (int e = lane; e < HC::EV * NL * 6; e += 64) tb_[HC::oG + e] = gt[e];
+        for (int r = lane; r < RP * LD; r += 64) tb_[HC::oY + r] = 0.0, tb_[HC::oW + r] = 0.0;   // padding rows / columns stay zero
     }
     wave_sync();
     // 3. the tangents and the Hessian accumulation
-    d4_t D[NTI * (NTI + 1) / 2];
+    d4_t D[SPW][NTT];
 #pragma unroll
-    for (int t_ = 0; t_ < NTI * (NTI + 1) / 2; ++t_) D[t_] = d4_t{0.0, 0.0, 0.0, 0.0};
-    for (int r = lane; r < RP * LD; r += 64) Y[r] = 0.0, W[r] = 0.0;   // padding rows / columns stay zero
-    wave_sync();
+    for (int s_ = 0; s_ < SPW; ++s_)
+#pragma unroll
+        for (int t_ = 0; t_ < NTT; ++t_) D[s_][t_] = d4_t{0.0, 0.0, 0.0, 0.0};
     {
         double dxc[NX], acc[NX], dk[NX], dxt[NX], du[NU], dd[3 * NL];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) du[i] = lane == i ? 1.0 : 0.0;
+        for (int i = 0; i < NU; ++i) du[i] = dl == i ? 1.0 : 0.0;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) dxc[i] = lane == NU + i ? 1.0 : 0.0;      // lanes >= NW carry the zero direction
+        for (int i = 0; i < NX; ++i) dxc[i] = dl == NU + i ? 1.0 : 0.0;      // lanes >= NW of a group carry the zero direction
         const int lr = lane >> 4, lc = lane & 15;
         auto accumulate = [&](int e) {   // publish this evaluation point's Y, W = G Y and add Y' W to the tiles
-            const double *G = Gt + (size_t)e * NL * 6;
-            if (lane < NW) {
+            const double *G = mine + HC::oG + (size_t)e * NL * 6;
+            double *Y = mine + HC::oY, *W = mine + HC::oW;
+            if (dl < NW) {
 #pragma unroll
                 for (int i = 0; i < NL; ++i) {
                     const double *g = G + i * 6, d0 = dd[3 * i], d1 = dd[3 * i + 1], d2 = dd[3 * i + 2];
-                    Y[(3 * i) * LD + lane] = d0, Y[(3 * i + 1) * LD + lane] = d1, Y[(3 * i + 2) * LD + lane] = d2;
-                    W[(3 * i) * LD + lane] = g[0] * d0 + g[1] * d1 + g[3] * d2;
-                    W[(3 * i + 1) * LD + lane] = g[1] * d0 + g[2] * d1 + g[4] * d2;
-                    W[(3 * i + 2) * LD + lane] = g[3] * d0 + g[4] * d1 + g[5] * d2;
+                    Y[(3 * i) * LD + dl] = d0, Y[(3 * i + 1) * LD + dl] = d1, Y[(3 * i + 2) * LD + dl] = d2;
+                    W[(3 * i) * LD + dl] = g[0] * d0 + g[1] * d1 + g[3] * d2;
+                    W[(3 * i + 1) * LD + dl] = g[1] * d0 + g[2] * d1 + g[4] * d2;
+                    W[(3 * i + 2) * LD + dl] = g[3] * d0 + g[4] * d1 + g[5] * d2;
                 }
             }
             wave_sync();
 #pragma unroll
-            for (int ks = 0; ks < RP / 4; ++ks) {
-                double ya[NTI], wb[NTI];
+            for (int s_ = 0; s_ < SPW; ++s_) {
+                const double *Ys = lds + s_ * HC::TOTAL + HC::oY, *Ws = lds + s_ * HC::TOTAL + HC::oW;
 #pragma unroll
-                for (int t_ = 0; t_ < NTI; ++t_) ya[t_] = Y[(4 * ks + lr) * LD + 16 * t_ + lc], wb[t_] = W[(4 * ks + lr) * LD + 16 * t_ + lc];
+                for (int ks = 0; ks < RP / 4; ++ks) {
+                    double ya[NTI], wb[NTI];
 #pragma unroll
-                for (int ti = 0; ti < NTI; ++ti)
+                    for (int t_ = 0; t_ < NTI; ++t_) ya[t_] = Ys[(4 * ks + lr) * LD + 16 * t_ + lc], wb[t_] = Ws[(4 * ks + lr) * LD + 16 * t_ + lc];
 #pragma unroll
-                    for (int tj = 0; tj <= ti; ++tj)
-                        D[ti * (ti + 1) / 2 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[ti], wb[tj], D[ti * (ti + 1) / 2 + tj], 0, 0, 0);
+                    for (int ti = 0; ti < NTI; ++ti)
+#pragma unroll
+                        for (int tj = 0; tj <= ti; ++tj)
+                            D[s_][ti * (ti + 1) / 2 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[ti], wb[tj], D[s_][ti * (ti + 1) / 2 + tj], 0, 0, 0);
+                }
             }
             wave_sync();
         };
+        // the tangent of the ODE link by link, the coefficients of the next link in flight while this one is computed (as in
+        // chain_dir_pass: one wavefront per SIMD, nothing else covers an LDS round trip)
+        constexpr int Mm = M::M;
+        double tq[2][12];
+        double Cr[3 * NL];
+#pragma unroll
+        for (int i = 0; i < 3 * NL; ++i) Cr[i] = th[7 * NL + i];
+        auto fetch = [&](const double *src, double (&t)[12]) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) t[j] = src[j];
+        };
+        auto eval = [&](const double *tb, const double *dxe, auto par0) {
+#pragma unroll
+            for (int i = 0; i < 3 * Mm; ++i) dk[3 * (Mm + 1) + i] = 0.0;
+            static_for<NL>([&](auto i_) {
+                constexpr int i = decltype(i_)::value, cur = (decltype(par0)::value + i) & 1;
+                fetch(tb + (i + 1) * TAB2, tq[cur ^ 1]);     // (i + 1 = NL: link 0 of the next evaluation point, the tables are contiguous)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) tq[cur][9 + j] = Cr[3 * i + j];
+                __builtin_amdgcn_sched_barrier(0);
+                M::template ode_tan_link<i, true>(tq[cur], dxe, du, dk + 3 * (Mm + 1), dd);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#pragma unroll
+            for (int i = 0; i < 3 * Mm; ++i) dk[i] = dxe[3 * (Mm + 1) + i];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dk[3 * Mm + j] = du[j];
+        };
+        constexpr int P1 = NL & 1, P2 = (2 * NL) & 1, P3 = (3 * NL) & 1;
+        fetch(tab, tq[0]);
         for (int s = 0; s < steps; ++s) {
             const double *tb = tab + (size_t)(4 * s) * NL * TAB2;
-            M::template ode_tan<TAB2, true>(tb, th, dxc, du, dk, dd);
+            eval(tb, dxc, std::integral_constant<int, 0>{});
             accumulate(4 * s);
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc[i] = dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
-            M::template ode_tan<TAB2, true>(tb + NL * TAB2, th, dxt, du, dk, dd);
+            eval(tb + NL * TAB2, dxt, std::integral_constant<int, P1>{});
             accumulate(4 * s + 1);
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
-            M::template ode_tan<TAB2, true>(tb + 2 * NL * TAB2, th, dxt, du, dk, dd);
+            eval(tb + 2 * NL * TAB2, dxt, std::integral_constant<int, P2>{});
             accumulate(4 * s + 2);
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + h * dk[i];
-            M::template ode_tan<TAB2, true>(tb + 3 * NL * TAB2, th, dxt, du, dk, dd);
+            eval(tb + 3 * NL * TAB2, dxt, std::integral_constant<int, P3>{});
             accumulate(4 * s + 3);
 #pragma unroll
             for (int i = 0; i < NX; ++i) dxc[i] = dxc[i] + (h / 6.0) * (acc[i] + dk[i]);
         }
-        // Hex_k = c_k hess l_k + the accumulated second-order term; D[r] holds (row 4 r + lane / 16, column lane % 16) of its tile
-        const double ckk = sp.cost_kind == 0 ? sp.dT : (k == 0 ? sp.dT : pow(sp.gamma, (double)k) * sp.dT);
-        double *Hex = w + lay.Hex + (size_t)k * NW * NW;
+        // Hex_k = c_k hess l_k + the accumulated second-order term; D[.][r] holds (row 4 r + lane / 16, column lane % 16) of its tile
 #pragma unroll
-        for (int ti = 0; ti < NTI; ++ti)
+        for (int s_ = 0; s_ < SPW; ++s_) {
+            const int k = k0 + s_;
+            if (k >= N) break;
+            const double ckk = sp.cost_kind == 0 ? sp.dT : (k == 0 ? sp.dT : pow(sp.gamma, (double)k) * sp.dT);
+            double *Hex = w + lay.Hex + (size_t)k * NW * NW;
 #pragma unroll
-            for (int tj = 0; tj <= ti; ++tj)
+            for (int ti = 0; ti < NTI; ++ti)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * ti + 4 * r + lr, j = 16 * tj + lc;
-                    if (i < NW && j < NW) {
-                        const double v = fma(ckk, M::hess(false, i, j, th), D[ti * (ti + 1) / 2 + tj][r]);
-                        Hex[i * NW + j] = v;
-                        if (ti != tj) Hex[j * NW + i] = v;
+                for (int tj = 0; tj <= ti; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * ti + 4 * r + lr, j = 16 * tj + lc;
+                        if (i < NW && j < NW) {
+                            const double v = fma(ckk, M::hess(false, i, j, th), D[s_][ti * (ti + 1) / 2 + tj][r]);
+                            Hex[i * NW + j] = v;
+                            if (ti != tj) Hex[j * NW + i] = v;
+                        }
                     }
-                }
+        }
     }
 }
 

@@ -343,11 +343,12 @@ struct ChainDev {
     // so that  d Fs_ij = a_ij d dist_ij + b_ij (dist_i . d dist_i).  `tab` ([NL][TAB] doubles, LDS) is written when `store` is set.
     // With SECOND also the second-order pieces  c_ij = D_ij / m_i  L_ij / n_i^3  and  e_i = 3 / n_i^2  (Hessian of the spring force).
     static constexpr int TAB = 9, TAB2 = 13;
-    template <bool SECOND>
+    // COMPACT: p holds the NTD differentiable parameters only (td_index order: the disturbance w right after the link coefficients)
+    template <bool SECOND, bool COMPACT = false>
     MPCRL_DI static void ode_coef(const double *x, const double *u, const double *p, double *f, double *tab, bool store) {
         constexpr int TS_ = SECOND ? TAB2 : TAB;
         const double *pos = x, *vel = x + 3 * (M + 1);
-        const double *m = p, *D = p + NL, *L = p + 4 * NL, *C = p + 7 * NL, *w = p + OFF_W;
+        const double *m = p, *D = p + NL, *L = p + 4 * NL, *C = p + 7 * NL, *w = p + (COMPACT ? 10 * NL : OFF_W);
         double *acc = f + 3 * (M + 1);
 #pragma unroll
         for (int i = 0; i < 3 * M; ++i) acc[i] = (i % 3 == 2) ? w[i] + (-9.81) : w[i];
@@ -384,7 +385,12 @@ struct ChainDev {
     // tangents d dist_i of this direction are also returned (the second-order sweep of the sensitivities publishes them).
     template <int TS_, bool DD>
     MPCRL_DI static void ode_tan(const double *tab, const double *p, const double *dx, const double *du, double *df, double *dd) {
-        const double *C = p + 7 * NL;
+        ode_tan_c<TS_, DD>(tab, p + 7 * NL, dx, du, df, dd);
+    }
+    // (the same with the damping coefficients C_ij — the only parameters the tangent reads — given directly: the direction pass
+    // keeps them in LDS next to the tables instead of fetching them from the parameter vector at every evaluation point)
+    template <int TS_, bool DD>
+    MPCRL_DI static void ode_tan_c(const double *tab, const double *C, const double *dx, const double *du, double *df, double *dd) {
         const double *dpos = dx, *dvel = dx + 3 * (M + 1);
         double *dacc = df + 3 * (M + 1);
 #pragma unroll
@@ -410,6 +416,28 @@ struct ChainDev {
         for (int i = 0; i < 3 * M; ++i) df[i] = dvel[i];
 #pragma unroll
         for (int j = 0; j < 3; ++j) df[3 * M + j] = du[j];
+    }
+    // One link of ode_tan_c with the link's 12 coefficients already in registers (t: dist, a, b of ode_coef, then C_i), accumulating into the
+    // acceleration tangents dacc[3 M]: the direction pass fetches the coefficients of the NEXT link from LDS while this one is computed.
+    template <int I, bool DD = false>
+    MPCRL_DI static void ode_tan_link(const double (&t)[12], const double *dx, const double *du, double *dacc, double *dd = nullptr) {
+        const double *dpos = dx, *dvel = dx + 3 * (M + 1);
+        double dd_[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dd_[j] = I ? dpos[3 * I + j] - dpos[3 * (I > 0 ? I - 1 : 0) + j] : dpos[j];
+        if constexpr (DD) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dd[3 * I + j] = dd_[j];
+        }
+        const double dot = t[0] * dd_[0] + t[1] * dd_[1] + t[2] * dd_[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double dvr = I < M ? dvel[3 * (I < M ? I : 0) + j] : du[j];
+            const double ddv = I ? dvr - dvel[3 * (I > 0 ? I - 1 : 0) + j] : dvr;
+            const double dFt = fma(t[3 + j], dd_[j], fma(t[6 + j], dot, t[9 + j] * ddv));
+            if (I < M) dacc[3 * (I < M ? I : 0) + j] -= dFt;
+            if (I > 0) dacc[3 * (I > 0 ? I - 1 : 0) + j] += dFt;
+        }
     }
     // ode_tan_T: the transpose of ode_tan at the same point — xb += (df/dx)' kb (ub is not needed by its caller) — and, per link,
     // the force adjoint q_i = (adjoint of acc_{i-1}) - (adjoint of acc_i), which weights the link's spring force in kb' f.

@@ -143,6 +143,22 @@ int fill_large_spec(const MpcrlProblemSpec &s, LargeSpec &d) {
     return 0;
 }
 
+// n_mass (3 .. 7, a free integer in the reference: rlmpc/mpc/chain_mass/ocp_utils.py:344-350) -> the instantiation of the chain kernels
+template <class T>
+struct TypeTag {
+    using type = T;
+};
+template <class F>
+long chain_dispatch(int n_mass, F &&f) {
+    switch (n_mass) {
+        case 3: return f(TypeTag<ChainDev<3>>{});
+        case 4: return f(TypeTag<ChainDev<4>>{});
+        case 5: return f(TypeTag<ChainDev<5>>{});
+        case 6: return f(TypeTag<ChainDev<6>>{});
+        default: return f(TypeTag<ChainDev<7>>{});
+    }
+}
+
 template <class M>
 int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
     a.ws = h->ws, a.ws_stride = h->ws_stride;
@@ -161,7 +177,7 @@ int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
         const bool want_pi = (a.flags & MPCRL_SENS_PI) && a.dpi && !a.u0fix;
         if (want_pi) {
             hipLaunchKernelGGL((chain_point_kernel<M, true>), dim3((unsigned)(((long)B * N + 63) / 64)), dim3(64), 0, st, h->large, a);
-            hipLaunchKernelGGL(chain_sens_ad_kernel<M>, dim3((unsigned)(B * N)), dim3(64), 0, st, h->large, a);
+            hipLaunchKernelGGL(chain_sens_ad_kernel<M>, dim3((unsigned)(B * HexCfg<M>::groups(N))), dim3(64), 0, st, h->large, a);
             hipLaunchKernelGGL(chain_sens_riccati_kernel<M>, dim3(B), dim3(64), lds_bytes, st, h->large, a);
             if (MPCRL_CHAIN_MIX2)
                 hipLaunchKernelGGL(chain_sens_mix2_kernel<M>, dim3((unsigned)(((long)B * N * M::NU + 63) / 64)), dim3(64), (unsigned)((M::NTD + M::NX) * 64 * sizeof(double)), st,
@@ -354,11 +370,9 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
         case MPCRL_MODEL_CHAIN:
             h->is_large = true;
             h->n_mass = (spec->nx / 3 - 1) / 2 + 2;
-            if (spec->nu != 3 || !(h->n_mass == 3 || h->n_mass == 5 || h->n_mass == 7) || spec->nx != (2 * (h->n_mass - 2) + 1) * 3 ||
-                spec->n_consts != spec->nx)
+            if (spec->nu != 3 || h->n_mass < 3 || h->n_mass > 7 || spec->nx != (2 * (h->n_mass - 2) + 1) * 3 || spec->n_consts != spec->nx)
                 rc = MPCRL_E_MODEL;
-            else if ((h->n_mass == 3 && spec->np != ChainDev<3>::NP) || (h->n_mass == 5 && spec->np != ChainDev<5>::NP) ||
-                     (h->n_mass == 7 && spec->np != ChainDev<7>::NP))
+            else if (spec->np != chain_dispatch(h->n_mass, [](auto m_) { return (long)decltype(m_)::type::NP; }))
                 rc = MPCRL_E_MODEL;
             break;
         default: rc = MPCRL_E_MODEL;
@@ -383,8 +397,7 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
     if (!rc) rc = dev_alloc(&h->cold_mask, B, h->bytes);
     if (!rc) rc = dev_alloc(&h->order_state, 4, h->bytes);
     if (!rc && h->is_large) {
-        h->ws_stride = h->n_mass == 3 ? LargeLayout<ChainDev<3>>(spec->N).total
-                                      : (h->n_mass == 5 ? LargeLayout<ChainDev<5>>(spec->N).total : LargeLayout<ChainDev<7>>(spec->N).total);
+        h->ws_stride = (size_t)chain_dispatch(h->n_mass, [&](auto m_) { return (long)LargeLayout<typename decltype(m_)::type>(spec->N).total; });
         rc = dev_alloc(&h->ws, B * h->ws_stride, h->bytes);
         if (!rc) rc = dev_alloc(&h->consts_dev, (size_t)spec->n_consts, h->bytes);
         if (!rc) {
@@ -600,8 +613,7 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
         la.B = a.B, la.flags = a.flags, la.theta_stride = a.theta_stride, la.perm = a.perm, la.cold = a.cold, la.x0 = a.x0, la.u0fix = a.u0fix, la.theta = a.theta;
         la.X = a.X, la.U = a.U, la.PI = a.PI, la.BND = a.BND, la.RES = a.RES, la.LAG = a.LAG, la.ws = nullptr, la.ws_stride = 0;
         la.u0_out = a.u0_out, la.V = a.V, la.dV = a.dV, la.dpi = a.dpi, la.status = a.status, la.iters = a.iters;
-        rc = h->n_mass == 3 ? launch_large<ChainDev<3>>(h, la, st)
-                            : (h->n_mass == 5 ? launch_large<ChainDev<5>>(h, la, st) : launch_large<ChainDev<7>>(h, la, st));
+        rc = (int)chain_dispatch(h->n_mass, [&](auto m_) { return (long)launch_large<typename decltype(m_)::type>(h, la, st); });
     } else
         switch (h->model) {
             case MPCRL_MODEL_CARTPOLE: rc = launch_small<CartpoleDev>(h, a, st); break;

@@ -719,6 +719,8 @@ extern "C" int mpc_oracle_solve(const OracleSpec *sp, int B, const double *x0, c
             if (sp->nx == Chain<5>::NX) return run<Chain<5>>(ARGS);
             if (sp->nx == Chain<7>::NX) return run<Chain<7>>(ARGS);
             if (sp->nx == Chain<3>::NX) return run<Chain<3>>(ARGS);
+            if (sp->nx == Chain<4>::NX) return run<Chain<4>>(ARGS);
+            if (sp->nx == Chain<6>::NX) return run<Chain<6>>(ARGS);
             return -2;
     }
 #undef ARGS

@@ -230,10 +230,11 @@ def test_mirror_certifies_the_hip_iterate_linear():
 
 
 def test_mirror_certifies_the_hip_iterate_chain():
-    """n_mass 3 (4 instances) and n_mass 5 (2 instances; 2 385 KKT unknowns x 499 parameters, ~15 s of autograd + dense LU each)."""
+    """n_mass 3 (4 instances), the even size 4 (2 instances: the ragged row groups of the round-4 sweeps against the mirror of the
+    reference's own nlp.py) and n_mass 5 (2 instances; 2 385 KKT unknowns x 499 parameters, ~15 s of autograd + dense LU each)."""
     from mpc4rl_amd import MPCBatch, chain_mass_ocp
     rng = np.random.default_rng(13)
-    for n_mass, B in ((3, 4), (5, 2)):
+    for n_mass, B in ((3, 4), (4, 2), (5, 2)):
         ocp = chain_mass_ocp(n_mass=n_mass, tol=1e-8)   # the mirror's thresholds are looser, du0/dp at 1e-6 needs the KKT point
         M = n_mass - 2
         x0 = np.tile(ocp.x0, (B, 1))

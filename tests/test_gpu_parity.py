@@ -315,6 +315,30 @@ def test_chain_mass_n3_vs_oracle(oracle_port):
     assert rel_err(r.dpi_dp.cpu().numpy(), ref.dpi, floor=np.abs(ref.dpi).max()) < RTOL
 
 
+@pytest.mark.parametrize("n_mass", [4, 6])
+def test_chain_mass_even_sizes_vs_oracle(oracle_port, n_mass):
+    """n_mass is a free integer in the reference (rlmpc/mpc/chain_mass/ocp_utils.py:344-350).  The even sizes (nx = 15 / 27) are the
+    ones whose state count is not a multiple of the 4-row MFMA groups less one: the ragged row groups of the round-4 sweeps
+    (chain_kernel.hpp OmCfg::RAGGED) run only here.  Solve, value / policy gradients and the RTI step against the oracle port."""
+    from mpc4rl_amd import MPCBatch, chain_mass_ocp
+    from oracle.problems import make_chain_mass
+    ocp, P = chain_mass_ocp(n_mass=n_mass), make_chain_mass(n_mass=n_mass)
+    assert ocp.nx == (2 * (n_mass - 2) + 1) * 3 and ocp.n_p == P.n_p
+    rng = np.random.default_rng(n_mass)
+    B = 12
+    x0 = np.tile(ocp.x0, (B, 1))
+    x0[:, 3 * (n_mass - 3):3 * (n_mass - 2)] += rng.normal(0.0, 1e-2, (B, 3))     # the last free mass, displaced
+    x0[:, 3 * (n_mass - 1):] += rng.normal(0.0, 1e-2, (B, ocp.nx - 3 * (n_mass - 1)))   # and some velocity
+    theta = np.tile(P.p0, (B, 1)) * rng.uniform(0.97, 1.03, (B, P.n_p))
+    _, r, ref = run_both(ocp, P, oracle_port, x0, theta=theta)
+    st = r.status.cpu().numpy()
+    assert np.all(st == 0) and np.array_equal(st, ref.status)
+    assert np.abs(r.iters.cpu().numpy()[:, 0] - ref.sqp_iter).max() <= 1
+    assert rel_err(r.u0.cpu().numpy(), ref.u0) < RTOL and rel_err(r.V.cpu().numpy(), ref.V) < RTOL
+    assert rel_err(r.dV_dp.cpu().numpy(), ref.dV) < RTOL
+    assert rel_err(r.dpi_dp.cpu().numpy(), ref.dpi, floor=np.abs(ref.dpi).max()) < RTOL
+
+
 def test_cartpole_cost_parameters_reach_the_kernel(oracle_port):
     """W_0, W, W_e, yref_0, yref, yref_e are part of p and the solve uses them (set_parameter / cost_set, mpc.py:233-257), per
     instance; their gradient entries stay zero (non-parameterised NLS mirror, nlp.py:1039-1055)."""
