@@ -2996,7 +2996,6 @@ __global__ void __launch_bounds__(64) chain_init_kernel(const LargeSpec sp, cons
 template <class M, bool SECOND, bool TH_LDS>
 __device__ MPCRL_PHASE_FN void chain_point_pass(const double *X_, const double *U_, const double *th_, double *w_, int N, int k, double h, int steps, double *lacc_) {
     constexpr int NX = M::NX, NU = M::NU, NL = M::NL, TS = SECOND ? M::TAB2 : M::TAB;
-    static_assert(!(TH_LDS && SECOND), "the second-order pass reads the full parameter vector");
     const double *X = as_global(X_), *U = as_global(U_), *th = TH_LDS ? as_lds(th_) : as_global(th_);
     double *w = as_global(w_);
     const LargeLayout<M> lay(N);
@@ -3004,19 +3003,19 @@ __device__ MPCRL_PHASE_FN void chain_point_pass(const double *X_, const double *
     double u[NU];
 #pragma unroll
     for (int i = 0; i < NU; ++i) u[i] = U[k * NU + i];
+    struct AccReg {
+        double a[NX];
+        MPCRL_DI double &operator[](int i) { return a[i]; }
+    };
+    struct AccLds {
+        double *p;
+        int st;
+        MPCRL_DI double &operator[](int i) const { return p[i * st]; }
+    };
     {
         // (TH_LDS: the RK4 accumulator of the lane lives in LDS, entry i at lacc[i N + k].  With all four arrays in registers the
         // compiler kept ~8 doubles of them in scratch, and every reload — an s_waitcnt vmcnt(0) — also waited for the table stores in
         // flight, 40 scattered lines each: ~20 drains per RK4 step were most of this pass's time.)
-        struct AccReg {
-            double a[NX];
-            MPCRL_DI double &operator[](int i) { return a[i]; }
-        };
-        struct AccLds {
-            double *p;
-            int st;
-            MPCRL_DI double &operator[](int i) const { return p[i * st]; }
-        };
         std::conditional_t<TH_LDS, AccLds, AccReg> acc;
         if constexpr (TH_LDS) acc.p = as_lds(lacc_) + k, acc.st = N;
         double xc[NX], kk[NX], xt[NX];
@@ -3064,7 +3063,9 @@ __device__ MPCRL_PHASE_FN void chain_point_pass(const double *X_, const double *
     if constexpr (SECOND) {   // the adjoint: kb_e = d(nu' F) / d(k_e) at every evaluation point, last step first; G_{e,i} from its force part
         const double *nu = w + lay.ynu;
         double *Gt = w + lay.gtab + (size_t)k * 8 * NL * 6;
-        double lb[NX], acc[NX], kb[NX], Xb[NX], q[3 * NL];
+        std::conditional_t<TH_LDS, AccLds, AccReg> acc;
+        if constexpr (TH_LDS) acc.p = as_lds(lacc_) + k, acc.st = N;
+        double lb[NX], kb[NX], Xb[NX], q[3 * NL];
 #pragma unroll
         for (int i = 0; i < NX; ++i) lb[i] = nu[(k + 1) * NX + i];
         for (int s = steps - 1; s >= 0; --s) {
@@ -3099,13 +3100,15 @@ __device__ MPCRL_PHASE_FN void chain_point_pass(const double *X_, const double *
     }
 }
 
+// One wavefront per instance, lane = stage (N <= 64): the instance's differentiable parameters and the lanes' RK4 accumulators sit in LDS
+// (as in the SQP kernel's call).  Until round 4 the lanes of a wavefront ran over (instance, stage) pairs with everything in
+// registers: ~50 doubles of them in scratch, every reload waiting for the scattered table stores in flight — 261 us at n_mass 5 for a
+// pass that takes 35 us inside the SQP kernel.
 template <class M, bool SECOND>
 __global__ void __launch_bounds__(64) chain_point_kernel(const LargeSpec sp, const LargeArgs a) {
     constexpr int NX = M::NX, NU = M::NU;
-    const int N = sp.N;
-    const long gid = (long)blockIdx.x * 64 + threadIdx.x;
-    const int inst = (int)(gid / N);
-    if (inst >= a.B) return;
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // NTD + N NX doubles
+    const int N = sp.N, inst = blockIdx.x, lane = threadIdx.x;
     const LargeLayout<M> lay(N);
     double *w = a.ws + (size_t)inst * a.ws_stride;
     if constexpr (SECOND) {
@@ -3114,8 +3117,11 @@ __global__ void __launch_bounds__(64) chain_point_kernel(const LargeSpec sp, con
     } else {
         if (w[lay.state + ST_ACTIVE] == 0.0) return;
     }
-    chain_point_pass<M, SECOND>(a.X + (size_t)inst * (N + 1) * NX, a.U + (size_t)inst * N * NU, a.theta + (size_t)inst * a.theta_stride, w, N,
-                                (int)(gid - (long)inst * N), sp.h, sp.rk_steps);
+    const double *th = a.theta + (size_t)inst * a.theta_stride;
+    for (int e = lane; e < M::NTD; e += 64) lds[e] = th[M::td_index(e)];
+    wave_sync();
+    if (lane < N)
+        chain_point_pass<M, SECOND, true>(a.X + (size_t)inst * (N + 1) * NX, a.U + (size_t)inst * N * NU, lds, w, N, lane, sp.h, sp.rk_steps, lds + M::NTD);
 }
 
 // ---- dynamics linearisation, the DIRECTION pass: fills [B A]_k of all stages of ONE instance, run by the instance's own wavefront
@@ -3706,7 +3712,10 @@ __global__ void __launch_bounds__(64) chain_sens_mix2_kernel(const LargeSpec sp,
     if (inst >= a.B) return;
     const int status = a.status[inst];
     if (!(status == 0 || status == 2)) return;
-    const int it = (int)(gid - (long)inst * per), iu = it / N, k = it - iu * N;
+    // (the control index runs fastest: the NU lanes of a stage read the SAME table entries — every table access of this kernel is a gather,
+    // one cache line per lane, and the kernel runs on the rate of those requests; with the stage index fastest all 64 lanes of a load
+    // went to different lines)
+    const int it = (int)(gid - (long)inst * per), k = it / NU, iu = it - k * NU;
     const LargeLayout<M> lay(N);
     double *w = a.ws + (size_t)inst * a.ws_stride;
     const double *th = a.theta + (size_t)inst * a.theta_stride;
