@@ -3134,13 +3134,18 @@ __global__ void __launch_bounds__(64) chain_point_kernel(const LargeSpec sp, con
 template <class M>
 struct DirCfg {
     static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NL = M::NL, EV = 8;
-    static constexpr int TSZ = EV * NL * M::TAB;                    // doubles of one stage's first-order table
+    static constexpr int TSZ = EV * NL * M::TAB;                    // doubles of one stage's first-order table in the workspace
+    // In LDS a link's record is 12 doubles — its 9 coefficients and the link's 3 damping coefficients — on a 16-byte boundary: six
+    // ds_read_b128 per link (4 LDS cycles each) where the 9 + 3 doubles at odd offsets were five ds_read2_b64 (8 cycles each: the
+    // instruction runs at half the LDS rate) and two ds_read_b64.  Four wavefronts per CU run this pass at the same time and it is
+    // bound by the LDS pipe they share.
+    static constexpr int LREC = 12, TSZL = EV * NL * LREC;
     static constexpr int SPAN = (64 + NW - 1) / NW + 1;              // stages a step of 64 consecutive (stage, direction) items can touch
-    static constexpr int BIG = ChainCfg<M>::LDS_TOTAL - ChainCfg<M>::oBig;
-    static constexpr bool FITS = SPAN * TSZ <= BIG;                  // else whole stages per step
+    static constexpr bool FITS = SPAN * TSZL <= 2048;                // else whole stages per step
+    static constexpr int NST = FITS ? SPAN : 64 / NW;                // stage tables in LDS
     static constexpr int LP = FITS ? 64 : (64 / NW) * NW;            // items per step
-    static constexpr int CO = (FITS ? SPAN : 64 / NW) * TSZ;         // after the tables: the instance's NTD differentiable parameters
-    static_assert(CO + M::NTD <= BIG, "tables of a step fit the LDS region");
+    static constexpr int CO = NST * TSZL;                            // after the tables: the instance's NTD differentiable parameters
+    static_assert(ChainCfg<M>::oBig % 2 == 0, "16-byte records");
 };
 
 template <class M>
@@ -3152,7 +3157,7 @@ __device__ MPCRL_PHASE_FN void chain_dir_pass(const double *th_, double *w_, dou
     const LargeLayout<M> lay(N);
     const int items = N * NW;
     // the tables of step i + 1 are requested before step i is computed and go to LDS after it: one global round trip per step hidden
-    constexpr int NPF = ((DC::FITS ? DC::SPAN : 64 / NW) * TSZ + 63) / 64;
+    constexpr int NPF = (DC::NST * TSZ + 63) / 64, LREC = DC::LREC, TSZL = DC::TSZL;
     double pf[NPF];
     auto request = [&](int i0) {
         const int k_lo = i0 / NW, cnt = (min(N - 1, (i0 + DC::LP - 1) / NW) - k_lo + 1) * TSZ;
@@ -3163,20 +3168,25 @@ __device__ MPCRL_PHASE_FN void chain_dir_pass(const double *th_, double *w_, dou
         }
     };
     request(0);
-    const double *Cl = tabl + DC::CO + 7 * NL;       // damping coefficients of the compact parameter copy the caller staged
+    // the damping coefficients (out of the compact parameter copy the caller staged) go into every link record once: a record's
+    // link index is a function of its position
+    for (int r = lane; r < DC::NST * DC::EV * NL; r += 64)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) tabl[r * LREC + 9 + j] = tabl[DC::CO + 7 * NL + 3 * (r % NL) + j];
     for (int i0 = 0; i0 < items; i0 += DC::LP) {
         const int k_lo = i0 / NW, k_hi = min(N - 1, (i0 + DC::LP - 1) / NW);
 #pragma unroll
         for (int j = 0; j < NPF; ++j) {
             const int e = lane + 64 * j;
-            if (e < (k_hi - k_lo + 1) * TSZ) tabl[e] = pf[j];
+            const int ks = e / TSZ, idx = e - ks * TSZ, rec = idx / M::TAB;
+            if (e < (k_hi - k_lo + 1) * TSZ) tabl[ks * TSZL + rec * LREC + (idx - rec * M::TAB)] = pf[j];
         }
         wave_sync();
         if (i0 + DC::LP < items) request(i0 + DC::LP);
         const int it_ = i0 + lane;
         const bool on = lane < DC::LP && it_ < items;
         const int k = on ? it_ / NW : k_lo, d = on ? it_ - k * NW : 0;
-        const double *mytab = tabl + (size_t)(k - k_lo) * TSZ;
+        const double *mytab = tabl + (size_t)(k - k_lo) * TSZL;
         double dxc[NX], acc[NX], dk[NX], dxt[NX], du[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) du[i] = d == i ? 1.0 : 0.0;
@@ -3188,18 +3198,25 @@ __device__ MPCRL_PHASE_FN void chain_dir_pass(const double *th_, double *w_, dou
         // right in front of its use (55 waits on an empty LDS queue per RK4 step: the pass ran on LDS latency).
         constexpr int Mm = M::M;
         double tq[2][12];
-        auto fetch = [&](const double *src, int link, double (&t)[12]) {   // 9 coefficients of the point + the link's damping
+        auto fetch = [&](const double *src, double (&t)[12]) {   // a link record: 9 coefficients of the point + the link's damping
+            if constexpr (NX <= 21) {
+                const d2_t *s2 = (const d2_t *)__builtin_assume_aligned(src, 16);
 #pragma unroll
-            for (int j = 0; j < 9; ++j) t[j] = src[j];
+                for (int j = 0; j < 6; ++j) {
+                    const d2_t v = s2[j];
+                    t[2 * j] = v.x, t[2 * j + 1] = v.y;
+                }
+            } else {   // (n_mass 6, 7: the lane is out of registers and the aligned register quads of ds_read_b128 cost more than they save: 2.53 vs 2.08 ms)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) t[9 + j] = Cl[3 * link + j];
+                for (int j = 0; j < 12; ++j) t[j] = src[j];
+            }
         };
         auto eval = [&](const double *tb, const double *dxe, auto par0) {   // dk = (d f / d x) dxe + (d f / d u) du; par0: buffer of link 0
 #pragma unroll
             for (int i = 0; i < 3 * Mm; ++i) dk[3 * (Mm + 1) + i] = 0.0;
             static_for<NL>([&](auto i_) {
                 constexpr int i = decltype(i_)::value, cur = (decltype(par0)::value + i) & 1;
-                fetch(tb + (i + 1) * TAB, i + 1 < NL ? i + 1 : 0, tq[cur ^ 1]);   // (i + 1 = NL: link 0 of the next evaluation point, the tables are contiguous)
+                fetch(tb + (i + 1) * LREC, tq[cur ^ 1]);   // (i + 1 = NL: link 0 of the next evaluation point, the tables are contiguous)
                 __builtin_amdgcn_sched_barrier(0);
                 M::template ode_tan_link<i>(tq[cur], dxe, du, dk + 3 * (Mm + 1));
                 __builtin_amdgcn_sched_barrier(0);
@@ -3211,19 +3228,19 @@ __device__ MPCRL_PHASE_FN void chain_dir_pass(const double *th_, double *w_, dou
         };
         constexpr int P1 = NL & 1, P2 = (2 * NL) & 1, P3 = (3 * NL) & 1;   // buffer parity at the start of the evaluation points
         static_assert(((4 * NL) & 1) == 0, "an RK4 step ends on the buffer it started with");
-        fetch(mytab, 0, tq[0]);
+        fetch(mytab, tq[0]);
         for (int s_ = 0; s_ < steps; ++s_) {
-            const double *tb = mytab + (size_t)(4 * s_) * NL * TAB;
+            const double *tb = mytab + (size_t)(4 * s_) * NL * LREC;
             eval(tb, dxc, std::integral_constant<int, 0>{});
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc[i] = dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
-            eval(tb + NL * TAB, dxt, std::integral_constant<int, P1>{});
+            eval(tb + NL * LREC, dxt, std::integral_constant<int, P1>{});
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
-            eval(tb + 2 * NL * TAB, dxt, std::integral_constant<int, P2>{});
+            eval(tb + 2 * NL * LREC, dxt, std::integral_constant<int, P2>{});
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + h * dk[i];
-            eval(tb + 3 * NL * TAB, dxt, std::integral_constant<int, P3>{});
+            eval(tb + 3 * NL * LREC, dxt, std::integral_constant<int, P3>{});
 #pragma unroll
             for (int i = 0; i < NX; ++i) dxc[i] = dxc[i] + (h / 6.0) * (acc[i] + dk[i]);
         }
