@@ -13,6 +13,8 @@ from .problems import Problem
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libmpc_oracle.so")
+# MPC_ORACLE_LIB: another build of the same source (tests/test_oracle_sanitizers.py runs the ASan + UBSan one, `make asan`)
+_LIB_OVERRIDE = os.environ.get("MPC_ORACLE_LIB")
 
 SENS_V, SENS_PI, WARM, EXACT, RTI = 1, 2, 4, 8, 16
 _dp = C.POINTER(C.c_double)
@@ -30,6 +32,8 @@ class OracleSpec(C.Structure):
 
 
 def build(force: bool = False) -> str:
+    if _LIB_OVERRIDE:
+        return _LIB_OVERRIDE
     if force or not os.path.exists(LIB_PATH):
         subprocess.check_call(["make", "-C", os.path.join(_HERE, "cpu")] + (["-B"] if force else []))
     return LIB_PATH
