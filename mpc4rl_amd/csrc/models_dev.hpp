@@ -68,6 +68,8 @@ struct CartpoleDev {
     // d(x0)/dt = x1, so for RK4 with any step the columns of A for x0 and x1 are e_0 and [T, 1, 0, 0]' (T = step length) exactly.
     // Only u, theta, theta_dot are carried as jet directions.
     __host__ __device__ static constexpr bool soft_coord(int) { return false; }
+    static constexpr int NSOFT = 1;                                        // (no soft coordinate: a dummy slot)
+    __host__ __device__ static constexpr int soft_slot(int) { return 0; }
     static constexpr int NLD = 3;
     MPCRL_DI static constexpr int lin_coord(int d) { return d == 0 ? 0 : d + 2; }   // stage-vector coordinate (v = [u; x]) of direction d
     template <class F>
@@ -121,6 +123,9 @@ struct LinearDev {
     MPCRL_DI static int tc_index(int i) { return 8 + i; }   // V_0, f_0, f_1, f_2
     MPCRL_DI static bool p_has_gradient(int) { return true; }
     __host__ __device__ static constexpr bool soft_coord(int i) { return i == NU; }   // idxsbx = [0]: the first state (linear_system/acados.py:73-131)
+    // slack state (s, its multiplier pair, the row slack) is carried for the soft coordinates only: NSOFT slots, soft_slot(i) of coordinate i
+    static constexpr int NSOFT = 1;
+    __host__ __device__ static constexpr int soft_slot(int) { return 0; }
     static constexpr int NLD = NX + NU;
     MPCRL_DI static constexpr int lin_coord(int d) { return d; }
     template <class F>

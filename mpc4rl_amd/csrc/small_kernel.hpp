@@ -173,14 +173,40 @@ struct SmallSolver {
     const bool term, first;
     bool qmode;
     double ck;                    // cost scaling c_k of this stage
-    double thd[NTD], thc[NTC > 0 ? NTC : 1];
+    // the instance's differentiable / cost parameters: registers, or (M::DISCRETE, the linear-system model: 12 doubles that are read a
+    // few times per SQP iteration and were simply parked in scratch) an LDS copy per instance slot of the wavefront
+    template <int NN, bool LDS_>
+    struct ThStore {
+        double a[NN > 0 ? NN : 1];
+        MPCRL_DI double operator[](int i) const { return a[i]; }
+        MPCRL_DI void set(int i, double v) { a[i] = v; }
+        MPCRL_DI const double *ptr() const { return a; }
+        MPCRL_DI void bind(double *) {}
+    };
+    template <int NN>
+    struct ThStore<NN, true> {
+        double *p;
+        MPCRL_DI double operator[](int i) const { return p[i]; }
+        MPCRL_DI void set(int i, double v) { p[i] = v; }   // (every lane of the instance writes the same value)
+        MPCRL_DI const double *ptr() const { return p; }
+        MPCRL_DI void bind(double *q_) { p = q_; }
+    };
+    static constexpr bool TH_LDS = M::DISCRETE;
+    static constexpr int TH_DOUBLES = NTD + (NTC > 0 ? NTC : 1);
+    ThStore<NTD, TH_LDS> thd;
+    ThStore<NTC, TH_LDS> thc;
+    MPCRL_DI void bind_theta(double *slot_base) { thd.bind(slot_base), thc.bind(slot_base + NTD); }
     // NLP iterate of this stage
     double x[NX], u[NU], nu_[NX];   // nu_ = multiplier of x_k = F(x_{k-1},u_{k-1})   (k >= 1)
     // linearisation of the dynamics leaving this stage (k < N) and cost gradient
     double A[NX * NX], Bm[NX * NU], r[NX], q[NW];
     // inequality rows of this stage: [side 0 lower / 1 upper][coordinate of v = [u; x]]
     double lam[2][NW], t[2][NW], aff[2][NW];
-    double s[2][SOFT ? NW : 1], lams[2][SOFT ? NW : 1], ts[2][SOFT ? NW : 1], affs[2][SOFT ? NW : 1];
+    // slack state of the L1-soft bounds: one slot per coordinate the model's OCP can soften (M::NSOFT, M::soft_slot) — carried for all NW
+    // coordinates it was 24 doubles of state per lane in the linear-system kernel for ONE soft coordinate, most of them spilled
+    static constexpr int NS = M::NSOFT;
+    MPCRL_DI static constexpr int ss(int i) { return M::soft_slot(i); }
+    double s[2][NS], lams[2][NS], ts[2][NS], affs[2][NS];
     // QP iterate and Newton step
     double dx[NX], du[NU], nuq[NX], Dx[NX], Du[NU], Dnu[NX];
     // Riccati factors of this stage
@@ -243,7 +269,7 @@ struct SmallSolver {
     MPCRL_DI double BA(int m, int j) const { return j < NU ? Bget(m * NU + (j < NU ? j : 0)) : Aget(m * NX + (j >= NU ? j - NU : 0)); }
     // slack(v) of the bound row on side sd, coordinate i, at value v
     MPCRL_DI double bslack(int sd, int i, double v) const {
-        const double sv = SOFT && softc(i) ? s[sd][SOFT ? i : 0] : 0.0;
+        const double sv = SOFT && softc(i) ? s[sd][ss(i)] : 0.0;
         return sd ? ubv(i) - v + sv : v + sv - lbv(i);
     }
 
@@ -302,14 +328,14 @@ struct SmallSolver {
                 }
             }
         }
-        double val = M::cost_grad(term, k, x, u, sp, thc, Hc, ctab + NHT, q);
+        double val = M::cost_grad(term, k, x, u, sp, thc.ptr(), Hc, ctab + NHT, q);
 #pragma unroll
         for (int i = 0; i < NW; ++i) q[i] *= ck;
         val *= ck;
         if constexpr (SOFT) {
 #pragma unroll
             for (int i = 0; i < NW; ++i)
-                if (softc(i)) val += zw(0, i) * s[0][i] + zw(1, i) * s[1][i];
+                if (softc(i)) val += zw(0, i) * s[0][ss(i)] + zw(1, i) * s[1][ss(i)];
         }
         return val;
     }
@@ -345,9 +371,9 @@ struct SmallSolver {
                     rc = fmax(rc, fabs(lam[sd][i] * h));
                     if constexpr (SOFT) {
                         if (softc(i)) {
-                            ri = fmax(ri, -s[sd][i]);
-                            rc = fmax(rc, fabs(lams[sd][i] * s[sd][i]));
-                            rs = fmax(rs, fabs(zw(sd, i) - lam[sd][i] - lams[sd][i]));
+                            ri = fmax(ri, -s[sd][ss(i)]);
+                            rc = fmax(rc, fabs(lams[sd][ss(i)] * s[sd][ss(i)]));
+                            rs = fmax(rs, fabs(zw(sd, i) - lam[sd][i] - lams[sd][ss(i)]));
                         }
                     }
                 }
@@ -1077,7 +1103,7 @@ struct SmallSolver {
             const double rd1 = t1 - bslack(sd, i, v);
             const double e1 = (rm_(l1, t1, aff[sd][i], pass, smu) - l1 * rd1) * it1;
             if (SOFT && softc(i)) {
-                const int ii = SOFT ? i : 0;
+                const int ii = ss(i);
                 const double l2 = lams[sd][ii], t2 = ts[sd][ii], it2 = fast_rcp(t2);
                 const double w2 = l2 * it2;
                 const double e2 = (rm_(l2, t2, affs[sd][ii], pass, smu) - l2 * (t2 - s[sd][ii])) * it2;
@@ -1101,7 +1127,7 @@ struct SmallSolver {
         const double rm1 = rm_(l1, t1, aff[sd][i], pass, smu);
         dss = 0.0, dt2 = 0.0, dl2 = 0.0, rat = 0.0;
         if (SOFT && softc(i)) {
-            const int ii = SOFT ? i : 0;
+            const int ii = ss(i);
             const double l2 = lams[sd][ii], t2 = ts[sd][ii], it2 = fast_rcp(t2);
             const double w1 = l1 * it1, w2 = l2 * it2;
             const double rd2 = t2 - s[sd][ii];
@@ -1151,7 +1177,7 @@ struct SmallSolver {
                 cnt += 1.0;
                 if (SOFT && softc(i)) {
                     cnt += 1.0;
-                    const int ii = SOFT ? i : 0;
+                    const int ii = ss(i);
                     if (act) {
                         if (warm) {
                             double l = lams[sd][ii], tt = fmax(s[sd][ii], ts[sd][ii]);
@@ -1226,7 +1252,7 @@ struct SmallSolver {
                         rloc = fmax(rloc, fabs(t[sd][i] - bslack(sd, i, v)));
                         muloc = fma(lam[sd][i], t[sd][i], muloc);
                         if (SOFT && softc(i)) {
-                            const int ii = SOFT ? i : 0;
+                            const int ii = ss(i);
                             rloc = fmax(rloc, fabs(ts[sd][ii] - s[sd][ii]));
                             rloc = fmax(rloc, fabs(zw(sd, i) - lam[sd][i] - lams[sd][ii]));
                             muloc = fma(lams[sd][ii], ts[sd][ii], muloc);
@@ -1286,7 +1312,7 @@ struct SmallSolver {
                     aff[sd][i] = dl1 * dt1;   // only read by the corrector (pass = 1)
                     c12[0] = fma(lam[sd][i], dt1, fma(t[sd][i], dl1, c12[0])), c12[1] = fma(dl1, dt1, c12[1]);
                     if (SOFT && softc(i)) {
-                        const int ii = SOFT ? i : 0;
+                        const int ii = ss(i);
                         affs[sd][ii] = dl2 * dt2;
                         c12[0] = fma(lams[sd][ii], dt2, fma(ts[sd][ii], dl2, c12[0])), c12[1] = fma(dl2, dt2, c12[1]);
                     }
@@ -1319,7 +1345,7 @@ struct SmallSolver {
                         lam[sd][i] = fma(alpha, dl1, lam[sd][i]);
                         t[sd][i] = fma(alpha, dt1, t[sd][i]);
                         if (SOFT && softc(i)) {
-                            const int ii = SOFT ? i : 0;
+                            const int ii = ss(i);
                             lams[sd][ii] = fma(alpha, dl2, lams[sd][ii]);
                             ts[sd][ii] = fma(alpha, dt2, ts[sd][ii]);
                             s[sd][ii] = fma(alpha, dss, s[sd][ii]);
@@ -1385,7 +1411,7 @@ struct SmallSolver {
                     rmax = fmax(rmax, rat);
                     d12[0] = fma(lam[sd][i], dt1, fma(t[sd][i], dl1, d12[0])), d12[1] = fma(dl1, dt1, d12[1]);
                     if (SOFT && softc(i)) {
-                        const int ii = SOFT ? i : 0;
+                        const int ii = ss(i);
                         d12[0] = fma(lams[sd][ii], dt2, fma(ts[sd][ii], dl2, d12[0])), d12[1] = fma(dl2, dt2, d12[1]);
                     }
                 }
@@ -1620,10 +1646,13 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
     S.fill_cost_table(c_lds, slot < ipw ? slot : 0, slot < ipw, th);
     SmallSolver<M>::wave_lds_sync();
     S.load_hc();
+    // (lanes past the last instance slot shadow another instance: they get a slot of their own)
+    __shared__ double th_slots[SmallSolver<M>::TH_LDS ? (M::MAX_IPW + 1) * SmallSolver<M>::TH_DOUBLES : 1];
+    S.bind_theta(th_slots + (slot < ipw ? slot : M::MAX_IPW) * SmallSolver<M>::TH_DOUBLES);
 #pragma unroll
-    for (int i = 0; i < NTD; ++i) S.thd[i] = th[M::td_index(i)];
+    for (int i = 0; i < NTD; ++i) S.thd.set(i, th[M::td_index(i)]);
 #pragma unroll
-    for (int i = 0; i < NTC; ++i) S.thc[i] = th[M::tc_index(i)];
+    for (int i = 0; i < NTC; ++i) S.thc.set(i, th[M::tc_index(i)]);
     const double *x0 = a.x0 + inst * NX;
     const double *u0f = S.qmode ? a.u0fix + inst * NU : a.x0 + inst * NX;
 #pragma unroll
@@ -1644,8 +1673,12 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             S.lam[0][i] = S.lam[1][i] = 0.0, S.t[0][i] = S.t[1][i] = 1.0, S.aff[0][i] = S.aff[1][i] = 0.0;
-            if constexpr (SOFT) S.s[0][i] = S.s[1][i] = 0.0, S.lams[0][i] = S.lams[1][i] = 0.0, S.ts[0][i] = S.ts[1][i] = 1.0,
-                                S.affs[0][i] = S.affs[1][i] = 0.0;
+            if constexpr (SOFT) {
+                if (M::soft_coord(i)) {
+                    const int j = S.ss(i);
+                    S.s[0][j] = S.s[1][j] = 0.0, S.lams[0][j] = S.lams[1][j] = 0.0, S.ts[0][j] = S.ts[1][j] = 1.0, S.affs[0][j] = S.affs[1][j] = 0.0;
+                }
+            }
         }
     } else {
 #pragma unroll
@@ -1665,10 +1698,13 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
             S.lam[0][i] = cold ? 0.0 : l0, S.lam[1][i] = cold ? 0.0 : l1, S.t[0][i] = cold ? 1.0 : t0, S.t[1][i] = cold ? 1.0 : t1;
             S.aff[0][i] = S.aff[1][i] = 0.0;
             if constexpr (SOFT) {
-                const double s0 = bnd[4 * nb + i], s1 = bnd[5 * nb + i], m0 = bnd[6 * nb + i], m1 = bnd[7 * nb + i], u0_ = bnd[8 * nb + i],
-                             u1_ = bnd[9 * nb + i];
-                S.s[0][i] = cold ? 0.0 : s0, S.s[1][i] = cold ? 0.0 : s1, S.lams[0][i] = cold ? 0.0 : m0, S.lams[1][i] = cold ? 0.0 : m1;
-                S.ts[0][i] = cold ? 1.0 : u0_, S.ts[1][i] = cold ? 1.0 : u1_, S.affs[0][i] = S.affs[1][i] = 0.0;
+                if (M::soft_coord(i)) {
+                    const int j = S.ss(i);
+                    const double s0 = bnd[4 * nb + i], s1 = bnd[5 * nb + i], m0 = bnd[6 * nb + i], m1 = bnd[7 * nb + i], u0_ = bnd[8 * nb + i],
+                                 u1_ = bnd[9 * nb + i];
+                    S.s[0][j] = cold ? 0.0 : s0, S.s[1][j] = cold ? 0.0 : s1, S.lams[0][j] = cold ? 0.0 : m0, S.lams[1][j] = cold ? 0.0 : m1;
+                    S.ts[0][j] = cold ? 1.0 : u0_, S.ts[1][j] = cold ? 1.0 : u1_, S.affs[0][j] = S.affs[1][j] = 0.0;
+                }
             }
         }
     }
@@ -1790,7 +1826,7 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
                 if (S.has(sd, i)) {
                     lag = fma(-S.lam[sd][i], S.bslack(sd, i, S.vc(i)), lag);
                     if constexpr (SOFT) {
-                        if (S.softc(i)) lag = fma(-S.lams[sd][i], S.s[sd][i], lag);
+                        if (S.softc(i)) lag = fma(-S.lams[sd][S.ss(i)], S.s[sd][S.ss(i)], lag);
                     }
                 }
         }
@@ -1820,9 +1856,12 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
         for (int i = 0; i < NW; ++i) {
             bnd[0 * nb + i] = S.has(0, i) ? S.lam[0][i] : 0.0, bnd[1 * nb + i] = S.has(1, i) ? S.lam[1][i] : 0.0;
             bnd[2 * nb + i] = S.has(0, i) ? S.t[0][i] : 1.0, bnd[3 * nb + i] = S.has(1, i) ? S.t[1][i] : 1.0;
-            if constexpr (SOFT) {
-                bnd[4 * nb + i] = S.s[0][i], bnd[5 * nb + i] = S.s[1][i], bnd[6 * nb + i] = S.lams[0][i], bnd[7 * nb + i] = S.lams[1][i];
-                bnd[8 * nb + i] = S.ts[0][i], bnd[9 * nb + i] = S.ts[1][i];
+            if constexpr (SOFT) {   // (coordinates the model cannot soften keep the values of a cold iterate)
+                const bool sc = M::soft_coord(i);
+                const int j = S.ss(i);
+                bnd[4 * nb + i] = sc ? S.s[0][j] : 0.0, bnd[5 * nb + i] = sc ? S.s[1][j] : 0.0;
+                bnd[6 * nb + i] = sc ? S.lams[0][j] : 0.0, bnd[7 * nb + i] = sc ? S.lams[1][j] : 0.0;
+                bnd[8 * nb + i] = sc ? S.ts[0][j] : 1.0, bnd[9 * nb + i] = sc ? S.ts[1][j] : 1.0;
             }
         }
     }
@@ -1934,9 +1973,9 @@ __global__ void __launch_bounds__(64, 1) small_solve_sliced_kernel(const SmallSp
         S.ctab = c_lds + loc * SmallSolver<M>::CTAB + S.stage_kind() * SmallSolver<M>::CSET;
         S.load_hc();
 #pragma unroll
-        for (int i = 0; i < NTD; ++i) S.thd[i] = th_lds[loc * TH + i];
+        for (int i = 0; i < NTD; ++i) S.thd.set(i, th_lds[loc * TH + i]);
 #pragma unroll
-        for (int i = 0; i < NTC; ++i) S.thc[i] = th_lds[loc * TH + NTD + i];
+        for (int i = 0; i < NTC; ++i) S.thc.set(i, th_lds[loc * TH + NTD + i]);
     };
     load_params();
     // ---- cold start of the resident instances (MPC.reset, mpc.py:204-210), or their stored iterates
@@ -2390,10 +2429,13 @@ __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, cons
     S.fill_cost_table(c_lds, slot < ipw ? slot : 0, slot < ipw, th);
     SmallSolver<M>::wave_lds_sync();
     S.load_hc();
+    // (lanes past the last instance slot shadow another instance: they get a slot of their own)
+    __shared__ double th_slots[SmallSolver<M>::TH_LDS ? (M::MAX_IPW + 1) * SmallSolver<M>::TH_DOUBLES : 1];
+    S.bind_theta(th_slots + (slot < ipw ? slot : M::MAX_IPW) * SmallSolver<M>::TH_DOUBLES);
 #pragma unroll
-    for (int i = 0; i < NTD; ++i) S.thd[i] = th[M::td_index(i)];
+    for (int i = 0; i < NTD; ++i) S.thd.set(i, th[M::td_index(i)]);
 #pragma unroll
-    for (int i = 0; i < NTC; ++i) S.thc[i] = th[M::tc_index(i)];
+    for (int i = 0; i < NTC; ++i) S.thc.set(i, th[M::tc_index(i)]);
     const size_t nb = (size_t)(N + 1) * NW;
     const double *bnd = a.BND + (size_t)inst * 10 * nb + (size_t)k * NW;
 #pragma unroll
