@@ -59,6 +59,13 @@ constexpr double CHAIN_TOL_MU_FACTOR = 1.0;
 #ifndef MPCRL_CHAIN_ROWS_IN_REGS
 #define MPCRL_CHAIN_ROWS_IN_REGS 1     // qp_solve_rows: the bound rows of a QP in registers (at most 128 rows)
 #endif
+#ifndef MPCRL_CHAIN_MERGE_CALLS
+#ifdef MPCRL_PROFILE_PHASES
+#define MPCRL_CHAIN_MERGE_CALLS 0   // (the phase profile times the sweeps one by one)
+#else
+#define MPCRL_CHAIN_MERGE_CALLS 1   // predictor = factor + forward, corrector = backward + forward as ONE phase call each (half the callee-saved register traffic)
+#endif
+#endif
 #ifndef MPCRL_CHAIN_FUSE_GT
 #define MPCRL_CHAIN_FUSE_GT 1   // [B A]_k' nu_{k+1} (stationarity residual) formed by the direction pass from the columns it holds; 0: a stage pass over [B A]
 #endif
@@ -166,6 +173,10 @@ struct LargeLayout {
 
 enum { ST_ACTIVE = 0, ST_IT = 1, ST_NIPM = 2, ST_TIGHT = 3, ST_STEPN = 4, ST_COST = 5, ST_RES = 6, ST_STATUS = 10 };
 
+template <class M, bool SECOND, bool TH_LDS>
+__device__ __forceinline__ void chain_point_body(const double *X, const double *U, const double *th, double *w, int N, int k, double h, int steps, double *lacc);
+template <class M>
+__device__ __forceinline__ void chain_dir_body(const double *th, double *w, double *tabl, int N, int lane, double h, int steps);
 template <class M, bool SECOND, bool TH_LDS = false>
 __device__ void chain_point_pass(const double *X, const double *U, const double *th, double *w, int N, int k, double h, int steps, double *lacc = nullptr);
 
@@ -2407,6 +2418,7 @@ struct ChainSolver {
     MPCRL_DI bool qp_solve_rows(HS &hs, const double *x0, const double *u0f, int &n_it, double warm_mu, double tol_res, double tol_mu, bool rg_ready) {
         const bool warm = warm_mu > 0.0;
         const int ne = (N + 1) * NW;
+        constexpr bool MERGED = MPCRL_CHAIN_MERGE_CALLS != 0 && USE_V2 && std::is_same<HS, HessConst<M>>::value;
         for (int e = lane; e < (N + 1) * NX; e += NT) dx[e] = e < NX ? x0[e] - X[e] : 0.0, nuq[e] = warm ? NUv[e] : 0.0;
         for (int e = lane; e < N * NU; e += NT) du[e] = (qmode && e < NU) ? u0f[e] - U[e] : 0.0;
         wave_sync();
@@ -2528,14 +2540,21 @@ struct ChainSolver {
                 }
                 wave_sync();
                 ph(1);
-                if (pass == 0) {
-                    if (!factor_call<HS>(ctx(), hs.hex_offset(), rt.off, rb.off)) fail = true;
-                    ph(2);
+                if constexpr (MERGED) {
+                    if (pass == 0) {
+                        if (!pred_call<HS>(ctx(), hs.hex_offset(), rt.off, rb.off)) fail = true;
+                    } else
+                        corr_call(ctx(), rt.off, rb.off);
                 } else {
-                    backward_vec_call(ctx(), rt.off);
-                    ph(3);
+                    if (pass == 0) {
+                        if (!factor_call<HS>(ctx(), hs.hex_offset(), rt.off, rb.off)) fail = true;
+                        ph(2);
+                    } else {
+                        backward_vec_call(ctx(), rt.off);
+                        ph(3);
+                    }
+                    forward_call<false>(ctx(), rb.off);
                 }
-                forward_call<false>(ctx(), rb.off);
                 ph(4);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) dvr[j] = on[j] ? Dx[(int)Doff[j]] : 0.0;      // the direction at the rows: the one load of the pass
@@ -2888,6 +2907,29 @@ struct ChainSolver {
         o.cost = S.round_start(x0, u0f, o.res);
         return o;
     }
+    // the whole start of an SQP round as ONE call: parameter / multiplier staging, point pass, direction pass, round_start.  As
+    // three calls their prologues and epilogues moved ~70 KB per wavefront and round through scratch (MPCRL_CHAIN_MERGE_CALLS).
+    __device__ MPCRL_PHASE_FN static RoundStart round_call(Ctx c, const double *x0, const double *u0f, double h, int steps) {
+        ChainSolver S = from_ctx(c);
+        using DC_ = DirCfg<M>;
+        double *const big = S.lds + Cfg::oBig;
+        const int N_ = S.N, lane_ = S.lane;
+        for (int e = lane_; e < M::NTD; e += NT) big[DC_::CO + e] = S.th[M::td_index(e)];
+        if constexpr (Cfg::FUSE_GT)
+            batched_pass<8>((N_ + 1) * NX, lane_, [&](int e) { return S.NUv[e]; }, [&](int e, double v) { big[DC_::CO + M::NTD + e] = v; });
+        wave_sync();
+        if (lane_ < N_)
+            chain_point_body<M, false, true>(S.X, S.U, big + DC_::CO, (double *)S.BA.base, N_, lane_, h, steps,
+                                             big + DC_::CO + M::NTD + (Cfg::FUSE_GT ? (N_ + 1) * NX : 0));
+        wave_sync();
+        __builtin_amdgcn_sched_barrier(0);
+        chain_dir_body<M>(S.th, (double *)S.BA.base, big, N_, lane_, h, steps);
+        wave_sync();
+        __builtin_amdgcn_sched_barrier(0);
+        RoundStart o;
+        o.cost = S.round_start(x0, u0f, o.res);
+        return o;
+    }
     __device__ MPCRL_PHASE_FN static double qp_residuals_call(Ctx c) {
         ChainSolver S = from_ctx(c);
         if constexpr (USE_V2 && MPCRL_CHAIN_SCALE_RES)
@@ -2923,6 +2965,24 @@ struct ChainSolver {
     __device__ MPCRL_PHASE_FN static void costate_call(Ctx c) {
         ChainSolver S = from_ctx(c);
         S.costate_nu();
+    }
+    // predictor and corrector as one call each (round-4 sweeps of the SQP only).  Every phase call saves and restores the callee-saved
+    // half of the registers its body uses — 29 KB per wavefront for the factor sweep, ~20 KB for a vector sweep, through scratch, i.e.
+    // HBM traffic at 1024 resident wavefronts: ~1.9 GB written and read back per step of 1024 solves at n_mass 5 with four calls per
+    // interior-point iteration.  The time is the same either way (measured: 8.68 vs 8.69 ms), the bytes are not.
+    template <class HS>
+    __device__ MPCRL_PHASE_FN static bool pred_call(Ctx c, unsigned hex_off, unsigned g_off, unsigned bb_off) {
+        ChainSolver S = from_ctx(c);
+        typename HessV2<HS>::type hs;
+        hs.init(S, hex_off);
+        const bool ok = S.template factor2<typename HessV2<HS>::type, false>(hs, S.arr(g_off), S.arr(bb_off));
+        S.template forward2<false>(S.arr(bb_off));
+        return ok;
+    }
+    __device__ MPCRL_PHASE_FN static void corr_call(Ctx c, unsigned g_off, unsigned bb_off) {
+        ChainSolver S = from_ctx(c);
+        S.backward_vec2(S.arr(g_off));
+        S.template forward2<false>(S.arr(bb_off));
     }
     template <bool want_nu>
     __device__ MPCRL_PHASE_FN static void forward_call(Ctx c, unsigned bb_off) {
@@ -2994,7 +3054,13 @@ __global__ void __launch_bounds__(64) chain_init_kernel(const LargeSpec sp, cons
 // out of the parameter vector in global memory every evaluation point fetched its ~50-75 coefficients again, behind the table
 // stores of the point before.
 template <class M, bool SECOND, bool TH_LDS>
+MPCRL_DI void chain_point_body(const double *X_, const double *U_, const double *th_, double *w_, int N, int k, double h, int steps, double *lacc_);
+template <class M, bool SECOND, bool TH_LDS>
 __device__ MPCRL_PHASE_FN void chain_point_pass(const double *X_, const double *U_, const double *th_, double *w_, int N, int k, double h, int steps, double *lacc_) {
+    chain_point_body<M, SECOND, TH_LDS>(X_, U_, th_, w_, N, k, h, steps, lacc_);
+}
+template <class M, bool SECOND, bool TH_LDS>
+MPCRL_DI void chain_point_body(const double *X_, const double *U_, const double *th_, double *w_, int N, int k, double h, int steps, double *lacc_) {
     constexpr int NX = M::NX, NU = M::NU, NL = M::NL, TS = SECOND ? M::TAB2 : M::TAB;
     const double *X = as_global(X_), *U = as_global(U_), *th = TH_LDS ? as_lds(th_) : as_global(th_);
     double *w = as_global(w_);
@@ -3149,7 +3215,13 @@ struct DirCfg {
 };
 
 template <class M>
+MPCRL_DI void chain_dir_body(const double *th_, double *w_, double *tabl_, int N, int lane, double h, int steps);
+template <class M>
 __device__ MPCRL_PHASE_FN void chain_dir_pass(const double *th_, double *w_, double *tabl_, int N, int lane, double h, int steps) {
+    chain_dir_body<M>(th_, w_, tabl_, N, lane, h, steps);
+}
+template <class M>
+MPCRL_DI void chain_dir_body(const double *th_, double *w_, double *tabl_, int N, int lane, double h, int steps) {
     using DC = DirCfg<M>;
     const double *th = as_global(th_);
     double *w = as_global(w_), *tabl = as_lds(tabl_);
@@ -3301,20 +3373,25 @@ __global__ void __launch_bounds__(64, 1) chain_sqp_kernel(const LargeSpec sp, co
         n_ipm = (int)S.state[ST_NIPM];
         const bool last_tight = S.state[ST_TIGHT] != 0.0;
         const double stepn = S.state[ST_STEPN];
-        // ---- linearisation at the current iterate
+        // ---- linearisation at the current iterate, cost, NLP residuals
         wave_sync();
-        for (int e = lane; e < M::NTD; e += NT) lds[Cfg::oBig + DirCfg<M>::CO + e] = S.th[M::td_index(e)];   // (the QP phases reuse the region)
-        if constexpr (Cfg::FUSE_GT)
-            batched_pass<8>((N + 1) * NX, lane, [&](int e) { return S.NUv[e]; }, [&](int e, double v) { lds[Cfg::oBig + DirCfg<M>::CO + M::NTD + e] = v; });
-        wave_sync();
-        if (lane < N)
-            chain_point_pass<M, false, true>(S.X, S.U, lds + Cfg::oBig + DirCfg<M>::CO, w, N, lane, sp.h, sp.rk_steps,
-                                             lds + Cfg::oBig + DirCfg<M>::CO + M::NTD + (Cfg::FUSE_GT ? (N + 1) * NX : 0));
-        wave_sync();
-        S.ph(6);
-        chain_dir_pass<M>(S.th, w, lds + Cfg::oBig, N, lane, sp.h, sp.rk_steps);
-        S.ph(8);
-        const auto rs0 = ChainSolver<M>::round_start_call(S.ctx(), x0, u0f);
+        typename ChainSolver<M>::RoundStart rs0;
+        if constexpr (MPCRL_CHAIN_MERGE_CALLS != 0 && ChainSolver<M>::USE_V2) {
+            rs0 = ChainSolver<M>::round_call(S.ctx(), x0, u0f, sp.h, sp.rk_steps);
+        } else {
+            for (int e = lane; e < M::NTD; e += NT) lds[Cfg::oBig + DirCfg<M>::CO + e] = S.th[M::td_index(e)];   // (the QP phases reuse the region)
+            if constexpr (Cfg::FUSE_GT)
+                batched_pass<8>((N + 1) * NX, lane, [&](int e) { return S.NUv[e]; }, [&](int e, double v) { lds[Cfg::oBig + DirCfg<M>::CO + M::NTD + e] = v; });
+            wave_sync();
+            if (lane < N)
+                chain_point_pass<M, false, true>(S.X, S.U, lds + Cfg::oBig + DirCfg<M>::CO, w, N, lane, sp.h, sp.rk_steps,
+                                                 lds + Cfg::oBig + DirCfg<M>::CO + M::NTD + (Cfg::FUSE_GT ? (N + 1) * NX : 0));
+            wave_sync();
+            S.ph(6);
+            chain_dir_pass<M>(S.th, w, lds + Cfg::oBig, N, lane, sp.h, sp.rk_steps);
+            S.ph(8);
+            rs0 = ChainSolver<M>::round_start_call(S.ctx(), x0, u0f);
+        }
         cost = rs0.cost;
 #pragma unroll
         for (int j = 0; j < 4; ++j) res[j] = rs0.res[j];
