@@ -129,7 +129,9 @@ struct OmCfg {
     // streamed stage block: per row group the full column tiles (64 lanes each), then the columns < NW of the last tile compactly
     // (4 x LV doubles, lane lr LV + lc): exactly the NW x NW entries the vector sweeps read when NW is a multiple of 4
     static constexpr int CT = 4 * LV, GSZ = RG * (TV * 64 + CT);
-    static constexpr int HBS = 4 * RG;               // stride of the per-stage Omega vectors
+    // stride of the per-stage Omega vectors: 4 RG slots + 2, so that the 16 stages a batched MFMA pass reads as its 16 operand columns
+    // (lane lc -> stage k0 + lc) fall on 16 different bank pairs (4 RG doubles alone: a 4-way conflict at n_mass 5, 2-way at n_mass 7)
+    static constexpr int HBS = 4 * RG + 2;
     MPCRL_DI static unsigned goff(int rg, int tj, int lr, int lc) {   // register (rg, tj) of lane (lr, lc) inside a block
         if (tj < TV) return (unsigned)((rg * TV + tj) * 64 + lr * 16 + lc);
         return (unsigned)(RG * TV * 64 + rg * CT + lr * LV + (lc < LV ? lc : (LV > 0 ? LV - 1 : 0)));
@@ -3205,7 +3207,10 @@ struct DirCfg {
     // ds_read_b128 per link (4 LDS cycles each) where the 9 + 3 doubles at odd offsets were five ds_read2_b64 (8 cycles each: the
     // instruction runs at half the LDS rate) and two ds_read_b64.  Four wavefronts per CU run this pass at the same time and it is
     // bound by the LDS pipe they share.
-    static constexpr int LREC = 12, TSZL = EV * NL * LREC;
+    // (+ 8 doubles between the stages' tables: EV NL LREC doubles is a multiple of the 64 banks for every chain size, so the lanes of
+    // two stages in one ds_read_b128 lane group read different addresses on the SAME banks — a 2-way conflict in three of the four
+    // groups of a step; 16 dwords apart they do not meet)
+    static constexpr int LREC = 12, TSZL = EV * NL * LREC + 8;
     static constexpr int SPAN = (64 + NW - 1) / NW + 1;              // stages a step of 64 consecutive (stage, direction) items can touch
     static constexpr bool FITS = SPAN * TSZL <= 2048;                // else whole stages per step
     static constexpr int NST = FITS ? SPAN : 64 / NW;                // stage tables in LDS
@@ -3242,9 +3247,11 @@ MPCRL_DI void chain_dir_body(const double *th_, double *w_, double *tabl_, int N
     request(0);
     // the damping coefficients (out of the compact parameter copy the caller staged) go into every link record once: a record's
     // link index is a function of its position
-    for (int r = lane; r < DC::NST * DC::EV * NL; r += 64)
+    for (int r = lane; r < DC::NST * DC::EV * NL; r += 64) {
+        const int st_ = r / (DC::EV * NL), rr = r - st_ * (DC::EV * NL);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) tabl[r * LREC + 9 + j] = tabl[DC::CO + 7 * NL + 3 * (r % NL) + j];
+        for (int j = 0; j < 3; ++j) tabl[st_ * TSZL + rr * LREC + 9 + j] = tabl[DC::CO + 7 * NL + 3 * (rr % NL) + j];
+    }
     for (int i0 = 0; i0 < items; i0 += DC::LP) {
         const int k_lo = i0 / NW, k_hi = min(N - 1, (i0 + DC::LP - 1) / NW);
 #pragma unroll
