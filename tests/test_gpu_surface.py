@@ -281,3 +281,16 @@ def test_constraints_set_get_L_and_nlp_set(oracle_port):
         assert abs(lm.get_L() - lm.get_V()) < 1e-5          # lam'h + pi'g vanish at a KKT point up to the barrier parameter
     assert mpc.nlp.vars.val["gamma"] == 1.0 and mpc.nlp.vars.val["dT", 0] == mpc.ocp.dT
     assert np.allclose(mpc.nlp.vars.val["x", 0], x1)
+
+
+def test_chain_sizes_the_library_accepts():
+    """n_mass is a free integer in the reference (chain_mass/ocp_utils.py:344-350); the library instantiates 3 .. 7 and refuses the
+    rest at construction (MPCRL_E_MODEL), never at solve time."""
+    from mpc4rl_amd import MPCBatch, chain_mass_ocp
+    for n_mass in (3, 4, 5, 6, 7):
+        mpc = MPCBatch(chain_mass_ocp(n_mass=n_mass), 2)
+        assert mpc.n_p == chain_mass_ocp(n_mass=n_mass).n_p
+        del mpc
+    for n_mass in (8, 9):
+        with pytest.raises(RuntimeError, match="mpcrl_create failed"):
+            MPCBatch(chain_mass_ocp(n_mass=n_mass), 2)
