@@ -59,6 +59,9 @@ constexpr double CHAIN_TOL_MU_FACTOR = 1.0;
 #ifndef MPCRL_CHAIN_ROWS_IN_REGS
 #define MPCRL_CHAIN_ROWS_IN_REGS 1     // qp_solve_rows: the bound rows of a QP in registers (at most 128 rows)
 #endif
+#ifndef MPCRL_CHAIN_TH2
+#define MPCRL_CHAIN_TH2 1       // with du0*/dp: grad_theta (nu' F) from the point tables (chain_sens_th2_kernel) instead of chain_sens_th_kernel's reverse sweep
+#endif
 #ifndef MPCRL_CHAIN_MERGE_CALLS
 #ifdef MPCRL_PROFILE_PHASES
 #define MPCRL_CHAIN_MERGE_CALLS 0   // (the phase profile times the sweeps one by one)
@@ -3498,6 +3501,61 @@ __global__ void __launch_bounds__(64) chain_sens_th_kernel(const LargeSpec sp, c
     disc_map_adj_p<M, true, double>(jx, ju, th, lm, xb, ub, tb, sp.h, sp.rk_steps);
     double *term = w + lay.term + (size_t)k * NTD;
     for (int d = 0; d < NTD; ++d) term[d] = tb[d];
+}
+
+// grad_theta (nu_{k+1}' F_k) on the POINT TABLES (when du0*/dp is wanted, chain_point_kernel<M, true> has already walked the adjoint of
+// the RK4 map and left, per evaluation point and link, the geometry and the force adjoint q_{e,i}): the parameter adjoint of ode_adj_p
+// written out in those quantities — the values of which chain_sens_mix2_kernel forms the tangents.  One lane per (instance, stage), no
+// re-evaluation of the map, nothing spilled (the reverse sweep of chain_sens_th_kernel holds four stage vectors and the NTD
+// accumulators as one body: 459 / 1 243 spilled registers at n_mass 5 / 7).  The adjoint of the accelerations that the disturbance
+// gradient needs is the running sum of the q_{e,i} from the last link down.
+template <class M>
+__global__ void __launch_bounds__(64) chain_sens_th2_kernel(const LargeSpec sp, const LargeArgs a) {
+    constexpr int NTD = M::NTD, NL = M::NL, TAB2 = M::TAB2, MM = M::M;
+    const int N = sp.N;
+    const long gid = (long)blockIdx.x * 64 + threadIdx.x;
+    const int inst = (int)(gid / N);
+    if (inst >= a.B) return;
+    const int status = a.status[inst];
+    if (!(status == 0 || status == 2)) return;
+    const int k = (int)(gid - (long)inst * N);
+    const LargeLayout<M> lay(N);
+    double *w = a.ws + (size_t)inst * a.ws_stride;
+    const double *th = a.theta + (size_t)inst * a.theta_stride;
+    const double *tab = w + lay.ptab + (size_t)k * 8 * NL * TAB2, *qv = w + lay.qvtab + (size_t)k * 8 * NL * 6;
+    const double *mp = th, *Dp = th + NL, *Lp = th + 4 * NL;
+    double thb[NTD];
+#pragma unroll
+    for (int d = 0; d < NTD; ++d) thb[d] = 0.0;
+    const int ne = 4 * sp.rk_steps;
+#pragma unroll 1
+    for (int e = 0; e < ne; ++e) {
+        double accb[3] = {0.0, 0.0, 0.0};      // adjoint of the acceleration of mass i - 1 while link i is visited (i = NL - 1 .. 1)
+#pragma unroll
+        for (int i = NL - 1; i >= 0; --i) {
+            const double *t = tab + ((size_t)e * NL + i) * TAB2, *q = qv + ((size_t)e * NL + i) * 6, *dv = q + 3;
+            const double inrm = sqrt(t[12] * (1.0 / 3.0)), im = 1.0 / mp[i];
+            double thm = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double Lj = Lp[3 * i + j], dm = Dp[3 * i + j] * im;
+                const double g = 1.0 - Lj * inrm, fd = q[j] * t[j];
+                const double gd = im * (fd * g);
+                thb[7 * NL + 3 * i + j] += q[j] * dv[j];
+                thb[NL + 3 * i + j] += gd;
+                thm -= dm * gd;
+                thb[4 * NL + 3 * i + j] -= dm * (fd * inrm);
+                if (i > 0) {   // q_i = accb_{i-1} - accb_i  (accb_M = 0: the last link ends at the driven mass)
+                    accb[j] = q[j] + (i < MM ? accb[j] : 0.0);
+                    thb[10 * NL + 3 * (i - 1) + j] += accb[j];
+                }
+            }
+            thb[i] += thm;
+        }
+    }
+    double *term = w + lay.term + (size_t)k * NTD;
+#pragma unroll
+    for (int d = 0; d < NTD; ++d) term[d] = thb[d];
 }
 
 // Exact Lagrangian Hessian of a stage, Hex_k = c_k hess l_k + hess (nu_{k+1}' F_k)(x_k, u_k), ONE WAVEFRONT PER (instance, stage).

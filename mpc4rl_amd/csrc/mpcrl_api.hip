@@ -173,10 +173,13 @@ int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
     hipLaunchKernelGGL(chain_sqp_kernel<M>, dim3(B), dim3(64), lds_bytes, st, h->large, a);
     HIP_OK(hipGetLastError());
     if (a.flags & (MPCRL_SENS_V | MPCRL_SENS_PI)) {
-        hipLaunchKernelGGL(chain_sens_th_kernel<M>, dim3((unsigned)(((long)B * N + 63) / 64)), dim3(64), 0, st, h->large, a);
         const bool want_pi = (a.flags & MPCRL_SENS_PI) && a.dpi && !a.u0fix;
+        if (!want_pi || !MPCRL_CHAIN_TH2)   // grad_theta (nu' F): by its own reverse sweep, or (below) from the tables of the second-order point pass
+            hipLaunchKernelGGL(chain_sens_th_kernel<M>, dim3((unsigned)(((long)B * N + 63) / 64)), dim3(64), 0, st, h->large, a);
         if (want_pi) {
             hipLaunchKernelGGL((chain_point_kernel<M, true>), dim3((unsigned)B), dim3(64), (unsigned)((M::NTD + N * M::NX) * sizeof(double)), st, h->large, a);
+            if (MPCRL_CHAIN_TH2)
+                hipLaunchKernelGGL(chain_sens_th2_kernel<M>, dim3((unsigned)(((long)B * N + 63) / 64)), dim3(64), 0, st, h->large, a);
             hipLaunchKernelGGL(chain_sens_ad_kernel<M>, dim3((unsigned)(B * HexCfg<M>::groups(N))), dim3(64), 0, st, h->large, a);
             hipLaunchKernelGGL(chain_sens_riccati_kernel<M>, dim3(B), dim3(64), lds_bytes, st, h->large, a);
             if (MPCRL_CHAIN_MIX2)

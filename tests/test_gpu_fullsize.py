@@ -140,9 +140,13 @@ def test_chain5_bench_size_vs_port(oracle_port):
     r2 = mpc.solve(x0, sens_v=True)
     assert int(r2.iters[:, 0].max()) == 0 and torch.allclose(r2.V, r.V, rtol=1e-13)
     perm = rng.permutation(B)
-    rp = MPCBatch(ocp, B).solve(x0[perm], sens_v=True, cold=True)
+    rp = MPCBatch(ocp, B).solve(x0[perm], sens_v=True, sens_pi=True, cold=True)      # (the same request: bit for bit)
     idx = torch.as_tensor(perm, device=r.V.device)
-    assert torch.equal(rp.V, r.V[idx]) and torch.equal(rp.dV_dp, r.dV_dp[idx])
+    assert torch.equal(rp.V, r.V[idx]) and torch.equal(rp.dV_dp, r.dV_dp[idx]) and torch.equal(rp.dpi_dp, r.dpi_dp[idx])
+    # dV/dp alone takes grad_theta (nu' F) from its own reverse sweep (chain_sens_th_kernel), with du0*/dp from the tables of the
+    # second-order point pass (chain_sens_th2_kernel): two evaluation orders of the same sums
+    rv = MPCBatch(ocp, B).solve(x0[perm], sens_v=True, cold=True)
+    assert torch.equal(rv.V, rp.V) and torch.allclose(rv.dV_dp, rp.dV_dp, rtol=1e-11, atol=1e-11 * float(rp.dV_dp.abs().max()))
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------

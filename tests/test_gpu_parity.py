@@ -288,9 +288,13 @@ def test_chain_mass_n7_vs_oracle_and_full_size_properties(oracle_port):
     r2 = mpc.solve(x0, sens_v=True, sens_pi=True)
     assert int(r2.iters[:, 0].max()) == 0 and torch.allclose(r2.V, r.V, rtol=1e-13) and torch.allclose(r2.dV_dp, r.dV_dp, rtol=1e-10, atol=1e-12)
     perm = rng.permutation(B)
-    rp = MPCBatch(ocp, B).solve(x0[perm], sens_v=True, cold=True)
+    rp = MPCBatch(ocp, B).solve(x0[perm], sens_v=True, sens_pi=True, cold=True)      # (the same request: bit for bit)
     idx = torch.as_tensor(perm, device=r.V.device)
-    assert torch.equal(rp.V, r.V[idx]) and torch.equal(rp.dV_dp, r.dV_dp[idx])
+    assert torch.equal(rp.V, r.V[idx]) and torch.equal(rp.dV_dp, r.dV_dp[idx]) and torch.equal(rp.dpi_dp, r.dpi_dp[idx])
+    # dV/dp alone takes grad_theta (nu' F) from its own reverse sweep (chain_sens_th_kernel), with du0*/dp from the tables of the
+    # second-order point pass (chain_sens_th2_kernel): two evaluation orders of the same sums
+    rv = MPCBatch(ocp, B).solve(x0[perm], sens_v=True, cold=True)
+    assert torch.equal(rv.V, rp.V) and torch.allclose(rv.dV_dp, rp.dV_dp, rtol=1e-11, atol=1e-11 * float(rp.dV_dp.abs().max()))
     ref8 = oracle_port.solve(P, x0[:8])
     assert rel_err(r.u0.cpu().numpy()[:8], ref8.u0) < RTOL and rel_err(r.dV_dp.cpu().numpy()[:8], ref8.dV) < RTOL
 
