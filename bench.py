@@ -230,29 +230,17 @@ def timed_steps(step, args, dist_mod, dev, rank=0):
     return elapsed, kern_ms, r
 
 
-def dry_line(args, world, rccl_ranks, elapsed, metric):
+def dry_line(args, world, rccl_ranks, elapsed, metric, secondary=None):
     """What a dry run prints instead of the bench line: the plumbing's figures, no throughput."""
     print(json.dumps({"metric": metric, "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                       "ms_per_step": 1e3 * elapsed / args.steps, "dryrun": True, "workload": args.workload,
-                      **({"rccl_ranks": rccl_ranks} if rccl_ranks is not None else {})}), flush=True)
+                      **({"rccl_ranks": rccl_ranks} if rccl_ranks is not None else {}),
+                      **({"secondary": secondary} if secondary is not None else {})}), flush=True)
 
 
-def chain_bench(args):
-    """BASELINE config 4: chain_mass n_mass = 5 (nx=21) / 7 (nx=33), N=40, batch 1024 PER GPU, GN-SQP tol 1e-5 + sensitivities, "1 -> 8
-    GPU scaling".  x0 = masses on the x axis (examples/chain_mass.py:17-25) + N(0, 1e-2) velocity perturbation, seed = rank
-    (SURVEY.md §8d).  The instances are independent per parameter point (examples/chain_mass.py:133-174): every rank solves its own
-    1024, and a step ends with the ONE all-reduce of the 499- / 1173-dim theta-gradient sum a data-parallel update needs (§8e)."""
-    world, rank, local, dist, dev = init_ranks(args)
-    rccl_ranks = count_ranks(dist, dev)
-    n_mass = 5 if args.workload == "chain5" else 7
-    B = args.batch if args.batch != B_PER_GPU else 1024
-    sens = not args.no_sens
-    metric = f"MPC+KKT-sens solves/sec, chain_mass n_mass={n_mass} N=40 batch={B}"
-    if DRY:
-        elapsed, _, _ = timed_steps(None, args, dist, dev, rank)
-        if rank == 0:
-            dry_line(args, world, rccl_ranks, elapsed, metric)
-        return finish_ranks(dist)
+def chain_measure(n_mass, B, sens, steps, warmup, world, rank, dist, dev):
+    """One chain_mass measurement through timed_steps: (job seconds, HIP-event ms per step, summary dict for the JSON line, ocp, x0).
+    x0 = masses on the x axis (examples/chain_mass.py:17-25) + N(0, 1e-2) velocity perturbation, seed = rank."""
     from mpc4rl_amd import MPCBatch, chain_mass_ocp
     from mpc4rl_amd.distributed import allreduce_weighted_grad
     ocp = chain_mass_ocp(n_mass=n_mass)
@@ -269,34 +257,60 @@ def chain_bench(args):
             allreduce_weighted_grad(r.dV_dp, r.V)     # local reduction kernel + one all_reduce of n_p + 2 doubles
         return r
 
-    elapsed, kern_ms, r = timed_steps(step, args, dist, dev, rank)
+    elapsed, kern_ms, r = timed_steps(step, argparse.Namespace(steps=steps, warmup=warmup), dist, dev, rank)
     it = r.iters.cpu().numpy()
     conv = float((r.status == 0).float().mean().item())
+    # iterate + outputs, plus the streamed stage factors of every Riccati sweep
+    nx, nu, N, n_th = ocp.nx, ocp.nu, ocp.N, ocp.n_p
+    b_alg = algorithmic_bytes_per_solve(N, nx, nu, n_th, sens)
+    b_sweep = 2 * 8 * N * ((nx + nu) ** 2 + (nx + nu))
+    sweeps = float(it[:, 1].mean()) + (1 + nu if sens else 0)
+    achieved = (b_alg + sweeps * b_sweep) * B / (kern_ms * 1e-3) / 1e9
+    fp64 = sweeps * riccati_sweep_flops(N, nx, nu) * B / (kern_ms * 1e-3) / 1e12
+    traffic, traffic_src = measured_traffic(f"chain{n_mass}", B, sens, False)
+    summ = {"value": world * B * steps / elapsed, "unit": "solves/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+            "workload": f"chain_mass n_mass={n_mass} nx={nx} nu={nu} N={N}, {B} instances/GPU, cold-start GN-SQP tol 1e-5"
+                        + (f" + dV/dp + du0*/dp ({n_th}-dim p)" if sens else ""),
+            "converged_fraction": conv, "sqp_iters_mean": float(it[:, 0].mean()), "ipm_iters_mean": float(it[:, 1].mean()),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_solve": b_alg + sweeps * b_sweep, "sweeps_per_solve": sweeps,
+                         "fp64": {"achieved": fp64, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp64 / FP64_MFMA_PEAK_TFLOPS,
+                                  "note": "SURVEY.md 8d: sweeps/s x F_sweep, sweeps = interior-point iterations + 1 + nu"}}}
+    del mpc
+    return elapsed, kern_ms, summ, ocp, x0
+
+
+def chain_bench(args):
+    """BASELINE config 4: chain_mass n_mass = 5 (nx=21) / 7 (nx=33), N=40, batch 1024 PER GPU, GN-SQP tol 1e-5 + sensitivities, "1 -> 8
+    GPU scaling".  The instances are independent per parameter point (examples/chain_mass.py:133-174): every rank solves its own
+    1024, and a step ends with the ONE all-reduce of the 499- / 1173-dim theta-gradient sum a data-parallel update needs (§8e)."""
+    world, rank, local, dist, dev = init_ranks(args)
+    rccl_ranks = count_ranks(dist, dev)
+    n_mass = 5 if args.workload == "chain5" else 7
+    B = args.batch if args.batch != B_PER_GPU else 1024
+    sens = not args.no_sens
+    metric = f"MPC+KKT-sens solves/sec, chain_mass n_mass={n_mass} N=40 batch={B}"
+    if DRY:
+        elapsed, _, _ = timed_steps(None, args, dist, dev, rank)
+        if rank == 0:
+            dry_line(args, world, rccl_ranks, elapsed, metric)
+        return finish_ranks(dist)
+    elapsed, kern_ms, summ, ocp, x0 = chain_measure(n_mass, B, sens, args.steps, args.warmup, world, rank, dist, dev)
     if rank == 0:
-        # iterate + outputs, plus the streamed stage factors of every Riccati sweep
         nx, nu, N, n_th = ocp.nx, ocp.nu, ocp.N, ocp.n_p
-        b_alg = algorithmic_bytes_per_solve(N, nx, nu, n_th, sens)
-        b_sweep = 2 * 8 * N * ((nx + nu) ** 2 + (nx + nu))
-        sweeps = float(it[:, 1].mean()) + (1 + nu if sens else 0)
-        achieved = (b_alg + sweeps * b_sweep) * B / (kern_ms * 1e-3) / 1e9
-        fp64 = sweeps * riccati_sweep_flops(N, nx, nu) * B / (kern_ms * 1e-3) / 1e12
-        traffic, traffic_src = measured_traffic(args.workload, B, sens, False)
         peak_meas = measured_hbm_peak(dev)
-        out = {"metric": metric, "value": world * B * args.steps / elapsed,
-               "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        roof = dict(summ["roofline"])
+        roof.update({"peak_measured": peak_meas, "frac_of_measured": (roof["achieved"] / peak_meas) if peak_meas else None})
+        out = {"metric": metric, "value": summ["value"],
+               "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": summ["ms_per_step"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": f"chain_mass n_mass={n_mass} nx={nx} nu={nu} N={N}, {B} instances/GPU, cold-start GN-SQP tol 1e-5"
-                                      + (f" + dV/dp + du0*/dp ({n_th}-dim p)" if sens else ""),
+               "config": {"workload": summ["workload"],
                           "batch_per_gpu": B, "parallelism": f"instances sharded over {world} GPU(s)"
                           + (f"; one all-reduce of the {n_th}-dim theta-gradient per step" if world > 1 and sens else ""),
-                          "converged_fraction": conv, "sqp_iters_mean": float(it[:, 0].mean()),
-                          "ipm_iters_mean": float(it[:, 1].mean())},
-               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                            "peak_measured": peak_meas, "frac_of_measured": (achieved / peak_meas) if peak_meas else None,
-                            "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms,
-                            "algorithmic_bytes_per_solve": b_alg + sweeps * b_sweep, "sweeps_per_solve": sweeps,
-                            "fp64": {"achieved": fp64, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fp64 / FP64_MFMA_PEAK_TFLOPS,
-                                     "note": "SURVEY.md 8d: sweeps/s x F_sweep, sweeps = interior-point iterations + 1 + nu"}}}
+                          "converged_fraction": summ["converged_fraction"], "sqp_iters_mean": summ["sqp_iters_mean"],
+                          "ipm_iters_mean": summ["ipm_iters_mean"]},
+               "roofline": roof}
         if rccl_ranks is not None:
             out["rccl_ranks"] = rccl_ranks
         if world == 1 and not args.no_cpu:
@@ -304,6 +318,79 @@ def chain_bench(args):
             out["cpu_baseline"] = cpu_baseline_guarded(make_chain_mass(n_mass=n_mass), x0, sens, label=f"chain_mass n_mass={n_mass}: ")
         print(json.dumps(out), flush=True)
     finish_ranks(dist)
+
+
+def small_measure(linear, B, sens, rti, steps, warmup, world, rank, dist, dev):
+    """One cartpole / linear-system measurement through timed_steps: (job seconds, summary dict, ocp, x0, statuses, iteration counts)."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp, linear_system_ocp
+    from mpc4rl_amd.distributed import allreduce_weighted_grad
+    n_theta = 12 if linear else N_THETA
+    ocp = linear_system_ocp(discount_factor=0.99) if linear else cartpole_ocp()
+    mpc = MPCBatch(ocp, B, device=dev)
+    if linear:   # the state box of the linear-system environment (linear_system/environment.py: x in [0, 1] x [-1, 1]), interior part
+        rng = np.random.default_rng(rank)
+        x0_np = np.column_stack([rng.uniform(0.15, 0.85, B), rng.uniform(-0.5, 0.5, B)])
+    else:
+        x0_np = make_inputs(B, rank)
+    x0 = torch.as_tensor(x0_np, device=dev)
+
+    def step():
+        # cold start every step (MPC.reset semantics) so that every step does the same, full work
+        r = mpc.solve(x0, sens_v=sens, sens_pi=sens, cold=not rti, rti=rti)
+        if dist is not None and sens:
+            # data-parallel RL update: one all-reduce of [sum_i dV_i/dtheta, sum_i V_i, count] (SURVEY.md §8e)
+            allreduce_weighted_grad(r.dV_dp[:, :n_theta], r.V)   # K5 reduction kernel + one all_reduce of 5 doubles
+        return r
+
+    if rti:
+        mpc.solve(x0, cold=True)            # converge once; RTI steps then start from that iterate
+    elapsed, kern_ms, r = timed_steps(step, argparse.Namespace(steps=steps, warmup=warmup), dist, dev, rank)
+    status = r.status.cpu().numpy()
+    iters = r.iters.cpu().numpy()
+    bytes_per = algorithmic_bytes_per_solve(ocp.N, ocp.nx, ocp.nu, n_theta, sens)
+    achieved = bytes_per * B / (kern_ms * 1e-3) / 1e9
+    # SURVEY.md §8d: algorithmic flops = Riccati sweeps x F_sweep, sweeps per solve = interior-point iterations (+ 1 sensitivity
+    # factorisation + nu adjoint solves)
+    sweeps = float(iters[:, 1].mean()) + (1 + ocp.nu if sens else 0)
+    fp64_tflops = sweeps * riccati_sweep_flops(ocp.N, ocp.nx, ocp.nu) * B / (kern_ms * 1e-3) / 1e12
+    traffic, traffic_src = measured_traffic("linear" if linear else "cartpole", B, sens, rti)
+    name = "linear system N=40 nx=2 nu=1" if linear else "cartpole N=20 nx=4 nu=1"
+    summ = {"value": B * world * steps / elapsed, "unit": "solves/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+            "workload": ("%s, %d instances/GPU, %s" % (name, B, "RTI (1 SQP iteration, warm)" if rti else "cold-start full-step SQP to tol 1e-6"))
+                        + (" + dV/dp + du0*/dp" if sens else ""),
+            "converged_fraction": float((status == 0).mean()), "sqp_iters_mean": float(iters[:, 0].mean()),
+            "sqp_iters_max": int(iters[:, 0].max()), "ipm_iters_mean": float(iters[:, 1].mean()), "ipm_iters_max": int(iters[:, 1].max()),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_solve": bytes_per, "sweeps_per_solve": sweeps,
+                         "fp64": {"achieved": fp64_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": fp64_tflops / FP64_MFMA_PEAK_TFLOPS,
+                                  "note": "SURVEY.md 8d: sweeps/s x F_sweep, sweeps = interior-point iterations + 1 + nu; the path is a "
+                                          "serial dependency chain, not flop-bound"}}}
+    del mpc
+    return elapsed, summ, ocp, x0_np, status, iters
+
+
+SECONDARY = (("chain5", 10, 3), ("chain7", 5, 2), ("linear", 50, 5))   # (workload, steps, warm-ups): BASELINE configs 4 and 1
+
+
+def secondary_lines(world, rank, dist, dev):
+    """The other single-GPU configurations of BASELINE.json, measured by the SAME timed_steps right after the headline's timed region,
+    so that the driver's one bench run also times them: chain n_mass 5 / 7 at 1024 instances + sensitivities (config 4), the
+    linear-system OCP at 4096 (config 1 batched).  Each entry: ms_per_step, value (solves/s), iteration counts, roofline {frac, traffic}."""
+    out = {}
+    for wl, steps, warmup in SECONDARY:
+        try:
+            if DRY:
+                elapsed, _, _ = timed_steps(None, argparse.Namespace(steps=steps, warmup=warmup), dist, dev, rank)
+                out[wl] = {"ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup, "dryrun": True}
+            elif wl == "linear":
+                out[wl] = small_measure(True, B_PER_GPU, True, False, steps, warmup, world, rank, dist, dev)[1]
+            else:
+                out[wl] = chain_measure(int(wl[5:]), 1024, True, steps, warmup, world, rank, dist, dev)[2]
+        except Exception as e:   # the headline line must still come out
+            out[wl] = {"value": None, "error": repr(e)}
+    return out
 
 
 class _StdoutToStderr:
@@ -427,6 +514,8 @@ def main():
     ap.add_argument("--no-sens", action="store_true", help="forward solve only (BASELINE config 2)")
     ap.add_argument("--rti", action="store_true", help="one SQP iteration from the stored iterate (build-side mode)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="headline run: skip the chain5 / chain7 / linear figures measured after "
+                    "the headline's timed region and attached to the line as `secondary`")
     ap.add_argument("--no-graph", action="store_true", help="td3 workload: eager launches instead of replayed HIP graphs")
     ap.add_argument("--workload", default="cartpole", choices=["cartpole", "linear", "chain5", "chain7", "td3"],
                     help="cartpole = the headline metric (default); linear = the 2-state OCP of config 1 batched; chain5/chain7 = BASELINE "
@@ -444,86 +533,52 @@ def main():
     world, rank, local, dist, dev = init_ranks(args)
     rccl_ranks = count_ranks(dist, dev)
 
-    n_theta = 12 if linear else N_THETA
     B = args.batch
     sens = not args.no_sens
     metric = ("MPC+KKT-sens solves/sec, %s batch=%d" if sens else "MPC solves/sec, %s batch=%d") % (
         "linear_system N=40" if linear else "cartpole N=20", B)
+    want_secondary = not args.no_secondary and not linear and world == 1 and sens and not args.rti and B == B_PER_GPU
     if DRY:
         elapsed, _, _ = timed_steps(None, args, dist, dev, rank)
+        sec = secondary_lines(world, rank, dist, dev) if want_secondary else None
         if rank == 0:
-            dry_line(args, world, rccl_ranks, elapsed, metric)
+            dry_line(args, world, rccl_ranks, elapsed, metric, sec)
         return finish_ranks(dist)
-    from mpc4rl_amd import MPCBatch, cartpole_ocp, linear_system_ocp
-    from mpc4rl_amd.distributed import allreduce_weighted_grad
-    ocp = linear_system_ocp(discount_factor=0.99) if linear else cartpole_ocp()
-    mpc = MPCBatch(ocp, B, device=dev)
-    if linear:   # the state box of the linear-system environment (linear_system/environment.py: x in [0, 1] x [-1, 1]), interior part
-        rng = np.random.default_rng(rank)
-        x0_np = np.column_stack([rng.uniform(0.15, 0.85, B), rng.uniform(-0.5, 0.5, B)])
-    else:
-        x0_np = make_inputs(B, rank)
-    x0 = torch.as_tensor(x0_np, device=dev)
+    elapsed, summ, ocp, x0_np, status, iters = small_measure(linear, B, sens, args.rti, args.steps, args.warmup, world, rank, dist, dev)
+    # the headline's timed region is over: the other configurations are measured after it, never inside it
+    sec = secondary_lines(world, rank, dist, dev) if want_secondary else None
 
-    def step():
-        # cold start every step (MPC.reset semantics) so that every step does the same, full work
-        r = mpc.solve(x0, sens_v=sens, sens_pi=sens, cold=not args.rti, rti=args.rti)
-        if dist is not None and sens:
-            # data-parallel RL update: one all-reduce of [sum_i dV_i/dtheta, sum_i V_i, count]
-            allreduce_weighted_grad(r.dV_dp[:, :n_theta], r.V)   # K5 reduction kernel + one all_reduce of 5 doubles
-        return r
-
-    if args.rti:
-        mpc.solve(x0, cold=True)            # converge once; RTI steps then start from that iterate
-    elapsed, kern_ms, r = timed_steps(step, args, dist, dev, rank)
-
-    status = r.status.cpu().numpy()
-    iters = r.iters.cpu().numpy()
     if rank == 0:
-        solves = B * world * args.steps
-        bytes_per = algorithmic_bytes_per_solve(ocp.N, ocp.nx, ocp.nu, n_theta, sens)
-        achieved = bytes_per * B / (kern_ms * 1e-3) / 1e9
+        kern_ms = summ["roofline"]["kernel_ms"]
         # matrix-core work of the factor sweep: 6 v_mfma_f64_4x4x4 block-products (128 flop each) per stage step and instance
         mfma_tflops = 0.0 if linear else float(iters[:, 1].sum()) * ocp.N * 6 * 128 / (kern_ms * 1e-3) / 1e12
-        # algorithmic flops = Riccati sweeps x F_sweep, sweeps per solve = interior-point iterations (+ 1 sensitivity
-        # factorisation + nu adjoint solves)
-        sweeps = float(iters[:, 1].mean()) + (1 + ocp.nu if sens else 0)
-        fp64_tflops = sweeps * riccati_sweep_flops(ocp.N, ocp.nx, ocp.nu) * B / (kern_ms * 1e-3) / 1e12
-        traffic, traffic_src = measured_traffic(args.workload, B, sens, args.rti)
         peak_meas = measured_hbm_peak(dev)
-        name = "linear system N=40 nx=2 nu=1" if linear else "cartpole N=20 nx=4 nu=1"
+        roof = dict(summ["roofline"])
+        roof.update({"peak_measured": peak_meas, "frac_of_measured": (roof["achieved"] / peak_meas) if peak_meas else None,
+                     "mfma_f64_hw": {"achieved": mfma_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": mfma_tflops / FP64_MFMA_PEAK_TFLOPS,
+                                     "note": "hardware flops of the 6 v_mfma_f64_4x4x4 per factor-sweep stage step (padded 4x4x4 "
+                                             "products; vector sweeps excluded): the MFMAs of the recursion wait on each other"}})
         out = {
             "metric": metric,
-            "value": solves / elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": summ["value"], "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": summ["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("%s, %d instances/GPU, %s" % (
-                name, B, "RTI (1 SQP iteration, warm)" if args.rti else "cold-start full-step SQP to tol 1e-6")) +
-                (" + dV/dp + du0*/dp" if sens else "") + ("" if linear else (" (BASELINE config 3)" if sens else " (BASELINE config 2)")),
-                "batch_per_gpu": B, "parallelism": f"instances sharded over {world} GPU(s)" +
-                ("; one all-reduce of the theta-gradient per step" if world > 1 and sens else ""),
-                "converged_fraction": float((status == 0).mean()), "sqp_iters_mean": float(iters[:, 0].mean()),
-                "sqp_iters_max": int(iters[:, 0].max()), "ipm_iters_mean": float(iters[:, 1].mean()),
-                "ipm_iters_max": int(iters[:, 1].max())},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "peak_measured": peak_meas,
-                         "frac_of_measured": (achieved / peak_meas) if peak_meas else None,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_solve": bytes_per, "sweeps_per_solve": sweeps,
-                         "fp64": {"achieved": fp64_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": fp64_tflops / FP64_MFMA_PEAK_TFLOPS,
-                                  "note": "SURVEY.md 8d: sweeps/s x F_sweep (7 673 flop per sweep), sweeps = interior-point "
-                                          "iterations + 1 + nu; the path is a serial dependency chain, not flop-bound"},
-                         "mfma_f64_hw": {"achieved": mfma_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                      "frac": mfma_tflops / FP64_MFMA_PEAK_TFLOPS,
-                                         "note": "hardware flops of the 6 v_mfma_f64_4x4x4 per factor-sweep stage step (padded 4x4x4 "
-                                                 "products; vector sweeps excluded): the MFMAs of the recursion wait on each other"}},
+            "config": {"workload": summ["workload"] + ("" if linear else (" (BASELINE config 3)" if sens else " (BASELINE config 2)")),
+                       "batch_per_gpu": B, "parallelism": f"instances sharded over {world} GPU(s)" +
+                       ("; one all-reduce of the theta-gradient per step" if world > 1 and sens else ""),
+                       "converged_fraction": summ["converged_fraction"], "sqp_iters_mean": summ["sqp_iters_mean"],
+                       "sqp_iters_max": summ["sqp_iters_max"], "ipm_iters_mean": summ["ipm_iters_mean"],
+                       "ipm_iters_max": summ["ipm_iters_max"]},
+            "roofline": roof,
         }
         if rccl_ranks is not None:
             out["rccl_ranks"] = rccl_ranks   # an all-reduce of ones over the job's communicator: how many ranks RCCL really joined
         if world == 1 and not args.no_cpu:
             from oracle.problems import make_cartpole, make_linear_system
             out["cpu_baseline"] = cpu_baseline_guarded(make_linear_system(gamma=0.99) if linear else make_cartpole(), x0_np, sens)
+        if sec is not None:
+            out["secondary"] = sec
         print(json.dumps(out), flush=True)
     finish_ranks(dist)
 

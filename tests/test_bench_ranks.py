@@ -7,14 +7,15 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
-def _run(gpus, extra_env=None, workload=None):
+def _run(gpus, extra_env=None, workload=None, extra_args=()):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["MPCRL_BENCH_DRYRUN"] = "1"
     env.update(extra_env or {})
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "5", "--warmup", "1"]
-                         + (["--workload", workload] if workload else []),
+                         + (["--workload", workload] if workload else []) + list(extra_args),
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -43,6 +44,21 @@ def test_every_workload_is_rank_aware():
 def test_gpus_1_stays_in_process():
     line = _run(1)
     assert line["n_gpus"] == 1 and "rccl_ranks" not in line      # no communicator, no claim
+
+
+def test_headline_line_carries_the_secondary_configurations():
+    """The driver only runs `bench.py --gpus 1`: the chain (BASELINE config 4) and linear-system (config 1) figures ride on that ONE
+    line as `secondary`, measured by the same timed_steps AFTER the headline's timed region (its ms_per_step must not contain them);
+    `--no-secondary` and every non-headline workload leave the field out."""
+    import bench
+    line = _run(1)
+    sec = line["secondary"]
+    assert set(sec) == {wl for wl, _, _ in bench.SECONDARY} == {"chain5", "chain7", "linear"}
+    for wl, steps, warmup in bench.SECONDARY:
+        assert sec[wl]["steps"] == steps and sec[wl]["warmup"] == warmup and sec[wl]["ms_per_step"] >= 1.0
+    assert line["ms_per_step"] < 5.0                 # 1 ms sleeps: the ~70 secondary steps are not in the headline's region
+    assert "secondary" not in _run(1, workload="linear") and "secondary" not in _run(2)
+    assert "secondary" not in _run(1, extra_args=["--no-secondary"])
 
 
 def test_traffic_figure_is_bound_to_the_kernel_sources(tmp_path, monkeypatch):
