@@ -52,6 +52,14 @@
 extern "C" {
 #endif
 
+/* ABI version = what mpcrl_version() of the library returns.  Bumped whenever the signature or the meaning of an exported function
+ * changes; a binding must compare the two before its first call (mpc4rl_amd/_lib.py does).
+ *   100  rounds 1-3
+ *   110  round 4/5: mpcrl_query_time_sliced(h, flags, stream) gained `stream`; mpcrl_env_cartpole_step / _reset and
+ *        mpcrl_env_linear_step gained `obs_f32` (obs became void*); mpcrl_set_exit_rule accepts the chain of masses;
+ *        mpcrl_create refuses chain horizons whose trajectories do not fit the LDS of one workgroup (MPCRL_E_ARG) */
+#define MPCRL_ABI_VERSION 110
+
 enum { MPCRL_MODEL_CARTPOLE = 0, MPCRL_MODEL_LINEAR = 1, MPCRL_MODEL_CHAIN = 2 };
 /* how the stage-cost scaling c_k is built (rlmpc/mpc/nlp.py:1044-1055 vs 1083-1091) */
 enum { MPCRL_COST_NLS = 0, MPCRL_COST_EXTERNAL = 1 };
@@ -108,7 +116,8 @@ int mpcrl_set_options(mpcrl_handle h, double tol, int max_iter);
  * wavefront iterating to max_iter).  Every `window` SQP iterations of an instance the best NLP residual seen so far must have
  * dropped below `factor` times its value at the previous check, else the instance ends with status 2 (as at max_iter) and its
  * lanes are free.  window = 0 (default): off.  1 <= window <= 255, 0 < factor <= 1.  Instances that converge with the rule on
- * return bit for bit what they return with it off.  cartpole / linear system only (MPCRL_E_MODEL for the chain of masses). */
+ * return bit for bit what they return with it off.  All three model families (the chain of masses since ABI 110: there an instance
+ * has a wavefront — a SIMD — to itself, and a diverging one holds it to max_iter). */
 int mpcrl_set_exit_rule(mpcrl_handle h, int window, double factor);
 
 /* Scheduling hint (no effect on results): perm[B] int32 on the device, a permutation of 0..B-1 — slot i of a launch works on
@@ -193,7 +202,8 @@ int mpcrl_weighted_grad_sum(const double *grad, int64_t ld, const double *weight
  *         u01 [B] uniform [0, 1) numbers drawn by the caller; obs [B, 4] (may be NULL) = the state of EVERY environment after it.
  * obs_f32 != 0: obs is float (what the reference's gymnasium environments return, environment.py:166,186), else double; the state
  * is always double (the reference's numpy state).  No handle: the three environment calls launch on the device that owns `state`
- * (hipPointerGetAttributes), whatever device is current in the calling thread; MPCRL_E_ARG if it is not device memory. */
+ * (hipPointerGetAttributes), whatever device is current in the calling thread; device or managed memory (hipMalloc / hipMallocManaged),
+ * MPCRL_E_ARG for anything else (host-registered or unknown pointers). */
 int mpcrl_env_cartpole_step(const double *par, int B, double *state, int64_t *steps, const double *action, void *obs, int obs_f32,
                             double *reward, uint8_t *terminated, uint8_t *truncated, void *stream);
 int mpcrl_env_cartpole_reset(int B, double *state, int64_t *steps, const uint8_t *mask, const double *u01, void *obs, int obs_f32,
@@ -205,7 +215,7 @@ int mpcrl_env_cartpole_reset(int B, double *state, int64_t *steps, const uint8_t
 int mpcrl_env_linear_step(const double *par, int B, double *state, const double *action, const double *u01, void *obs, int obs_f32,
                           double *cost, void *stream);
 
-/* Bytes of device memory held by the handle; library version. */
+/* Bytes of device memory held by the handle; library version (MPCRL_ABI_VERSION of the header it was built from). */
 int64_t mpcrl_workspace_bytes(mpcrl_handle h);
 int mpcrl_version(void);
 

@@ -7,6 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPCRL_LIB_PATH") or os.path.join(_HERE, "libmpcrl_hip.so")   # the override is for instrumented builds (profiles/microbench)
 
+ABI_VERSION = 110        # MPCRL_ABI_VERSION of include/mpcrl.h this binding was written against
 SENS_V, SENS_PI, RTI, COLD = 1, 2, 4, 8
 MODEL_CARTPOLE, MODEL_LINEAR, MODEL_CHAIN = 0, 1, 2
 COST_NLS, COST_EXTERNAL = 0, 1
@@ -44,6 +45,10 @@ def load():
             f"mpc4rl_amd: {LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
+    lib.mpcrl_version.restype = C.c_int
+    if lib.mpcrl_version() != ABI_VERSION and not os.environ.get("MPCRL_SKIP_ABI_CHECK"):   # (the override: A/B runs against older builds) extern "C" links whatever the signatures are: refuse a library built from another header
+        raise RuntimeError(f"mpc4rl_amd: {LIB_PATH} reports ABI version {lib.mpcrl_version()}, this binding expects {ABI_VERSION}; rebuild it "
+                           "(`python -c 'import __graft_entry__ as g; g.build()'`).")
     vp = C.c_void_p
     lib.mpcrl_create.argtypes = [C.POINTER(ProblemSpec), C.c_int, C.c_int, C.POINTER(vp)]
     lib.mpcrl_destroy.argtypes = [vp]

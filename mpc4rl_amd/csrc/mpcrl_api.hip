@@ -1,9 +1,7 @@
 // mpcrl_api.hip — C ABI of libmpcrl_hip.so (include/mpcrl.h): handle management, workspace, kernel launches.
 // Everything here is host glue; the arithmetic lives in small_kernel.hpp (cartpole, linear system) and
 // chain_kernel.hpp (chain of masses).
-#include "../../include/mpcrl.h"
-
-#include <hip/hip_runtime.h>
+#include "mpcrl_host.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -12,53 +10,13 @@
 #include <cstring>
 #include <new>
 
-#include "chain_kernel.hpp"
+#include "small_kernel.hpp"
 #include "reduce_kernel.hpp"
 #include "order_kernel.hpp"
 #include "iterate_kernel.hpp"
 #include "env_kernel.hpp"
 
 using namespace mpcrl;
-
-struct MpcrlSolver {
-    int model, B, device, nx, nu, np, N;
-    SmallSpec small;
-    LargeSpec large;
-    bool is_large = false;
-    int n_mass = 0;
-    double *ws = nullptr, *consts_dev = nullptr;
-    int *perm = nullptr, *cold_mask = nullptr;
-    bool have_perm = false, have_cold_mask = false;
-    double *order_state = nullptr;   // order_kernel.hpp: {spread, minimum, coordinate} of the last from-scratch packing order
-    unsigned order_calls = 0;
-    size_t ws_stride = 0;
-    double *theta = nullptr;   // [np] or [B, np]
-    int theta_stride = 0;
-    double *X = nullptr, *U = nullptr, *PI = nullptr, *BND = nullptr, *RES = nullptr, *LAG = nullptr;
-    int64_t bytes = 0;
-    int n_simd = 1024;          // SIMDs of the device (one resident wavefront each for the small solve kernel)
-    int slice_mode = 0;         // mpcrl_set_launch_mode / MPCRL_TIME_SLICE: 0 = automatic, 1 = whenever legal, -1 = never
-    // automatic mode: the two launch shapes of the small solve kernel are timed against each other on the caller's own batches
-    // (choose_launch below): [0] = time-sliced, [1] = plain
-    struct Tuner {
-        hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-        bool pending[2] = {false, false};
-        float ms[2] = {-1.f, -1.f};
-        unsigned calls = 0;
-    } tune[2];                  // [0] cold calls, [1] warm calls (different work per instance: timed separately)
-    int planned = -1;           // what mpcrl_query_time_sliced promised for the next solve (-1: nothing promised)
-    bool have_iterate = false;
-    bool dual_cold = false;   // the stored bound multipliers are placeholders (set_iterate without bnd): next solve = MPCRL_COLD_DUAL
-};
-
-#define HIP_OK(expr)                                                                          \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess) {                                                               \
-            fprintf(stderr, "mpcrl: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return MPCRL_E_HIP;                                                               \
-        }                                                                                     \
-    } while (0)
 
 namespace {
 
@@ -87,7 +45,8 @@ int device_of(const void *p) {
         (void)hipGetLastError();
         return -1;
     }
-    return at.type == hipMemoryTypeDevice ? at.device : -1;
+    // device memory, or managed memory (its home device); host-registered / unregistered pointers are refused
+    return (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged) ? at.device : -1;
 }
 #define ON_DEVICE_OF(ptr)                       \
     const int dev_of_ = device_of((ptr));       \
@@ -143,58 +102,16 @@ int fill_large_spec(const MpcrlProblemSpec &s, LargeSpec &d) {
     return 0;
 }
 
-// n_mass (3 .. 7, a free integer in the reference: rlmpc/mpc/chain_mass/ocp_utils.py:344-350) -> the instantiation of the chain kernels
-template <class T>
-struct TypeTag {
-    using type = T;
-};
-template <class F>
-long chain_dispatch(int n_mass, F &&f) {
+// n_mass (3 .. 7, a free integer in the reference: rlmpc/mpc/chain_mass/ocp_utils.py:344-350) -> the translation unit of that chain size
+const MpcrlChainEntry *chain_entry(int n_mass) {
     switch (n_mass) {
-        case 3: return f(TypeTag<ChainDev<3>>{});
-        case 4: return f(TypeTag<ChainDev<4>>{});
-        case 5: return f(TypeTag<ChainDev<5>>{});
-        case 6: return f(TypeTag<ChainDev<6>>{});
-        default: return f(TypeTag<ChainDev<7>>{});
+        case 3: return mpcrl_chain_entry_3();
+        case 4: return mpcrl_chain_entry_4();
+        case 5: return mpcrl_chain_entry_5();
+        case 6: return mpcrl_chain_entry_6();
+        case 7: return mpcrl_chain_entry_7();
+        default: return nullptr;
     }
-}
-
-template <class M>
-int launch_large(MpcrlSolver *h, LargeArgs a, hipStream_t st) {
-    a.ws = h->ws, a.ws_stride = h->ws_stride;
-    const int B = h->B, N = h->N, NW = M::NX + M::NU;
-    const int max_iter = (a.flags & MPCRL_RTI) ? 1 : h->large.max_iter;
-    auto blocks = [](long items) { return dim3((unsigned)((items + 255) / 256)); };
-    const unsigned lds_bytes = (unsigned)(ChainCfg<M>::lds_doubles(N) * sizeof(double));   // the solver kernels' LDS depends on the horizon
-    if (lds_bytes + 1024 > 64 * 1024) return MPCRL_E_ARG;
-    hipLaunchKernelGGL(chain_init_kernel<M>, dim3(B), dim3(64), 0, st, h->large, a);
-    // the whole SQP loop of an instance runs inside one wavefront of one launch (linearisation, QP, step; chain_kernel.hpp)
-    (void)max_iter, (void)blocks;
-    hipLaunchKernelGGL(chain_sqp_kernel<M>, dim3(B), dim3(64), lds_bytes, st, h->large, a);
-    HIP_OK(hipGetLastError());
-    if (a.flags & (MPCRL_SENS_V | MPCRL_SENS_PI)) {
-        const bool want_pi = (a.flags & MPCRL_SENS_PI) && a.dpi && !a.u0fix;
-        if (!want_pi || !MPCRL_CHAIN_TH2)   // grad_theta (nu' F): by its own reverse sweep, or (below) from the tables of the second-order point pass
-            hipLaunchKernelGGL(chain_sens_th_kernel<M>, dim3((unsigned)(((long)B * N + 63) / 64)), dim3(64), 0, st, h->large, a);
-        if (want_pi) {
-            hipLaunchKernelGGL((chain_point_kernel<M, true>), dim3((unsigned)B), dim3(64), (unsigned)((M::NTD + N * M::NX) * sizeof(double)), st, h->large, a);
-            if (MPCRL_CHAIN_TH2)
-                hipLaunchKernelGGL(chain_sens_th2_kernel<M>, dim3((unsigned)(((long)B * N + 63) / 64)), dim3(64), 0, st, h->large, a);
-            hipLaunchKernelGGL(chain_sens_ad_kernel<M>, dim3((unsigned)(B * HexCfg<M>::groups(N))), dim3(64), 0, st, h->large, a);
-            hipLaunchKernelGGL(chain_sens_riccati_kernel<M>, dim3(B), dim3(64), lds_bytes, st, h->large, a);
-            if (MPCRL_CHAIN_MIX2)
-                hipLaunchKernelGGL(chain_sens_mix2_kernel<M>, dim3((unsigned)(((long)B * N * M::NU + 63) / 64)), dim3(64), (unsigned)((M::NTD + M::NX) * 64 * sizeof(double)), st,
-                                   h->large, a);
-            else
-                hipLaunchKernelGGL(chain_sens_mix_kernel<M>, blocks((long)B * N * M::NU), dim3(256), 0, st, h->large, a);
-        }
-        {   // one workgroup of 1024 lanes per instance; its trajectories staged in LDS (chain_sens_out_kernel)
-            const unsigned smem = (unsigned)((64 + (1 + M::NU) * ((N + 1) * M::NX + N * M::NU)) * sizeof(double));
-            hipLaunchKernelGGL(chain_sens_out_kernel<M>, dim3((unsigned)B), dim3(1024), smem, st, h->large, a);
-        }
-        HIP_OK(hipGetLastError());
-    }
-    return 0;
 }
 
 // Time-sliced launch (small_solve_sliced_kernel): ipw + 1 instances per wavefront, ipw of them advancing per round.  Such a
@@ -337,18 +254,25 @@ int fill_cold_iterate(MpcrlSolver *h, const double *x0, bool primal, hipStream_t
 extern "C" {
 
 #ifdef MPCRL_PROFILE_PHASES
-int mpcrl_debug_phases(unsigned long long *out, int reset) {
+int mpcrl_debug_phases(unsigned long long *out, int reset) {   // summed over the translation units (each has its own counters)
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_ticks), sizeof(unsigned long long) * 16));
     if (reset) {
         unsigned long long z[16] = {0};
         HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), z, sizeof(z)));
     }
+    for (int n = 3; n <= 7; ++n) {
+        unsigned long long t[16];
+        if (!chain_entry(n)->debug_phases) continue;
+        const int rc = chain_entry(n)->debug_phases(t, reset);
+        if (rc) return rc;
+        for (int i = 0; i < 16; ++i) out[i] += t[i];
+    }
     return 0;
 }
 #endif
 
-int mpcrl_version(void) { return 100; }
+int mpcrl_version(void) { return MPCRL_ABI_VERSION; }
 
 int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_handle *out) {
     if (!spec || !out || batch <= 0) return MPCRL_E_ARG;
@@ -375,8 +299,10 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
             h->n_mass = (spec->nx / 3 - 1) / 2 + 2;
             if (spec->nu != 3 || h->n_mass < 3 || h->n_mass > 7 || spec->nx != (2 * (h->n_mass - 2) + 1) * 3 || spec->n_consts != spec->nx)
                 rc = MPCRL_E_MODEL;
-            else if (spec->np != chain_dispatch(h->n_mass, [](auto m_) { return (long)decltype(m_)::type::NP; }))
+            else if (spec->np != chain_entry(h->n_mass)->np)
                 rc = MPCRL_E_MODEL;
+            else if (spec->N >= 1 && spec->N < 64 && !chain_entry(h->n_mass)->fits(spec->N))
+                rc = MPCRL_E_ARG;   // the horizon's trajectories / tables do not fit the LDS of one workgroup at this chain size
             break;
         default: rc = MPCRL_E_MODEL;
     }
@@ -400,7 +326,7 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
     if (!rc) rc = dev_alloc(&h->cold_mask, B, h->bytes);
     if (!rc) rc = dev_alloc(&h->order_state, 4, h->bytes);
     if (!rc && h->is_large) {
-        h->ws_stride = (size_t)chain_dispatch(h->n_mass, [&](auto m_) { return (long)LargeLayout<typename decltype(m_)::type>(spec->N).total; });
+        h->ws_stride = chain_entry(h->n_mass)->ws_doubles(spec->N);
         rc = dev_alloc(&h->ws, B * h->ws_stride, h->bytes);
         if (!rc) rc = dev_alloc(&h->consts_dev, (size_t)spec->n_consts, h->bytes);
         if (!rc) {
@@ -470,8 +396,8 @@ int mpcrl_set_options(mpcrl_handle h, double tol, int max_iter) {
 
 int mpcrl_set_exit_rule(mpcrl_handle h, int window, double factor) {
     if (!h || window < 0 || window > 255 || !(factor > 0.0 && factor <= 1.0)) return MPCRL_E_ARG;
-    if (h->is_large) return window == 0 ? 0 : MPCRL_E_MODEL;   // the chain kernel runs the reference's rule only
     h->small.exit_window = window, h->small.exit_factor = factor;
+    h->large.exit_window = window, h->large.exit_factor = factor;
     return 0;
 }
 
@@ -494,11 +420,14 @@ int mpcrl_set_cold_mask(mpcrl_handle h, const int32_t *mask, void *stream) {
 int mpcrl_query_time_sliced(mpcrl_handle h, int flags, void *stream) {
     if (!h) return MPCRL_E_ARG;
     if (h->is_large) return 0;
+    ON_DEVICE(h->device);
     if (!h->have_iterate) flags |= MPCRL_COLD;
     {   // a solve launched into a stream capture times nothing and takes the shape preferred so far (launch_small): answer with that
         // shape, not with the probe shape the call counter would select, and promise nothing
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+        const bool query_failed = hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess;
+        if (query_failed) (void)hipGetLastError();   // (not sticky for the caller's next HIP call)
+        const bool capturing = query_failed || cap != hipStreamCaptureStatusNone;
         if (capturing && h->slice_mode == 0) {
             bool by_rule = false, cand = false;
             if (h->model == MPCRL_MODEL_CARTPOLE) cand = sliced_candidate<CartpoleDev>(h, flags, nullptr, &by_rule);
@@ -616,7 +545,7 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
         la.B = a.B, la.flags = a.flags, la.theta_stride = a.theta_stride, la.perm = a.perm, la.cold = a.cold, la.x0 = a.x0, la.u0fix = a.u0fix, la.theta = a.theta;
         la.X = a.X, la.U = a.U, la.PI = a.PI, la.BND = a.BND, la.RES = a.RES, la.LAG = a.LAG, la.ws = nullptr, la.ws_stride = 0;
         la.u0_out = a.u0_out, la.V = a.V, la.dV = a.dV, la.dpi = a.dpi, la.status = a.status, la.iters = a.iters;
-        rc = (int)chain_dispatch(h->n_mass, [&](auto m_) { return (long)launch_large<typename decltype(m_)::type>(h, la, st); });
+        rc = chain_entry(h->n_mass)->launch(h, la, st);
     } else
         switch (h->model) {
             case MPCRL_MODEL_CARTPOLE: rc = launch_small<CartpoleDev>(h, a, st); break;

@@ -26,7 +26,7 @@
 namespace mpcrl {
 
 #ifdef MPCRL_PROFILE_PHASES
-extern __device__ unsigned long long g_phase_ticks[16];
+static __device__ unsigned long long g_phase_ticks[16];   // (one copy per translation unit: mpcrl_debug_phases sums them)
 #define PHW(i) do { unsigned long long n_ = clock64(); phw[i] += n_ - pht; pht = n_; } while (0)
 #define PHW_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_phase_ticks[i_], phw[i_]); } while (0)
 #else

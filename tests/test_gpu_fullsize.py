@@ -112,9 +112,23 @@ def test_linear_bench_inputs_vs_port(oracle_port):
     assert same.all()
 
 
+def chain_all_vs_port(r, ref, B, name):
+    """Every instance of a chain batch against the port: statuses and SQP iteration counts, interior-point counts (equal except where a
+    stopping test is met to within rounding), the four outputs at 1e-6 (rows scaled by the instance's largest reference entry)."""
+    st, it = r.status.cpu().numpy(), r.iters.cpu().numpy()
+    assert np.array_equal(st, ref.status) and np.all(ref.status == 0)
+    sqp_eq, ipm_eq = (it[:, 0] == ref.sqp_iter).mean(), (it[:, 1] == ref.ipm_iter).mean()
+    e = {"u0": rel_rows(r.u0.cpu().numpy(), ref.u0), "V": rel_rows(r.V.cpu().numpy(), ref.V), "dV": rel_rows(r.dV_dp.cpu().numpy(), ref.dV),
+         "dpi": rel_rows(r.dpi_dp.cpu().numpy(), ref.dpi, floor=1e-300)}
+    print(f"{name}: B {B} sqp iters equal {sqp_eq:.4f} ipm iters equal {ipm_eq:.4f} " + " ".join(f"{k} {v.max():.2e}" for k, v in e.items()))
+    assert np.abs(it[:, 0] - ref.sqp_iter).max() <= 1 and sqp_eq > 0.97 and ipm_eq > 0.95
+    for k, v in e.items():
+        assert v.max() < RTOL, (k, float(v.max()), int(v.argmax()))
+
+
 def test_chain5_bench_size_vs_port(oracle_port):
-    """BASELINE config 4 (n_mass = 5, N = 40, B = 1024, the inputs of `bench.py --workload chain5`): 64 instances against the port,
-    the whole batch through size-independent properties."""
+    """BASELINE config 4 (n_mass = 5, N = 40, B = 1024, the inputs of `bench.py --workload chain5`): ALL 1024 instances against the
+    port (statuses, iteration counts, u0*, V, dV/dp, du0*/dp at 1e-6), then size-independent properties of the batch."""
     from mpc4rl_amd import MPCBatch, chain_mass_ocp
     from oracle.problems import make_chain_mass
     ocp, P = chain_mass_ocp(n_mass=5), make_chain_mass(n_mass=5)
@@ -127,15 +141,7 @@ def test_chain5_bench_size_vs_port(oracle_port):
     assert bool((r.status == 0).all())
     assert float(mpc.get_iterate()[4].max()) < 1e-5 and float(r.u0.abs().max()) <= 1.0 + 1e-9
     assert bool(torch.isfinite(r.dV_dp).all()) and bool(torch.isfinite(r.dpi_dp).all())
-    pick = rng.choice(B, 64, replace=False)
-    ref = oracle_port.solve(P, x0[pick])
-    assert np.all(ref.status == 0)
-    it = r.iters.cpu().numpy()[pick]
-    assert np.abs(it[:, 0] - ref.sqp_iter).max() <= 1
-    for name, a, b in (("u0", r.u0, ref.u0), ("V", r.V, ref.V), ("dV", r.dV_dp, ref.dV)):
-        assert rel_rows(a.cpu().numpy()[pick], b).max() < RTOL, name
-    dpi = r.dpi_dp.cpu().numpy()[pick]
-    assert (np.abs(dpi - ref.dpi).reshape(64, -1).max(1) / np.abs(ref.dpi).reshape(64, -1).max(1)).max() < RTOL
+    chain_all_vs_port(r, oracle_port.solve(P, x0), B, "chain n_mass 5 bench inputs")
     # a second call from the stored iterate needs no iteration and reproduces the outputs; the batch order changes nothing
     r2 = mpc.solve(x0, sens_v=True)
     assert int(r2.iters[:, 0].max()) == 0 and torch.allclose(r2.V, r.V, rtol=1e-13)
@@ -143,10 +149,10 @@ def test_chain5_bench_size_vs_port(oracle_port):
     rp = MPCBatch(ocp, B).solve(x0[perm], sens_v=True, sens_pi=True, cold=True)      # (the same request: bit for bit)
     idx = torch.as_tensor(perm, device=r.V.device)
     assert torch.equal(rp.V, r.V[idx]) and torch.equal(rp.dV_dp, r.dV_dp[idx]) and torch.equal(rp.dpi_dp, r.dpi_dp[idx])
-    # dV/dp alone takes grad_theta (nu' F) from its own reverse sweep (chain_sens_th_kernel), with du0*/dp from the tables of the
-    # second-order point pass (chain_sens_th2_kernel): two evaluation orders of the same sums
+    # dV/dp has ONE evaluation order whatever the flags (grad_theta (nu' F) always comes off the tables of the second-order point pass,
+    # chain_sens_th2_kernel): the same bits with and without du0*/dp
     rv = MPCBatch(ocp, B).solve(x0[perm], sens_v=True, cold=True)
-    assert torch.equal(rv.V, rp.V) and torch.allclose(rv.dV_dp, rp.dV_dp, rtol=1e-11, atol=1e-11 * float(rp.dV_dp.abs().max()))
+    assert torch.equal(rv.V, rp.V) and torch.equal(rv.dV_dp, rp.dV_dp)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -252,6 +258,41 @@ def test_mirror_certifies_the_hip_iterate_chain():
         dk = r.dpi_dp.cpu().numpy()
         assert (np.abs(dk - dpi).reshape(B, -1).max(1) / np.abs(dpi).reshape(B, -1).max(1)).max() < RTOL
         assert rel_rows(mpc.get_lagrangian().cpu().numpy(), L).max() < RTOL
+
+
+def test_mirror_certifies_the_hip_iterate_chain_n6_n7():
+    """The perf dimension of BASELINE config 4 against the reference-anchored leg: one perturbed instance each of n_mass 6 (nx 27: 2 787
+    KKT unknowns x 823 parameters) and n_mass 7 (nx 33: 3 357 x 1 173) at tol 1e-8 — the reference's update_nlp thresholds at the HIP
+    iterate, dL/dp and dz/dp[:nu] of the mirror against the kernels' dV/dp, du0*/dp at 1e-6.  Both run at once (~45 s / ~70 s of autograd
+    + dense LU on one core each)."""
+    from mpc4rl_amd import MPCBatch, chain_mass_ocp
+    from oracle.from_iterate import certify_job
+    rng = np.random.default_rng(17)
+    jobs, held = [], []
+    for n_mass in (6, 7):
+        ocp = chain_mass_ocp(n_mass=n_mass, tol=1e-8)
+        M = n_mass - 2
+        x0 = np.tile(ocp.x0, (1, 1))
+        x0[:, 3 * (M + 1):] += rng.normal(0.0, 1e-2, (1, 3 * M))
+        mpc = MPCBatch(ocp, 1)
+        r = mpc.solve(x0, sens_v=True, sens_pi=True, cold=True)
+        assert bool((r.status == 0).all())
+        x, u, pi, bnd, _ = [t.cpu().numpy() for t in mpc.get_iterate()]
+        jobs.append(("chain", {"n_mass": n_mass}, x[0], u[0], pi[0], bnd[0], x0[0], None, None, None, float(r.V[0])))
+        held.append((n_mass, r, mpc.get_lagrangian().cpu().numpy()))
+    saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+    os.environ.update({k: "1" for k in saved})
+    try:
+        with mp.get_context("spawn").Pool(2) as pool:
+            rows = pool.map(certify_job, jobs, chunksize=1)
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    for (n_mass, r, L_dev), (dL, dpi, L, sc, smax, stat) in zip(held, rows):
+        e_dV = rel_rows(r.dV_dp.cpu().numpy(), dL[None])
+        e_dpi = np.abs(r.dpi_dp.cpu().numpy()[0] - dpi).max() / np.abs(dpi).max()
+        print(f"mirror certification chain n_mass {n_mass}: dV/dp {float(e_dV.max()):.2e} du0/dp {float(e_dpi):.2e} stationarity {stat:.2e}")
+        assert e_dV.max() < RTOL and e_dpi < RTOL and abs(L_dev[0] - L) <= RTOL * max(1.0, abs(L))
 
 
 def _cores():
@@ -392,6 +433,40 @@ def test_divergence_exit_rule(oracle_port, monkeypatch):
     assert rel_rows(r1.u0.cpu().numpy()[ok], ref.u0[ok]).max() < RTOL and rel_rows(r1.V.cpu().numpy()[ok], ref.V[ok]).max() < RTOL
     # misuse
     assert on.lib.mpcrl_set_exit_rule(on._h, 300, 0.1) < 0 and on.lib.mpcrl_set_exit_rule(on._h, 10, 0.0) < 0
+
+
+def test_divergence_exit_rule_chain(oracle_port):
+    """mpcrl_set_exit_rule on the chain of masses (ABI 110; each instance has a wavefront — a SIMD — to itself, so a diverging one holds
+    it for max_iter rounds): 64 instances of n_mass 5 whose velocities / positions are perturbed by N(0, 2) / N(0, 0.05), a few of which
+    full-step SQP does not solve.  Under (window 5, factor 0.5): the same statuses as the port under the same rule, nobody iterates to
+    max_iter any more, and every instance that still converges returns bit for bit what it returns with the rule off."""
+    from mpc4rl_amd import MPCBatch, chain_mass_ocp
+    from oracle.problems import make_chain_mass
+    ocp, P = chain_mass_ocp(n_mass=5), make_chain_mass(n_mass=5)
+    rng = np.random.default_rng(2)
+    B = 64
+    x0 = np.tile(ocp.x0, (B, 1))
+    x0[:, 12:] += rng.normal(0.0, 2.0, (B, 9))
+    x0[:, :12] += rng.normal(0.0, 0.05, (B, 12))
+    off = MPCBatch(ocp, B)
+    r0 = off.solve(x0, sens_v=True, sens_pi=True, cold=True)
+    on = MPCBatch(ocp, B)
+    on.set_exit_rule(5, 0.5)
+    r1 = on.solve(x0, sens_v=True, sens_pi=True, cold=True)
+    st0, st1 = r0.status.cpu().numpy(), r1.status.cpu().numpy()
+    it0, it1 = r0.iters.cpu().numpy(), r1.iters.cpu().numpy()
+    ref0 = oracle_port.solve(P, x0)
+    ref1 = oracle_port.solve(P, x0, exit_window=5, exit_factor=0.5)
+    print(f"chain exit rule: statuses off {np.bincount(st0, minlength=5)} on {np.bincount(st1, minlength=5)} (port {np.bincount(ref1.status, minlength=5)}), "
+          f"SQP iterations max off {it0[:, 0].max()} on {it1[:, 0].max()} (port {ref1.sqp_iter.max()})")
+    assert (st0 == 2).sum() >= 1 and it0[:, 0].max() == 50                       # the inputs do contain instances that run to max_iter
+    assert np.array_equal(st0, ref0.status) and np.array_equal(st1, ref1.status)
+    assert it1[:, 0].max() < 50 and np.abs(it1[:, 0] - ref1.sqp_iter).max() <= 1
+    conv1 = st1 == 0
+    assert np.all(st0[conv1] == 0) and conv1.sum() >= (st0 == 0).sum() - 2
+    for a, b in ((r0.u0, r1.u0), (r0.V, r1.V), (r0.dV_dp, r1.dV_dp), (r0.dpi_dp, r1.dpi_dp), (r0.iters, r1.iters)):
+        assert np.array_equal(a.cpu().numpy()[conv1], b.cpu().numpy()[conv1], equal_nan=True)
+    assert rel_rows(r1.u0.cpu().numpy()[conv1], ref1.u0[conv1]).max() < RTOL and rel_rows(r1.V.cpu().numpy()[conv1], ref1.V[conv1]).max() < RTOL
 
 
 @pytest.mark.gpu

@@ -294,3 +294,27 @@ def test_chain_sizes_the_library_accepts():
     for n_mass in (8, 9):
         with pytest.raises(RuntimeError, match="mpcrl_create failed"):
             MPCBatch(chain_mass_ocp(n_mass=n_mass), 2)
+
+
+def test_chain_horizons_the_library_accepts(oracle_port):
+    """The chain kernels stage whole trajectories in LDS (the output reduction: (1 + nu) x ((N + 1) nx + N nu) doubles): a horizon whose
+    requests do not fit one workgroup's 64 KB is refused by mpcrl_create (MPCRL_E_ARG), never at solve time after the SQP has run.
+    n_mass 7 (nx 33): N = 55 is the longest horizon; it solves with sensitivities and agrees with the port; N = 56 is refused.
+    n_mass 5 (nx 21) runs up to the 63 stages a wavefront has lanes for."""
+    from mpc4rl_amd import MPCBatch, chain_mass_ocp
+    from oracle.problems import make_chain_mass
+    with pytest.raises(RuntimeError, match="mpcrl_create failed"):
+        MPCBatch(chain_mass_ocp(n_mass=7, N=56), 2)
+    rng = np.random.default_rng(4)
+    for n_mass, N in ((7, 55), (5, 63)):
+        ocp = chain_mass_ocp(n_mass=n_mass, N=N)
+        P = make_chain_mass(n_mass=n_mass, N=N)
+        M = n_mass - 2
+        x0 = np.tile(ocp.x0, (4, 1))
+        x0[:, 3 * (M + 1):] += rng.normal(0.0, 1e-2, (4, 3 * M))
+        r = MPCBatch(ocp, 4).solve(x0, sens_v=True, sens_pi=True, cold=True)
+        ref = oracle_port.solve(P, x0)
+        assert bool((r.status == 0).all()) and np.all(ref.status == 0)
+        for a, b in ((r.u0, ref.u0), (r.V, ref.V), (r.dV_dp, ref.dV), (r.dpi_dp, ref.dpi)):
+            a, b = a.cpu().numpy().reshape(4, -1), np.asarray(b).reshape(4, -1)
+            assert (np.abs(a - b).max(1) / np.maximum(np.abs(b).max(1), 1e-300)).max() < 1e-6
