@@ -111,12 +111,16 @@ struct OmCfg {
 template <class M>
 struct LargeLayout {
     static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD;
+    // stage block of the linearisation: rows 0 .. NX - 1 = [B A]_k (columns in stage-vector order [u; x]), rows NX .. NX + NU - 1 =
+    // [0 | -K_k], the feedback gain the factor sweep of the current interior-point iteration left there — one block, one address
+    // pattern for the vector sweeps, which multiply with [A B] and K instead of a stored closed-loop matrix
+    static constexpr int BAS = NW * NW;
     size_t BA, r, q, dx, du, nuq, Dx, Du, rg, rb, rt, Dg, lamw, tw, aff, p, kff, Hex, term, ynu, state, Ydx, Ydu, Ydnu,
         term2, ptab, gtab, qvtab, G2, P2, hb2, minv2, mvu2, total;
     __host__ __device__ explicit LargeLayout(int N) {
         size_t o = 0;
         auto take = [&](size_t n) { size_t s = o; o += (n + 1) & ~(size_t)1; return s; };   // every array 16-byte aligned
-        BA = take((size_t)N * NX * NW), r = take((size_t)N * NX), q = take((size_t)(N + 1) * NW);
+        BA = take((size_t)N * BAS + 2), r = take((size_t)N * NX), q = take((size_t)(N + 1) * NW);
         // (+ 2: a dump slot behind the array — masked lanes of the sweeps store there instead of branching)
         dx = take((size_t)(N + 1) * NX), du = take((size_t)N * NU), nuq = take((size_t)(N + 1) * NX + 2);
         Dx = take((size_t)(N + 1) * NX + 2), Du = take((size_t)N * NU + 2);

@@ -320,7 +320,7 @@ MPCRL_DI void chain_dir_body(const double *th_, double *w_, double *tabl_, int N
             for (int i = 0; i < NX; ++i) dxc[i] = dxc[i] + (h / 6.0) * (acc[i] + dk[i]);
         }
         if (on) {
-            double *BA = w + lay.BA + (size_t)k * NX * NW;
+            double *BA = w + lay.BA + (size_t)k * LargeLayout<M>::BAS;
 #pragma unroll
             for (int i = 0; i < NX; ++i) BA[i * NW + d] = dxc[i];
             if constexpr (ChainCfg<M>::FUSE_GT) {

@@ -72,7 +72,7 @@ struct HessGlobal {
 template <class M>
 struct ChainSolver {
     using Cfg = ChainCfg<M>;
-    static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD, NP = M::NP, NT = 64;
+    static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NTD = M::NTD, NP = M::NP, NT = 64, BAS = LargeLayout<M>::BAS;
     const LargeSpec *spp;   // kernel-argument copy of the problem (set-up only)
     const double *xs;       // x_ss (device)
     int N, lane;
@@ -224,7 +224,7 @@ struct ChainSolver {
     MPCRL_DI double GTnu(const WsArr &nu, int k, int i) const {
         double a = 0.0;
         if (k < N) {
-            const WsArr Bk = BA + (k * NX * NW + i);
+            const WsArr Bk = BA + (k * BAS + i);
             for (int m = 0; m < NX; ++m) a = fma(Bk[m * NW], nu[(k + 1) * NX + m], a);
         }
         if (i >= NU && k > 0) a -= nu[k * NX + i - NU];
@@ -294,7 +294,7 @@ struct ChainSolver {
                 N,
                 [&](int k, auto sl) {
                     constexpr int d = decltype(sl)::value;
-                    blk_load(BA + k * NX * NW, NX * NW / 2, nB[d], lane);
+                    blk_load(BA + k * BAS, NX * NW / 2, nB[d], lane);
                     ng[d] = rg[k * NW + lj], nn[d] = NUv[(k + 1) * NX + lx];
                     {
                         const bool c_ = lane >= NU && lane < NW && k > 0;
@@ -396,7 +396,7 @@ struct ChainSolver {
                 static_for<RG>([&](auto rg_) {
                     constexpr int rg = decltype(rg_)::value;
 #pragma unroll
-                    for (int tj = 0; tj < NTR; ++tj) nA[d][rg][tj] = BA[k * NX * NW + rbase + colnat[tj] + (4 * rg - (rg >= GQ ? NU : 0)) * NW];
+                    for (int tj = 0; tj < NTR; ++tj) nA[d][rg][tj] = BA[k * BAS + rbase + colnat[tj] + (4 * rg - (rg >= GQ ? NU : 0)) * NW];
                 });
             },
             [&](int k, auto sl, auto refill) {
@@ -500,9 +500,12 @@ struct ChainSolver {
         return rloc;
     }
 
-    // STORE_P: P_k goes to HBM as well (only the adjoint solves of the sensitivities multiply with it afterwards: forward2_sens).
-    template <class HS, bool STORE_P>
+    // SENS = false (the QPs of the SQP): the sweep leaves -K_k in the rows NX.. of the stage block of [B A]_k (LargeLayout::BAS) — the
+    // vector sweeps multiply with [A B] and K; nothing of the size of a stage block is written.  SENS = true (the adjoint
+    // factorisation of the sensitivities): the closed-loop block G_k and P_k go to HBM for forward2_sens.
+    template <class HS, bool SENS>
     MPCRL_DI bool factor2(HS &hs, const WsArr g, const WsArr bb) {
+        constexpr bool STORE_P = SENS;
         using O = OmCfg<M>;
         constexpr int RG = O::RG, NT = O::NT, NTR = O::NTR, GQ = O::GQ, TQ = O::TQ, RQ = O::RQ, LQ = O::LQ, TV = O::TV, LV = O::LV;
         constexpr int FD = NTR <= 2 ? 2 : 1;     // prefetch slots (a stage is 3 - 9 us of work: one stage ahead covers the HBM latency; registers at n_mass 7)
@@ -565,13 +568,13 @@ struct ChainSolver {
             [&](int idx, auto sl) {
                 constexpr int d = decltype(sl)::value;
                 const int k = N - 1 - idx;
-                const WsArr Bk = BA + k * NX * NW;
+                const WsArr Bk = BA + k * BAS;
                 static_for<RG>([&](auto rg_) {
                     constexpr int rg = decltype(rg_)::value;
                     const int xr = om_xr<rg>(lr), nt = om_nat<rg>(lr);
 #pragma unroll
                     for (int tj = 0; tj < NT; ++tj) {
-                        const int ow = k * NX * NW + rbase + colnat[tj] + (4 * rg - (rg >= GQ ? NU : 0)) * NW;
+                        const int ow = k * BAS + rbase + colnat[tj] + (4 * rg - (rg >= GQ ? NU : 0)) * NW;
                         nW[d][rg][tj] = BA[(tj == TV && vcl) ? (int)bbrel + k * NX + xr : ow];
                     }
                     const bool rok = !RAGGED || rg < RG - 1 || 4 * rg + lr < NW;
@@ -579,7 +582,7 @@ struct ChainSolver {
                 });
 #pragma unroll
                 for (int ti = 0; ti < NTR; ++ti) {
-                    nBt[d][ti] = Bk[btoff[ti]];
+                    if constexpr (SENS) nBt[d][ti] = Bk[btoff[ti]];
                     ndx[d][ti] = (ti != TV && 16 * ti + LV < NW) ? Dg[k * NW + O::nat(16 * ti + LV < NW ? 16 * ti + LV : 0)] : 0.0;
                 }
             },
@@ -613,8 +616,10 @@ struct ChainSolver {
                         }
                     });
                 });
+                if constexpr (SENS) {
 #pragma unroll
-                for (int ti = 0; ti < NTR; ++ti) Bt[ti] = btok[ti] ? nBt[d][ti] : 0.0;
+                    for (int ti = 0; ti < NTR; ++ti) Bt[ti] = btok[ti] ? nBt[d][ti] : 0.0;
+                }
                 refill();
                 // ---- T = P W, row tile by row tile (the column tile of P it read is dead afterwards)
                 d4_t Tt[NTR][NT];
@@ -742,28 +747,39 @@ struct ChainSolver {
                 for (int ta = 0; ta < NTR; ++ta)
 #pragma unroll
                     for (int tb = 0; tb < NT; ++tb) Mt[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Sr[ta], nK[tb], Mt[ta][tb], 0, 0, 0);
+                if constexpr (SENS) {
 #pragma unroll
-                for (int ti = 0; ti < NTR; ++ti)
+                    for (int ti = 0; ti < NTR; ++ti)
 #pragma unroll
-                    for (int tj = 0; tj < NT; ++tj) Wt[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bt[ti], nKz[tj], Wt[ti][tj], 0, 0, 0);
+                        for (int tj = 0; tj < NT; ++tj) Wt[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bt[ti], nKz[tj], Wt[ti][tj], 0, 0, 0);
 #pragma unroll
-                for (int tj = 0; tj < NT; ++tj) Wt[TQ][tj][RQ] = padl ? nKz[tj] : Wt[TQ][tj][RQ];
-                // ---- out: G_k and P_k in the register layout (full 512-byte bursts); from the lanes of the vector column hb_k, and
-                // p_k, kff_k in natural order for the other phases; R^-1 from the lanes that hold its entries
-                static_for<RG>([&](auto rg_) {
-                    constexpr int rg = decltype(rg_)::value;
-#pragma unroll
-                    for (int tj = 0; tj < TV; ++tj) {
-                        G2[k * O::GSZ + (rg * TV + tj) * 64 + gbase] = Wt[rg / 4][tj][rg % 4];
-                        if constexpr (STORE_P) P2[k * O::GSZ + (rg * TV + tj) * 64 + gbase] = Mt[rg / 4][tj][rg % 4];
-                    }
-                });
-                if (wcl)      // the last column tile: its columns < NW, compactly
+                    for (int tj = 0; tj < NT; ++tj) Wt[TQ][tj][RQ] = padl ? nKz[tj] : Wt[TQ][tj][RQ];
+                    // ---- out: G_k and P_k in the register layout (full 512-byte bursts)
                     static_for<RG>([&](auto rg_) {
                         constexpr int rg = decltype(rg_)::value;
-                        G2[k * O::GSZ + RG * TV * 64 + rg * O::CT + cbase] = Wt[rg / 4][TV][rg % 4];
-                        if constexpr (STORE_P) P2[k * O::GSZ + RG * TV * 64 + rg * O::CT + cbase] = Mt[rg / 4][TV][rg % 4];
+#pragma unroll
+                        for (int tj = 0; tj < TV; ++tj) {
+                            G2[k * O::GSZ + (rg * TV + tj) * 64 + gbase] = Wt[rg / 4][tj][rg % 4];
+                            P2[k * O::GSZ + (rg * TV + tj) * 64 + gbase] = Mt[rg / 4][tj][rg % 4];
+                        }
                     });
+                    if (wcl)      // the last column tile: its columns < NW, compactly
+                        static_for<RG>([&](auto rg_) {
+                            constexpr int rg = decltype(rg_)::value;
+                            G2[k * O::GSZ + RG * TV * 64 + rg * O::CT + cbase] = Wt[rg / 4][TV][rg % 4];
+                            P2[k * O::GSZ + RG * TV * 64 + rg * O::CT + cbase] = Mt[rg / 4][TV][rg % 4];
+                        });
+                } else {
+                    // ---- out: -K_k into rows NX .. NX + NU - 1 of the stage block, natural column order, zeros in the control columns
+                    // (lane (lr = l, lc) holds -K(l, slot 16 tj + lc); columns past NW and the vector column go to the dump slot)
+#pragma unroll
+                    for (int tj = 0; tj < NT; ++tj) {
+                        const bool cok = padl && 16 * tj + lc < NW;
+                        BA[cok ? k * BAS + (NX + lr) * NW + colnat[tj] : N * BAS] = nKz[tj];
+                    }
+                }
+                // from the lanes of the vector column hb_k, and p_k, kff_k in natural order for the other phases; R^-1 from the lanes
+                // that hold its entries
                 if (vcl) {
                     static_for<RG>([&](auto rg_) {
                         constexpr int rg = decltype(rg_)::value;
@@ -805,13 +821,16 @@ struct ChainSolver {
                         [&](int e, double v) { dst[e] = v; });
     }
 
-    // ---- backward vector sweep for a new right-hand side g on the stored G_k: [p_k; mv_u] = g + G_k' [p_{k+1} + hb_k; g_u],
-    // a chain of MFMAs whose B operand is the previous result (column 0 of the lanes carries the vector), then kff = R^-1 mv_u.
-    // The two vectors of the horizon (g, hb) are staged in LDS in Omega order first: the stream of the G_k blocks is all that is
-    // left in the global-memory queue (the sweep is bound by HBM bandwidth: depth x block = bytes in flight).
+    // ---- backward vector sweep for a new right-hand side g on the factors of the current iteration (K_k in the stage block, hb_k):
+    //     [A'v; mv_u] = g + [A B]_k' v,  v = p_{k+1} + hb_k          p_k = (g_x + A'v) - K_k' mv_u          kff_k = R_k^-1 mv_u
+    // (= g_x - K'g_u + Acl'v with Acl = A - B K, which is never formed).  Two dependent groups of MFMAs per stage: [A B]' v with
+    // [A B]_k as it lies in the workspace as the A operand and the previous result registers as the B operand (column 0 of the lanes
+    // carries the vector; the 16 columns are identical copies), then the rank-NU term with the lanes (lr = l, lc) holding -K(l, .) as
+    // the A operand and the control rows of the first result as the B operand.  The two vectors of the horizon (g, hb) are staged in
+    // LDS in Omega order first: the stream of the stage blocks is all that is left in the global-memory queue.
     MPCRL_DI void backward_vec2(const WsArr g) {
         using O = OmCfg<M>;
-        constexpr int RG = O::RG, NTR = O::NTR, GQ = O::GQ, TV = O::TV, D = NTR <= 2 ? 4 : 2;   // (stages in flight: registers at n_mass 7)
+        constexpr int RG = O::RG, NTR = O::NTR, GQ = O::GQ, D = NTR <= 2 ? 4 : 2;   // (stages in flight: registers at n_mass 7)
         constexpr bool RAGGED = 4 * RG > NW;
         const int lr = lane >> 4, lc = lane & 15;
         const bool padl = lr < NU;
@@ -819,9 +838,13 @@ struct ChainSolver {
         stage_vec_lds<false>(lg, g, N);
         batched_pass<4>(N * O::HBS, lane, [&](int e) { return hb2[e]; }, [&](int e, double v) { lhb[e] = v; });
         wave_sync();
-        unsigned goffs[NTR];
+        int colnat[NTR];
 #pragma unroll
-        for (int ti = 0; ti < NTR; ++ti) goffs[ti] = O::goff(0, ti, lr, lc);
+        for (int tj = 0; tj < NTR; ++tj) {
+            const int c = 16 * tj + lc;
+            colnat[tj] = c < NW ? O::nat(c < NW ? c : 0) : 0;
+        }
+        const int rbase = lr * NW, kbase = (NX + (padl ? lr : 0)) * NW;
         d4_t R[NTR];
         static_for<NTR>([&](auto ti_) {
             static_for<4>([&](auto r_) {
@@ -840,7 +863,7 @@ struct ChainSolver {
                 const bool rok = (rg != GQ || !padl) && (!RAGGED || rg < RG - 1 || 4 * rg + lr < NW);
                 p[rok ? N * NX + om_xr<rg>(lr) : (N + 1) * NX] = R[rg / 4][rg % 4];
             });
-        double nG[D][RG][NTR];
+        double nA[D][RG][NTR], nK[D][NTR];
         staged_loop<D>(
             N,
             [&](int idx, auto sl) {
@@ -849,35 +872,50 @@ struct ChainSolver {
                 static_for<RG>([&](auto rg_) {
                     constexpr int rg = decltype(rg_)::value;
 #pragma unroll
-                    for (int ti = 0; ti < NTR; ++ti) nG[d][rg][ti] = G2[k * O::GSZ + goffs[ti] + rg * (ti < TV ? TV * 64 : O::CT)];
+                    for (int tj = 0; tj < NTR; ++tj) nA[d][rg][tj] = BA[k * BAS + rbase + colnat[tj] + (4 * rg - (rg >= GQ ? NU : 0)) * NW];
                 });
+#pragma unroll
+                for (int tj = 0; tj < NTR; ++tj) nK[d][tj] = BA[k * BAS + kbase + colnat[tj]];
             },
             [&](int idx, auto sl, auto refill) {
                 constexpr int d = decltype(sl)::value;
                 const int k = N - 1 - idx;
-                double vop[RG], gt[RG];
+                double Ak[RG][NTR], Kt[NTR], vop[RG], gt[RG];
                 static_for<RG>([&](auto rg_) {
                     constexpr int rg = decltype(rg_)::value;
+#pragma unroll
+                    for (int tj = 0; tj < NTR; ++tj) {
+                        double v = nA[d][rg][tj];
+                        if constexpr (rg == GQ) v = padl ? 0.0 : v;                                  // pad rows of W
+                        if constexpr (RAGGED && rg == RG - 1) v = 4 * rg + lr < NW ? v : 0.0;
+                        if (RAGGED) v = 16 * tj + lc < NW ? v : 0.0;                                 // (columns past NW: result rows that feed the next operand)
+                        Ak[rg][tj] = v;
+                    }
                     gt[rg] = lg[k * O::HBS + 4 * rg + lr];
                     double v = R[rg / 4][rg % 4] + lhb[k * O::HBS + 4 * rg + lr];
-                    if constexpr (rg == GQ) v = padl ? gt[rg] : v;
+                    if constexpr (rg == GQ) v = padl ? 0.0 : v;
                     vop[rg] = v;
                 });
+#pragma unroll
+                for (int tj = 0; tj < NTR; ++tj) {
+                    const double v = nK[d][tj];
+                    Kt[tj] = (padl && 16 * tj + lc < NW) ? v : 0.0;
+                }
+                refill();
                 d4_t acc[NTR];
 #pragma unroll
                 for (int ti = 0; ti < NTR; ++ti)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[ti][r] = 4 * ti + r < RG ? gt[4 * ti + r < RG ? 4 * ti + r : 0] : 0.0;
-                double Gk[RG][NTR];
-#pragma unroll
-                for (int rg = 0; rg < RG; ++rg)
-#pragma unroll
-                    for (int ti = 0; ti < NTR; ++ti) Gk[rg][ti] = nG[d][rg][ti];
-                refill();
 #pragma unroll
                 for (int ks = 0; ks < RG; ++ks)
 #pragma unroll
-                    for (int ti = 0; ti < NTR; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gk[ks][ti], vop[ks], acc[ti], 0, 0, 0);
+                    for (int ti = 0; ti < NTR; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[ks][ti], vop[ks], acc[ti], 0, 0, 0);
+                // the control rows now hold mv_u = g_u + B'v (lanes lr < NU of the group's register): operand of the rank-NU term
+                const double mvu = acc[GQ / 4][GQ % 4];
+                const double mop = padl ? mvu : 0.0;
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Kt[ti], mop, acc[ti], 0, 0, 0);
                 if (lc == 0)
                     static_for<RG>([&](auto rg_) {
                         constexpr int rg = decltype(rg_)::value;
@@ -906,12 +944,14 @@ struct ChainSolver {
         wave_sync();
     }
 
-    // ---- forward sweep: [dx_{k+1}; du_k] = [b_k; -kff_k] + G_k [dx_k; -kff_k] (the control slots of the operand carry -kff: the
-    // x rows of G hold [Acl | B], its pad rows [-K | 0]).
-    // G_k is wanted as an A operand (contraction over its COLUMNS): the transposed access pattern of the streamed block.
+    // ---- forward sweep on the same blocks:  du_k = -kff_k - K_k dx_k,   dx_{k+1} = b_k + A_k dx_k + B_k du_k.
+    // One A operand per (row tile, k-step) serves both: G0 = [A B; -K 0] in Omega coordinates (x rows from [B A]_k, control rows from
+    // the K rows of the stage block: one gather, the lane's row decides which), contraction over its COLUMNS — the transposed access
+    // pattern of the block.  Phase 1: [A dx + b; du] = [b; -kff] + G0 [dx; 0]; phase 2 adds B du: the control k-step again with du
+    // in the control slots of the operand.
     MPCRL_DI void forward2(const WsArr bb) {
         using O = OmCfg<M>;
-        constexpr int RG = O::RG, NTR = O::NTR, GQ = O::GQ, TV = O::TV, LV = O::LV, D = NTR <= 2 ? 4 : 2;
+        constexpr int RG = O::RG, NTR = O::NTR, GQ = O::GQ, D = NTR <= 2 ? 4 : 2;
         constexpr bool RAGGED = 4 * RG > NW;
         const int lr = lane >> 4, lc = lane & 15;
         const bool padl = lr < NU;
@@ -924,13 +964,20 @@ struct ChainSolver {
             lbk[k * O::HBS + O::Q + (e - k * NU)] = kff[e];
         }
         wave_sync();
-        // element (row a, column b) of a streamed block: this lane wants a = 16 ti + lc (rows past the block: its last row), b = 4 ks + lr
-        unsigned tfull[NTR], tcomp[NTR];
+        // element (row slot a, column slot b) of G0: this lane wants a = 16 ti + lc, b = 4 ks + lr
+        int rowoff[NTR], coloff[RG];
+        bool rowok[NTR], colok[RG];
 #pragma unroll
         for (int ti = 0; ti < NTR; ++ti) {
-            const int a_ = 16 * ti + lc, a = a_ < 4 * RG ? a_ : 4 * RG - 1;
-            tfull[ti] = (unsigned)((a >> 2) * TV * 64 + (a & 3) * 16 + lr);
-            tcomp[ti] = (unsigned)(RG * TV * 64 + (a >> 2) * O::CT + (a & 3) * LV + lr);
+            const int a = 16 * ti + lc, ac = a < NW ? a : 0, xr = O::xrow(ac);
+            rowok[ti] = a < NW;
+            rowoff[ti] = (xr >= 0 ? xr : NX + (ac - O::Q)) * NW;      // a state row of [B A], or row NX + l of the K rows
+        }
+#pragma unroll
+        for (int ks = 0; ks < RG; ++ks) {
+            const int b_ = 4 * ks + lr;
+            colok[ks] = b_ < NW;
+            coloff[ks] = O::nat(b_ < NW ? b_ : 0);
         }
         if (lane < NX) Dx[lane] = 0.0;
         double w[RG];
@@ -944,8 +991,7 @@ struct ChainSolver {
 #pragma unroll
                 for (int ti = 0; ti < NTR; ++ti)
 #pragma unroll
-                    for (int ks = 0; ks < RG; ++ks)
-                        nGt[d][ti][ks] = G2[k * O::GSZ + (ks / 4 < TV ? tfull[ti] + (ks / 4) * 64 : tcomp[ti]) + 4 * (ks % 4)];
+                    for (int ks = 0; ks < RG; ++ks) nGt[d][ti][ks] = BA[k * BAS + rowoff[ti] + coloff[ks]];
             },
             [&](int k, auto sl, auto refill) {
                 constexpr int d = decltype(sl)::value;
@@ -961,17 +1007,24 @@ struct ChainSolver {
                         acc[ti][r] = c;
                     });
                 });
-                w[GQ] = padl ? acc[GQ / 4][GQ % 4] : w[GQ];                   // operand: -kff_k in the control slots as well
                 double Gk[NTR][RG];
 #pragma unroll
                 for (int ti = 0; ti < NTR; ++ti)
 #pragma unroll
-                    for (int ks = 0; ks < RG; ++ks) Gk[ti][ks] = nGt[d][ti][ks];
+                    for (int ks = 0; ks < RG; ++ks) {
+                        const double v = nGt[d][ti][ks];
+                        Gk[ti][ks] = (!RAGGED || (rowok[ti] && colok[ks])) ? v : 0.0;
+                    }
                 refill();
+                w[GQ] = padl ? 0.0 : w[GQ];                                   // phase 1: the control slots of the operand are empty
 #pragma unroll
                 for (int ks = 0; ks < RG; ++ks)
 #pragma unroll
                     for (int ti = 0; ti < NTR; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gk[ti][ks], w[ks], acc[ti], 0, 0, 0);
+                const double du_ = acc[GQ / 4][GQ % 4];                       // control rows: du_k = -kff_k - K_k dx_k
+                const double w2 = padl ? du_ : 0.0;
+#pragma unroll
+                for (int ti = 0; ti < NTR; ++ti) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Gk[ti][GQ], w2, acc[ti], 0, 0, 0);   // + B du
                 if (lc == 0)      // the vector sits in column 0: rows past NW go to the dump slot
                     static_for<RG>([&](auto rg_) {
                         constexpr int rg = decltype(rg_)::value;
@@ -1191,7 +1244,7 @@ struct ChainSolver {
                 static_for<RG>([&](auto rg_) {
                     constexpr int rg = decltype(rg_)::value;
 #pragma unroll
-                    for (int tj = 0; tj < NTR; ++tj) nA[d][rg][tj] = BA[k * NX * NW + rbase + colnat[tj] + (4 * rg - (rg >= GQ ? NU : 0)) * NW];
+                    for (int tj = 0; tj < NTR; ++tj) nA[d][rg][tj] = BA[k * BAS + rbase + colnat[tj] + (4 * rg - (rg >= GQ ? NU : 0)) * NW];
                 });
             },
             [&](int idx, auto sl, auto refill) {

@@ -1,13 +1,13 @@
 """Phase breakdown of the chain kernel (one wavefront per instance): shader-clock ticks of lane 0 per phase, summed over the
 batch.  Needs a library built with -DMPCRL_PROFILE_PHASES, selected through MPCRL_LIB_PATH:
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -amdgpu-mfma-vgpr-form -DMPCRL_PROFILE_PHASES mpc4rl_amd/csrc/mpcrl_api.hip -o mpc4rl_amd/libmpcrl_prof.so
-  MPCRL_LIB_PATH=mpc4rl_amd/libmpcrl_prof.so python profiles/microbench/chain_phases.py [n_mass]
+  make -C mpc4rl_amd/csrc -j8 OUT=../../ab/prof.so BUILD=build_prof EXTRA=-DMPCRL_PROFILE_PHASES
+  MPCRL_LIB_PATH=ab/prof.so python profiles/microbench/chain_phases.py [n_mass]
 """
 import ctypes as C, numpy as np, torch, sys, time
 sys.path.insert(0, '.')
 from mpc4rl_amd import MPCBatch, chain_mass_ocp, _lib
 n_mass = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-ocp = chain_mass_ocp(n_mass=n_mass); B = 1024
+ocp = chain_mass_ocp(n_mass=n_mass); B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 rng = np.random.default_rng(0)
 M = n_mass - 2
 x0 = np.tile(ocp.x0, (B, 1))

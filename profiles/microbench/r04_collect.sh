@@ -16,7 +16,7 @@ timeout 300 bash profiles/microbench/hbm_traffic.sh cartpole 3 1 > /dev/null 2>&
 timeout 300 bash profiles/microbench/hbm_traffic.sh linear 3 1 --workload linear > /dev/null 2>&1
 timeout 300 bash profiles/microbench/hbm_traffic.sh chain5 2 1 --workload chain5 > /dev/null 2>&1
 timeout 400 bash profiles/microbench/hbm_traffic.sh chain7 2 1 --workload chain7 > /dev/null 2>&1
-if [ -f mpc4rl_amd/libmpcrl_prof.so ]; then
-  (MPCRL_LIB_PATH=$PWD/mpc4rl_amd/libmpcrl_prof.so python profiles/microbench/chain_phases.py 5; MPCRL_LIB_PATH=$PWD/mpc4rl_amd/libmpcrl_prof.so python profiles/microbench/chain_phases.py 7) > gpurun_out/r04_chain_phases.txt 2>/dev/null
+if [ -f ab/prof.so ]; then
+  (MPCRL_LIB_PATH=$PWD/ab/prof.so python profiles/microbench/chain_phases.py 5; MPCRL_LIB_PATH=$PWD/ab/prof.so python profiles/microbench/chain_phases.py 7) > gpurun_out/r04_chain_phases.txt 2>/dev/null
 fi
 ls -la gpurun_out | tail -40
