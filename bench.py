@@ -44,7 +44,7 @@ def make_inputs(B, rank):
     return x0
 
 
-TRAFFIC_FILE = os.path.join("profiles", "r04_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r05_hbm_traffic.json")
 
 
 def csrc_hash():

@@ -11,7 +11,7 @@ from .problems import OcpDescription, cartpole_ocp, chain_mass_ocp, linear_syste
 from .batch import MPCBatch, SolveResult  # noqa: F401
 from .envs import BatchedCartPoleSwingUpEnv, BatchedLinearSystemEnv  # noqa: F401
 from .qlearning import BatchedQLearning  # noqa: F401
-from .td3 import BatchedTD3, ContinuousCritic, DeviceReplayBuffer, MPCActor  # noqa: F401
+from .td3 import BatchedTD3, ContinuousCritic, DeviceReplayBuffer, MPCActor, MPCTD3Policy  # noqa: F401
 from .config import cartpole_ocp_from_config, read_config, store_iterate, load_iterate  # noqa: F401
 from .mpc import MPC, CartpoleMPC, ChainMassMPC, LinearSystemMPC  # noqa: F401
 

@@ -320,7 +320,8 @@ struct ChainCfg {
         big = big > tab ? big : tab, big = big > vec ? big : vec, big = big > cst ? big : cst;
         // the direction pass: its tables, the compact parameter copy and the multipliers of the whole horizon
         // (and the point pass's RK4 accumulators: NX per stage lane)
-        const int dir = DirCfg<M>::CO + M::NTD + (FUSE_GT ? (N + 1) * NX : 0) + N * NX;
+        const int pacc = N * NX > 64 * DirCfg<M>::ACCL ? N * NX : 64 * DirCfg<M>::ACCL;      // (the direction pass's accumulators reuse the region)
+        const int dir = DirCfg<M>::CO + M::NTD + (FUSE_GT ? (N + 1) * NX : 0) + pacc;
         big = big > dir ? big : dir;
         return oBig + big + (big & 1);
     }

@@ -212,6 +212,10 @@ struct DirCfg {
     static constexpr int NST = FITS ? SPAN : 64 / NW;                // stage tables in LDS
     static constexpr int LP = FITS ? 64 : (64 / NW) * NW;            // items per step
     static constexpr int CO = NST * TSZL;                            // after the tables: the instance's NTD differentiable parameters
+#ifndef MPCRL_CHAIN_DIR_ACCL
+#define MPCRL_CHAIN_DIR_ACCL 16
+#endif
+    static constexpr int ACCL = NX > 21 ? MPCRL_CHAIN_DIR_ACCL : 0;   // entries of the lane's RK4 accumulator kept in LDS (64 lanes x ACCL doubles)
     static_assert(ChainCfg<M>::oBig % 2 == 0, "16-byte records");
 };
 
@@ -262,7 +266,19 @@ MPCRL_DI void chain_dir_body(const double *th_, double *w_, double *tabl_, int N
         const bool on = lane < DC::LP && it_ < items;
         const int k = on ? it_ / NW : k_lo, d = on ? it_ - k * NW : 0;
         const double *mytab = tabl + (size_t)(k - k_lo) * TSZL;
-        double dxc[NX], acc[NX], dk[NX], dxt[NX], du[NU];
+        // (n_mass 6 / 7: the four NX-vectors of the lane overflow the 256 vector registers — AGPR copies inside the loop; the first ACCL
+        // entries of the RK4 accumulator live in LDS instead, [index][lane], where the point pass kept its accumulators: dead by now)
+        constexpr int ACCL = DC::ACCL;
+        struct Acc {
+            double r[NX - ACCL > 0 ? NX - ACCL : 1];
+            double *p;
+            MPCRL_DI double get(int i) const { return i < ACCL ? p[i * 64] : r[i >= ACCL ? i - ACCL : 0]; }
+            MPCRL_DI void set(int i, double v) {
+                if (i < ACCL) p[i * 64] = v; else r[i >= ACCL ? i - ACCL : 0] = v;
+            }
+        } acc;
+        acc.p = tabl + DC::CO + M::NTD + (ChainCfg<M>::FUSE_GT ? (N + 1) * NX : 0) + lane;
+        double dxc[NX], dk[NX], dxt[NX], du[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) du[i] = d == i ? 1.0 : 0.0;
 #pragma unroll
@@ -308,16 +324,16 @@ MPCRL_DI void chain_dir_body(const double *th_, double *w_, double *tabl_, int N
             const double *tb = mytab + (size_t)(4 * s_) * NL * LREC;
             eval(tb, dxc, std::integral_constant<int, 0>{});
 #pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
+            for (int i = 0; i < NX; ++i) acc.set(i, dk[i]), dxt[i] = dxc[i] + (0.5 * h) * dk[i];
             eval(tb + NL * LREC, dxt, std::integral_constant<int, P1>{});
 #pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + (0.5 * h) * dk[i];
+            for (int i = 0; i < NX; ++i) acc.set(i, acc.get(i) + 2.0 * dk[i]), dxt[i] = dxc[i] + (0.5 * h) * dk[i];
             eval(tb + 2 * NL * LREC, dxt, std::integral_constant<int, P2>{});
 #pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = acc[i] + 2.0 * dk[i], dxt[i] = dxc[i] + h * dk[i];
+            for (int i = 0; i < NX; ++i) acc.set(i, acc.get(i) + 2.0 * dk[i]), dxt[i] = dxc[i] + h * dk[i];
             eval(tb + 3 * NL * LREC, dxt, std::integral_constant<int, P3>{});
 #pragma unroll
-            for (int i = 0; i < NX; ++i) dxc[i] = dxc[i] + (h / 6.0) * (acc[i] + dk[i]);
+            for (int i = 0; i < NX; ++i) dxc[i] = dxc[i] + (h / 6.0) * (acc.get(i) + dk[i]);
         }
         if (on) {
             double *BA = w + lay.BA + (size_t)k * LargeLayout<M>::BAS;

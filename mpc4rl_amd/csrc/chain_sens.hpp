@@ -82,6 +82,9 @@ __global__ void __launch_bounds__(64) chain_sens_th2_kernel(const LargeSpec sp, 
 //      (3 NL x NW) and W = G Y and accumulates  Hex += Y' W  on the matrix cores: v_mfma_f64_16x16x4, lower tile triangle, operands
 //      straight out of LDS in their register layout (A(i, k) and B(k, j) both at lane 16 k + i|j: measured,
 //      profiles/microbench/mfma_f64_16x16x4_probe.hip), results D[r](4 r + lane / 16, lane % 16) stored row-coalesced.
+#ifndef MPCRL_CHAIN_AD_ACC_LDS
+#define MPCRL_CHAIN_AD_ACC_LDS 1
+#endif
 template <class M>
 struct HexCfg {
     static constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NL = M::NL, TAB2 = M::TAB2, EV = 8;
@@ -105,7 +108,10 @@ __global__ void __launch_bounds__(64, 1) chain_sens_ad_kernel(const LargeSpec sp
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NL = M::NL, TAB2 = M::TAB2, LD = HC::LD, RP = HC::RP, NTI = HC::NTI;
     constexpr int GW = HC::GW, SPW = HC::SPW, NTT = NTI * (NTI + 1) / 2;
     typedef double d4_t __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) double lds[SPW * HC::TOTAL];
+    // (n_mass 7 — one stage per wavefront — keeps the lanes' RK4 accumulator in LDS, [index][lane]: with all four NX-vectors of the tangent
+    // propagation in registers the kernel spilled 109 of them)
+    constexpr bool ACC_LDS = MPCRL_CHAIN_AD_ACC_LDS != 0 && SPW == 1 && (HC::TOTAL + 64 * NX) * 8 <= 40 * 1024;
+    __shared__ __attribute__((aligned(16))) double lds[SPW * HC::TOTAL + (ACC_LDS ? 64 * NX : 0)];
     const int N = sp.N, lane = threadIdx.x, NG = HC::groups(N);
     const int inst = blockIdx.x / NG, k0 = (blockIdx.x - inst * NG) * SPW;
     const int status = a.status[inst];
@@ -134,7 +140,17 @@ __global__ void __launch_bounds__(64, 1) chain_sens_ad_kernel(const LargeSpec sp
 #pragma unroll
         for (int t_ = 0; t_ < NTT; ++t_) D[s_][t_] = d4_t{0.0, 0.0, 0.0, 0.0};
     {
-        double dxc[NX], acc[NX], dk[NX], dxt[NX], du[NU], dd[3 * NL];
+        struct AccReg {
+            double a[NX];
+            MPCRL_DI double &operator[](int i) { return a[i]; }
+        };
+        struct AccLds {
+            double *p;
+            MPCRL_DI double &operator[](int i) const { return p[i * 64]; }
+        };
+        std::conditional_t<ACC_LDS, AccLds, AccReg> acc;
+        if constexpr (ACC_LDS) acc.p = lds + SPW * HC::TOTAL + lane;
+        double dxc[NX], dk[NX], dxt[NX], du[NU], dd[3 * NL];
 #pragma unroll
         for (int i = 0; i < NU; ++i) du[i] = dl == i ? 1.0 : 0.0;
 #pragma unroll

@@ -79,6 +79,59 @@ class MPCActor:
         return step
 
 
+class MPCTD3Policy:
+    """The shape of rlmpc/td3/policies.py:225-361 (``MPCTD3Policy(BasePolicy)``) without stable-baselines3 (not installable here): the
+    attributes an SB3 ``TD3`` algorithm reaches for — ``actor``, ``actor_target``, ``critic``, ``critic_target`` with their
+    ``optimizer``s — and the methods it calls (``make_actor``, ``make_critic``, ``forward``, ``_predict``, ``set_training_mode``), with
+    the reference's argument names.  ``observation_space`` / ``action_space`` only need ``.shape`` (gymnasium spaces or stand-ins);
+    ``lr_schedule`` is a callable of the remaining progress (``lr_schedule(1)`` at construction, policies.py:322,342); ``mpc`` is an
+    ``OcpDescription`` (the reference passes its MPC object: here the actor owns a batched handle built from the same description).
+    ``forward(obs)`` is ONE batched solve where the reference's Actor.forward loops ``_predict`` over the batch (policies.py:186-197).
+    The actor's "parameters" are the MPC's theta (policies.py:215-222); its optimiser step is ``MPCActor.dpg_step``."""
+
+    def __init__(self, observation_space, action_space, lr_schedule, mpc, net_arch=None, n_critics: int = 1, batch: int = 1, device=None,
+                 optimizer_class=torch.optim.Adam, optimizer_kwargs=None, share_features_extractor: bool = False):
+        self.observation_space, self.action_space = observation_space, action_space
+        self.net_arch = [400, 300] if net_arch is None else list(net_arch)          # policies.py:288-292
+        self.optimizer_class, self.optimizer_kwargs = optimizer_class, dict(optimizer_kwargs or {})
+        self.actor_kwargs = {"mpc": mpc, "batch": batch, "device": device}
+        self.critic_kwargs = {"n_critics": n_critics, "net_arch": self.net_arch}
+        self.share_features_extractor = share_features_extractor                  # (observations are states: nothing to extract)
+        self.training = True
+        self._build(lr_schedule)
+
+    def _build(self, lr_schedule) -> None:                                        # policies.py:318-353
+        self.actor = self.make_actor()
+        self.actor_target = self.make_actor()
+        self.actor.lr = float(lr_schedule(1))                                     # (the reference builds an optimiser it never steps, policies.py:332)
+        self.critic = self.make_critic()
+        self.critic_target = self.make_critic()
+        self.critic_target.load_state_dict(self.critic.state_dict())
+        self.critic.optimizer = self.optimizer_class(self.critic.parameters(), lr=float(lr_schedule(1)), **self.optimizer_kwargs)
+        self.critic_target.train(False)
+
+    def make_actor(self, features_extractor=None) -> "MPCActor":                  # policies.py:355-357
+        kw = self.actor_kwargs
+        return MPCActor(kw["mpc"], kw["batch"], kw["device"])
+
+    def make_critic(self, features_extractor=None) -> ContinuousCritic:           # policies.py:359-361
+        obs_dim, act_dim = int(self.observation_space.shape[0]), int(self.action_space.shape[0])
+        critic = ContinuousCritic(obs_dim, act_dim, self.critic_kwargs["net_arch"], self.critic_kwargs["n_critics"])
+        return critic.to(self.actor.mpc.device if hasattr(self, "actor") else "cpu")
+
+    def forward(self, observation: torch.Tensor, deterministic: bool = False) -> torch.Tensor:
+        return self._predict(observation, deterministic=deterministic)
+
+    def _predict(self, observation: torch.Tensor, deterministic: bool = False) -> torch.Tensor:
+        return self.actor(observation)                                            # a deterministic policy either way
+
+    __call__ = forward
+
+    def set_training_mode(self, mode: bool) -> None:
+        self.critic.train(mode)
+        self.training = mode
+
+
 class DeviceReplayBuffer:
     """Ring buffer of transitions on the device, filled E environments at a time (stable_baselines3's ReplayBuffer as
     scripts/cartpole_mpc_as_td3_agent_closed_loop.py:47-58 uses it: obs, next_obs, action, reward, done)."""
@@ -383,7 +436,8 @@ class BatchedTD3:
                 "gens": [g.get_state() for g in gens], "obs": self.obs.clone(), "ended": self._ended.clone(), "stats": self._stats.clone(),
                 "env": (self.env.state.clone(), self.env.steps.clone()) if hasattr(self.env, "steps") else None,
                 "buf": [t.clone() for t in (self.buffer.obs, self.buffer.next_obs, self.buffer.act, self.buffer.rew, self.buffer.done)],
-                "pos": (self.buffer.pos, self.buffer.full), "iter": self.actor.mpc.get_iterate() if hasattr(self.actor.mpc, "get_iterate") else None}
+                "pos": (self.buffer.pos, self.buffer.full), "iter": self.actor.mpc.get_iterate() if hasattr(self.actor.mpc, "get_iterate") else None,
+                "iter_flags": (self.actor.mpc.has_iterate, self.actor.mpc.duals_valid)}
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
             for dp in (False, True):
@@ -414,8 +468,14 @@ class BatchedTD3:
             self.buffer.pos, self.buffer.full = snap["pos"]
             self.buffer.pos_t.fill_(self.buffer.pos)
             if snap["iter"] is not None:
+                # the roll-out actor's warm start exactly as it was: iterate, and whether its bound multipliers came from a solve
+                # (the replay handles only ever solve cold: their stored iterates are never read)
                 x_, u_, pi_, bnd_, _ = snap["iter"]
-                self.actor.mpc.set_iterate(x_, u_, pi_, bnd_)
+                had, duals = snap["iter_flags"]
+                if not had:
+                    self.actor.mpc.reset()
+                else:
+                    self.actor.mpc.set_iterate(x_, u_, pi_, bnd_ if duals else None)
         torch.cuda.synchronize(self.device)
 
         def capture(fn):

@@ -1,4 +1,4 @@
-"""Builds profiles/r04_hbm_traffic.json from the per-workload counter passes that profiles/microbench/hbm_traffic.sh left in
+"""Builds profiles/<round>_hbm_traffic.json (round tag = argv[1], default r05) from the per-workload counter passes that profiles/microbench/hbm_traffic.sh left in
 gpurun_out/<workload>_hbm.json, and stamps it with the hash of the kernel sources (bench.csrc_hash): bench.py reports
 roofline.traffic from this file only while the sources still hash to the same value.
     python profiles/microbench/merge_traffic.py        (in the dev container, after the GPU run)
@@ -25,5 +25,6 @@ for w, B in batches.items():
     write = sum(v.get("WRITE_SIZE", 0.0) for v in keep.values())
     out[w] = {"batch": B, "command": d["command"], "fetch_bytes_per_step_raw": fetch, "write_bytes_per_step": write,
               "traffic_bytes_per_step": fetch + write, "kernels": keep}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r04_hbm_traffic.json"), "w"), indent=1)
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{TAG}_hbm_traffic.json"), "w"), indent=1)
 print({k: (v["traffic_bytes_per_step"] if isinstance(v, dict) else v) for k, v in out.items() if k != "method"})

@@ -432,3 +432,31 @@ def test_td3_config5_full_size_on_one_gpu():
         assert float((r.status == 0).double().mean()) > 0.999 and bool(torch.isfinite(r.dpi_dp).all())
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sb3_shaped_td3_policy():
+    """`MPCTD3Policy` keeps the attribute and method names an SB3 TD3 algorithm uses on rlmpc/td3/policies.py:225-361 (stable-baselines3
+    itself is not installable here): actor / actor_target / critic / critic_target, make_actor / make_critic, forward / _predict,
+    set_training_mode; forward(obs) is one batched solve and equals the scaled u0* of the MPC; the target critic starts as a copy."""
+    from types import SimpleNamespace
+    from mpc4rl_amd import MPCBatch, MPCTD3Policy, cartpole_ocp
+    ocp = cartpole_ocp()
+    B = 48
+    pol = MPCTD3Policy(SimpleNamespace(shape=(4,)), SimpleNamespace(shape=(1,)), lambda progress: 1e-3, ocp, net_arch=[32, 32], n_critics=2,
+                       batch=B, device="cuda")
+    for name in ("actor", "actor_target", "critic", "critic_target"):
+        assert hasattr(pol, name)
+    assert isinstance(pol.critic.optimizer, torch.optim.Adam) and pol.actor.lr == 1e-3
+    rng = np.random.default_rng(3)
+    obs = torch.as_tensor(rng.uniform(-1, 1, (B, 4)) * np.array([0.5, 1.0, 0.3, 1.0]), dtype=torch.float32, device="cuda")
+    a = pol(obs)
+    assert a.shape == (B, 1) and a.dtype == torch.float32 and float(a.abs().max()) <= 1.0 + 1e-6
+    ref = MPCBatch(ocp, B).solve(obs.to(torch.float64), cold=True)
+    assert torch.allclose(a.to(torch.float64), ref.u0 / 30.0, atol=1e-6)         # scale_action with u in [-30, 30] (mpc.py:290-301)
+    assert torch.equal(pol._predict(obs), pol.forward(obs))                      # warm call from the stored iterate: the same action
+    q, qt = pol.critic(obs, a), pol.critic_target(obs, a)
+    assert len(q) == 2 and all(torch.equal(x, y) for x, y in zip(q, qt))
+    pol.set_training_mode(False)
+    assert not pol.critic.training and not pol.critic_target.training
+    assert pol.actor.parameters().shape == (ocp.n_p,)
