@@ -53,7 +53,8 @@ def csrc_hash():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "mpc4rl_amd", "csrc")
-    for f in sorted(os.listdir(d)) + [os.path.join("..", "..", "include", "mpcrl.h")]:
+    srcs = [f for f in sorted(os.listdir(d)) if f.endswith((".hpp", ".hip")) or f == "Makefile"]      # (not the build directories)
+    for f in srcs + [os.path.join("..", "..", "include", "mpcrl.h")]:
         h.update(os.path.basename(f).encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

@@ -177,17 +177,29 @@ def chain_job(job):
     return z[: P.nu].copy(), v, [kkt["stationarity"], kkt["feasibility"], kkt["min_multiplier"]]
 
 
-def _run(job):
-    kind, payload = job
-    return {"cartpole": cartpole_job, "linear": linear_job, "chain": chain_job}[kind](payload)
+PARTS = "/tmp/g7_parts"
 
 
-def main(procs=8):
-    import multiprocessing as mp
+def _run(item):
+    """One job; its result is pickled under PARTS as soon as it is there (the chain n_mass 5 solve runs for hours: a later
+    `make_thirdparty_grad.py assemble` builds the file from whatever is complete)."""
+    import pickle
+    idx, (kind, payload) = item
+    f = os.path.join(PARTS, f"{idx}.pkl")
+    if os.path.exists(f):
+        return idx
+    r = {"cartpole": cartpole_job, "linear": linear_job, "chain": chain_job}[kind](payload)
+    with open(f + ".tmp", "wb") as fh:
+        pickle.dump(r, fh)
+    os.replace(f + ".tmp", f)
+    return idx
+
+
+def job_list():
     delta = (1e-5, 1e-4)
     g6 = np.load(os.path.join(HERE, "g6_thirdparty.npz"))
     Pc = make_cartpole()
-    cp_rows = [0, 3, 8, 11]                   # two swing-up starts, two near-upright states of G6 (nominal parameters)
+    cp_rows = [8, 11, 9, 10]                  # near-upright states of G6 (nominal parameters): u0* is not saturated there
     jobs = []
     for r in cp_rows:
         p = Pc.p0.copy()
@@ -200,21 +212,35 @@ def main(procs=8):
         jobs += [("linear", (x0, gamma, None, delta)) for x0 in g6[f"lin_{tag}_x0"]]
     chain_x0 = {}
     rng = np.random.default_rng(31)
+    from mpc4rl_amd.problems import chain_mass_ocp
     for n_mass in (3, 5):
-        from mpc4rl_amd.problems import chain_mass_ocp
         ocp = chain_mass_ocp(n_mass=n_mass)
         M = n_mass - 2
         x0 = ocp.x0.copy()
         x0[3 * (M + 1):] += rng.normal(0.0, 1e-2, 3 * M)
         chain_x0[n_mass] = x0
         jobs.append(("chain", (n_mass, x0)))
-    # the long jobs first
-    order = sorted(range(len(jobs)), key=lambda i: {"chain": 0, "cartpole": 1, "linear": 2}[jobs[i][0]])
-    with mp.get_context("spawn").Pool(procs) as pool:
-        res_sorted = pool.map(_run, [jobs[i] for i in order], chunksize=1)
-    res = [None] * len(jobs)
-    for i, r in zip(order, res_sorted):
-        res[i] = r
+    return jobs, delta, g6, cp_rows, lin_x0, chain_x0
+
+
+def main(procs=7, assemble_only=False):
+    import multiprocessing as mp
+    import pickle
+    os.makedirs(PARTS, exist_ok=True)
+    jobs, delta, g6, cp_rows, lin_x0, chain_x0 = job_list()
+    if not assemble_only:
+        # the long jobs first
+        order = sorted(range(len(jobs)), key=lambda i: {"chain": 0, "cartpole": 1, "linear": 2}[jobs[i][0]])
+        with mp.get_context("spawn").Pool(procs) as pool:
+            for idx in pool.imap_unordered(_run, [(i, jobs[i]) for i in order], chunksize=1):
+                print("done", idx, jobs[idx][0], flush=True)
+    res = []
+    for i in range(len(jobs)):
+        f = os.path.join(PARTS, f"{i}.pkl")
+        res.append(pickle.load(open(f, "rb")) if os.path.exists(f) else None)
+    missing = [i for i, r in enumerate(res) if r is None]
+    print("missing jobs:", [(i, jobs[i][0]) for i in missing])
+    assert all(jobs[i][0] == "chain" for i in missing), "only a chain solve may be left out"
     out = {"delta": np.array(delta)}
     o = 0
     cp = res[o:o + 3 * len(cp_rows)]
@@ -247,12 +273,13 @@ def main(procs=8):
         out[f"lin_{tag}_polished_V"] = np.array([c["V"] for c in part])
         out[f"lin_{tag}_polished_kkt"] = np.array([c["kkt"] for c in part])
     for n_mass in (3, 5):
-        u0, v, kkt = res[o]
+        if res[o] is not None:
+            u0, v, kkt = res[o]
+            out[f"chain{n_mass}_x0"], out[f"chain{n_mass}_u0"], out[f"chain{n_mass}_V"], out[f"chain{n_mass}_kkt"] = chain_x0[n_mass], u0, v, np.array(kkt)
         o += 1
-        out[f"chain{n_mass}_x0"], out[f"chain{n_mass}_u0"], out[f"chain{n_mass}_V"], out[f"chain{n_mass}_kkt"] = chain_x0[n_mass], u0, v, np.array(kkt)
     np.savez(os.path.join(HERE, "g7_thirdparty_grad.npz"), **out)
     print("wrote g7_thirdparty_grad.npz")
 
 
 if __name__ == "__main__":
-    main()
+    main(assemble_only=len(sys.argv) > 1 and sys.argv[1] == "assemble")
