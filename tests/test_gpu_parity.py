@@ -608,3 +608,55 @@ def test_time_sliced_launch_warm_calls(N, tf, B, monkeypatch):
     it = lambda r, m: float(r.iters[m][:, 0].double().mean())
     assert it(sa[1], ok) < 0.9 * it(sa[0], ok)                      # a warm call is warm ...
     assert it(sa[2], ok & mask) > 1.1 * it(sa[2], ok & ~mask)       # ... and an instance of the cold mask is not
+
+
+def test_hip_vs_third_party_gradients_and_chain_solutions():
+    """G7 (tests/golden/make_thirdparty_grad.py): dV/dp and du0*/dp of the HIP path against central differences of a THIRD-PARTY solver's
+    V and u0* (scipy SLSQP on cartpole, a certified active-set polish of trust-constr on the linear system) at 1e-5, and u0*, V of the
+    chain of masses against SLSQP's KKT points at 1e-6 — gradients and a chain solution that no code of this repository produced."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp, chain_mass_ocp, linear_system_ocp
+    if not os.path.exists(os.path.join(GOLD, "g7_thirdparty_grad.npz")):
+        pytest.skip("tests/golden/g7_thirdparty_grad.npz has not been generated (make_thirdparty_grad.py, ~1.5 h on 8 cores)")
+    g7 = np.load(os.path.join(GOLD, "g7_thirdparty_grad.npz"))
+
+    def held(fd0, fd1, mine):
+        fd0, fd1, mine = (np.asarray(a, float).reshape(len(fd0), -1) for a in (fd0, fd1, mine))
+        scale = np.maximum(np.abs(fd0).max(1, keepdims=True), 1.0)
+        ok = np.abs(fd0 - fd1) <= 2e-6 * scale
+        assert ok.mean() > 0.8
+        return float(np.where(ok, np.abs(mine - fd0) / scale, 0.0).max())
+
+    B = len(g7["cp_x0"])
+    ocp = cartpole_ocp(tol=1e-9)
+    theta = np.tile(ocp.p0, (B, 1))
+    theta[:, :3] = g7["cp_theta_model"]
+    mpc = MPCBatch(ocp, B)
+    mpc.set_theta(torch.as_tensor(theta))
+    r = mpc.solve(g7["cp_x0"], sens_v=True, sens_pi=True, cold=True)
+    assert bool((r.status == 0).all())
+    assert rel_err(r.u0.cpu().numpy(), g7["cp_u0"]) < RTOL and rel_err(r.V.cpu().numpy(), g7["cp_V"]) < RTOL
+    e_v = held(g7["cp_dV_d0"], g7["cp_dV_d1"], r.dV_dp.cpu().numpy()[:, :3])
+    e_pi = held(g7["cp_du0_d0"][:, :, 0], g7["cp_du0_d1"][:, :, 0], r.dpi_dp.cpu().numpy()[:, 0, :3])
+    print("cartpole vs third-party finite differences: dV/dp", e_v, "du0*/dp", e_pi)
+    assert e_v < 1e-5 and e_pi < 1e-5
+    for tag, gamma in (("g099", 0.99), ("g09", 0.9)):
+        ml = MPCBatch(linear_system_ocp(discount_factor=gamma), len(g7[f"lin_{tag}_x0"]))
+        ml.set_options(tol=1e-9)
+        rl = ml.solve(g7[f"lin_{tag}_x0"], sens_v=True, sens_pi=True, cold=True)
+        assert bool((rl.status == 0).all())
+        assert rel_err(rl.u0.cpu().numpy(), g7[f"lin_{tag}_u0"]) < RTOL and rel_err(rl.V.cpu().numpy(), g7[f"lin_{tag}_V"]) < RTOL
+        e_v = held(g7[f"lin_{tag}_dV_d0"], g7[f"lin_{tag}_dV_d1"], rl.dV_dp.cpu().numpy())
+        e_pi = held(g7[f"lin_{tag}_du0_d0"][:, :, 0], g7[f"lin_{tag}_du0_d1"][:, :, 0], rl.dpi_dp.cpu().numpy()[:, 0, :])
+        print("linear", tag, "vs third-party finite differences: dV/dp", e_v, "du0*/dp", e_pi)
+        assert e_v < 1e-5 and e_pi < 1e-5
+        mp_ = MPCBatch(linear_system_ocp(discount_factor=gamma), len(g7[f"lin_{tag}_polished_x0"]))
+        mp_.set_options(tol=1e-9)
+        rp = mp_.solve(g7[f"lin_{tag}_polished_x0"], cold=True)
+        assert rel_err(rp.u0.cpu().numpy(), g7[f"lin_{tag}_polished_u0"]) < RTOL and rel_err(rp.V.cpu().numpy(), g7[f"lin_{tag}_polished_V"]) < RTOL
+    for n_mass in (3, 5):
+        if f"chain{n_mass}_x0" not in g7.files:
+            continue
+        mc = MPCBatch(chain_mass_ocp(n_mass=n_mass, tol=1e-9), 1)
+        rc = mc.solve(g7[f"chain{n_mass}_x0"][None], cold=True)
+        assert int(rc.status[0]) == 0
+        assert rel_err(rc.u0.cpu().numpy(), g7[f"chain{n_mass}_u0"][None]) < RTOL and abs(float(rc.V[0]) - float(g7[f"chain{n_mass}_V"])) < RTOL * max(1.0, abs(float(rc.V[0])))

@@ -322,3 +322,54 @@ def test_third_party_solver_agrees_with_the_goldens_and_the_port(oracle_port):
         assert rel(g2["u0"], g6[f"lin_{tag}_u0"]) < 1e-6 and rel(g2["V"], g6[f"lin_{tag}_V"]) < 1e-6
         r = oracle_port.solve(make_linear_system(gamma=gamma), g6[f"lin_{tag}_x0"])
         assert np.all(r.status == 0) and rel(r.u0, g6[f"lin_{tag}_u0"]) < 1e-6 and rel(r.V, g6[f"lin_{tag}_V"]) < 1e-6
+
+
+def test_third_party_gradients_and_chain_solutions_vs_the_port(oracle_port):
+    """G7 (tests/golden/make_thirdparty_grad.py): central differences of a third-party solver's V and u0* over the parameters — the
+    reference's own check of dpi/dp is finite differences along a parameter sweep (rlmpc/examples/chain_mass.py:28-64) — and SLSQP
+    solutions of the chain-of-masses NLP.  The port's dV/dp and du0*/dp against them at 1e-5 (the differences carry the solver's
+    own noise: only entries where the steps 1e-5 and 1e-4 agree to 2e-6 of the row's scale are used), its u0*, V at 1e-6."""
+    from oracle.problems import make_cartpole, make_chain_mass, make_linear_system
+    if not os.path.exists(os.path.join(GOLD, "g7_thirdparty_grad.npz")):
+        pytest.skip("tests/golden/g7_thirdparty_grad.npz has not been generated (make_thirdparty_grad.py, ~1.5 h on 8 cores)")
+    g7 = np.load(os.path.join(GOLD, "g7_thirdparty_grad.npz"))
+
+    def held(fd0, fd1, mine, tol=1e-5):
+        fd0, fd1, mine = (np.asarray(a, float).reshape(len(fd0), -1) for a in (fd0, fd1, mine))
+        scale = np.maximum(np.abs(fd0).max(1, keepdims=True), 1.0)
+        ok = np.abs(fd0 - fd1) <= 2e-6 * scale
+        assert ok.mean() > 0.8, ok.mean()
+        err = np.where(ok, np.abs(mine - fd0) / scale, 0.0)
+        return float(err.max())
+
+    # cartpole: 4 near-upright states x (M, m, l)
+    P = make_cartpole()
+    B = len(g7["cp_x0"])
+    theta = np.tile(P.p0, (B, 1))
+    theta[:, :3] = g7["cp_theta_model"]
+    r = oracle_port.solve(P, g7["cp_x0"], p=theta, tol=1e-9)
+    assert np.all(r.status == 0)
+    assert np.abs(r.u0 - g7["cp_u0"]).max() < 1e-6 * np.abs(g7["cp_u0"]).max() and np.abs(r.V - g7["cp_V"]).max() < 1e-6 * np.abs(g7["cp_V"]).max()
+    assert held(g7["cp_dV_d0"], g7["cp_dV_d1"], r.dV[:, :3]) < 1e-5
+    assert held(g7["cp_du0_d0"][:, :, 0], g7["cp_du0_d1"][:, :, 0], r.dpi[:, 0, :3]) < 1e-5
+    # linear system: 2 states with an interior u0* x 12 parameters, both discount factors; every point KKT-certified to 1e-12
+    for tag, gamma in (("g099", 0.99), ("g09", 0.9)):
+        Pl = make_linear_system(gamma=gamma)
+        assert g7[f"lin_{tag}_kkt"][:, :2].max() < 1e-11 and g7[f"lin_{tag}_kkt_d0"].max() < 1e-11
+        r = oracle_port.solve(Pl, g7[f"lin_{tag}_x0"], tol=1e-9)
+        assert np.all(r.status == 0)
+        assert np.abs(r.u0 - g7[f"lin_{tag}_u0"]).max() < 1e-6 and np.abs(r.V - g7[f"lin_{tag}_V"]).max() < 1e-6 * np.abs(g7[f"lin_{tag}_V"]).max()
+        assert held(g7[f"lin_{tag}_dV_d0"], g7[f"lin_{tag}_dV_d1"], r.dV) < 1e-5
+        assert held(g7[f"lin_{tag}_du0_d0"][:, :, 0], g7[f"lin_{tag}_du0_d1"][:, :, 0], r.dpi[:, 0, :]) < 1e-5
+        # G6's rows, polished: what trust-constr stopped at 2e-6 of is now a KKT point to 1e-12
+        assert g7[f"lin_{tag}_polished_kkt"][:, :2].max() < 1e-11
+        r = oracle_port.solve(Pl, g7[f"lin_{tag}_polished_x0"], tol=1e-9)
+        assert np.abs(r.u0 - g7[f"lin_{tag}_polished_u0"]).max() < 1e-6 and np.abs(r.V - g7[f"lin_{tag}_polished_V"]).max() < 1e-6 * max(1.0, np.abs(r.V).max())
+    # chain of masses: SLSQP from the reference's cold iterate
+    for n_mass in (3, 5):
+        if f"chain{n_mass}_x0" not in g7.files:
+            continue
+        assert g7[f"chain{n_mass}_kkt"][0] < 1e-10 and g7[f"chain{n_mass}_kkt"][1] < 1e-10 and g7[f"chain{n_mass}_kkt"][2] >= 0.0
+        r = oracle_port.solve(make_chain_mass(n_mass=n_mass), g7[f"chain{n_mass}_x0"][None], tol=1e-9)
+        assert r.status[0] == 0
+        assert np.abs(r.u0[0] - g7[f"chain{n_mass}_u0"]).max() < 1e-6 and abs(r.V[0] - float(g7[f"chain{n_mass}_V"])) < 1e-6 * max(1.0, abs(r.V[0]))
