@@ -11,6 +11,7 @@
 #include <new>
 
 #include "small_kernel.hpp"
+#include "linear_kernel.hpp"
 #include "reduce_kernel.hpp"
 #include "order_kernel.hpp"
 #include "iterate_kernel.hpp"
@@ -224,7 +225,18 @@ int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
             if (!lds && warm) hipLaunchKernelGGL((small_solve_sliced_kernel<M, false, true>), dim3((unsigned)waves4), dim3(64), 0, st, h->small, a);
         }
     }
-    if (!sliced) hipLaunchKernelGGL(small_solve_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
+    bool lq = false;
+    if constexpr (std::is_same<M, LinearDev>::value) {
+        // the linear-system model: three stages per lane, four instances per wavefront (linear_kernel.hpp) unless switched off
+        // (MPCRL_LINEAR_SPL=1 at mpcrl_create: one stage per lane, small_solve_kernel) or the horizon leaves it no advantage
+        constexpr int SPL = 3;
+        const int lpi3 = lq_lanes_per_instance<SPL>(h->N), ipw3 = std::min(64 / lpi3, 8);
+        if (h->linear_spl == SPL && ipw3 > ipw) {
+            lq = true;
+            hipLaunchKernelGGL(lq_solve_kernel<SPL>, dim3((unsigned)((h->B + ipw3 - 1) / ipw3)), dim3(64), 0, st, h->small, a);
+        }
+    }
+    if (!sliced && !lq) hipLaunchKernelGGL(small_solve_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
     HIP_OK(hipGetLastError());
     if (timed_shape >= 0) {
         MpcrlSolver::Tuner &t = h->tune[(a.flags & MPCRL_COLD) ? 0 : 1];
@@ -285,6 +297,8 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->n_simd = 4 * cus;
         const char *e = std::getenv("MPCRL_TIME_SLICE");   // tests, profiling: same as mpcrl_set_launch_mode
         if (e && *e) h->slice_mode = (*e == '0') ? -1 : 1;
+        const char *l = std::getenv("MPCRL_LINEAR_SPL");   // stages per lane of the linear-system solve kernel: 3 (default) or 1
+        if (l && *l == '1') h->linear_spl = 1;
     }
     int rc = 0;
     switch (spec->model) {

@@ -33,6 +33,7 @@ struct MpcrlSolver {
     int64_t bytes = 0;
     int n_simd = 1024;          // SIMDs of the device (one resident wavefront each for the small solve kernel)
     int slice_mode = 0;         // mpcrl_set_launch_mode / MPCRL_TIME_SLICE: 0 = automatic, 1 = whenever legal, -1 = never
+    int linear_spl = 3;         // linear-system model: stages per lane of the solve kernel (3: linear_kernel.hpp; 1: small_solve_kernel)
     // automatic mode: the two launch shapes of the small solve kernel are timed against each other on the caller's own batches
     // (choose_launch below): [0] = time-sliced, [1] = plain
     struct Tuner {
