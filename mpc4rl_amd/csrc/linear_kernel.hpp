@@ -19,11 +19,36 @@
 
 namespace mpcrl {
 
-template <int SPL>
+// ---- cross-lane moves inside a DPP row (16 lanes): VALU moves, no LDS-crossbar round trip.  All 64 lanes must be active.
+template <int CTRL>
+MPCRL_DI double dpp_move(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// butterfly all-reduce over a row: partners lane ^ 1, lane ^ 2 (quad permutations), 7 - lane of the half row, 15 - lane of the row.
+// Every lane of the row ends with the same bits (the additions commute), no broadcast needed.
+template <int NMAX, int NSUM>
+MPCRL_DI void row_reduce(double *mx, double *sm) {
+#define MPCRL_ROW_STEP(CTRL)                                                                  \
+    {                                                                                         \
+        double om[NMAX > 0 ? NMAX : 1], os[NSUM > 0 ? NSUM : 1];                              \
+        _Pragma("unroll") for (int i = 0; i < NMAX; ++i) om[i] = dpp_move<CTRL>(mx[i]);       \
+        _Pragma("unroll") for (int i = 0; i < NSUM; ++i) os[i] = dpp_move<CTRL>(sm[i]);       \
+        _Pragma("unroll") for (int i = 0; i < NMAX; ++i) mx[i] = fmax(mx[i], om[i]);          \
+        _Pragma("unroll") for (int i = 0; i < NSUM; ++i) sm[i] += os[i];                      \
+    }
+    MPCRL_ROW_STEP(0xB1) MPCRL_ROW_STEP(0x4E) MPCRL_ROW_STEP(0x141) MPCRL_ROW_STEP(0x140)
+#undef MPCRL_ROW_STEP
+}
+
+// ROW: the instance owns one DPP row (16 lanes, the live ones first): reductions and scans by DPP moves
+template <int SPL, bool ROW>
 struct LqSolver {
     static constexpr int NX = 2, NU = 1, NW = 3;
     const SmallSpec &sp;
-    const int N, lpi, pos, base;
+    const int N, lpi, lpl, pos, base;   // lpi: lanes of the slot of the instance; lpl: the ones that hold live stages
     bool qmode;
     const double *th;     // LDS: the instance's 12 parameters (A column-major 4, B 2, b 2, V_0, f 3)
     const double *bt;     // LDS: bounds by stage kind (first / interior / terminal): [kind][lb 3 | ub 3]
@@ -31,9 +56,14 @@ struct LqSolver {
     int kst[SPL], kind[SPL];
     bool first[SPL], term[SPL], dead[SPL], softs[SPL];
     unsigned hasm[SPL];
-    double ck[SPL], zwl[SPL], zwu[SPL];
+    double ck[SPL];
     double x[SPL][NX], u[SPL], nu[SPL][NX];
-    double r[SPL][NX], q[SPL][NW];
+    // parked in LDS ([slot][lane], the lane's own column: no synchronisation): what is read once per QP or once per row pass — the
+    // dynamics defect r, the cost gradient q, the weights of the L1 slacks.  24 doubles of a lane's ~220: the kernel spills without this.
+    double *park;
+    static constexpr int PK_R = 0, PK_Q = PK_R + SPL * NX, PK_ZW = PK_Q + SPL * NW, PK_N = PK_ZW + SPL * 2;
+    MPCRL_DI double r_(int j, int i) const { return park[(PK_R + j * NX + i) * 64]; }
+    MPCRL_DI double q_(int j, int i) const { return park[(PK_Q + j * NW + i) * 64]; }
     double lam[SPL][2][NW], t[SPL][2][NW], aff[SPL][2][NW];
     double s[SPL][2], lams[SPL][2], ts[SPL][2], affs[SPL][2];
     double dx[SPL][NX], du[SPL], nuq[SPL][NX], Dx[SPL][NX], Du[SPL], Dnu[SPL][NX];
@@ -42,7 +72,24 @@ struct LqSolver {
     double n_rows_c = -1.0;
     double x0r[NX], u0r;
 
-    MPCRL_DI LqSolver(const SmallSpec &sp_, int lpi_, int pos_, int base_) : sp(sp_), N(sp_.N), lpi(lpi_), pos(pos_), base(base_) {}
+    MPCRL_DI LqSolver(const SmallSpec &sp_, int lpi_, int lpl_, int pos_, int base_) : sp(sp_), N(sp_.N), lpi(lpi_), lpl(lpl_), pos(pos_), base(base_) {}
+
+    // reductions over the lanes of the instance, result in all of them
+    template <int NMAX, int NSUM>
+    MPCRL_DI void red(double *mx, double *sm) const {
+        if constexpr (ROW)
+            row_reduce<NMAX, NSUM>(mx, sm);
+        else
+            seg_reduce<NMAX, NSUM, true>(mx, sm, pos, lpi, base);
+    }
+    MPCRL_DI double red_sum(double v) const {
+        red<0, 1>(nullptr, &v);
+        return v;
+    }
+    MPCRL_DI double red_max(double v) const {   // (of non-negative values)
+        red<1, 0>(&v, nullptr);
+        return v;
+    }
 
     MPCRL_DI static constexpr int sym(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
     MPCRL_DI double A_(int i, int j) const { return th[j * 2 + i]; }      // column-major in p (linear_system/acados.py:60-62,89-90)
@@ -52,7 +99,7 @@ struct LqSolver {
     MPCRL_DI double ubv(int j, int i) const { return bt[kind[j] * 6 + 3 + i]; }
     MPCRL_DI bool has(int j, int sd, int i) const { return (hasm[j] >> (2 * i + sd)) & 1u; }
     MPCRL_DI bool softc(int j, int i) const { return i == NU && softs[j]; }
-    MPCRL_DI double zw(int j, int sd) const { return sd ? zwu[j] : zwl[j]; }
+    MPCRL_DI double zw(int j, int sd) const { return park[(PK_ZW + j * 2 + sd) * 64]; }
     MPCRL_DI bool fixed(int j, int i) const { return first[j] && (i >= NU || qmode); }
     MPCRL_DI double vc(int j, int i) const { return i < NU ? u[j] : x[j][i - NU]; }
     MPCRL_DI double dvq(int j, int i) const { return i < NU ? (term[j] ? 0.0 : du[j]) : dx[j][i - NU]; }
@@ -86,7 +133,7 @@ struct LqSolver {
             hasm[j] = dead[j] ? 0u : h;
             softs[j] = k > 0 && k < N && sp.soft[NU] != 0;
             const double g = sp.dT * pow(sp.gamma, (double)k);
-            zwl[j] = sp.zl[NU] * g, zwu[j] = sp.zu[NU] * g;
+            park[(PK_ZW + j * 2) * 64] = sp.zl[NU] * g, park[(PK_ZW + j * 2 + 1) * 64] = sp.zu[NU] * g;
         }
     }
 
@@ -97,19 +144,19 @@ struct LqSolver {
     // ---- linearise: r = F(x, u) - x_next, q = c_k grad l; returns c_k l_k (+ slack penalties)
     MPCRL_DI double linearize(int j, const double *xn) {
         const double f0 = th[0] * x[j][0] + th[2] * x[j][1] + th[4] * u[j] + th[6], f1 = th[1] * x[j][0] + th[3] * x[j][1] + th[5] * u[j] + th[7];
-        r[j][0] = term[j] ? 0.0 : f0 - xn[0], r[j][1] = term[j] ? 0.0 : f1 - xn[1];
-        double val;
+        park[(PK_R + j * NX) * 64] = term[j] ? 0.0 : f0 - xn[0], park[(PK_R + j * NX + 1) * 64] = term[j] ? 0.0 : f1 - xn[1];
+        double val, q[NW];
         if (!term[j]) {      // l = 1/2 y'y + f'y (+ V_0 at k = 0), y = [x; u]
-            q[j][0] = u[j] + th[11], q[j][1] = x[j][0] + th[9], q[j][2] = x[j][1] + th[10];
+            q[0] = u[j] + th[11], q[1] = x[j][0] + th[9], q[2] = x[j][1] + th[10];
             val = 0.5 * (x[j][0] * x[j][0] + x[j][1] * x[j][1] + u[j] * u[j]) + th[9] * x[j][0] + th[10] * x[j][1] + th[11] * u[j];
             if (first[j]) val += th[8];
         } else {
             const double p00 = sp.consts[0], p01 = 0.5 * (sp.consts[1] + sp.consts[2]), p11 = sp.consts[3];
-            q[j][0] = 0.0, q[j][1] = p00 * x[j][0] + p01 * x[j][1], q[j][2] = p01 * x[j][0] + p11 * x[j][1];
-            val = 0.5 * (x[j][0] * q[j][1] + x[j][1] * q[j][2]);
+            q[0] = 0.0, q[1] = p00 * x[j][0] + p01 * x[j][1], q[2] = p01 * x[j][0] + p11 * x[j][1];
+            val = 0.5 * (x[j][0] * q[1] + x[j][1] * q[2]);
         }
 #pragma unroll
-        for (int i = 0; i < NW; ++i) q[j][i] *= ck[j];
+        for (int i = 0; i < NW; ++i) park[(PK_Q + j * NW + i) * 64] = q[i] * ck[j];
         val *= ck[j];
         if (softs[j]) val += zw(j, 0) * s[j][0] + zw(j, 1) * s[j][1];
         return val;
@@ -129,7 +176,7 @@ struct LqSolver {
         for (int i = 0; i < NW; ++i) {
             if (term[j] && i < NU) continue;
             if (!fixed(j, i)) {
-                double g = q[j][i] + GTnu(j, nun, nu[j], i);
+                double g = q_(j, i) + GTnu(j, nun, nu[j], i);
                 if (has(j, 0, i)) g -= lam[j][0][i];
                 if (has(j, 1, i)) g += lam[j][1][i];
                 rs = fmax(rs, fabs(g));
@@ -147,7 +194,7 @@ struct LqSolver {
                     }
                 }
         }
-        if (!term[j]) re = fmax(fabs(r[j][0]), fabs(r[j][1]));
+        if (!term[j]) re = fmax(fabs(r_(j, 0)), fabs(r_(j, 1)));
         if (first[j]) {
             re = fmax(re, fmax(fabs(x[j][0] - x0r[0]), fabs(x[j][1] - x0r[1])));
             if (qmode) re = fmax(re, fabs(u[j] - u0r));
@@ -223,7 +270,7 @@ struct LqSolver {
     // computes throw-away values its own turn overwrites.  Only the lane whose turn it is reports its pivots.
     MPCRL_DI bool factor() {
         bool ok = true;
-        for (int ps = lpi - 1; ps >= 0; --ps) {
+        for (int ps = lpl - 1; ps >= 0; --ps) {
             double Pin[3], pin[NX];
 #pragma unroll
             for (int i = 0; i < 3; ++i) Pin[i] = lane_dn(P[0][i]);
@@ -259,7 +306,25 @@ struct LqSolver {
     }
     // Hillis-Steele scan over the lanes of the instance: afterwards lane `pos` holds the composition of the lane maps from itself to
     // the end of the instance (down = true: partners at pos + s, own map OUTER) / from the start to itself (partners at pos - s)
+    template <int SFT>
+    MPCRL_DI void scan_step(Aff &m, bool down) const {
+        Aff o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.M[i] = down ? dpp_move<0x100 + SFT>(m.M[i]) : dpp_move<0x110 + SFT>(m.M[i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) o.v[i] = down ? dpp_move<0x100 + SFT>(m.v[i]) : dpp_move<0x110 + SFT>(m.v[i]);
+        const bool valid = down ? pos + SFT < 16 : pos - SFT >= 0;
+        const Aff n = compose(m, o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m.M[i] = valid ? n.M[i] : m.M[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) m.v[i] = valid ? n.v[i] : m.v[i];
+    }
     MPCRL_DI void scan(Aff &m, bool down) const {
+        if constexpr (ROW) {      // row shifts (the lanes behind the live ones hold identity / constant maps)
+            scan_step<1>(m, down), scan_step<2>(m, down), scan_step<4>(m, down), scan_step<8>(m, down);
+            return;
+        }
         for (int sft = 1; sft < lpi; sft <<= 1) {
             Aff o;
 #pragma unroll
@@ -475,7 +540,7 @@ struct LqSolver {
                     }
                 }
             }
-        if (n_rows_c < 0.0) n_rows_c = seg_sum<true>(cnt, pos, lpi, base);
+        if (n_rows_c < 0.0) n_rows_c = red_sum(cnt);
         const double n_rows = n_rows_c;
         bool qlive = act, ok = false;
         double rinf_c = 0.0, musum_c = 0.0;
@@ -494,7 +559,7 @@ struct LqSolver {
                     for (int i = 0; i < NX; ++i) {
                         double a = 0.0;
                         if (!term[j]) {
-                            a = r[j][i] - dxn[i];
+                            a = r_(j, i) - dxn[i];
 #pragma unroll
                             for (int b = 0; b < NX; ++b) a = fma(A_(i, b), dx[j][b], a);
                             a = fma(B_(i), du[j], a);
@@ -506,7 +571,7 @@ struct LqSolver {
                     for (int i = 0; i < NW; ++i) {
                         rg[j][i] = 0.0;
                         if (term[j] && i < NU) continue;
-                        double a = q[j][i] + GTnu(j, nuqn, nuq[j], i), hdv = 0.0;
+                        double a = q_(j, i) + GTnu(j, nuqn, nuq[j], i), hdv = 0.0;
 #pragma unroll
                         for (int b = 0; b < NW; ++b) hdv = fma(Hs(j, i, b), dvq(j, b), hdv);
                         a = fma(ck[j], hdv, a);
@@ -529,7 +594,7 @@ struct LqSolver {
                         }
                     }
                 }
-                seg_reduce<1, 1, true>(&rloc, &muloc, pos, lpi, base);
+                red<1, 1>(&rloc, &muloc);
                 rinf = rloc, musum = muloc;
             } else
                 rinf = rinf_c, musum = musum_c;
@@ -578,7 +643,7 @@ struct LqSolver {
                 }
             {
                 double two[2] = {rmax, okbad};
-                seg_reduce<2, 2, true>(two, c12, pos, lpi, base);
+                red<2, 2>(two, c12);
                 rmax = two[0];
                 if (two[1] > 0.5) qlive = false;   // non-positive pivot: QP failure
             }
@@ -617,7 +682,7 @@ struct LqSolver {
                         if (softc(j, i)) d12[0] = fma(lams[j][sd], dt2, fma(ts[j][sd], dl2, d12[0])), d12[1] = fma(dl2, dt2, d12[1]);
                     }
                 }
-            seg_reduce<1, 2, true>(&rmax, d12, pos, lpi, base);
+            red<1, 2>(&rmax, d12);
             if (qlive) {
                 const double alpha = fmin(1.0, frac * fast_rcp(rmax));
 #pragma unroll
@@ -663,17 +728,18 @@ struct LqSolver {
 template <int SPL>
 __host__ __device__ constexpr int lq_lanes_per_instance(int N) { return (N + 1 + SPL - 1) / SPL; }
 
-template <int SPL>
+template <int SPL, bool ROW>
 __global__ void __launch_bounds__(64, 1) lq_solve_kernel(const SmallSpec sp, const SmallArgs a) {
     constexpr int NX = 2, NU = 1, NW = 3, MAXI = 8;
-    const int lane = threadIdx.x, N = sp.N, lpi = lq_lanes_per_instance<SPL>(N), ipw = min(64 / lpi, MAXI);
+    const int lane = threadIdx.x, N = sp.N, lpl = lq_lanes_per_instance<SPL>(N), lpi = ROW ? 16 : lpl, ipw = min(64 / lpi, MAXI);
     const int slot = lane / lpi, pos = lane - slot * lpi, base = slot * lpi;
     long inst = (long)blockIdx.x * ipw + slot;
     const bool valid = slot < ipw && inst < a.B;
     if (!valid) inst = a.B - 1;   // dead lanes shadow the last instance and never store
     if (a.perm) inst = a.perm[inst];
-    __shared__ double th_lds[(MAXI + 1) * 12], bt_lds[18];
-    LqSolver<SPL> S(sp, lpi, pos, base);
+    __shared__ double th_lds[(MAXI + 1) * 12], bt_lds[18], park_lds[LqSolver<SPL, ROW>::PK_N * 64];
+    LqSolver<SPL, ROW> S(sp, lpi, lpl, pos, base);
+    S.park = park_lds + lane;
     S.qmode = a.u0fix != nullptr;
     {   // the instance's parameters and the bound table (one copy per wavefront)
         double *thw = th_lds + (slot < ipw ? slot : MAXI) * 12;
@@ -753,7 +819,7 @@ __global__ void __launch_bounds__(64, 1) lq_solve_kernel(const SmallSpec sp, con
             sl = fmax(fabs(S.x0r[0] - S.x[0][0]), fabs(S.x0r[1] - S.x[0][1]));
             if (S.qmode) sl = fmax(sl, fabs(S.u0r - S.u[0]));
         }
-        stepn = seg_max<true>(sl, pos, lpi, base);
+        stepn = S.red_max(sl);
         if (cold) stepn = -1.0;
     }
     double Vout = 0.0, res_out[4] = {0, 0, 0, 0};
@@ -768,7 +834,7 @@ __global__ void __launch_bounds__(64, 1) lq_solve_kernel(const SmallSpec sp, con
             cost += S.linearize(j, xn);
             S.nlp_res_local(j, nun, res);
         }
-        seg_reduce<4, 1, true>(res, &cost, pos, lpi, base);
+        S.template red<4, 1>(res, &cost);
         const double rmax = fmax(fmax(res[0], res[1]), fmax(res[2], res[3]));
         if (live) {
             Vout = cost, n_sqp = it;
@@ -805,7 +871,7 @@ __global__ void __launch_bounds__(64, 1) lq_solve_kernel(const SmallSpec sp, con
                 sl = fmax(sl, fmax(fabs(S.dx[j][0]), fabs(S.dx[j][1])));
                 if (!S.term[j]) sl = fmax(sl, fabs(S.du[j]));
             }
-            stepn = seg_max<true>(sl, pos, lpi, base);
+            stepn = S.red_max(sl);
         }
         if (live) {
 #pragma unroll
@@ -827,7 +893,7 @@ __global__ void __launch_bounds__(64, 1) lq_solve_kernel(const SmallSpec sp, con
             for (int j = 0; j < SPL; ++j) {
                 if (S.dead[j]) continue;
                 const double *nun = j + 1 < SPL ? S.nu[j + 1 < SPL ? j + 1 : 0] : nuin;
-                if (!S.term[j]) lag = fma(nun[0], S.r[j][0], fma(nun[1], S.r[j][1], lag));
+                if (!S.term[j]) lag = fma(nun[0], S.r_(j, 0), fma(nun[1], S.r_(j, 1), lag));
 #pragma unroll
                 for (int i = 0; i < NW; ++i) {
                     if (S.term[j] && i < NU) continue;
@@ -839,7 +905,7 @@ __global__ void __launch_bounds__(64, 1) lq_solve_kernel(const SmallSpec sp, con
                         }
                 }
             }
-            lag = seg_sum<true>(lag, pos, lpi, base);
+            lag = S.red_sum(lag);
         }
     }
     if (valid && pos == 0) {

@@ -233,7 +233,11 @@ int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
         const int lpi3 = lq_lanes_per_instance<SPL>(h->N), ipw3 = std::min(64 / lpi3, 8);
         if (h->linear_spl == SPL && ipw3 > ipw) {
             lq = true;
-            hipLaunchKernelGGL(lq_solve_kernel<SPL>, dim3((unsigned)((h->B + ipw3 - 1) / ipw3)), dim3(64), 0, st, h->small, a);
+            const dim3 grid((unsigned)((h->B + ipw3 - 1) / ipw3));
+            if (ipw3 == 4)      // four instances: each in a DPP row of its own (cross-lane traffic by DPP moves)
+                hipLaunchKernelGGL((lq_solve_kernel<SPL, true>), grid, dim3(64), 0, st, h->small, a);
+            else
+                hipLaunchKernelGGL((lq_solve_kernel<SPL, false>), grid, dim3(64), 0, st, h->small, a);
         }
     }
     if (!sliced && !lq) hipLaunchKernelGGL(small_solve_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
