@@ -71,6 +71,9 @@ struct LqSolver {
     double rg[SPL][NW], rb[SPL][NX], rt[SPL][NW], Dg[SPL][NW];
     double n_rows_c = -1.0;
     double x0r[NX], u0r;
+#ifdef MPCRL_PROFILE_PHASES
+    unsigned long long phw[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pht = 0;
+#endif
 
     MPCRL_DI LqSolver(const SmallSpec &sp_, int lpi_, int lpl_, int pos_, int base_) : sp(sp_), N(sp_.N), lpi(lpi_), lpl(lpl_), pos(pos_), base(base_) {}
 
@@ -462,8 +465,11 @@ struct LqSolver {
             }
         }
     }
+    // ca, ci (pass 0): the corrector's barrier term of the coordinate is the predictor's + sum_rows (ca - smu ci) — its complementarity
+    // targets differ from the predictor's by aff - smu, and the term is linear in them — so the corrector needs no pass over the rows
+    // for its right-hand side: ca = sg aff / t, ci = sg / t (hard row); the soft pair eliminates its slack first
     MPCRL_DI void row_steps(int j, int i, int sd, double v, double dv, int pass, double smu, double &dt1, double &dl1, double &dt2, double &dl2,
-                            double &dss, double &rat) const {
+                            double &dss, double &rat, double *ca = nullptr, double *ci = nullptr) const {
         const double sg = sd ? -1.0 : 1.0;
         const double l1 = lam[j][sd][i], t1 = t[j][sd][i], it1 = fast_rcp(t1);
         const double rd1 = t1 - bslack(j, sd, i, v);
@@ -480,9 +486,17 @@ struct LqSolver {
             dt2 = -rd2 + dss;
             dl2 = (-rm2 - l2 * dt2) * it2;
             rat = fmax(-dl2 * fast_rcp(l2), -dt2 * it2);
+            dt1 = -rd1 + sg * dv + dss;
+            dl1 = (-rm1 - l1 * dt1) * it1;
+            if (ca) {
+                const double iw = fast_rcp(w1 + w2), c1 = sg * it1 * w2 * iw, c2 = sg * w1 * it2 * iw;
+                *ca = c1 * (dl1 * dt1) - c2 * (dl2 * dt2), *ci = c1 - c2;
+            }
+        } else {
+            dt1 = -rd1 + sg * dv;
+            dl1 = (-rm1 - l1 * dt1) * it1;
+            if (ca) *ci = sg * it1, *ca = *ci * (dl1 * dt1);
         }
-        dt1 = -rd1 + sg * dv + dss;
-        dl1 = (-rm1 - l1 * dt1) * it1;
         rat = fmax(rat, fmax(-dl1 * fast_rcp(l1), -dt1 * it1));
     }
 
@@ -542,6 +556,7 @@ struct LqSolver {
             }
         if (n_rows_c < 0.0) n_rows_c = red_sum(cnt);
         const double n_rows = n_rows_c;
+        PHW(10);
         bool qlive = act, ok = false;
         double rinf_c = 0.0, musum_c = 0.0;
         for (int it = 0;; ++it) {
@@ -608,6 +623,7 @@ struct LqSolver {
             }
             if (!__any(qlive)) break;
             if (qlive) ++n_it;
+            PHW(0);
             // ---- predictor
 #pragma unroll
             for (int j = 0; j < SPL; ++j)
@@ -618,8 +634,11 @@ struct LqSolver {
                     barrier_terms(j, i, v, 0, 0.0, Dg[j][i], e);
                     rt[j][i] = rg[j][i] + e;
                 }
+            PHW(1);
             const bool okf = factor();
+            PHW(2);
             forward_vec();
+            PHW(3);
             double okbad = okf ? 0.0 : 1.0, rmax = 1.0, c12[2] = {0.0, 0.0};
 #pragma unroll
             for (int j = 0; j < SPL; ++j)
@@ -627,11 +646,13 @@ struct LqSolver {
                 for (int i = 0; i < NW; ++i) {
                     if (term[j] && i < NU) continue;
                     const double v = vc(j, i) + dvq(j, i), dv = Dvq(j, i);
+                    Dg[j][i] = 0.0;      // (the factor is done with the barrier diagonal: the place collects ci, rt collects ca)
 #pragma unroll
                     for (int sd = 0; sd < 2; ++sd) {
                         if (!has(j, sd, i)) continue;
-                        double dt1, dl1, dt2, dl2, dss, rat;
-                        row_steps(j, i, sd, v, dv, 0, 0.0, dt1, dl1, dt2, dl2, dss, rat);
+                        double dt1, dl1, dt2, dl2, dss, rat, ca, ci;
+                        row_steps(j, i, sd, v, dv, 0, 0.0, dt1, dl1, dt2, dl2, dss, rat, &ca, &ci);
+                        rt[j][i] += ca, Dg[j][i] += ci;
                         rmax = fmax(rmax, rat);
                         aff[j][sd][i] = dl1 * dt1;
                         c12[0] = fma(lam[j][sd][i], dt1, fma(t[j][sd][i], dl1, c12[0])), c12[1] = fma(dl1, dt1, c12[1]);
@@ -647,6 +668,7 @@ struct LqSolver {
                 rmax = two[0];
                 if (two[1] > 0.5) qlive = false;   // non-positive pivot: QP failure
             }
+            PHW(4);
             const double a_aff = fast_rcp(rmax);
             const double mu_aff = fma(a_aff, fma(a_aff, c12[1], c12[0]), musum) * inv_rows;
             const double ratio = mu > 0.0 ? mu_aff * fast_rcp(mu) : 0.0;
@@ -656,14 +678,12 @@ struct LqSolver {
 #pragma unroll
             for (int j = 0; j < SPL; ++j)
 #pragma unroll
-                for (int i = 0; i < NW; ++i) {
-                    const double v = vc(j, i) + dvq(j, i);
-                    double dgi, ec;
-                    barrier_terms(j, i, v, 1, smu, dgi, ec);
-                    rt[j][i] = rg[j][i] + ec;
-                }
+                for (int i = 0; i < NW; ++i) rt[j][i] = fma(-smu, Dg[j][i], rt[j][i]);
+            PHW(5);
             backward_vec();
+            PHW(6);
             forward_vec();
+            PHW(7);
             rmax = 1.0;
             double d12[2] = {0.0, 0.0};
 #pragma unroll
@@ -717,6 +737,7 @@ struct LqSolver {
                 rinf_c = (1.0 - alpha) * rinf;
                 musum_c = fma(alpha, fma(alpha, d12[1], d12[0]), musum);
             }
+            PHW(8);
         }
         return ok;
     }
@@ -835,6 +856,9 @@ __global__ void __launch_bounds__(64, 1) lq_solve_kernel(const SmallSpec sp, con
             S.nlp_res_local(j, nun, res);
         }
         S.template red<4, 1>(res, &cost);
+#ifdef MPCRL_PROFILE_PHASES
+        { unsigned long long n_ = clock64(); if (S.pht) S.phw[9] += n_ - S.pht; S.pht = n_; }
+#endif
         const double rmax = fmax(fmax(res[0], res[1]), fmax(res[2], res[3]));
         if (live) {
             Vout = cost, n_sqp = it;
@@ -882,6 +906,9 @@ __global__ void __launch_bounds__(64, 1) lq_solve_kernel(const SmallSpec sp, con
             }
         }
     }
+#ifdef MPCRL_PROFILE_PHASES
+    if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_phase_ticks[i_], S.phw[i_]);
+#endif
     // ---- results
     double lag = 0.0;
     {
