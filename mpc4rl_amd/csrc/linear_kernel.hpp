@@ -686,6 +686,8 @@ struct LqSolver {
             PHW(7);
             rmax = 1.0;
             double d12[2] = {0.0, 0.0};
+            // the rows' multiplier steps of the corrector are kept for the update below in the places of quantities that are dead by
+            // now (dlam in aff / affs, ds in rt): the update recomputes only the cheap dt = -r_d + sg dv + ds, not the rows' reciprocals
 #pragma unroll
             for (int j = 0; j < SPL; ++j)
 #pragma unroll
@@ -698,8 +700,12 @@ struct LqSolver {
                         double dt1, dl1, dt2, dl2, dss, rat;
                         row_steps(j, i, sd, v, dv, 1, smu, dt1, dl1, dt2, dl2, dss, rat);
                         rmax = fmax(rmax, rat);
+                        aff[j][sd][i] = dl1;
                         d12[0] = fma(lam[j][sd][i], dt1, fma(t[j][sd][i], dl1, d12[0])), d12[1] = fma(dl1, dt1, d12[1]);
-                        if (softc(j, i)) d12[0] = fma(lams[j][sd], dt2, fma(ts[j][sd], dl2, d12[0])), d12[1] = fma(dl2, dt2, d12[1]);
+                        if (softc(j, i)) {
+                            affs[j][sd] = dl2, rt[j][sd] = dss;
+                            d12[0] = fma(lams[j][sd], dt2, fma(ts[j][sd], dl2, d12[0])), d12[1] = fma(dl2, dt2, d12[1]);
+                        }
                     }
                 }
             red<1, 2>(&rmax, d12);
@@ -714,15 +720,18 @@ struct LqSolver {
 #pragma unroll
                         for (int sd = 0; sd < 2; ++sd) {
                             if (!has(j, sd, i)) continue;
-                            double dt1, dl1, dt2, dl2, dss, rat;
-                            row_steps(j, i, sd, v, dv, 1, smu, dt1, dl1, dt2, dl2, dss, rat);
-                            lam[j][sd][i] = fma(alpha, dl1, lam[j][sd][i]);
-                            t[j][sd][i] = fma(alpha, dt1, t[j][sd][i]);
+                            const double sg = sd ? -1.0 : 1.0, rd1 = t[j][sd][i] - bslack(j, sd, i, v);
+                            double dss = 0.0;
                             if (softc(j, i)) {
-                                lams[j][sd] = fma(alpha, dl2, lams[j][sd]);
+                                dss = rt[j][sd];
+                                const double dt2 = -(ts[j][sd] - s[j][sd]) + dss;
+                                lams[j][sd] = fma(alpha, affs[j][sd], lams[j][sd]);
                                 ts[j][sd] = fma(alpha, dt2, ts[j][sd]);
                                 s[j][sd] = fma(alpha, dss, s[j][sd]);
                             }
+                            const double dt1 = -rd1 + sg * dv + dss;
+                            lam[j][sd][i] = fma(alpha, aff[j][sd][i], lam[j][sd][i]);
+                            t[j][sd][i] = fma(alpha, dt1, t[j][sd][i]);
                         }
                     }
 #pragma unroll
