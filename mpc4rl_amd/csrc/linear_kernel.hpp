@@ -207,7 +207,9 @@ struct LqSolver {
     }
 
     // ---- one backward Riccati stage (SmallSolver::riccati_stage<true> for nx = 2, nu = 1): (Pn, pn) of stage k + 1 -> K, Li, kff, P, p
-    MPCRL_DI bool riccati_stage(int j, const double *Pn, const double *pn) {
+    // ab: [A B] of the instance in registers (the serial loop must not wait for LDS inside its lane-dependent branches)
+    MPCRL_DI bool riccati_stage(int j, const double *Pn, const double *pn, const double *ab) {
+        auto BA = [&](int m, int i) { return i < NU ? ab[4 + m] : ab[(i - NU) * 2 + m]; };
         const double hsc = ck[j];
         if (term[j]) {
 #pragma unroll
@@ -273,6 +275,9 @@ struct LqSolver {
     // computes throw-away values its own turn overwrites.  Only the lane whose turn it is reports its pivots.
     MPCRL_DI bool factor() {
         bool ok = true;
+        double ab[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) ab[e] = th[e];
         for (int ps = lpl - 1; ps >= 0; --ps) {
             double Pin[3], pin[NX];
 #pragma unroll
@@ -282,7 +287,7 @@ struct LqSolver {
             bool okl = true;
 #pragma unroll
             for (int j = SPL - 1; j >= 0; --j) {
-                const bool o = j == SPL - 1 ? riccati_stage(j, Pin, pin) : riccati_stage(j, P[j + 1 < SPL ? j + 1 : 0], p[j + 1 < SPL ? j + 1 : 0]);
+                const bool o = j == SPL - 1 ? riccati_stage(j, Pin, pin, ab) : riccati_stage(j, P[j + 1 < SPL ? j + 1 : 0], p[j + 1 < SPL ? j + 1 : 0], ab);
                 okl = okl && o;
             }
             ok = ok && (okl || pos != ps);
@@ -345,6 +350,11 @@ struct LqSolver {
 
     // ---- vector-only backward sweep on the stored factors (SmallSolver::backward_scan): p_k, kff_k for the right-hand side rt
     MPCRL_DI void backward_vec() {
+        double ab[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) ab[e] = th[e];
+        auto A_ = [&](int i, int j) { return ab[j * 2 + i]; };
+        auto B_ = [&](int i) { return ab[4 + i]; };
         // hb_k = P_k bb_{k-1}
         double hb[SPL][NX], bprev[NX];
 #pragma unroll
@@ -404,6 +414,11 @@ struct LqSolver {
 
     // ---- forward sweep (SmallSolver::forward_scan): Dx, Du, Dnu
     MPCRL_DI void forward_vec() {
+        double ab[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) ab[e] = th[e];
+        auto A_ = [&](int i, int j) { return ab[j * 2 + i]; };
+        auto B_ = [&](int i) { return ab[4 + i]; };
         Aff sm[SPL];
 #pragma unroll
         for (int j = 0; j < SPL; ++j)
