@@ -107,6 +107,18 @@ struct LqSolver {
     MPCRL_DI double vc(int j, int i) const { return i < NU ? u[j] : x[j][i - NU]; }
     MPCRL_DI double dvq(int j, int i) const { return i < NU ? (term[j] ? 0.0 : du[j]) : dx[j][i - NU]; }
     MPCRL_DI double Dvq(int j, int i) const { return i < NU ? (term[j] ? 0.0 : Du[j]) : Dx[j][i - NU]; }
+    // the row passes of the interior-point iteration fetch the six bounds of a stage at once, ahead of the lane-dependent branches
+    // around its rows (a read inside a branch is waited for on the spot: one wavefront per SIMD has nothing to hide it behind)
+    double cbl[NW], cbu[NW], czw[2];      // (and the two slack weights of the stage)
+    MPCRL_DI void load_bounds(int j) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) cbl[i] = lbv(j, i), cbu[i] = ubv(j, i);
+        czw[0] = zw(j, 0), czw[1] = zw(j, 1);
+    }
+    MPCRL_DI double bslack_c(int j, int sd, int i, double v) const {
+        const double sv = softc(j, i) ? s[j][sd] : 0.0;
+        return sd ? cbu[i] - v + sv : v + sv - cbl[i];
+    }
     MPCRL_DI double bslack(int j, int sd, int i, double v) const {
         const double sv = softc(j, i) ? s[j][sd] : 0.0;
         return sd ? ubv(j, i) - v + sv : v + sv - lbv(j, i);
@@ -464,13 +476,13 @@ struct LqSolver {
             const double sg = sd ? -1.0 : 1.0;
             const double l1 = lam[j][sd][i], t1 = t[j][sd][i], it1 = fast_rcp(t1);
             const double w1 = l1 * it1;
-            const double rd1 = t1 - bslack(j, sd, i, v);
+            const double rd1 = t1 - bslack_c(j, sd, i, v);
             const double e1 = (rm_(l1, t1, aff[j][sd][i], pass, smu) - l1 * rd1) * it1;
             if (softc(j, i)) {
                 const double l2 = lams[j][sd], t2 = ts[j][sd], it2 = fast_rcp(t2);
                 const double w2 = l2 * it2;
                 const double e2 = (rm_(l2, t2, affs[j][sd], pass, smu) - l2 * (t2 - s[j][sd])) * it2;
-                const double rgs = zw(j, sd) - l1 - l2;
+                const double rgs = czw[sd] - l1 - l2;
                 const double iw = fast_rcp(w1 + w2);
                 dg += w1 * w2 * iw;
                 er += sg * (e1 * w2 - w1 * (rgs + e2)) * iw;
@@ -487,7 +499,7 @@ struct LqSolver {
                             double &dss, double &rat, double *ca = nullptr, double *ci = nullptr) const {
         const double sg = sd ? -1.0 : 1.0;
         const double l1 = lam[j][sd][i], t1 = t[j][sd][i], it1 = fast_rcp(t1);
-        const double rd1 = t1 - bslack(j, sd, i, v);
+        const double rd1 = t1 - bslack_c(j, sd, i, v);
         const double rm1 = rm_(l1, t1, aff[j][sd][i], pass, smu);
         dss = 0.0, dt2 = 0.0, dl2 = 0.0, rat = 0.0;
         if (softc(j, i)) {
@@ -496,7 +508,7 @@ struct LqSolver {
             const double rd2 = t2 - s[j][sd];
             const double rm2 = rm_(l2, t2, affs[j][sd], pass, smu);
             const double e1 = (rm1 - l1 * rd1) * it1, e2 = (rm2 - l2 * rd2) * it2;
-            const double rgs = zw(j, sd) - l1 - l2;
+            const double rgs = czw[sd] - l1 - l2;
             dss = -(rgs + e1 + e2 + sg * w1 * dv) * fast_rcp(w1 + w2);
             dt2 = -rd2 + dss;
             dl2 = (-rm2 - l2 * dt2) * it2;
@@ -644,6 +656,7 @@ struct LqSolver {
             for (int j = 0; j < SPL; ++j)
 #pragma unroll
                 for (int i = 0; i < NW; ++i) {
+                    if (i == 0) load_bounds(j);
                     const double v = vc(j, i) + dvq(j, i);
                     double e;
                     barrier_terms(j, i, v, 0, 0.0, Dg[j][i], e);
@@ -659,6 +672,7 @@ struct LqSolver {
             for (int j = 0; j < SPL; ++j)
 #pragma unroll
                 for (int i = 0; i < NW; ++i) {
+                    if (i == 0) load_bounds(j);
                     if (term[j] && i < NU) continue;
                     const double v = vc(j, i) + dvq(j, i), dv = Dvq(j, i);
                     Dg[j][i] = 0.0;      // (the factor is done with the barrier diagonal: the place collects ci, rt collects ca)
@@ -707,6 +721,7 @@ struct LqSolver {
             for (int j = 0; j < SPL; ++j)
 #pragma unroll
                 for (int i = 0; i < NW; ++i) {
+                    if (i == 0) load_bounds(j);
                     if (term[j] && i < NU) continue;
                     const double v = vc(j, i) + dvq(j, i), dv = Dvq(j, i);
 #pragma unroll
@@ -730,12 +745,13 @@ struct LqSolver {
                 for (int j = 0; j < SPL; ++j) {
 #pragma unroll
                     for (int i = 0; i < NW; ++i) {
+                        if (i == 0) load_bounds(j);
                         if (term[j] && i < NU) continue;
                         const double v = vc(j, i) + dvq(j, i), dv = Dvq(j, i);
 #pragma unroll
                         for (int sd = 0; sd < 2; ++sd) {
                             if (!has(j, sd, i)) continue;
-                            const double sg = sd ? -1.0 : 1.0, rd1 = t[j][sd][i] - bslack(j, sd, i, v);
+                            const double sg = sd ? -1.0 : 1.0, rd1 = t[j][sd][i] - bslack_c(j, sd, i, v);
                             double dss = 0.0;
                             if (softc(j, i)) {
                                 dss = rt[j][sd];
