@@ -40,6 +40,8 @@
  *   - how a batch is laid out over wavefronts (packing order, plain or time-sliced launch of the small
  *     solve kernel; environment MPCRL_TIME_SLICE=0/1 read at mpcrl_create overrides the automatic choice)
  *     never changes a result bit.
+ *   - linear-system model: environment MPCRL_LINEAR_SPL=1 at mpcrl_create keeps the one-stage-per-lane solve kernel instead
+ *     of the three-stages-per-lane one (same iteration, sums associated differently: results equal to rounding).
  *   - cartpole: a wavefront holds min(floor(64 / (N + 1)), 4) instances — four is the number of 4x4 blocks of the
  *     matrix-core sweeps — so horizons below N = 15 use fewer of its lanes than a lane-per-stage packing could.
  */

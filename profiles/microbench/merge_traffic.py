@@ -20,7 +20,7 @@ for w, B in batches.items():
     if not os.path.exists(f):
         continue
     d = json.load(open(f))
-    keep = {k: v for k, v in d["kernels"].items() if ("small_" in k or "chain_" in k or "order_kernel" in k or "rocclr_fill" in k)}
+    keep = {k: v for k, v in d["kernels"].items() if ("small_" in k or "lq_solve" in k or "chain_" in k or "order_kernel" in k or "rocclr_fill" in k)}
     fetch = sum(v.get("FETCH_SIZE", 0.0) for v in keep.values())
     write = sum(v.get("WRITE_SIZE", 0.0) for v in keep.values())
     out[w] = {"batch": B, "command": d["command"], "fetch_bytes_per_step_raw": fetch, "write_bytes_per_step": write,

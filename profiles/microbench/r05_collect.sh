@@ -25,4 +25,10 @@ if [ -f ab/prof.so ]; then
   (MPCRL_LIB_PATH=$PWD/ab/prof.so python profiles/microbench/chain_phases.py 5; MPCRL_LIB_PATH=$PWD/ab/prof.so python profiles/microbench/chain_phases.py 7) > gpurun_out/${T}_chain_phases.txt 2>/dev/null
 fi
 (timeout 300 bash profiles/microbench/pmc.sh "chain_sqp_kernel" --workload chain5 --steps 2 --warmup 1 --no-cpu) > gpurun_out/${T}_pmc.txt 2>/dev/null
+if [ -f ab/prof.so ]; then
+  MPCRL_LIB_PATH=$PWD/ab/prof.so python profiles/microbench/lq_phases.py > gpurun_out/${T}_lq_phases.txt 2>/dev/null
+fi
+(echo "== lq_solve_kernel<3, true>, bench.py --workload linear --steps 3 --warmup 1 (4 launches)"; timeout 300 bash profiles/microbench/pmc.sh "lq_solve_kernel" --workload linear --steps 3 --warmup 1 --no-cpu) > gpurun_out/${T}_lq_pmc.txt 2>/dev/null
+MPCRL_LINEAR_SPL=1 python bench.py --workload linear --steps 50 --warmup 10 --no-cpu --no-secondary > gpurun_out/${T}_final_linear_spl1_bench.json 2>/dev/null
+MPCRL_LINEAR_SPL=1 timeout 300 bash profiles/microbench/kstats.sh ${T}_linear_spl1 --workload linear --steps 50 --warmup 10 --no-cpu > /dev/null 2>&1
 ls -la gpurun_out | tail -40
