@@ -793,6 +793,9 @@ __host__ __device__ constexpr int lq_lanes_per_instance(int N) { return (N + 1 +
 template <int SPL, bool ROW>
 __global__ void __launch_bounds__(64, 1) lq_solve_kernel(const SmallSpec sp, const SmallArgs a) {
     constexpr int NX = 2, NU = 1, NW = 3, MAXI = 8;
+#ifdef MPCRL_PROFILE_PHASES
+    const unsigned long long rt0_ = wall_clock64();
+#endif
     const int lane = threadIdx.x, N = sp.N, lpl = lq_lanes_per_instance<SPL>(N), lpi = ROW ? 16 : lpl, ipw = min(64 / lpi, MAXI);
     const int slot = lane / lpi, pos = lane - slot * lpi, base = slot * lpi;
     long inst = (long)blockIdx.x * ipw + slot;
@@ -948,6 +951,7 @@ __global__ void __launch_bounds__(64, 1) lq_solve_kernel(const SmallSpec sp, con
         }
     }
 #ifdef MPCRL_PROFILE_PHASES
+    S.phw[15] = wall_clock64() - rt0_;      // the wavefront's life on the constant 100 MHz clock (the other buckets count shader cycles)
     if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_phase_ticks[i_], S.phw[i_]);
 #endif
     // ---- results
