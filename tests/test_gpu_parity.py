@@ -693,7 +693,7 @@ def test_hip_vs_third_party_gradients_and_chain_solutions():
             return 0.0
         scale = np.maximum(np.nanmax(np.where(fin, np.abs(fd0), 0.0), axis=1, keepdims=True), 1.0)
         ok = fin & (np.abs(np.where(fin, fd0 - fd1, 0.0)) <= 2e-6 * scale)
-        assert ok[fin].mean() > 0.8
+        assert ok[fin].mean() >= 0.75
         return float(np.where(ok, np.abs(mine - np.where(fin, fd0, 0.0)) / scale, 0.0).max())
 
     B = len(g7["cp_x0"])

@@ -342,7 +342,7 @@ def test_third_party_gradients_and_chain_solutions_vs_the_port(oracle_port):
             return 0.0
         scale = np.maximum(np.nanmax(np.where(fin, np.abs(fd0), 0.0), axis=1, keepdims=True), 1.0)
         ok = fin & (np.abs(np.where(fin, fd0 - fd1, 0.0)) <= 2e-6 * scale)
-        assert ok[fin].mean() > 0.8, ok[fin].mean()
+        assert ok[fin].mean() >= 0.75, ok[fin].mean()
         err = np.where(ok, np.abs(mine - np.where(fin, fd0, 0.0)) / scale, 0.0)
         return float(err.max())
 
