@@ -528,6 +528,89 @@ struct LqSolver {
         rat = fmax(rat, fmax(pass ? -dl1 * fast_rcp(l1) : (t1 + dt1) * it1, -dt1 * it1));
     }
 
+    // ---- sensitivities at the returned iterate (SmallSolver::sensitivities for this model, nlp.py:1211,1399-1424), run by the solve
+    // kernel itself at the end of a wavefront's life — the iterate is in its registers and the factor sweep is at hand, so the
+    // second launch of the one-stage layout (small_sens_kernel: 0.05 ms per 4096 instances, a tenth of the step) is not needed.
+    // dV/dp = dL/dp: sum_k nu_{k+1}' dF/dp + c_k dl/dp.  du0*/dp: ONE adjoint solve K y = -e_{u0} with the exact Lagrangian Hessian
+    // (the map is linear: c_k hess l) and the barrier diagonal lam / t of the bound rows (slacks are constants of the mirror,
+    // quirk q1), then du0*/dp = -sum_k (nu_{k+1}' d2F/dp dv y_v + y_{nu,k+1}' dF/dp + c_k y_v' d2l/dv dp).  F = A x + B u + b, p = [A
+    // column-major, B, b, V_0, f]: every derivative is written out.
+    MPCRL_DI void sens_tail(const SmallArgs &a, long inst, bool valid, int status) {
+        constexpr int NP = 12;
+        const bool sv = valid && (status == 0 || status == 2);
+        double *dVa = a.dV ? a.dV + inst * NP : nullptr, *dpia = a.dpi ? a.dpi + inst * NU * NP : nullptr;
+        const bool want_v = (a.flags & 1) && dVa, want_pi = (a.flags & 2) && dpia && !qmode;   // wave-uniform
+        double nuin[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) nuin[i] = lane_dn(nu[0][i]);
+        if (want_v) {
+            double acc[NP];
+#pragma unroll
+            for (int d = 0; d < NP; ++d) acc[d] = 0.0;
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) {
+                const double *nun = j + 1 < SPL ? nu[j + 1 < SPL ? j + 1 : 0] : nuin;
+                const double w = term[j] ? 0.0 : 1.0, c = term[j] ? 0.0 : ck[j];
+                acc[0] = fma(w * nun[0], x[j][0], acc[0]), acc[1] = fma(w * nun[1], x[j][0], acc[1]);
+                acc[2] = fma(w * nun[0], x[j][1], acc[2]), acc[3] = fma(w * nun[1], x[j][1], acc[3]);
+                acc[4] = fma(w * nun[0], u[j], acc[4]), acc[5] = fma(w * nun[1], u[j], acc[5]);
+                acc[6] += w * nun[0], acc[7] += w * nun[1];
+                acc[8] += first[j] ? c : 0.0;
+                acc[9] = fma(c, x[j][0], acc[9]), acc[10] = fma(c, x[j][1], acc[10]), acc[11] = fma(c, u[j], acc[11]);
+            }
+            red<0, NP>(nullptr, acc);
+            if (pos == 0 && valid)
+#pragma unroll
+                for (int d = 0; d < NP; ++d) dVa[d] = sv ? acc[d] : 0.0;
+        } else if (dVa && pos == 0 && valid) {
+#pragma unroll
+            for (int d = 0; d < NP; ++d) dVa[d] = 0.0;
+        }
+        if (!want_pi) {
+            if (dpia && pos == 0 && valid)
+#pragma unroll
+                for (int d = 0; d < NU * NP; ++d) dpia[d] = 0.0;
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                double d = 0.0;
+#pragma unroll
+                for (int sd = 0; sd < 2; ++sd)
+                    if (has(j, sd, i)) d += fmin(lam[j][sd][i] / t[j][sd][i], SENS_W_MAX);
+                Dg[j][i] = d;
+                rt[j][i] = (first[j] && i == 0) ? -1.0 : 0.0;
+            }
+            rb[j][0] = rb[j][1] = 0.0;
+        }
+        const bool okf = factor();
+        forward_vec();
+        const bool okall = red_max(okf ? 0.0 : 1.0) < 0.5;
+        double ynin[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) ynin[i] = lane_dn(Dnu[0][i]);
+        double acc[NP];
+#pragma unroll
+        for (int d = 0; d < NP; ++d) acc[d] = 0.0;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            const double *nun = j + 1 < SPL ? nu[j + 1 < SPL ? j + 1 : 0] : nuin, *ynn = j + 1 < SPL ? Dnu[j + 1 < SPL ? j + 1 : 0] : ynin;
+            const double w = term[j] ? 0.0 : 1.0, c = term[j] ? 0.0 : ck[j], yu = term[j] ? 0.0 : Du[j];
+            const double n0 = w * nun[0], n1 = w * nun[1], y0 = w * ynn[0], y1 = w * ynn[1];
+            acc[0] = fma(n0, Dx[j][0], fma(y0, x[j][0], acc[0])), acc[1] = fma(n1, Dx[j][0], fma(y1, x[j][0], acc[1]));
+            acc[2] = fma(n0, Dx[j][1], fma(y0, x[j][1], acc[2])), acc[3] = fma(n1, Dx[j][1], fma(y1, x[j][1], acc[3]));
+            acc[4] = fma(n0, yu, fma(y0, u[j], acc[4])), acc[5] = fma(n1, yu, fma(y1, u[j], acc[5]));
+            acc[6] += y0, acc[7] += y1;
+            acc[9] = fma(c, Dx[j][0], acc[9]), acc[10] = fma(c, Dx[j][1], acc[10]), acc[11] = fma(c, yu, acc[11]);
+        }
+        red<0, NP>(nullptr, acc);
+        if (pos == 0 && valid)
+#pragma unroll
+            for (int d = 0; d < NP; ++d) dpia[d] = sv ? (okall ? -acc[d] : NAN) : 0.0;
+    }
+
     // ---- Mehrotra predictor-corrector on the QP of the current linearisation (SmallSolver::qp_solve, three stages per lane)
     MPCRL_DI bool qp_solve(bool act, int &n_it, double warm_mu, double tol_res, double tol_mu) {
         const bool warm = warm_mu > 0.0;
@@ -955,6 +1038,7 @@ __global__ void __launch_bounds__(64, 1) lq_solve_kernel(const SmallSpec sp, con
     if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_phase_ticks[i_], S.phw[i_]);
 #endif
     // ---- results
+    if (a.flags & (1 | 2)) S.sens_tail(a, inst, valid, status);
     double lag = 0.0;
     {
         double nuin[NX];

@@ -248,7 +248,7 @@ int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
         t.pending[timed_shape] = true;
     }
 #if !MPCRL_FUSE_SENS
-    if (a.flags & (MPCRL_SENS_V | MPCRL_SENS_PI)) {
+    if ((a.flags & (MPCRL_SENS_V | MPCRL_SENS_PI)) && !lq) {   // (lq_solve_kernel runs the pass itself)
         hipLaunchKernelGGL(small_sens_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
         HIP_OK(hipGetLastError());
     }
