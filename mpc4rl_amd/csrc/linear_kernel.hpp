@@ -3,17 +3,26 @@
 // small_solve_kernel gives every shooting stage a lane: 41 lanes, one instance per wavefront, and the serial Riccati factor sweep — 60 %
 // of its instructions — runs with ONE useful lane of 64.  Its SQ counters (profiles/r05_small_pmc.txt): 103 k wave-instructions per
 // instance, 66 % of the VALU issue floor of that stream: only instances SHARING wave-instructions can make it faster.  Here a lane
-// holds SPL = 3 consecutive stages (stage = 3 pos + j), an instance takes ceil((N + 1) / 3) = 14 lanes and a wavefront FOUR instances:
-// 4096 instances are 1024 wavefronts, one per SIMD, one round.  The serial factor recursion still has N + 1 dependent stage steps, but
-// every wave-instruction of it now works for four instances, and two of three steps take P_{k+1} out of the lane's own registers
-// (a DPP shift per lane boundary instead of per stage); the vector sweeps compose the lane's three affine stage maps locally and scan
-// over 14 lanes (4 steps).  The row state of three stages is ~320 registers: one wavefront per SIMD.
+// holds SPL = 3 consecutive stages (stage = 3 pos + j), an instance takes ceil((N + 1) / 3) = 14 lanes and a wavefront FOUR instances,
+// each in a DPP row (16 lanes) of its own (ROW; other horizons: packed segments, up to eight instances): 4096 instances are 1024
+// wavefronts, one per SIMD, one round.
+//   * factor sweep: still N + 1 dependent stage steps, but every wave-instruction of it works for four instances and two of three
+//     steps take P_{k+1} out of the lane's own registers (one DPP shift per lane boundary);
+//   * vector sweeps: the lane composes its three affine stage maps, a Hillis-Steele scan over the row (4 steps of row_shr / row_shl
+//     moves), then the lane applies its maps;
+//   * reductions: butterfly all-reduce inside the row by DPP moves.  One wavefront per SIMD waits for every ds_bpermute round trip and
+//     for every LDS read inside a lane-dependent branch on the spot: nothing of either kind is left in the interior-point loop;
+//   * the rows: the corrector's right-hand side comes out of the predictor's row pass (no barrier pass), its multiplier steps are
+//     kept for the update (no third pass over the rows' reciprocals);
+//   * three stage objects are ~213 doubles per lane: r, q and the slack weights are parked in LDS columns, the rest fills 256 VGPRs +
+//     ~245 AGPRs without scratch;
+//   * the sensitivity pass (dV/dp, du0*/dp) runs at the end of the same kernel on the iterate in its registers (sens_tail).
 //
 // The iteration is the one of SmallSolver<LinearDev> (same constants, same formulas per stage and row; the sums of the
-// reductions and of the scans associate differently), so statuses and iteration counts equal the oracle port's.  The sensitivity pass
-// stays small_sens_kernel on the stored iterate.  Everything mpcrl_solve offers for the model is here: stored / cold iterates, the
-// per-instance cold mask, MPCRL_COLD_DUAL, Q-mode, per-instance parameters, RTI, the divergence exit, general box bounds with the
-// L1-soft first state, the Lagrangian.
+// reductions and of the scans associate differently, and the predictor's ratio test uses (t + dt) / t for -dlam / lam), so statuses
+// and iteration counts equal the oracle port's up to stopping tests met within rounding.  Everything mpcrl_solve offers for the model
+// is here: stored / cold iterates, the per-instance cold mask, MPCRL_COLD_DUAL, Q-mode, per-instance parameters, RTI, the divergence
+// exit, general box bounds with the L1-soft first state, the Lagrangian, both sensitivities.  DESIGN.md §3.1 has the measurements.
 #pragma once
 #include "small_kernel.hpp"
 
@@ -151,10 +160,6 @@ struct LqSolver {
             park[(PK_ZW + j * 2) * 64] = sp.zl[NU] * g, park[(PK_ZW + j * 2 + 1) * 64] = sp.zu[NU] * g;
         }
     }
-
-    // value of the NEXT / PREVIOUS stage for stage j of this lane (the lane's own registers, or one DPP shift at the lane boundary)
-    template <class F>
-    MPCRL_DI double nxt(int j, F &&f) const { return j + 1 < SPL ? f(j + 1 < SPL ? j + 1 : 0) : 0.0; }
 
     // ---- linearise: r = F(x, u) - x_next, q = c_k grad l; returns c_k l_k (+ slack penalties)
     MPCRL_DI double linearize(int j, const double *xn) {
