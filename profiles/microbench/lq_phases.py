@@ -17,11 +17,12 @@ t = time.perf_counter(); r = mpc.solve(x0t, cold=True); torch.cuda.synchronize()
 lib.mpcrl_debug_phases(out, 1)
 names = ["0 resid+check", "1 barrier pred", "2 factor", "3 fwd pred", "4 rows pred", "5 barrier corr", "6 bwd_vec", "7 fwd corr", "8 rows corr+step",
          "9 linearise+res", "10 qp setup", "11", "12", "13", "14", "15"]
-tot = sum(out)
+tot = sum(out[i] for i in range(15))      # bucket 15 is the wavefront's life on the constant 100 MHz clock, not shader cycles
 it = r.iters.cpu().numpy()
 W = (B + 3) // 4
 print("solve %.3f ms, ipm mean %.2f max %d; wavefronts %d" % (dt*1e3, it[:, 1].mean(), it[:, 1].max(), W))
-for i in range(16):
+for i in range(15):
     if out[i]:
         print("%-20s %9.0f ticks per wavefront  %5.1f%%" % (names[i], out[i] / W, 100.0 * out[i] / max(tot, 1)))
 print("total ticks per wavefront:", tot / W)
+print("wavefront life (s_memrealtime, 100 MHz): %.3f ms" % (out[15] / W * 1e-5))
