@@ -734,3 +734,27 @@ def test_hip_vs_third_party_gradients_and_chain_solutions():
         rc = mc.solve(g7[f"chain{n_mass}_x0"][None], cold=True)
         assert int(rc.status[0]) == 0
         assert rel_err(rc.u0.cpu().numpy(), g7[f"chain{n_mass}_u0"][None]) < RTOL and abs(float(rc.V[0]) - float(g7[f"chain{n_mass}_V"])) < RTOL * max(1.0, abs(float(rc.V[0])))
+
+
+def test_hip_vs_third_party_chain_gradients():
+    """G8 (tests/golden/make_thirdparty_chain_grad.py): dV/dp and du0*/dp of the HIP chain path (n_mass 3) against central differences of
+    scipy-SLSQP's V and u0* over four parameters of different kinds (mass, spring constant, rest length, damping) at 1e-5."""
+    from mpc4rl_amd import MPCBatch, chain_mass_ocp
+    f = os.path.join(GOLD, "g8_chain_grad.npz")
+    if not os.path.exists(f):
+        pytest.skip("tests/golden/g8_chain_grad.npz has not been generated (make_thirdparty_chain_grad.py, ~1 h)")
+    g8 = np.load(f)
+    mc = MPCBatch(chain_mass_ocp(n_mass=int(g8["n_mass"]), tol=1e-9), 1)
+    r = mc.solve(g8["x0"][None], sens_v=True, sens_pi=True, cold=True)
+    assert int(r.status[0]) == 0
+    assert rel_err(r.u0.cpu().numpy(), g8["u0"][None]) < RTOL and abs(float(r.V[0]) - float(g8["V"])) < RTOL * max(1.0, abs(float(g8["V"])))
+    idx = g8["p_index"]
+    dV, dpi = r.dV_dp.cpu().numpy()[0], r.dpi_dp.cpu().numpy()[0]
+    for name, mine, fd0, fd1 in (("dV/dp", dV[idx], g8["dV_d0"], g8["dV_d1"]), ("du0*/dp", dpi[:, idx].T, g8["du0_d0"], g8["du0_d1"])):
+        fd0, fd1, mine = (np.asarray(a, float).reshape(len(idx), -1) for a in (fd0, fd1, mine))
+        scale = np.maximum(np.abs(fd0).max(1, keepdims=True), 1.0)
+        ok = np.abs(fd0 - fd1) <= 2e-6 * scale
+        assert ok.mean() >= 0.75
+        err = float(np.where(ok, np.abs(mine - fd0) / scale, 0.0).max())
+        print("chain n_mass 3,", name, "HIP vs third-party finite differences:", err)
+        assert err < 1e-5, name
