@@ -4,7 +4,8 @@
 // of its instructions — runs with ONE useful lane of 64.  Its SQ counters (profiles/r05_small_pmc.txt): 103 k wave-instructions per
 // instance, 66 % of the VALU issue floor of that stream: only instances SHARING wave-instructions can make it faster.  Here a lane
 // holds SPL = 3 consecutive stages (stage = 3 pos + j), an instance takes ceil((N + 1) / 3) = 14 lanes and a wavefront FOUR instances,
-// each in a DPP row (16 lanes) of its own (ROW; other horizons: packed segments, up to eight instances): 4096 instances are 1024
+// each in a DPP row (16 lanes) of its own (RL = 16; up to 8 lanes per instance: half rows, eight instances; more than 16: packed
+// segments and __shfl): 4096 instances are 1024
 // wavefronts, one per SIMD, one round.
 //   * factor sweep: still N + 1 dependent stage steps, but every wave-instruction of it works for four instances and two of three
 //     steps take P_{k+1} out of the lane's own registers (one DPP shift per lane boundary);
@@ -36,9 +37,9 @@ MPCRL_DI double dpp_move(double v) {
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
-// butterfly all-reduce over a row: partners lane ^ 1, lane ^ 2 (quad permutations), 7 - lane of the half row, 15 - lane of the row.
-// Every lane of the row ends with the same bits (the additions commute), no broadcast needed.
-template <int NMAX, int NSUM>
+// butterfly all-reduce over a row (RL = 16) or a half row (RL = 8): partners lane ^ 1, lane ^ 2 (quad permutations), 7 - lane of the
+// half row, 15 - lane of the row.  Every lane ends with the same bits (the additions commute), no broadcast needed.
+template <int NMAX, int NSUM, int RL>
 MPCRL_DI void row_reduce(double *mx, double *sm) {
 #define MPCRL_ROW_STEP(CTRL)                                                                  \
     {                                                                                         \
@@ -48,13 +49,16 @@ MPCRL_DI void row_reduce(double *mx, double *sm) {
         _Pragma("unroll") for (int i = 0; i < NMAX; ++i) mx[i] = fmax(mx[i], om[i]);          \
         _Pragma("unroll") for (int i = 0; i < NSUM; ++i) sm[i] += os[i];                      \
     }
-    MPCRL_ROW_STEP(0xB1) MPCRL_ROW_STEP(0x4E) MPCRL_ROW_STEP(0x141) MPCRL_ROW_STEP(0x140)
+    MPCRL_ROW_STEP(0xB1) MPCRL_ROW_STEP(0x4E) MPCRL_ROW_STEP(0x141)
+    if constexpr (RL == 16) MPCRL_ROW_STEP(0x140)
 #undef MPCRL_ROW_STEP
 }
 
-// ROW: the instance owns one DPP row (16 lanes, the live ones first): reductions and scans by DPP moves
-template <int SPL, bool ROW>
+// RL = 16 / 8: the instance owns one DPP row / half row (the live lanes first): reductions and scans by DPP moves; RL = 0: packed
+// segments of any length, __shfl
+template <int SPL, int RL>
 struct LqSolver {
+    static constexpr bool ROW = RL != 0;
     static constexpr int NX = 2, NU = 1, NW = 3;
     const SmallSpec &sp;
     const int N, lpi, lpl, pos, base;   // lpi: lanes of the slot of the instance; lpl: the ones that hold live stages
@@ -90,7 +94,7 @@ struct LqSolver {
     template <int NMAX, int NSUM>
     MPCRL_DI void red(double *mx, double *sm) const {
         if constexpr (ROW)
-            row_reduce<NMAX, NSUM>(mx, sm);
+            row_reduce<NMAX, NSUM, RL>(mx, sm);
         else
             seg_reduce<NMAX, NSUM, true>(mx, sm, pos, lpi, base);
     }
@@ -338,7 +342,7 @@ struct LqSolver {
         for (int i = 0; i < 4; ++i) o.M[i] = down ? dpp_move<0x100 + SFT>(m.M[i]) : dpp_move<0x110 + SFT>(m.M[i]);
 #pragma unroll
         for (int i = 0; i < 2; ++i) o.v[i] = down ? dpp_move<0x100 + SFT>(m.v[i]) : dpp_move<0x110 + SFT>(m.v[i]);
-        const bool valid = down ? pos + SFT < 16 : pos - SFT >= 0;
+        const bool valid = down ? pos + SFT < RL : pos - SFT >= 0;
         const Aff n = compose(m, o);
 #pragma unroll
         for (int i = 0; i < 4; ++i) m.M[i] = valid ? n.M[i] : m.M[i];
@@ -347,7 +351,8 @@ struct LqSolver {
     }
     MPCRL_DI void scan(Aff &m, bool down) const {
         if constexpr (ROW) {      // row shifts (the lanes behind the live ones hold identity / constant maps)
-            scan_step<1>(m, down), scan_step<2>(m, down), scan_step<4>(m, down), scan_step<8>(m, down);
+            scan_step<1>(m, down), scan_step<2>(m, down), scan_step<4>(m, down);
+            if constexpr (RL == 16) scan_step<8>(m, down);
             return;
         }
         for (int sft = 1; sft < lpi; sft <<= 1) {
@@ -878,20 +883,20 @@ struct LqSolver {
 template <int SPL>
 __host__ __device__ constexpr int lq_lanes_per_instance(int N) { return (N + 1 + SPL - 1) / SPL; }
 
-template <int SPL, bool ROW>
+template <int SPL, int RL>
 __global__ void __launch_bounds__(64, 1) lq_solve_kernel(const SmallSpec sp, const SmallArgs a) {
     constexpr int NX = 2, NU = 1, NW = 3, MAXI = 8;
 #ifdef MPCRL_PROFILE_PHASES
     const unsigned long long rt0_ = wall_clock64();
 #endif
-    const int lane = threadIdx.x, N = sp.N, lpl = lq_lanes_per_instance<SPL>(N), lpi = ROW ? 16 : lpl, ipw = min(64 / lpi, MAXI);
+    const int lane = threadIdx.x, N = sp.N, lpl = lq_lanes_per_instance<SPL>(N), lpi = RL ? RL : lpl, ipw = min(64 / lpi, MAXI);
     const int slot = lane / lpi, pos = lane - slot * lpi, base = slot * lpi;
     long inst = (long)blockIdx.x * ipw + slot;
     const bool valid = slot < ipw && inst < a.B;
     if (!valid) inst = a.B - 1;   // dead lanes shadow the last instance and never store
     if (a.perm) inst = a.perm[inst];
-    __shared__ double th_lds[(MAXI + 1) * 12], bt_lds[18], park_lds[LqSolver<SPL, ROW>::PK_N * 64];
-    LqSolver<SPL, ROW> S(sp, lpi, lpl, pos, base);
+    __shared__ double th_lds[(MAXI + 1) * 12], bt_lds[18], park_lds[LqSolver<SPL, RL>::PK_N * 64];
+    LqSolver<SPL, RL> S(sp, lpi, lpl, pos, base);
     S.park = park_lds + lane;
     S.qmode = a.u0fix != nullptr;
     {   // the instance's parameters and the bound table (one copy per wavefront)

@@ -230,14 +230,17 @@ int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
         // the linear-system model: three stages per lane, four instances per wavefront (linear_kernel.hpp) unless switched off
         // (MPCRL_LINEAR_SPL=1 at mpcrl_create: one stage per lane, small_solve_kernel) or the horizon leaves it no advantage
         constexpr int SPL = 3;
-        const int lpi3 = lq_lanes_per_instance<SPL>(h->N), ipw3 = std::min(64 / lpi3, 8);
+        // lanes per instance -> layout: <= 8 half rows (eight instances per wavefront), <= 16 rows (four), else packed segments
+        const int lpi3 = lq_lanes_per_instance<SPL>(h->N), rl = lpi3 <= 8 ? 8 : (lpi3 <= 16 ? 16 : 0), ipw3 = rl ? 64 / rl : std::min(64 / lpi3, 8);
         if (h->linear_spl == SPL && ipw3 > ipw) {
             lq = true;
             const dim3 grid((unsigned)((h->B + ipw3 - 1) / ipw3));
-            if (ipw3 == 4)      // four instances: each in a DPP row of its own (cross-lane traffic by DPP moves)
-                hipLaunchKernelGGL((lq_solve_kernel<SPL, true>), grid, dim3(64), 0, st, h->small, a);
+            if (rl == 16)
+                hipLaunchKernelGGL((lq_solve_kernel<SPL, 16>), grid, dim3(64), 0, st, h->small, a);
+            else if (rl == 8)
+                hipLaunchKernelGGL((lq_solve_kernel<SPL, 8>), grid, dim3(64), 0, st, h->small, a);
             else
-                hipLaunchKernelGGL((lq_solve_kernel<SPL, false>), grid, dim3(64), 0, st, h->small, a);
+                hipLaunchKernelGGL((lq_solve_kernel<SPL, 0>), grid, dim3(64), 0, st, h->small, a);
         }
     }
     if (!sliced && !lq) hipLaunchKernelGGL(small_solve_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
