@@ -188,6 +188,8 @@ def _run(item):
     f = os.path.join(PARTS, f"{idx}.pkl")
     if os.path.exists(f):
         return idx
+    if kind == "chain" and payload[0] == 5 and os.environ.get("G7_SKIP_CHAIN5"):      # (SLSQP on its 960 unknowns did not finish in 3 h)
+        return idx
     r = {"cartpole": cartpole_job, "linear": linear_job, "chain": chain_job}[kind](payload)
     with open(f + ".tmp", "wb") as fh:
         pickle.dump(r, fh)
@@ -223,7 +225,7 @@ def job_list():
     return jobs, delta, g6, cp_rows, lin_x0, chain_x0
 
 
-def main(procs=7, assemble_only=False):
+def main(procs=int(os.environ.get("G7_PROCS", "7")), assemble_only=False):
     import multiprocessing as mp
     import pickle
     os.makedirs(PARTS, exist_ok=True)
