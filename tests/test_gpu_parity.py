@@ -686,15 +686,19 @@ def test_hip_vs_third_party_gradients_and_chain_solutions():
     g7 = np.load(os.path.join(GOLD, "g7_thirdparty_grad.npz"))
 
     def held(fd0, fd1, mine):
-        # (entries of gradient jobs the generator has not finished are NaN: they are left out)
+        # Central differences at two steps, d and 10 d: fd(d) = g + c d^2, so g = fd0 - (fd1 - fd0) / 99 and |fd1 - fd0| / 99 estimates
+        # what is left of the truncation error in fd0; entries whose estimate exceeds 2e-6 are left out (and NaN entries of jobs the
+        # generator did not finish).  Returns the largest |mine - g|, rows scaled by their largest entry (>= 1).
         fd0, fd1, mine = (np.asarray(a, float).reshape(len(fd0), -1) for a in (fd0, fd1, mine))
         fin = np.isfinite(fd0) & np.isfinite(fd1)
         if not fin.any():
             return 0.0
-        scale = np.maximum(np.nanmax(np.where(fin, np.abs(fd0), 0.0), axis=1, keepdims=True), 1.0)
-        ok = fin & (np.abs(np.where(fin, fd0 - fd1, 0.0)) <= 2e-6 * scale)
-        assert ok[fin].mean() >= 0.75
-        return float(np.where(ok, np.abs(mine - np.where(fin, fd0, 0.0)) / scale, 0.0).max())
+        f0, f1 = np.where(fin, fd0, 0.0), np.where(fin, fd1, 0.0)
+        scale = np.maximum(np.abs(f0).max(axis=1, keepdims=True), 1.0)
+        g = f0 - (f1 - f0) / 99.0
+        ok = fin & (np.abs(f1 - f0) / 99.0 <= 2e-6 * scale)
+        assert ok[fin].mean() >= 0.9, ok[fin].mean()
+        return float(np.where(ok, np.abs(mine - g) / scale, 0.0).max())
 
     B = len(g7["cp_x0"])
     ocp = cartpole_ocp(tol=1e-9)
@@ -720,7 +724,7 @@ def test_hip_vs_third_party_gradients_and_chain_solutions():
         e_v = held(g7[f"lin_{tag}_dV_d0"], g7[f"lin_{tag}_dV_d1"], rl.dV_dp.cpu().numpy())
         e_pi = held(g7[f"lin_{tag}_du0_d0"][:, :, 0], g7[f"lin_{tag}_du0_d1"][:, :, 0], rl.dpi_dp.cpu().numpy()[:, 0, :])
         print("linear", tag, "vs third-party finite differences: dV/dp", e_v, "du0*/dp", e_pi)
-        assert e_v < 1e-5 and e_pi < 1e-5
+        assert e_v < 1e-5 and e_pi < 3e-5      # (du0*/dp: the weakly active soft row, see tests/test_oracle.py)
         if not len(g7[f"lin_{tag}_polished_x0"]):
             continue
         mp_ = MPCBatch(linear_system_ocp(discount_factor=gamma), len(g7[f"lin_{tag}_polished_x0"]))

@@ -335,16 +335,19 @@ def test_third_party_gradients_and_chain_solutions_vs_the_port(oracle_port):
     g7 = np.load(os.path.join(GOLD, "g7_thirdparty_grad.npz"))
 
     def held(fd0, fd1, mine, tol=1e-5):
-        # (entries of gradient jobs the generator has not finished are NaN: they are left out)
+        # Central differences at two steps, d and 10 d: fd(d) = g + c d^2, so g = fd0 - (fd1 - fd0) / 99 and |fd1 - fd0| / 99 estimates
+        # what is left of the truncation error in fd0; entries whose estimate exceeds 2e-6 are left out (and NaN entries of jobs the
+        # generator did not finish).  Returns the largest |mine - g|, rows scaled by their largest entry (>= 1).
         fd0, fd1, mine = (np.asarray(a, float).reshape(len(fd0), -1) for a in (fd0, fd1, mine))
         fin = np.isfinite(fd0) & np.isfinite(fd1)
         if not fin.any():
             return 0.0
-        scale = np.maximum(np.nanmax(np.where(fin, np.abs(fd0), 0.0), axis=1, keepdims=True), 1.0)
-        ok = fin & (np.abs(np.where(fin, fd0 - fd1, 0.0)) <= 2e-6 * scale)
-        assert ok[fin].mean() >= 0.75, ok[fin].mean()
-        err = np.where(ok, np.abs(mine - np.where(fin, fd0, 0.0)) / scale, 0.0)
-        return float(err.max())
+        f0, f1 = np.where(fin, fd0, 0.0), np.where(fin, fd1, 0.0)
+        scale = np.maximum(np.abs(f0).max(axis=1, keepdims=True), 1.0)
+        g = f0 - (f1 - f0) / 99.0
+        ok = fin & (np.abs(f1 - f0) / 99.0 <= 2e-6 * scale)
+        assert ok[fin].mean() >= 0.9, ok[fin].mean()
+        return float(np.where(ok, np.abs(mine - g) / scale, 0.0).max())
 
     # cartpole: 4 near-upright states x (M, m, l)
     P = make_cartpole()
@@ -365,8 +368,11 @@ def test_third_party_gradients_and_chain_solutions_vs_the_port(oracle_port):
         if have.any():
             assert np.nanmax(g7[f"lin_{tag}_kkt"][:, :2]) < 1e-11 and np.nanmax(g7[f"lin_{tag}_kkt_d0"]) < 1e-11
             assert np.abs(r.u0 - g7[f"lin_{tag}_u0"])[have].max() < 1e-6 and np.abs(r.V - g7[f"lin_{tag}_V"])[have].max() < 1e-6 * np.abs(g7[f"lin_{tag}_V"][have]).max()
+        # du0*/dp at 3e-5 (measured 2e-5 on the offsets b and f, 1e-8 on A and B): every solution of this OCP ends with a weakly active
+        # soft row (the regulated state approaches its bound), where the reference's KKT sensitivity keeps the slacks constant
+        # (quirk q1) and the true solution map, which the finite differences follow, does not
         assert held(g7[f"lin_{tag}_dV_d0"], g7[f"lin_{tag}_dV_d1"], r.dV) < 1e-5
-        assert held(g7[f"lin_{tag}_du0_d0"][:, :, 0], g7[f"lin_{tag}_du0_d1"][:, :, 0], r.dpi[:, 0, :]) < 1e-5
+        assert held(g7[f"lin_{tag}_du0_d0"][:, :, 0], g7[f"lin_{tag}_du0_d1"][:, :, 0], r.dpi[:, 0, :]) < 3e-5
         # G6's rows, polished: what trust-constr stopped at 2e-6 of is now a KKT point to 1e-12
         if len(g7[f"lin_{tag}_polished_x0"]):
             assert g7[f"lin_{tag}_polished_kkt"][:, :2].max() < 1e-11
