@@ -1137,11 +1137,12 @@ struct SmallSolver {
             dss = -(rgs + e1 + e2 + sg * w1 * dv) * fast_rcp(w1 + w2);
             dt2 = -rd2 + dss;
             dl2 = (-rm2 - l2 * dt2) * it2;
-            rat = fmax(-dl2 * fast_rcp(l2), -dt2 * it2);
+            // (predictor: r_m = lam t, so -dlam / lam = (t + dt) / t — no reciprocal of the multiplier)
+            rat = fmax(pass ? -dl2 * fast_rcp(l2) : (t2 + dt2) * it2, -dt2 * it2);
         }
         dt1 = -rd1 + sg * dv + dss;
         dl1 = (-rm1 - l1 * dt1) * it1;
-        rat = fmax(rat, fmax(-dl1 * fast_rcp(l1), -dt1 * it1));
+        rat = fmax(rat, fmax(pass ? -dl1 * fast_rcp(l1) : (t1 + dt1) * it1, -dt1 * it1));
     }
 
     // ---- Mehrotra predictor-corrector on the QP of the current linearisation -----------------------
