@@ -20,8 +20,12 @@ from make_thirdparty_grad import cold, slsqp  # noqa: E402
 from oracle.problems import make_chain_mass  # noqa: E402
 
 torch.set_num_threads(1)
-N_MASS, LABELS, DELTA = 3, ("m_0", "D_1_0", "L_0_2", "C_1_0"), (1e-5, 1e-4)
-PARTS = "/tmp/g8_parts"
+# G8_NMASS=4 in the environment: the same for n_mass 4 (720 unknowns), two parameters, written to g8_chain4_grad.npz
+N_MASS = int(os.environ.get("G8_NMASS", "3"))
+LABELS = ("m_0", "D_1_0", "L_0_2", "C_1_0") if N_MASS == 3 else ("D_1_0", "C_2_0")
+DELTA = (1e-5, 1e-4)
+PARTS = "/tmp/g8_parts" if N_MASS == 3 else f"/tmp/g8_parts_{N_MASS}"
+OUT = "g8_chain_grad.npz" if N_MASS == 3 else f"g8_chain{N_MASS}_grad.npz"
 
 
 def state():
@@ -82,8 +86,8 @@ def main(assemble_only=False):
         out[f"dV_d{di}"] = np.array([res[lab][d][0] for lab in labs])
         out[f"du0_d{di}"] = np.array([res[lab][d][1] for lab in labs])          # [param, nu]
         out[f"kkt_d{di}"] = np.array([res[lab][d][2] for lab in labs])
-    np.savez(os.path.join(HERE, "g8_chain_grad.npz"), **out)
-    print("wrote g8_chain_grad.npz with", labs)
+    np.savez(os.path.join(HERE, OUT), **out)
+    print("wrote", OUT, "with", labs)
 
 
 if __name__ == "__main__":

@@ -740,13 +740,14 @@ def test_hip_vs_third_party_gradients_and_chain_solutions():
         assert rel_err(rc.u0.cpu().numpy(), g7[f"chain{n_mass}_u0"][None]) < RTOL and abs(float(rc.V[0]) - float(g7[f"chain{n_mass}_V"])) < RTOL * max(1.0, abs(float(rc.V[0])))
 
 
-def test_hip_vs_third_party_chain_gradients():
+@pytest.mark.parametrize("fixture", ["g8_chain_grad.npz", "g8_chain4_grad.npz"])
+def test_hip_vs_third_party_chain_gradients(fixture):
     """G8 (tests/golden/make_thirdparty_chain_grad.py): dV/dp and du0*/dp of the HIP chain path (n_mass 3) against central differences of
     scipy-SLSQP's V and u0* over four parameters of different kinds (mass, spring constant, rest length, damping) at 1e-5."""
     from mpc4rl_amd import MPCBatch, chain_mass_ocp
-    f = os.path.join(GOLD, "g8_chain_grad.npz")
+    f = os.path.join(GOLD, fixture)
     if not os.path.exists(f):
-        pytest.skip("tests/golden/g8_chain_grad.npz has not been generated (make_thirdparty_chain_grad.py, ~1 h)")
+        pytest.skip(f"tests/golden/{fixture} has not been generated (make_thirdparty_chain_grad.py, hours)")
     g8 = np.load(f)
     mc = MPCBatch(chain_mass_ocp(n_mass=int(g8["n_mass"]), tol=1e-9), 1)
     r = mc.solve(g8["x0"][None], sens_v=True, sens_pi=True, cold=True)
@@ -760,5 +761,5 @@ def test_hip_vs_third_party_chain_gradients():
         ok = np.abs(fd0 - fd1) <= 2e-6 * scale
         assert ok.mean() >= 0.75
         err = float(np.where(ok, np.abs(mine - fd0) / scale, 0.0).max())
-        print("chain n_mass 3,", name, "HIP vs third-party finite differences:", err)
+        print("chain n_mass", int(g8["n_mass"]), name, "HIP vs third-party finite differences:", err)
         assert err < 1e-5, name

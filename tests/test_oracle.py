@@ -388,13 +388,14 @@ def test_third_party_gradients_and_chain_solutions_vs_the_port(oracle_port):
         assert np.abs(r.u0[0] - g7[f"chain{n_mass}_u0"]).max() < 1e-6 and abs(r.V[0] - float(g7[f"chain{n_mass}_V"])) < 1e-6 * max(1.0, abs(r.V[0]))
 
 
-def test_third_party_chain_gradients_vs_the_port(oracle_port):
+@pytest.mark.parametrize("fixture", ["g8_chain_grad.npz", "g8_chain4_grad.npz"])
+def test_third_party_chain_gradients_vs_the_port(oracle_port, fixture):
     """G8 (tests/golden/make_thirdparty_chain_grad.py): dV/dp and du0*/dp of the chain-of-masses NLP (n_mass 3) against central differences
     of scipy-SLSQP's V and u0* over a mass, a spring constant, a rest length and a damping coefficient — the reference's own check of
     dpi/dp on the chain is a finite difference along its damping sweep (rlmpc/examples/chain_mass.py:28-64)."""
-    f = os.path.join(GOLD, "g8_chain_grad.npz")
+    f = os.path.join(GOLD, fixture)
     if not os.path.exists(f):
-        pytest.skip("tests/golden/g8_chain_grad.npz has not been generated (make_thirdparty_chain_grad.py, ~1 h)")
+        pytest.skip(f"tests/golden/{fixture} has not been generated (make_thirdparty_chain_grad.py, hours)")
     g8 = np.load(f)
     from oracle.problems import make_chain_mass
     P = make_chain_mass(n_mass=int(g8["n_mass"]))
@@ -409,5 +410,5 @@ def test_third_party_chain_gradients_vs_the_port(oracle_port):
         ok = np.abs(fd0 - fd1) <= 2e-6 * scale          # the two step sizes agree: the difference quotient is trustworthy there
         assert ok.mean() >= 0.75, (name, ok)
         err = float(np.where(ok, np.abs(mine - fd0) / scale, 0.0).max())
-        print("chain n_mass 3,", name, "port vs third-party finite differences:", err)
+        print("chain n_mass", int(g8["n_mass"]), name, "port vs third-party finite differences:", err)
         assert err < 1e-5, name
