@@ -10,6 +10,11 @@ cartpole OCPs (BASELINE.json config 3: cold-start full SQP to tol 1e-6 + dV/dp +
 kernel launch through the C ABI.  With N > 1 the batch is sharded (weak scaling, 4096 per rank) and the
 step ends with the single all-reduce of the accumulated theta-gradient that a data-parallel RL update
 needs.  Rank 0 prints ONE JSON line.
+
+Timing (timed_steps): `settle_steps` untimed steps of the same workload (an idle GPU reaches its sustained clocks only after ~20 of
+these 0.5 ms steps; --settle 0 = none), then the contract's W warm-ups, a barrier + device synchronisation, EXACTLY K timed steps,
+synchronisation + barrier, MAX over ranks.  The other single-GPU configurations of BASELINE.json (chain n_mass 5 / 7, linear system)
+are measured after the headline's timed region through the same timed_steps and attached as `secondary` (median of three windows).
 """
 import argparse
 import json
