@@ -1,4 +1,4 @@
-"""G7: third-party GRADIENTS and third-party CHAIN solutions.  `python tests/golden/make_thirdparty_grad.py` (dev container, ~20 minutes on 8 cores).
+"""G7: third-party GRADIENTS and third-party CHAIN solutions.  `python tests/golden/make_thirdparty_grad.py` (dev container: ~15 minutes on 8 cores with one BLAS thread per worker — OPENBLAS_NUM_THREADS=1 — plus 4.4 h for the chain n_mass 5 solve; resumable).
 
 G6 (make_thirdparty.py) holds u0*, V of KKT points found by scipy.optimize for cartpole and the linear system.  Here the same
 third-party solves are differentiated by CENTRAL DIFFERENCES over the parameters — the reference's own sanity check of dpi/dp is
