@@ -11,10 +11,12 @@ kernel launch through the C ABI.  With N > 1 the batch is sharded (weak scaling,
 step ends with the single all-reduce of the accumulated theta-gradient that a data-parallel RL update
 needs.  Rank 0 prints ONE JSON line.
 
-Timing (timed_steps): `settle_steps` untimed steps of the same workload (an idle GPU reaches its sustained clocks only after ~20 of
-these 0.5 ms steps; --settle 0 = none), then the contract's W warm-ups, a barrier + device synchronisation, EXACTLY K timed steps,
-synchronisation + barrier, MAX over ranks.  The other single-GPU configurations of BASELINE.json (chain n_mass 5 / 7, linear system)
-are measured after the headline's timed region through the same timed_steps and attached as `secondary` (median of three windows).
+Timing (timed_steps): W warm-ups, a barrier + device synchronisation, EXACTLY K timed steps, synchronisation + barrier, MAX over
+ranks.  Protocol by round: rounds 1-4 and 6 — the headline's `value` / `ms_per_step` come from that window alone (`settle_steps` 0);
+round 5 ran 40 untimed "settle" steps and the HBM-peak probe in front of the warm-ups (an idle GPU reaches its sustained clocks only
+after ~20 of these 0.5 ms steps), which this round reports as the separate `steady_state` field, measured by a second window AFTER the
+headline's.  The other configurations of BASELINE.json (chain n_mass 5 / 7, linear system, the TD3 closed loop) are measured after
+both through the same timed_steps and attached as `secondary` (median of three windows; they keep their disclosed settle steps).
 """
 import argparse
 import json
@@ -332,7 +334,7 @@ def chain_bench(args):
     finish_ranks(dist)
 
 
-def small_measure(linear, B, sens, rti, steps, warmup, world, rank, dist, dev):
+def small_measure(linear, B, sens, rti, steps, warmup, world, rank, dist, dev, settle_kind="small"):
     """One cartpole / linear-system measurement through timed_steps: (job seconds, summary dict, ocp, x0, statuses, iteration counts)."""
     from mpc4rl_amd import MPCBatch, cartpole_ocp, linear_system_ocp
     from mpc4rl_amd.distributed import allreduce_weighted_grad
@@ -348,7 +350,9 @@ def small_measure(linear, B, sens, rti, steps, warmup, world, rank, dist, dev):
 
     def step():
         # cold start every step (MPC.reset semantics) so that every step does the same, full work
-        r = mpc.solve(x0, sens_v=sens, sens_pi=sens, cold=not rti, rti=rti)
+        # (linear system: every step starts cold, so nobody will warm-start an interior point from this solve's bound multipliers
+        # and slacks — MPCRL_NO_BND_STORE leaves those ten planes of the stored iterate alone; x, u, pi are still written back)
+        r = mpc.solve(x0, sens_v=sens, sens_pi=sens, cold=not rti, rti=rti, store_bounds=not (linear and not rti))
         if dist is not None and sens:
             # data-parallel RL update: one all-reduce of [sum_i dV_i/dtheta, sum_i V_i, count]
             allreduce_weighted_grad(r.dV_dp[:, :n_theta], r.V)   # K5 reduction kernel + one all_reduce of 5 doubles
@@ -356,7 +360,7 @@ def small_measure(linear, B, sens, rti, steps, warmup, world, rank, dist, dev):
 
     if rti:
         mpc.solve(x0, cold=True)            # converge once; RTI steps then start from that iterate
-    settle = SETTLE["small"] if SETTLE_OVERRIDE is None else SETTLE_OVERRIDE
+    settle = settle_kind if isinstance(settle_kind, int) else (SETTLE[settle_kind] if SETTLE_OVERRIDE is None else SETTLE_OVERRIDE)
     elapsed, kern_ms, r = timed_steps(step, argparse.Namespace(steps=steps, warmup=warmup, settle=settle), dist, dev, rank)
     status = r.status.cpu().numpy()
     iters = r.iters.cpu().numpy()
@@ -367,7 +371,7 @@ def small_measure(linear, B, sens, rti, steps, warmup, world, rank, dist, dev):
     sweeps = float(iters[:, 1].mean()) + (1 + ocp.nu if sens else 0)
     fp64_tflops = sweeps * riccati_sweep_flops(ocp.N, ocp.nx, ocp.nu) * B / (kern_ms * 1e-3) / 1e12
     traffic, traffic_src = measured_traffic("linear" if linear else "cartpole", B, sens, rti)
-    name = "linear system N=40 nx=2 nu=1" if linear else "cartpole N=20 nx=4 nu=1"
+    name = "linear system N=40 nx=2 nu=1 (MPCRL_NO_BND_STORE)" if linear and not rti else ("linear system N=40 nx=2 nu=1" if linear else "cartpole N=20 nx=4 nu=1")
     summ = {"value": B * world * steps / elapsed, "unit": "solves/s", "steps": steps, "warmup": warmup, "settle_steps": settle, "ms_per_step": 1e3 * elapsed / steps,
             "workload": ("%s, %d instances/GPU, %s" % (name, B, "RTI (1 SQP iteration, warm)" if rti else "cold-start full-step SQP to tol 1e-6"))
                         + (" + dV/dp + du0*/dp" if sens else ""),
@@ -384,16 +388,23 @@ def small_measure(linear, B, sens, rti, steps, warmup, world, rank, dist, dev):
     return elapsed, summ, ocp, x0_np, status, iters
 
 
-SECONDARY = (("chain5", 10, 3), ("chain7", 5, 2), ("linear", 50, 5))   # (workload, steps, warm-ups): BASELINE configs 4 and 1
+SECONDARY = (("chain5", 10, 3), ("chain7", 5, 2), ("linear", 50, 5), ("td3", 20, 5))   # (workload, steps, warm-ups): BASELINE configs 4, 1, 5
 SECONDARY_WINDOWS = 3
-SETTLE = {"small": 40, "chain": 3, "td3": 10}      # untimed settle steps per workload kind (timed_steps); --settle N overrides
+# Untimed "settle" steps in front of the W warm-ups (timed_steps), disclosed in every line as `settle_steps`; --settle N overrides.
+# The HEADLINE line runs none (round 6: the driver's W and K are the whole protocol, as in rounds 1-4; round 5's headline ran 40 and
+# its figure is the `steady_state` field of this round's line).  The non-headline workloads keep theirs: they are measured after the
+# headline's region or by their own command lines, never by the driver's contract.
+SETTLE = {"headline": 0, "small": 40, "chain": 3, "td3": 10}
+STEADY_SETTLE = 40          # the headline's second, separately labelled window (`steady_state`)
 SETTLE_OVERRIDE = None
 
 
 def secondary_lines(world, rank, dist, dev):
     """The other single-GPU configurations of BASELINE.json, measured by the SAME timed_steps right after the headline's timed region,
     so that the driver's one bench run also times them: chain n_mass 5 / 7 at 1024 instances + sensitivities (config 4), the
-    linear-system OCP at 4096 (config 1 batched).  Each entry: ms_per_step, value (solves/s), iteration counts, roofline {frac, traffic}."""
+    linear-system OCP at 4096 (config 1 batched), the TD3 closed loop at 4096 environments with HIP graphs (config 5: ms_per_step,
+    env-steps/s, mpc_solves_per_s, the launch-shape probe times of its three solves).  Solver entries: ms_per_step, value (solves/s),
+    iteration counts, roofline {frac, traffic}."""
     out = {}
     for wl, steps, warmup in SECONDARY:
         try:
@@ -409,6 +420,8 @@ def secondary_lines(world, rank, dist, dev):
                 for _ in range(SECONDARY_WINDOWS):
                     if wl == "linear":
                         wins.append(small_measure(True, B_PER_GPU, True, False, steps, warmup, world, rank, dist, dev)[1])
+                    elif wl == "td3":      # config 5 at its per-GPU size, HIP graphs on (the step a training loop runs)
+                        wins.append(td3_measure(B_PER_GPU, steps, warmup, True, world, rank, dist, dev, SETTLE["td3"])[1])
                     else:
                         wins.append(chain_measure(int(wl[5:]), 1024, True, steps, warmup, world, rank, dist, dev)[2])
                 wins.sort(key=lambda w: w["ms_per_step"])
@@ -450,6 +463,8 @@ def init_ranks(args):
             dist.init_process_group("gloo")
             dist.barrier()
         return world, rank, local, dist, torch.device("cpu")
+    if os.environ.get("MPCRL_BENCH_SHARE_GPU"):   # test-only: several ranks on one device (tests/test_gpu_fullsize.py, a 1-GPU box)
+        local = local % max(1, torch.cuda.device_count())
     if world > 1 or os.environ.get("MPCRL_BENCH_FORCE_DIST"):   # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -479,24 +494,15 @@ def count_ranks(dist_mod, dev):
     return int(round(float(one.item())))
 
 
-def td3_bench(args):
-    """BASELINE config 5: cartpole TD3 closed loop — 4096 batched environments per GPU, the MPC as the actor (one launch per
-    environment step, warm-started, cold only where an episode ended), device replay, critic TD update with the target actor's
-    batched solve, delayed deterministic policy gradient through du0*/dtheta, ONE all-reduce (critic gradients + theta-gradient)
-    per update.  A step = one environment step of all environments + one TD3 update (batch 4096 per rank)."""
-    world, rank, local, dist, dev = init_ranks(args)
-    rccl_ranks = count_ranks(dist, dev)
-    if DRY:
-        elapsed, _, _ = timed_steps(None, args, dist, dev, rank)
-        if rank == 0:
-            dry_line(args, world, rccl_ranks, elapsed, "closed-loop environment steps/sec, cartpole TD3 with the MPC as actor")
-        return finish_ranks(dist)
+def td3_measure(E, steps, warmup, graphs, world, rank, dist, dev, settle):
+    """One TD3 closed-loop measurement through timed_steps: (job seconds, summary dict).  A step = one environment step of all E
+    environments + one TD3 update (batch E per rank); MPC solves per step and rank: E warm (roll-out actor) + E cold (target actor)
+    + E / policy_delay cold with du0*/dtheta (policy gradient)."""
     from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedTD3, cartpole_ocp
-    E = args.batch
     env = BatchedCartPoleSwingUpEnv(E, device=dev, seed=rank)
     agent = BatchedTD3(cartpole_ocp(), env, batch_size=E, buffer_steps=64, policy_delay=2, lr_actor=1e-6, seed=0, device=dev)
     agent.collect(4)                       # something to sample from
-    if not args.no_graph:
+    if graphs:
         agent.enable_graphs()              # fills the replay buffer, then captures the roll-out step and the update into HIP graphs
 
     def step():                            # no host synchronisation inside the timed region: statistics are read after it
@@ -504,31 +510,51 @@ def td3_bench(args):
         agent.train(1, stats=False)
 
     # the warm-up steps run here: the roll-out statistics are zeroed where the timed region starts
-    wa = argparse.Namespace(steps=args.steps, warmup=0)
-    settle = SETTLE["td3"] if SETTLE_OVERRIDE is None else SETTLE_OVERRIDE
-    for _ in range(settle + args.warmup):
+    for _ in range(settle + warmup):
         step()
     agent.collect(0)                       # zero the roll-out statistics
-    elapsed, _, _ = timed_steps(step, wa, dist, dev, rank)
+    elapsed, _, _ = timed_steps(step, argparse.Namespace(steps=steps, warmup=0), dist, dev, rank)
     st = agent.last_stats()
     tr = {"critic_loss": float(agent._graphs["update"][True]["loss"].item())} if agent._graphs else agent.train(1)
+    solves = world * steps * (E + E + E / agent.policy_delay)
+    summ = {"value": world * E * steps / elapsed, "unit": "env-steps/s", "steps": steps, "warmup": warmup, "settle_steps": settle,
+            "ms_per_step": 1e3 * elapsed / steps,
+            "workload": f"cartpole TD3 closed loop (BASELINE config 5): {E} environments/GPU, one environment step + one "
+                        f"TD3 update (batch {E}, policy_delay 2) per step; MPC solves per step and GPU: {E} warm (actor) "
+                        f"+ {E} cold (target actor) + {E // 2} cold with du0*/dtheta (policy gradient); "
+                        + ("roll-out step and update replayed as HIP graphs" if graphs else "eager launches"),
+            "mpc_solves_per_s": solves / elapsed, "converged_fraction": st["converged_fraction"], "critic_loss": tr["critic_loss"],
+            # launch shape of the solves (mpcrl_set_launch_mode 0): probe times in ms of the two shapes and the one in use
+            "replay_launch_shape": {"target_actor": list(agent.target_mpc.mpc.launch_times()), "policy": list(agent.pi_mpc.mpc.launch_times()),
+                                    "rollout_warm": list(agent.actor.mpc.launch_times(warm=True))}}
+    del agent, env
+    return elapsed, summ
+
+
+def td3_bench(args):
+    """BASELINE config 5: cartpole TD3 closed loop — 4096 batched environments per GPU, the MPC as the actor (one launch per
+    environment step, warm-started, cold only where an episode ended), device replay, critic TD update with the target actor's
+    batched solve, delayed deterministic policy gradient through du0*/dtheta, ONE all-reduce (critic gradients + theta-gradient)
+    per update.  A step = one environment step of all environments + one TD3 update (batch 4096 per rank)."""
+    world, rank, local, dist, dev = init_ranks(args)
+    rccl_ranks = count_ranks(dist, dev)
+    metric = "closed-loop environment steps/sec, cartpole TD3 with the MPC as actor"
+    if DRY:
+        elapsed, _, _ = timed_steps(None, args, dist, dev, rank)
+        if rank == 0:
+            dry_line(args, world, rccl_ranks, elapsed, metric)
+        return finish_ranks(dist)
+    settle = SETTLE["td3"] if SETTLE_OVERRIDE is None else SETTLE_OVERRIDE
+    elapsed, summ = td3_measure(args.batch, args.steps, args.warmup, not args.no_graph, world, rank, dist, dev, settle)
     if rank == 0:
-        # MPC solves per step and rank: E (roll-out, warm) + E (target actor, cold) + E / policy_delay (policy + sensitivities, cold)
-        solves = world * args.steps * (E + E + E / agent.policy_delay)
         print(json.dumps({
-            "metric": "closed-loop environment steps/sec, cartpole TD3 with the MPC as actor", "value": world * E * args.steps / elapsed,
-            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle, "ms_per_step": 1e3 * elapsed / args.steps,
+            "metric": metric, "value": summ["value"],
+            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle, "ms_per_step": summ["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"cartpole TD3 closed loop (BASELINE config 5): {E} environments/GPU, one environment step + one "
-                                   f"TD3 update (batch {E}, policy_delay 2) per step; MPC solves per step and GPU: {E} warm (actor) "
-                                   f"+ {E} cold (target actor) + {E // 2} cold with du0*/dtheta (policy gradient); "
-                                   + ("roll-out step and update replayed as HIP graphs" if not args.no_graph else "eager launches"),
+            "config": {"workload": summ["workload"],
                        "parallelism": f"environments sharded over {world} GPU(s); one all-reduce of the critic + theta gradients per update",
-                       "mpc_solves_per_s": solves / elapsed, "converged_fraction": st["converged_fraction"],
-                       "critic_loss": tr["critic_loss"],
-                       # launch shape of the replay solves (mpcrl_set_launch_mode 0): probe times in ms and the shape in use
-                       "replay_launch_shape": {"target_actor": list(agent.target_mpc.mpc.launch_times()), "policy": list(agent.pi_mpc.mpc.launch_times()),
-                                               "rollout_warm": list(agent.actor.mpc.launch_times(warm=True))}},
+                       "mpc_solves_per_s": summ["mpc_solves_per_s"], "converged_fraction": summ["converged_fraction"],
+                       "critic_loss": summ["critic_loss"], "replay_launch_shape": summ["replay_launch_shape"]},
             **({"rccl_ranks": rccl_ranks} if rccl_ranks is not None else {})}), flush=True)
     finish_ranks(dist)
 
@@ -543,7 +569,8 @@ def main():
     ap.add_argument("--rti", action="store_true", help="one SQP iteration from the stored iterate (build-side mode)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--settle", type=int, default=-1, help="untimed steps before the W warm-ups that bring an idle GPU to its sustained "
-                    "clocks (reported as settle_steps); -1 = per workload (cartpole / linear 40, chain 3, TD3 10), 0 = none")
+                    "clocks (reported as settle_steps); -1 = per workload (headline 0 + a separate steady_state window, linear 40, "
+                    "chain 3, TD3 10), 0 = none anywhere")
     ap.add_argument("--no-secondary", action="store_true", help="headline run: skip the chain5 / chain7 / linear figures measured after "
                     "the headline's timed region and attached to the line as `secondary`")
     ap.add_argument("--no-graph", action="store_true", help="td3 workload: eager launches instead of replayed HIP graphs")
@@ -576,11 +603,21 @@ def main():
         if rank == 0:
             dry_line(args, world, rccl_ranks, elapsed, metric, sec)
         return finish_ranks(dist)
-    # The box's achievable HBM rate (roofline.peak_measured) is probed BEFORE the measurement, on every rank: it is part of the line
-    # anyway, and ~50 ms of streaming copies also take the GPU out of its idle clocks — with the driver's W = 5, K = 20 the timed
-    # window is 10 ms long and otherwise runs while the clocks still ramp (0.550 ms/step against 0.531 at K = 50: DESIGN.md §5).
+    # The headline: the driver's contract and nothing else — W warm-ups, then EXACTLY K timed steps (no settle steps, the HBM probe
+    # after the region).  With W = 5, K = 20 the 10 ms window sits on the clock ramp of a GPU that was idle; what the
+    # same binary does once the clocks have settled is measured by a SECOND window after it and reported as `steady_state`, a
+    # separately labelled field that never feeds `value` / `ms_per_step`.
+    headline = not linear
+    elapsed, summ, ocp, x0_np, status, iters = small_measure(linear, B, sens, args.rti, args.steps, args.warmup, world, rank, dist, dev,
+                                                             settle_kind="headline" if headline else "small")
+    steady = None
+    if headline and SETTLE_OVERRIDE is None:
+        s_el, s_summ = small_measure(linear, B, sens, args.rti, args.steps, args.warmup, world, rank, dist, dev, settle_kind=STEADY_SETTLE)[:2]
+        steady = {"ms_per_step": s_summ["ms_per_step"], "value": s_summ["value"], "unit": "solves/s", "settle_steps": STEADY_SETTLE,
+                  "steps": args.steps, "warmup": args.warmup, "kernel_ms": s_summ["roofline"]["kernel_ms"],
+                  "note": "the same workload and W / K measured again after the headline's region and %d more untimed steps (sustained "
+                          "clocks): round 5's headline protocol; not part of value / ms_per_step" % STEADY_SETTLE}
     peak_meas = measured_hbm_peak(dev)
-    elapsed, summ, ocp, x0_np, status, iters = small_measure(linear, B, sens, args.rti, args.steps, args.warmup, world, rank, dist, dev)
     # the headline's timed region is over: the other configurations are measured after it, never inside it
     sec = secondary_lines(world, rank, dist, dev) if want_secondary else None
 
@@ -612,6 +649,8 @@ def main():
         if world == 1 and not args.no_cpu:
             from oracle.problems import make_cartpole, make_linear_system
             out["cpu_baseline"] = cpu_baseline_guarded(make_linear_system(gamma=0.99) if linear else make_cartpole(), x0_np, sens)
+        if steady is not None:
+            out["steady_state"] = steady
         if sec is not None:
             out["secondary"] = sec
         print(json.dumps(out), flush=True)

@@ -41,7 +41,9 @@
  *     solve kernel; environment MPCRL_TIME_SLICE=0/1 read at mpcrl_create overrides the automatic choice)
  *     never changes a result bit.
  *   - linear-system model: environment MPCRL_LINEAR_SPL=1 at mpcrl_create keeps the one-stage-per-lane solve kernel instead
- *     of the three-stages-per-lane one (same iteration, sums associated differently: results equal to rounding).
+ *     of the three-stages-per-lane one.  Same iteration, sums associated differently: results equal to rounding EXCEPT where a
+ *     stopping test is met within rounding — there the interior-point count can differ by one, an RTI call's status can differ,
+ *     and the outputs agree to the QP tolerance only (see ABI 110 below).
  *   - cartpole: a wavefront holds min(floor(64 / (N + 1)), 4) instances — four is the number of 4x4 blocks of the
  *     matrix-core sweeps — so horizons below N = 15 use fewer of its lanes than a lane-per-stage packing could.
  */
@@ -59,8 +61,14 @@ extern "C" {
  *   100  rounds 1-3
  *   110  round 4/5: mpcrl_query_time_sliced(h, flags, stream) gained `stream`; mpcrl_env_cartpole_step / _reset and
  *        mpcrl_env_linear_step gained `obs_f32` (obs became void*); mpcrl_set_exit_rule accepts the chain of masses;
- *        mpcrl_create refuses chain horizons whose trajectories do not fit the LDS of one workgroup (MPCRL_E_ARG) */
-#define MPCRL_ABI_VERSION 110
+ *        mpcrl_create refuses chain horizons whose trajectories do not fit the LDS of one workgroup (MPCRL_E_ARG).
+ *        Behavioural change under 110 (round 5): the linear-system model's default solve kernel became lq_solve_kernel (three
+ *        stages per lane; MPCRL_LINEAR_SPL=1 keeps the old one) — the SAME iteration with its sums associated differently, so a
+ *        stopping test that is met within rounding can end an interior-point loop one iteration earlier or later (< 1 % of
+ *        instances), or flip the status of an RTI call whose residual sits at the tolerance; outputs of such an instance then
+ *        agree with the one-stage kernel and the oracle port to the QP tolerance (1e-4 ... 1e-3 on du0/dp), not to rounding
+ *   120  round 6: mpcrl_solve flags MPCRL_NO_BND_STORE and MPCRL_EXACT_QP (test-only) */
+#define MPCRL_ABI_VERSION 120
 
 enum { MPCRL_MODEL_CARTPOLE = 0, MPCRL_MODEL_LINEAR = 1, MPCRL_MODEL_CHAIN = 2 };
 /* how the stage-cost scaling c_k is built (rlmpc/mpc/nlp.py:1044-1055 vs 1083-1091) */
@@ -71,9 +79,22 @@ enum {
     MPCRL_SENS_PI = 2, /* du0* / dp                        nlp.py:1413-1424 */
     MPCRL_RTI = 4,     /* one SQP iteration from the stored iterate (build-side mode; the reference always runs full SQP) */
     MPCRL_COLD = 8,    /* ignore the stored iterate: x_k = x0, u = 0, multipliers 0 (MPC.reset, mpc.py:204-210) */
-    MPCRL_COLD_DUAL = 16 /* start from the stored x, u, pi but ignore the stored bound multipliers / slacks (the interior point
+    MPCRL_COLD_DUAL = 16, /* start from the stored x, u, pi but ignore the stored bound multipliers / slacks (the interior point
                             starts from its default point).  Implied for the first solve after mpcrl_set_iterate(bnd = NULL):
                             the reference's `for stage: ocp_solver.set(stage, "x", x0)` initial guess (mpc.py:208-210) */
+    MPCRL_NO_BND_STORE = 32, /* ABI 120.  Do not write the bound multipliers / slacks of the solution back into the handle's stored
+                            iterate (ten planes of (N+1)(nx+nu) doubles per instance: 3.4 of the 4.7 KB a linear-system solve
+                            writes).  x, u, pi are still stored; the planes keep what they held, the NEXT solve behaves as with
+                            MPCRL_COLD_DUAL, and mpcrl_get_iterate's bnd describes the last solve that did store them
+                            (mpcrl_get_lagrangian stays current).  For callers that start every solve cold (a replay batch, the benchmark) or only ever
+                            warm-start the primal iterate.  Honoured by the linear-system solve kernel (lq_solve_kernel); the
+                            other kernels ignore it (they store, which is always allowed) */
+    MPCRL_EXACT_QP = 64  /* ABI 120, TEST-ONLY, cartpole, full SQP only (not with MPCRL_RTI; other models: MPCRL_E_ARG): every QP of
+                            the SQP is solved to the tight interior-point tolerance from a cold interior-point start, fixed
+                            fraction to the boundary, no predictor-only steps — what acados + HPIPM do with the reference's
+                            options (config/cartpole.yaml:8-14) and what the oracle's frozen ORACLE_EXACT mode does.  Runs the
+                            plain launch shape of a separate kernel instantiation; tests/test_gpu_fullsize.py holds the shipped
+                            (inexact-SQP) iteration to it at 1e-6 on the benchmark's inputs.  ~5 x slower: never use it to time */
 };
 enum { MPCRL_E_ARG = -1, MPCRL_E_MODEL = -2, MPCRL_E_HIP = -3, MPCRL_E_NOMEM = -4 };
 

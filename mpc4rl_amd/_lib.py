@@ -7,8 +7,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPCRL_LIB_PATH") or os.path.join(_HERE, "libmpcrl_hip.so")   # the override is for instrumented builds (profiles/microbench)
 
-ABI_VERSION = 110        # MPCRL_ABI_VERSION of include/mpcrl.h this binding was written against
+ABI_VERSION = 120        # MPCRL_ABI_VERSION of include/mpcrl.h this binding was written against
 SENS_V, SENS_PI, RTI, COLD = 1, 2, 4, 8
+COLD_DUAL, NO_BND_STORE, EXACT_QP = 16, 32, 64        # (EXACT_QP: test-only, include/mpcrl.h)
 MODEL_CARTPOLE, MODEL_LINEAR, MODEL_CHAIN = 0, 1, 2
 COST_NLS, COST_EXTERNAL = 0, 1
 NO_BOUND = 1e30

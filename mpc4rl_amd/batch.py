@@ -153,8 +153,12 @@ class MPCBatch:
         self._check(self.lib.mpcrl_set_order(self._h, _ptr(perm), self._stream()), "mpcrl_set_order")
 
     def solve(self, x0, u0=None, sens_v: bool = False, sens_pi: bool = False, rti: bool = False, cold: bool = False,
-              reorder: bool = True, cold_mask: Optional[torch.Tensor] = None) -> SolveResult:
-        """cold_mask [B] (bool / int): these instances ignore their stored iterate (per-environment ``mpc.reset`` at an episode end)."""
+              reorder: bool = True, cold_mask: Optional[torch.Tensor] = None, store_bounds: bool = True,
+              exact_qp: bool = False) -> SolveResult:
+        """cold_mask [B] (bool / int): these instances ignore their stored iterate (per-environment ``mpc.reset`` at an episode end).
+        store_bounds = False (MPCRL_NO_BND_STORE): the bound multipliers / slacks of the solution are not written back to the stored
+        iterate — for callers that start every solve cold; the next solve then starts its interior point from the default point.
+        exact_qp (MPCRL_EXACT_QP, test-only, cartpole): every QP solved to the tight tolerance, the reference's acados / HPIPM setting."""
         x0 = self._dev(x0, (self.B, self.nx))
         if cold_mask is not None:
             cm = cold_mask.to(device=self.device, dtype=torch.int32).reshape(self.B).contiguous()
@@ -162,7 +166,7 @@ class MPCBatch:
                 self._check(self.lib.mpcrl_set_cold_mask(self._h, _ptr(cm), self._stream()), "mpcrl_set_cold_mask")
         u0f = None if u0 is None else self._dev(u0, (self.B, self.nu))
         flags = (_lib.SENS_V if sens_v else 0) | (_lib.SENS_PI if sens_pi else 0) | (_lib.RTI if rti else 0) | \
-            (_lib.COLD if cold else 0)
+            (_lib.COLD if cold else 0) | (0 if store_bounds else _lib.NO_BND_STORE) | (_lib.EXACT_QP if exact_qp else 0)
         if reorder:
             if self.lib.mpcrl_query_time_sliced(self._h, flags, self._stream()) == 1:
                 # the time-sliced launch deals the batch out in quarters: no packing order needed (and none left over from before)
@@ -181,7 +185,7 @@ class MPCBatch:
             rc = self.lib.mpcrl_solve(self._h, _ptr(x0), _ptr(u0f), flags, _ptr(u0_out), _ptr(V), _ptr(dV), _ptr(dpi),
                                       _ptr(status), _ptr(iters), self._stream())
         self._check(rc, "mpcrl_solve")
-        self.has_iterate = self.duals_valid = True
+        self.has_iterate, self.duals_valid = True, bool(store_bounds)
         return SolveResult(u0_out, V, status, iters, dV, dpi)
 
     def get_action(self, x0) -> torch.Tensor:

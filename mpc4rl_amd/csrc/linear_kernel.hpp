@@ -902,7 +902,9 @@ __global__ void __launch_bounds__(64, 1) lq_solve_kernel(const SmallSpec sp, con
     {   // the instance's parameters and the bound table (one copy per wavefront)
         double *thw = th_lds + (slot < ipw ? slot : MAXI) * 12;
         const double *th = a.theta + (size_t)inst * a.theta_stride;
-        for (int e = pos; e < 12; e += lpi) thw[e] = th[e];
+        // (the lanes past the last instance slot fill THEIR slot completely, however few they are: at N = 60..62 there is one)
+        const int spare = 64 - ipw * lpi;
+        for (int e = slot < ipw ? pos : lane - ipw * lpi; e < 12; e += slot < ipw ? lpi : spare) thw[e] = th[e];
         if (lane < 18) {
             const int kd = lane / 6, e = lane - kd * 6, sd = e / 3, i = e - sd * 3;
             double v;
@@ -1095,6 +1097,7 @@ __global__ void __launch_bounds__(64, 1) lq_solve_kernel(const SmallSpec sp, con
                 if (!S.first[j]) a.PI[(inst * N + k - 1) * NX + i] = S.nu[j][i];
             }
             if (!S.term[j]) a.U[(inst * N + k) * NU] = S.u[j];
+            if (a.flags & 32) continue;      // MPCRL_NO_BND_STORE (wave-uniform): the caller will not warm-start the interior point from this solve
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 bnd[0 * nb + i] = S.has(j, 0, i) ? S.lam[j][0][i] : 0.0, bnd[1 * nb + i] = S.has(j, 1, i) ? S.lam[j][1][i] : 0.0;

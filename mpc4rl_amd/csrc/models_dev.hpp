@@ -38,7 +38,11 @@ struct SmallSpec {
 struct CartpoleDev {
     static constexpr int NX = 4, NU = 1, NW = 5, NP = 83, NTD = 3, NTC = 0;
     static constexpr bool DISCRETE = false, HAS_SOFT = false, SKIP_CORRECTOR = true;
-    static constexpr int MAX_IPW = 4;   // instances per wavefront: the matrix-core factor sweep has four 4x4 blocks
+    static constexpr bool EXACT_QP = false;   // (true only in CartpoleDevExact below)
+#ifndef MPCRL_CARTPOLE_MAX_IPW
+#define MPCRL_CARTPOLE_MAX_IPW 4
+#endif
+    static constexpr int MAX_IPW = MPCRL_CARTPOLE_MAX_IPW;   // instances per wavefront: the matrix-core factor sweep has four 4x4 blocks
 #ifndef MPCRL_CARTPOLE_SEG_SKIP
 #define MPCRL_CARTPOLE_SEG_SKIP 0
 #endif
@@ -114,9 +118,19 @@ struct CartpoleDev {
     MPCRL_DI static void cost_mixed(bool, const double *, double, double *) {}
 };
 
+// Test-only model variant behind MPCRL_EXACT_QP (include/mpcrl.h): the cartpole OCP with every QP solved to the tight interior-point
+// tolerance — no inexact-SQP forcing term, no interior-point warm start across QPs, fixed fraction to the boundary, no predictor-only
+// steps: what acados + HPIPM do with the reference's options (config/cartpole.yaml:8-14), and the device-side twin of the frozen
+// exact-QP mode the CPU checker of the test suite has.  A separate instantiation of the plain solve kernel: the shipped kernels compile
+// to the code they had without it.
+struct CartpoleDevExact : CartpoleDev {
+    static constexpr bool SKIP_CORRECTOR = false, EXACT_QP = true;
+};
+
 struct LinearDev {
     static constexpr int NX = 2, NU = 1, NW = 3, NP = 12, NTD = 8, NTC = 4;
     static constexpr bool DISCRETE = true, HAS_SOFT = true, SKIP_CORRECTOR = false;
+    static constexpr bool EXACT_QP = false;
     static constexpr int MAX_IPW = 21;   // N >= 2
     static constexpr bool SEG_SKIP = true;
     MPCRL_DI static int td_index(int i) { return i; }

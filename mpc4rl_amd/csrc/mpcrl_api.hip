@@ -183,6 +183,14 @@ template <class M>
 int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
     const int lpi = h->N + 1, ipw = std::min(64 / lpi, M::MAX_IPW);
     const int blocks = (h->B + ipw - 1) / ipw;
+    if constexpr (std::is_same<M, CartpoleDev>::value) {
+        if (a.flags & MPCRL_EXACT_QP) {   // test-only: the exact-QP instantiation of the plain solve kernel, then the shipped sensitivity pass
+            hipLaunchKernelGGL(small_solve_kernel<CartpoleDevExact>, dim3(blocks), dim3(64), 0, st, h->small, a);
+            if (a.flags & (MPCRL_SENS_V | MPCRL_SENS_PI)) hipLaunchKernelGGL(small_sens_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
+            HIP_OK(hipGetLastError());
+            return 0;
+        }
+    }
     bool sliced = false;
     int timed_shape = -1;
     if constexpr (!M::HAS_SOFT) {
@@ -232,10 +240,13 @@ int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
         constexpr int SPL = 3;
         // lanes per instance -> layout: <= 8 half rows (eight instances per wavefront), <= 16 rows (four), else packed segments
         const int lpi3 = lq_lanes_per_instance<SPL>(h->N), rl = lpi3 <= 8 ? 8 : (lpi3 <= 16 ? 16 : 0), ipw3 = rl ? 64 / rl : std::min(64 / lpi3, 8);
-        if (h->linear_spl == SPL && ipw3 > ipw) {
+        static_assert(LinearDev::HAS_SOFT, "the lq branch relies on `sliced` staying false for this model (no time-sliced launch with soft bounds)");
+        if (!sliced && h->linear_spl != 1 && ipw3 > ipw) {
             lq = true;
             const dim3 grid((unsigned)((h->B + ipw3 - 1) / ipw3));
-            if (rl == 16)
+            if (rl == 0 && h->linear_spl == 4)      // horizons 48 <= N <= 63 with FOUR stages per lane: 16 lanes per instance, rows again
+                hipLaunchKernelGGL((lq_solve_kernel<4, 16>), dim3((unsigned)((h->B + 3) / 4)), dim3(64), 0, st, h->small, a);
+            else if (rl == 16)
                 hipLaunchKernelGGL((lq_solve_kernel<SPL, 16>), grid, dim3(64), 0, st, h->small, a);
             else if (rl == 8)
                 hipLaunchKernelGGL((lq_solve_kernel<SPL, 8>), grid, dim3(64), 0, st, h->small, a);
@@ -306,6 +317,7 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
         if (e && *e) h->slice_mode = (*e == '0') ? -1 : 1;
         const char *l = std::getenv("MPCRL_LINEAR_SPL");   // stages per lane of the linear-system solve kernel: 3 (default) or 1
         if (l && *l == '1') h->linear_spl = 1;
+        if (l && *l == '4') h->linear_spl = 4;      // (as 3, but four stages per lane where three need more than a DPP row: N >= 48)
     }
     int rc = 0;
     switch (spec->model) {
@@ -547,6 +559,7 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
     if ((flags & MPCRL_SENS_PI) && !dpi_dp) return MPCRL_E_ARG;
     ON_DEVICE(h->device);
     hipStream_t st = (hipStream_t)stream;
+    if ((flags & MPCRL_EXACT_QP) && (h->model != MPCRL_MODEL_CARTPOLE || (flags & MPCRL_RTI))) return MPCRL_E_ARG;
     if (!h->have_iterate) flags |= MPCRL_COLD;
     if (h->dual_cold) flags |= MPCRL_COLD_DUAL;
     SmallArgs a;
@@ -573,7 +586,8 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
             case MPCRL_MODEL_LINEAR: rc = launch_small<LinearDev>(h, a, st); break;
             default: rc = MPCRL_E_MODEL;
         }
-    if (!rc) h->have_iterate = true, h->dual_cold = false;
+    // (a solve that left the bound planes alone: the next one must not start its interior point from them)
+    if (!rc) h->have_iterate = true, h->dual_cold = (flags & MPCRL_NO_BND_STORE) != 0;
     return rc;
 }
 

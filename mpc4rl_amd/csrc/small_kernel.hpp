@@ -47,6 +47,9 @@ constexpr double IPM_ADAPT_C = 1e1, IPM_ADAPT_CAP = 3e-2;
 // it is the Newton step of a QP that is all but solved: it is taken and the corrector's two vector sweeps are not run.  Models opt in
 // (M::SKIP_CORRECTOR: the cartpole — a third of its interior-point iterations, none more needed).
 constexpr double IPM_SKIP_SIGMA = 3e-6;
+#ifndef MPCRL_MX_SLOTS
+#define MPCRL_MX_SLOTS 64        // stage slots of the matrix-layout sweeps in LDS (one per lane)
+#endif
 // Adjoint (sensitivity) solve: the stiffness lam / t of an active bound row is capped.  A row whose slack the interior point took to
 // 1e-18 pins its coordinate either way (the answer moves by O(1 / stiffness)), but 1e19 on the diagonal of a STATE block costs the
 // Riccati recursion all sixteen digits of the entries next to it (against a dense pivoted solve on the hardest test instances:
@@ -584,8 +587,13 @@ struct SmallSolver {
     static constexpr int mxAH = 0, mxCol = 32, mxRow = 48, mxK = 56, mxMisc = 60,
                          MSLOT = 66,   // 64 slots = 33 KB: four single-wave workgroups fit one CU's LDS, with room for a parked instance;
                                        // 66 doubles = 132 words = 4 mod 64 banks: the stage lanes' ds_*_b128 are conflict-free
-                         mxFlag = 64 * MSLOT, mxDump = mxFlag + 4, MX_LDS = mxDump + 2;
+                         MX_SLOTS = MPCRL_MX_SLOTS, mxFlag = MX_SLOTS * MSLOT, mxDump = mxFlag + 4, MX_LDS = mxDump + 2;
     double *ms = nullptr;   // LDS, 64 slots of MSLOT doubles (one per stage lane)
+    // (MPCRL_MX_SLOTS < 64, an experiment build: the lanes past the last instance share the last slot as a dump)
+    MPCRL_DI static int my_slot() {
+        const int l = threadIdx.x & 63;
+        return MX_SLOTS == 64 ? l : (l < MX_SLOTS - 1 ? l : MX_SLOTS - 1);
+    }
     // LDS cost table, one per instance of the wavefront: for each stage kind (0 = stage 0, 1 = interior, 2 = terminal) the packed
     // lower triangle of the UNSCALED stage-cost Hessian and the reference point of the residual (cartpole: W_0 / W / W_e and
     // yref_0 / yref / yref_e out of the instance's parameter vector, so that set_parameter / cost_set reach the solve as they do
@@ -642,7 +650,7 @@ struct SmallSolver {
     // stage lane -> slot: everything of the stage but A_k (written by the linearisation, never overwritten); the sweeps overwrite most of it
     template <class HF>
     MPCRL_DI void mx_publish(HF Hs, const double *g, const double *bb) {
-        double *sl = ms + (threadIdx.x & 63) * MSLOT;
+        double *sl = ms + my_slot() * MSLOT;
 #pragma unroll
         for (int i = 0; i < NX; ++i)
 #pragma unroll
@@ -812,7 +820,7 @@ struct SmallSolver {
         mx_chain<true>();
         wave_lds_sync();
         PHW(3);
-        const double *sl = ms + (threadIdx.x & 63) * MSLOT;
+        const double *sl = ms + my_slot() * MSLOT;
         const mx_d2 k01 = lds_pair(sl + mxK), k23 = lds_pair(sl + mxK + 2), rk = lds_pair(sl + mxMisc);
         const double Kl[NX] = {k01.x, k01.y, k23.x, k23.y};
 #pragma unroll
@@ -826,7 +834,7 @@ struct SmallSolver {
     }
     // Corrector: new right-hand side g (bb unchanged), same factorisation: backward chain, feed-forward terms, forward chain
     MPCRL_DI void mx_corr(const double *g, const double *bb) {
-        double *sl = ms + (threadIdx.x & 63) * MSLOT;
+        double *sl = ms + my_slot() * MSLOT;
         const mx_d2 k01 = lds_pair(sl + mxK), k23 = lds_pair(sl + mxK + 2);
         const double Kl[NX] = {k01.x, k01.y, k23.x, k23.y};
 #pragma unroll
@@ -840,7 +848,7 @@ struct SmallSolver {
         wave_lds_sync();
         PHW(6);
         // kff_k = (g_u + beta_k + B_k' p_{k+1}) / R_k,  d_k = bb_k - B_k kff_k   (stage-parallel: p_{k+1} is read out of the next slot)
-        const double *nx_ = (term || (threadIdx.x & 63) == 63) ? sl : sl + MSLOT;   // (lane 63 has no slot behind it)
+        const double *nx_ = (term || (threadIdx.x & 63) >= MX_SLOTS - 1) ? sl : sl + MSLOT;   // (the last slot has none behind it)
         const mx_d2 rk = lds_pair(sl + mxMisc);
         double mvu = g[0] + sl[mxMisc + 2];
 #pragma unroll
@@ -865,7 +873,7 @@ struct SmallSolver {
     // Dnu_k = P_k Dx_k + p_k (multipliers of the arriving dynamics).  own_p: the terminal lane's p_N is its own g_x (predictor /
     // adjoint right-hand side, where the slots hold p_k for k < N only); after the backward chain p_N is in the slot as well
     MPCRL_DI void mx_dnu(const double *g, bool own_p) {
-        const double *sl = ms + (threadIdx.x & 63) * MSLOT;
+        const double *sl = ms + my_slot() * MSLOT;
         double Pl[NPK];
 #pragma unroll
         for (int i = 0; i < NX; ++i)
@@ -1330,7 +1338,7 @@ struct SmallSolver {
             const double ratio = mu > 0.0 ? mu_aff * fast_rcp(mu) : 0.0;
             const double sig3 = ratio * ratio * ratio;
             const double smu = sig3 * mu;
-            const double frac = M::DISCRETE ? IPM_FRAC : fmax(IPM_FRAC, 1.0 - mu);   // fraction to the boundary -> 1 as mu -> 0 (LQ model: fixed)
+            const double frac = (M::DISCRETE || M::EXACT_QP) ? IPM_FRAC : fmax(IPM_FRAC, 1.0 - mu);   // fraction to the boundary -> 1 as mu -> 0 (LQ model, exact-QP mode: fixed)
             // the step along (Dx, Du, Dnu) and the rows' directions of `pass`: rows of (i, sd) only read their own side's state, so they
             // can be advanced in place; e12: sum lam t after the step = musum + alpha e12[0] + alpha^2 e12[1]
             auto take_step = [&](int pass, double smu_, double alpha, const double *e12) {
@@ -1621,8 +1629,11 @@ MPCRL_DI void small_sens_tail(SmallSolver<M> &S, const SmallArgs &a, long inst, 
 #ifndef MPCRL_LINEAR_OCC
 #define MPCRL_LINEAR_OCC 2   // linear system (one instance per wavefront, N = 40): two wavefronts per SIMD measured faster than one
 #endif
+#ifndef MPCRL_CARTPOLE_OCC
+#define MPCRL_CARTPOLE_OCC 1     // (2 + MPCRL_CARTPOLE_MAX_IPW=2 + MPCRL_MX_SLOTS=43: the two-wavefronts-per-SIMD experiment of round 6, profiles/README.md)
+#endif
 template <class M>
-__global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_solve_kernel(const SmallSpec sp, const SmallArgs a) {
+__global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : MPCRL_CARTPOLE_OCC) small_solve_kernel(const SmallSpec sp, const SmallArgs a) {
     constexpr int NX = M::NX, NU = M::NU, NW = NX + NU, NP = M::NP, NTD = M::NTD, NTC = M::NTC;
     constexpr bool SOFT = M::HAS_SOFT;
     const int lane = threadIdx.x;
@@ -1783,11 +1794,11 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : 1) small_
             }
         }
         // QP tolerances of this iteration (per instance)
-        const double rr_ = fmin(1.0, rmax), ad_ = (rmax < sp.tol || M::DISCRETE) ? 0.0 : IPM_ADAPT_C * rr_ * rr_;   // LQ model: first QP is the answer
+        const double rr_ = fmin(1.0, rmax), ad_ = (rmax < sp.tol || M::DISCRETE || M::EXACT_QP) ? 0.0 : IPM_ADAPT_C * rr_ * rr_;   // LQ model: first QP is the answer
         const double tol_res = fmin(IPM_ADAPT_CAP, fmax(IPM_TOL_RES, ad_)), tol_mu = fmin(0.1 * IPM_ADAPT_CAP, fmax(IPM_TOL_MU, 1e-2 * ad_));
         if (live) last_tight = tol_res <= IPM_TOL_RES && tol_mu <= IPM_TOL_MU;
         if (!__any(live)) break;
-        const double warm_mu = stepn < 0.0 ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
+        const double warm_mu = (stepn < 0.0 || M::EXACT_QP) ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
         const bool ok = S.qp_solve(live, S.x0r, S.u0r, n_ipm, warm_mu, tol_res, tol_mu);
         if (live && !ok) status = 4, live = false;
         {

@@ -5,7 +5,14 @@ The reference's own sanity check of dpi/dp on the chain is finite differences al
 n_mass = 3 NLP (N = 40: 480 unknowns, bounds on the controls) at the perturbed state of G7 and at p (1 +- delta) for four parameters
 (the mass m_0, a spring constant D_1_0, a rest length L_0_2 and the swept kind of parameter, the damping C_1_0), delta = 1e-5 and
 1e-4; every point is KKT-certified.  Central differences of V and u0* give dV/dp and du0*/dp columns that the port and the HIP path
-are held to.  Inputs and expected outputs only (g8_chain_grad.npz)."""
+are held to.  Inputs and expected outputs only (g8_chain_grad.npz).
+
+G8_NMASS=5 (round 6): the size the reference's own test runs (tests/test_chain_mass.py -> rlmpc/examples/chain_mass.py:133-174 sweeps
+C_3_0 at n_mass 5): 960 unknowns, the state of G7's chain5 rows, the parameters C_3_0 (the swept one) and the mass m_1.  A cold SLSQP
+solve of this NLP took 4.4 h (G7) and its full vector was not kept, so the BASE solve starts from the KKT point the C++ port finds
+(u0*, V of which equal G7's SLSQP numbers at 1e-6); SLSQP polishes it to its own stopping test and the certificate is computed here.
+The base point does not enter a central difference: each gradient entry is the difference of two SLSQP solutions at p (1 +- delta),
+which SLSQP reaches from the base point by its own iteration, each KKT-certified."""
 import os
 import sys
 
@@ -22,7 +29,7 @@ from oracle.problems import make_chain_mass  # noqa: E402
 torch.set_num_threads(1)
 # G8_NMASS=4 in the environment: the same for n_mass 4 (720 unknowns), two parameters, written to g8_chain4_grad.npz
 N_MASS = int(os.environ.get("G8_NMASS", "3"))
-LABELS = ("m_0", "D_1_0", "L_0_2", "C_1_0") if N_MASS == 3 else ("D_1_0", "C_2_0")
+LABELS = {3: ("m_0", "D_1_0", "L_0_2", "C_1_0"), 4: ("D_1_0", "C_2_0"), 5: ("C_3_0", "m_1")}[N_MASS]
 DELTA = (1e-5, 1e-4)
 PARTS = "/tmp/g8_parts" if N_MASS == 3 else f"/tmp/g8_parts_{N_MASS}"
 OUT = "g8_chain_grad.npz" if N_MASS == 3 else f"g8_chain{N_MASS}_grad.npz"
@@ -30,6 +37,8 @@ OUT = "g8_chain_grad.npz" if N_MASS == 3 else f"g8_chain{N_MASS}_grad.npz"
 
 def state():
     from mpc4rl_amd.problems import chain_mass_ocp
+    if N_MASS == 5:                          # G7's chain5 state (its generator draws it after the n_mass-3 one from the same stream)
+        return chain_mass_ocp(n_mass=5), np.load(os.path.join(HERE, "g7_thirdparty_grad.npz"))["chain5_x0"]
     rng = np.random.default_rng(31)          # the state of G7's chain rows
     ocp = chain_mass_ocp(n_mass=N_MASS)
     M = N_MASS - 2
@@ -48,8 +57,15 @@ def job(label):
     j = ocp.p_labels.index(label)
     p0 = P.p0.copy()
     nlp = Nlp(P, x0, p0)
-    zb, vb, _ = slsqp(nlp, cold(nlp, x0), max_rounds=6)
+    z_start = cold(nlp, x0)
+    if N_MASS == 5:
+        from oracle import cpu_port
+        r = cpu_port.solve(P, x0[None], tol=1e-9, flags=0)
+        assert r.status[0] == 0
+        z_start = np.concatenate([r.U[0].ravel(), r.X[0, 1:].ravel()])
+    zb, vb, itb = slsqp(nlp, z_start, max_rounds=6)
     kb = certify(nlp, zb)
+    print("chain", label, "base", zb[: P.nu], vb, itb, kb, flush=True)
     out = {"j": j, "u0": zb[: P.nu].copy(), "V": vb, "kkt": [kb["stationarity"], kb["feasibility"], kb["min_multiplier"]]}
     for d in DELTA:
         pp, pm = p0.copy(), p0.copy()

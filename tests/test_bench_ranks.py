@@ -47,16 +47,16 @@ def test_gpus_1_stays_in_process():
 
 
 def test_headline_line_carries_the_secondary_configurations():
-    """The driver only runs `bench.py --gpus 1`: the chain (BASELINE config 4) and linear-system (config 1) figures ride on that ONE
+    """The driver only runs `bench.py --gpus 1`: the chain (BASELINE config 4), linear-system (config 1) and TD3 (config 5) figures ride on that ONE
     line as `secondary`, measured by the same timed_steps AFTER the headline's timed region (its ms_per_step must not contain them);
     `--no-secondary` and every non-headline workload leave the field out."""
     import bench
     line = _run(1)
     sec = line["secondary"]
-    assert set(sec) == {wl for wl, _, _ in bench.SECONDARY} == {"chain5", "chain7", "linear"}
+    assert set(sec) == {wl for wl, _, _ in bench.SECONDARY} == {"chain5", "chain7", "linear", "td3"}
     for wl, steps, warmup in bench.SECONDARY:
         assert sec[wl]["steps"] == steps and sec[wl]["warmup"] == warmup and sec[wl]["ms_per_step"] >= 1.0
-    assert line["ms_per_step"] < 5.0                 # 1 ms sleeps: the ~70 secondary steps are not in the headline's region
+    assert line["ms_per_step"] < 5.0                 # 1 ms sleeps: the ~90 secondary steps are not in the headline's region
     assert "secondary" not in _run(1, workload="linear") and "secondary" not in _run(2)
     assert "secondary" not in _run(1, extra_args=["--no-secondary"])
 

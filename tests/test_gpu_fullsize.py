@@ -520,3 +520,95 @@ def test_launch_shape_tuner(monkeypatch):
         small.solve(x[:96], cold=True)
     torch.cuda.synchronize()
     assert small.launch_times()[:2] == (-1.0, -1.0)
+
+
+def test_exact_qp_mode_on_the_device_bench_inputs(oracle_port):
+    """SURVEY §7 hard-part 4 on the PRODUCT (round 6; until now shown on the CPU port only, tests/test_exact_vs_inexact.py): the
+    reference solves every QP to HPIPM's tolerance (config/cartpole.yaml:8-14, mpc.py:42); the shipped kernels run an inexact-SQP /
+    warm-started interior-point iteration.  MPCRL_EXACT_QP (test-only flag, a separate instantiation of the plain solve kernel:
+    forcing term off, cold interior-point starts, fixed fraction to the boundary, no predictor-only steps) runs the 4096 benchmark
+    inputs the exact way ON THE DEVICE: (a) the shipped iteration returns the same u0*, V, dV/dp, du0*/dp at 1e-6, every instance;
+    (b) the exact device mode is the port's frozen ORACLE_EXACT mode: statuses, iteration counts, outputs."""
+    import bench
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    from oracle.problems import make_cartpole
+    x0 = bench.make_inputs(4096, 0)
+    xt = torch.as_tensor(x0, device="cuda")
+    mpc = MPCBatch(cartpole_ocp(), 4096)
+    a = mpc.solve(xt, sens_v=True, sens_pi=True, cold=True)
+    e = mpc.solve(xt, sens_v=True, sens_pi=True, cold=True, exact_qp=True)
+    torch.cuda.synchronize()
+    assert bool((a.status == 0).all()) and bool((e.status == 0).all())
+    for name in ("u0", "V", "dV_dp", "dpi_dp"):
+        err = rel_rows(getattr(a, name).cpu().numpy(), getattr(e, name).cpu().numpy())
+        print("shipped vs exact-QP on the device:", name, float(err.max()))
+        assert err.max() < RTOL, (name, float(err.max()))
+    ia, ie = a.iters.cpu().numpy(), e.iters.cpu().numpy()
+    print("iterations shipped / exact: sqp %.2f / %.2f, interior point %.2f / %.2f" % (ia[:, 0].mean(), ie[:, 0].mean(), ia[:, 1].mean(), ie[:, 1].mean()))
+    assert abs(ia[:, 0].mean() - ie[:, 0].mean()) < 0.5 and ia[:, 1].mean() < 0.5 * ie[:, 1].mean()
+    ref = oracle_port.solve(make_cartpole(), x0, exact=True)
+    compare(e, ref, 1.0, name="exact-QP mode, device vs port")
+    # the flag is refused where it has no kernel
+    from mpc4rl_amd import linear_system_ocp
+    lin = MPCBatch(linear_system_ocp(), 4)
+    with pytest.raises(RuntimeError):
+        lin.solve(np.full((4, 2), 0.3), cold=True, exact_qp=True)
+    with pytest.raises(RuntimeError):
+        mpc.solve(xt, rti=True, exact_qp=True)
+
+
+def test_no_bnd_store_linear():
+    """MPCRL_NO_BND_STORE (round 6): same outputs bit for bit, the bound planes of the stored iterate untouched, x / u / pi stored,
+    and the next solve starts its interior point from the default point — exactly what a set_iterate(x, u, pi, bnd=None) does."""
+    from mpc4rl_amd import MPCBatch, linear_system_ocp
+    rng = np.random.default_rng(5)
+    B = 512
+    x0 = np.column_stack([rng.uniform(0.15, 0.85, B), rng.uniform(-0.5, 0.5, B)])
+    x1 = x0 + rng.uniform(-0.02, 0.02, x0.shape)
+    A, Bm = MPCBatch(linear_system_ocp(discount_factor=0.99), B), MPCBatch(linear_system_ocp(discount_factor=0.99), B)
+    bnd_before = A.get_iterate()[3].clone()
+    ra = A.solve(x0, sens_v=True, sens_pi=True, cold=True, store_bounds=False)
+    rb = Bm.solve(x0, sens_v=True, sens_pi=True, cold=True)
+    for n in ("u0", "V", "dV_dp", "dpi_dp", "status", "iters"):
+        assert torch.equal(getattr(ra, n), getattr(rb, n)), n
+    xa, ua, pa, bnda, _ = A.get_iterate()
+    xb, ub, pb, bndb, _ = Bm.get_iterate()
+    assert torch.equal(xa, xb) and torch.equal(ua, ub) and torch.equal(pa, pb)
+    assert torch.equal(bnda, bnd_before) and not torch.equal(bndb, bnd_before)
+    assert not A.duals_valid and Bm.duals_valid
+    Bm.set_iterate(xb, ub, pb, None)                   # primal / costate guess only: MPCRL_COLD_DUAL on the next solve
+    ra2, rb2 = A.solve(x1, sens_v=True, sens_pi=True), Bm.solve(x1, sens_v=True, sens_pi=True)
+    for n in ("u0", "V", "dV_dp", "dpi_dp", "status", "iters"):
+        assert torch.equal(getattr(ra2, n), getattr(rb2, n)), n
+    assert A.duals_valid
+
+
+def test_two_rccl_ranks_on_the_one_gpu():
+    """the only piece of the N > 1 path that never ran with RCCL and more than one rank (no multi-GPU node so
+    far).  bench.py --gpus 2 with both ranks on cuda:0 (MPCRL_BENCH_SHARE_GPU), 512 chain instances each: the line must report
+    rccl_ranks == 2.  RCCL may refuse two ranks on one device ("Duplicate GPU detected"); then the refusal is what gets recorded
+    (gpurun_out/r06_rccl_two_ranks_one_gpu.txt, copied to profiles/) and the test asserts that it is THAT error and nothing else."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"MPCRL_BENCH_SHARE_GPU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "NCCL_DEBUG": "WARN"})
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "chain5", "--batch", "512", "--steps", "3",
+                          "--warmup", "1", "--no-cpu"], env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    rec = os.path.join(root, "gpurun_out", "r06_rccl_two_ranks_one_gpu.txt")
+    if out.returncode == 0 and lines:
+        line = json.loads(lines[0])
+        with open(rec, "w") as fh:
+            fh.write("bench.py --gpus 2 --workload chain5 --batch 512, both ranks on cuda:0 (MPCRL_BENCH_SHARE_GPU=1):\n" + lines[0] + "\n")
+        assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2, line
+        assert "one all-reduce" in line["config"]["parallelism"]
+    else:
+        text = out.stderr + out.stdout
+        keep = [ln for ln in text.splitlines() if "alt_rsmi" not in ln and
+                any(w in ln for w in ("Duplicate GPU", "NCCL", "RCCL", "invalid usage", "ncclInvalidUsage", "Error", "error"))]
+        with open(rec, "w") as fh:
+            fh.write("bench.py --gpus 2 with both ranks on cuda:0 (MPCRL_BENCH_SHARE_GPU=1): RCCL refused, rc %d\n" % out.returncode + "\n".join(keep[-40:]) + "\n")
+        print("\n".join(keep[-12:]))
+        assert any(("Duplicate GPU" in ln) or ("invalid usage" in ln) or ("ncclInvalidUsage" in ln) for ln in keep), text[-3000:]

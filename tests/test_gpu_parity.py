@@ -610,7 +610,7 @@ def test_time_sliced_launch_warm_calls(N, tf, B, monkeypatch):
     assert it(sa[2], ok & mask) > 1.1 * it(sa[2], ok & ~mask)       # ... and an instance of the cold mask is not
 
 
-@pytest.mark.parametrize("N,B", [(40, 4096), (40, 101), (20, 37), (39, 64), (47, 50), (48, 50), (63, 23)])
+@pytest.mark.parametrize("N,B", [(40, 4096), (40, 101), (20, 37), (39, 64), (47, 50), (48, 50), (61, 21), (63, 23)])
 def test_linear_kernel_three_stages_per_lane_vs_one(N, B, monkeypatch):
     """lq_solve_kernel (linear_kernel.hpp: three stages per lane; four instances per wavefront in DPP rows at 9..16 lanes per instance,
     eight in half rows up to 8 lanes, packed segments beyond 16) against small_solve_kernel<LinearDev> (MPCRL_LINEAR_SPL=1: one stage per lane) on a closed-loop
