@@ -235,23 +235,23 @@ int launch_small(MpcrlSolver *h, const SmallArgs &a, hipStream_t st) {
     }
     bool lq = false;
     if constexpr (std::is_same<M, LinearDev>::value) {
-        // the linear-system model: three stages per lane, four instances per wavefront (linear_kernel.hpp) unless switched off
-        // (MPCRL_LINEAR_SPL=1 at mpcrl_create: one stage per lane, small_solve_kernel) or the horizon leaves it no advantage
-        constexpr int SPL = 3;
-        // lanes per instance -> layout: <= 8 half rows (eight instances per wavefront), <= 16 rows (four), else packed segments
-        const int lpi3 = lq_lanes_per_instance<SPL>(h->N), rl = lpi3 <= 8 ? 8 : (lpi3 <= 16 ? 16 : 0), ipw3 = rl ? 64 / rl : std::min(64 / lpi3, 8);
+        // the linear-system model: several stages per lane, four (eight) instances per wavefront each in a DPP row (half row) of its own
+        // (linear_kernel.hpp) unless switched off (MPCRL_LINEAR_SPL=1 at mpcrl_create: one stage per lane, small_solve_kernel) or the
+        // horizon leaves it no advantage.  Three stages per lane while they fit a row (N <= 47); beyond that FOUR (N <= 63 = the longest
+        // horizon mpcrl_create accepts: 16 lanes again).  Round 5 packed those horizons in segments of 17-22 lanes with __shfl
+        // (lq_solve_kernel<3, 0>): 1.31-1.54 ms per 4096 solves at N = 48..63 against 0.99-1.20 of the one-stage kernels and 0.69-0.74 of
+        // <4, 16> (profiles/r06_lq_long_horizons.txt) — gone.
+        const int lpi3 = lq_lanes_per_instance<3>(h->N), rl = lpi3 <= 8 ? 8 : 16, ipw3 = 64 / rl;
         static_assert(LinearDev::HAS_SOFT, "the lq branch relies on `sliced` staying false for this model (no time-sliced launch with soft bounds)");
-        if (!sliced && h->linear_spl != 1 && ipw3 > ipw) {
+        if (!sliced && h->linear_spl != 1 && ipw3 > ipw && h->N + 1 <= 64) {
             lq = true;
             const dim3 grid((unsigned)((h->B + ipw3 - 1) / ipw3));
-            if (rl == 0 && h->linear_spl == 4)      // horizons 48 <= N <= 63 with FOUR stages per lane: 16 lanes per instance, rows again
-                hipLaunchKernelGGL((lq_solve_kernel<4, 16>), dim3((unsigned)((h->B + 3) / 4)), dim3(64), 0, st, h->small, a);
+            if (lpi3 > 16)
+                hipLaunchKernelGGL((lq_solve_kernel<4, 16>), grid, dim3(64), 0, st, h->small, a);
             else if (rl == 16)
-                hipLaunchKernelGGL((lq_solve_kernel<SPL, 16>), grid, dim3(64), 0, st, h->small, a);
-            else if (rl == 8)
-                hipLaunchKernelGGL((lq_solve_kernel<SPL, 8>), grid, dim3(64), 0, st, h->small, a);
+                hipLaunchKernelGGL((lq_solve_kernel<3, 16>), grid, dim3(64), 0, st, h->small, a);
             else
-                hipLaunchKernelGGL((lq_solve_kernel<SPL, 0>), grid, dim3(64), 0, st, h->small, a);
+                hipLaunchKernelGGL((lq_solve_kernel<3, 8>), grid, dim3(64), 0, st, h->small, a);
         }
     }
     if (!sliced && !lq) hipLaunchKernelGGL(small_solve_kernel<M>, dim3(blocks), dim3(64), 0, st, h->small, a);
@@ -317,7 +317,6 @@ int mpcrl_create(const MpcrlProblemSpec *spec, int batch, int device, mpcrl_hand
         if (e && *e) h->slice_mode = (*e == '0') ? -1 : 1;
         const char *l = std::getenv("MPCRL_LINEAR_SPL");   // stages per lane of the linear-system solve kernel: 3 (default) or 1
         if (l && *l == '1') h->linear_spl = 1;
-        if (l && *l == '4') h->linear_spl = 4;      // (as 3, but four stages per lane where three need more than a DPP row: N >= 48)
     }
     int rc = 0;
     switch (spec->model) {

@@ -613,7 +613,7 @@ def test_time_sliced_launch_warm_calls(N, tf, B, monkeypatch):
 @pytest.mark.parametrize("N,B", [(40, 4096), (40, 101), (20, 37), (39, 64), (47, 50), (48, 50), (61, 21), (63, 23)])
 def test_linear_kernel_three_stages_per_lane_vs_one(N, B, monkeypatch):
     """lq_solve_kernel (linear_kernel.hpp: three stages per lane; four instances per wavefront in DPP rows at 9..16 lanes per instance,
-    eight in half rows up to 8 lanes, packed segments beyond 16) against small_solve_kernel<LinearDev> (MPCRL_LINEAR_SPL=1: one stage per lane) on a closed-loop
+    eight in half rows up to 8 lanes; FOUR stages per lane in rows at N = 48..63, round 6) against small_solve_kernel<LinearDev> (MPCRL_LINEAR_SPL=1: one stage per lane) on a closed-loop
     sequence — cold solve with both gradients, warm solves at moved states, a per-instance cold mask, Q-mode, a stored iterate without
     multipliers, a real-time iteration, per-instance parameters — over horizons that exercise every lane layout (N + 1 = 3 x lanes
     exactly, one and two dead stages in the last lane, lanes behind the live ones, more than 16 lanes).  Same iteration, other
