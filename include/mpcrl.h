@@ -25,6 +25,8 @@
  *   ocp_solver.get(stage, "x"|"u"|"pi"|"lam"|"t"|"sl"|"su")   mpcrl_get_iterate
  *   ocp_solver.set(stage, "x"|"u"|"pi", v) / load_iterate      mpcrl_set_iterate
  *     rlmpc/mpc/nlp.py:1354-1372, rlmpc/examples/chain_mass.py:119-120
+ *   the one warm solver object SB3's replay loop reuses          mpcrl_get_iterate_rows / mpcrl_set_iterate_rows
+ *     rlmpc/td3/policies.py:186-213                              (per-transition iterates of a replay buffer)
  *
  * Conventions
  *   - plain C, no torch types.  Every array argument of mpcrl_solve / *_iterate / mpcrl_reset /
@@ -67,7 +69,7 @@ extern "C" {
  *        stopping test that is met within rounding can end an interior-point loop one iteration earlier or later (< 1 % of
  *        instances), or flip the status of an RTI call whose residual sits at the tolerance; outputs of such an instance then
  *        agree with the one-stage kernel and the oracle port to the QP tolerance (1e-4 ... 1e-3 on du0/dp), not to rounding
- *   120  round 6: mpcrl_solve flags MPCRL_NO_BND_STORE and MPCRL_EXACT_QP (test-only) */
+ *   120  round 6: mpcrl_solve flags MPCRL_NO_BND_STORE and MPCRL_EXACT_QP (test-only); mpcrl_get_iterate_rows / mpcrl_set_iterate_rows */
 #define MPCRL_ABI_VERSION 120
 
 enum { MPCRL_MODEL_CARTPOLE = 0, MPCRL_MODEL_LINEAR = 1, MPCRL_MODEL_CHAIN = 2 };
@@ -204,6 +206,15 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
  *   res [B, 4]: stationarity, equality, inequality, complementarity residual of the last solve */
 int mpcrl_get_iterate(mpcrl_handle h, double *x, double *u, double *pi, double *bnd, double *res, void *stream);
 int mpcrl_set_iterate(mpcrl_handle h, const double *x, const double *u, const double *pi, const double *bnd, void *stream);
+/* ABI 120.  The same moves with a ROW INDEX, for tables of iterates that hold more (or other) rows than the handle has instances —
+ * a replay buffer that keeps, next to every transition, the iterate the roll-out policy's solve ended with (mpc4rl_amd/td3.py,
+ * replay_iterates; the reference's SB3 loop keeps ONE solver and warm-starts every replay solve from the previous, unrelated sample:
+ * rlmpc/td3/policies.py:186-213).  x [rows, (N+1) nx], u [rows, N nu], pi [rows, N nx], bnd [rows, 10 (N+1)(nu+nx)] device;
+ * index [B] int64 device (NULL = identity).  get: table row index[i] := stored iterate of instance i (NULL arrays are skipped).
+ * set: stored iterate of instance i := table row index[i]; bnd = NULL as in mpcrl_set_iterate (next solve: MPCRL_COLD_DUAL).
+ * One launch each, no host synchronisation: capture-safe. */
+int mpcrl_get_iterate_rows(mpcrl_handle h, double *x, double *u, double *pi, double *bnd, const int64_t *index, void *stream);
+int mpcrl_set_iterate_rows(mpcrl_handle h, const double *x, const double *u, const double *pi, const double *bnd, const int64_t *index, void *stream);
 /* L [B] device: the Lagrangian of the mirror NLP at the iterate the last solve returned, L = cost + pi'g + lam'h
  * (nlp.L, rlmpc/mpc/nlp.py:1180,1390; MPC.get_L, rlmpc/mpc/common/mpc.py:325-332). */
 int mpcrl_get_lagrangian(mpcrl_handle h, double *L, void *stream);

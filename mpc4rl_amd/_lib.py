@@ -31,7 +31,7 @@ class ProblemSpec(C.Structure):
 
 
 EXPORTS = ["mpcrl_create", "mpcrl_destroy", "mpcrl_set_theta", "mpcrl_set_gamma", "mpcrl_set_options", "mpcrl_set_exit_rule", "mpcrl_set_order", "mpcrl_set_bounds", "mpcrl_set_cold_mask", "mpcrl_reset",
-           "mpcrl_solve", "mpcrl_get_iterate", "mpcrl_set_iterate", "mpcrl_get_lagrangian", "mpcrl_weighted_grad_sum", "mpcrl_env_cartpole_step", "mpcrl_env_cartpole_reset", "mpcrl_env_linear_step", "mpcrl_auto_order", "mpcrl_query_time_sliced", "mpcrl_set_launch_mode", "mpcrl_get_launch_times", "mpcrl_workspace_bytes", "mpcrl_version"]
+           "mpcrl_solve", "mpcrl_get_iterate", "mpcrl_set_iterate", "mpcrl_get_iterate_rows", "mpcrl_set_iterate_rows", "mpcrl_get_lagrangian", "mpcrl_weighted_grad_sum", "mpcrl_env_cartpole_step", "mpcrl_env_cartpole_reset", "mpcrl_env_linear_step", "mpcrl_auto_order", "mpcrl_query_time_sliced", "mpcrl_set_launch_mode", "mpcrl_get_launch_times", "mpcrl_workspace_bytes", "mpcrl_version"]
 
 _lib = None
 
@@ -64,6 +64,8 @@ def load():
     lib.mpcrl_solve.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     lib.mpcrl_get_iterate.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.mpcrl_set_iterate.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.mpcrl_get_iterate_rows.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.mpcrl_set_iterate_rows.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.mpcrl_get_lagrangian.argtypes = [vp, vp, vp]
     lib.mpcrl_auto_order.argtypes = [vp, vp, vp]
     lib.mpcrl_query_time_sliced.argtypes = [vp, C.c_int, vp]

@@ -220,6 +220,29 @@ class MPCBatch:
                         "mpcrl_set_iterate")
         self.has_iterate, self.duals_valid = True, bnd is not None
 
+    def _row_tables(self, x, u, pi, bnd, index):
+        nw = self.nx + self.nu
+        lens = ((self.N + 1) * self.nx, self.N * self.nu, self.N * self.nx, 10 * (self.N + 1) * nw)
+        for t, n in zip((x, u, pi, bnd), lens):
+            if t is not None and not (t.dtype == torch.float64 and t.is_contiguous() and t.device == self.device and t.numel() % n == 0):
+                raise ValueError("iterate tables are contiguous float64 tensors on the handle's device with whole rows")
+        if index is not None and not (index.dtype == torch.int64 and index.is_contiguous() and index.numel() == self.B and index.device == self.device):
+            raise ValueError("index: contiguous int64 [B] on the handle's device")
+
+    def get_iterate_rows(self, x, u, pi, bnd, index: Optional[torch.Tensor] = None) -> None:
+        """Table row index[i] := stored iterate of instance i (mpcrl_get_iterate_rows; the tables are the caller's, any number of rows,
+        rows laid out as get_iterate's; None = skip that array)."""
+        self._row_tables(x, u, pi, bnd, index)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.mpcrl_get_iterate_rows(self._h, _ptr(x), _ptr(u), _ptr(pi), _ptr(bnd), _ptr(index), self._stream()), "mpcrl_get_iterate_rows")
+
+    def set_iterate_rows(self, x, u, pi, bnd, index: Optional[torch.Tensor] = None) -> None:
+        """Stored iterate of instance i := table row index[i] (mpcrl_set_iterate_rows); bnd = None as in set_iterate."""
+        self._row_tables(x, u, pi, bnd, index)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.mpcrl_set_iterate_rows(self._h, _ptr(x), _ptr(u), _ptr(pi), _ptr(bnd), _ptr(index), self._stream()), "mpcrl_set_iterate_rows")
+        self.has_iterate, self.duals_valid = True, bnd is not None
+
     def get_lagrangian(self) -> torch.Tensor:
         """[B] Lagrangian of the mirror NLP at the iterate of the last solve (nlp.L, nlp.py:1180,1390)."""
         L = torch.empty((self.B,), dtype=torch.float64, device=self.device)

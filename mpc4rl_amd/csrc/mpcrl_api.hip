@@ -693,4 +693,30 @@ int mpcrl_set_iterate(mpcrl_handle h, const double *x, const double *u, const do
     return 0;
 }
 
+int mpcrl_get_iterate_rows(mpcrl_handle h, double *x, double *u, double *pi, double *bnd, const int64_t *index, void *stream) {
+    if (!h || !(x || u || pi || bnd)) return MPCRL_E_ARG;
+    ON_DEVICE(h->device);
+    const int N = h->N, nx = h->nx, nu = h->nu, nw = nx + nu;
+    hipLaunchKernelGGL(iterate_rows_kernel<false>, dim3((unsigned)h->B), dim3(256), 0, (hipStream_t)stream, h->X, h->U, h->PI, h->BND, x, u, pi, bnd,
+                       (const long *)index, (N + 1) * nx, N * nu, N * nx, 10 * (N + 1) * nw);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int mpcrl_set_iterate_rows(mpcrl_handle h, const double *x, const double *u, const double *pi, const double *bnd, const int64_t *index, void *stream) {
+    if (!h || !x || !u || !pi) return MPCRL_E_ARG;
+    ON_DEVICE(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int N = h->N, nx = h->nx, nu = h->nu, nw = nx + nu;
+    if (!bnd) {   // multipliers 0, slacks t = 1: the state MPCRL_COLD would build
+        int rc = fill_cold_iterate(h, nullptr, false, st);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(iterate_rows_kernel<true>, dim3((unsigned)h->B), dim3(256), 0, st, h->X, h->U, h->PI, h->BND, (double *)x, (double *)u, (double *)pi,
+                       (double *)bnd, (const long *)index, (N + 1) * nx, N * nu, N * nx, 10 * (N + 1) * nw);
+    HIP_OK(hipGetLastError());
+    h->have_iterate = true, h->dual_cold = bnd == nullptr;
+    return 0;
+}
+
 }  // extern "C"

@@ -136,9 +136,17 @@ class DeviceReplayBuffer:
     """Ring buffer of transitions on the device, filled E environments at a time (stable_baselines3's ReplayBuffer as
     scripts/cartpole_mpc_as_td3_agent_closed_loop.py:47-58 uses it: obs, next_obs, action, reward, done)."""
 
-    def __init__(self, capacity_steps: int, num_envs: int, obs_dim: int, act_dim: int, device, dtype=torch.float32):
+    def __init__(self, capacity_steps: int, num_envs: int, obs_dim: int, act_dim: int, device, dtype=torch.float32, iterate_dims=None):
+        """iterate_dims = (len x, len u, len pi, len bnd) per environment: the buffer also keeps, per transition, the solver iterate the
+        roll-out policy ended with at ``obs`` (float64; BatchedTD3(replay_iterates=True)) and whether that solve converged."""
         kw = dict(dtype=dtype, device=device)
         self.cap, self.E = capacity_steps, num_envs
+        self.iters = None
+        if iterate_dims is not None:
+            # flat tables [capacity_steps * num_envs, len]: row = step * num_envs + env (what mpcrl_get/set_iterate_rows index)
+            self.iters = [torch.zeros(capacity_steps * num_envs, n, dtype=torch.float64, device=device) for n in iterate_dims]
+            self.iter_ok = torch.zeros(capacity_steps, num_envs, dtype=torch.bool, device=device)
+            self._env_ids = torch.arange(num_envs, dtype=torch.int64, device=device)
         self.obs = torch.zeros(capacity_steps, num_envs, obs_dim, **kw)
         self.next_obs = torch.zeros(capacity_steps, num_envs, obs_dim, **kw)
         self.act = torch.zeros(capacity_steps, num_envs, act_dim, **kw)
@@ -147,20 +155,28 @@ class DeviceReplayBuffer:
         self.pos, self.full = 0, False
         self.pos_t = torch.zeros(1, dtype=torch.int64, device=device)      # the write position as the device sees it (graph replays)
 
-    def add(self, obs, next_obs, act, rew, done) -> None:
+    def add(self, obs, next_obs, act, rew, done, iterate=None, iterate_ok=None) -> None:
         i = self.pos
         self.obs[i], self.next_obs[i], self.act[i] = obs.to(self.obs.dtype), next_obs.to(self.obs.dtype), act.to(self.obs.dtype)
         self.rew[i], self.done[i] = rew.to(self.obs.dtype), done.to(self.obs.dtype)
+        if self.iters is not None:
+            iterate.get_iterate_rows(*self.iters, index=i * self.E + self._env_ids)      # rows of slot i := the handle's stored iterates
+            self.iter_ok[i] = iterate_ok
         self._advance()
+        if self.iters is not None:
+            self.pos_t.fill_(self.pos)       # (the device-side copy of the write position: sample_with_iterates reads it)
 
     def _advance(self) -> None:
         self.pos = (self.pos + 1) % self.cap
         self.full = self.full or self.pos == 0
 
-    def add_at_device_pos(self, obs, next_obs, act, rew, done) -> None:
+    def add_at_device_pos(self, obs, next_obs, act, rew, done, iterate=None, iterate_ok=None) -> None:
         """add() with the position read from ``pos_t`` on the device: the identical launches whatever the position, so that a captured
         roll-out step can be replayed.  The host mirror (pos, full) is advanced by the caller once per replay (_advance)."""
         dt = self.obs.dtype
+        if self.iters is not None:
+            iterate.get_iterate_rows(*self.iters, index=self.pos_t * self.E + self._env_ids)
+            self.iter_ok.index_copy_(0, self.pos_t, iterate_ok[None])
         self.obs.index_copy_(0, self.pos_t, obs.to(dt)[None])
         self.next_obs.index_copy_(0, self.pos_t, next_obs.to(dt)[None])
         self.act.index_copy_(0, self.pos_t, act.to(dt)[None])
@@ -177,7 +193,22 @@ class DeviceReplayBuffer:
             raise RuntimeError("DeviceReplayBuffer.sample: the buffer is empty (call collect() / add() first)")
         idx = torch.randint(0, steps * self.E, (n,), device=self.obs.device, generator=gen)
         f = lambda t: t[:steps].reshape(steps * self.E, *t.shape[2:])[idx]
+        self.last_idx, self.last_steps = idx, steps
         return f(self.obs), f(self.next_obs), f(self.act), f(self.rew), f(self.done)
+
+    def iterates_of_last_sample(self):
+        """For the transitions of the last sample(): (rows for obs, ok, rows for next_obs, ok) — row numbers into ``iters``.  The
+        iterate for obs is the roll-out policy's own solution there.  For next_obs it is the roll-out solution of the NEXT step of the
+        same environment where that exists and is that state (the episode went on, the slot is not the one about to be overwritten /
+        not yet written) — else the solution at obs, one step earlier: the warm start the closed loop itself uses."""
+        idx, steps, E = self.last_idx, self.last_steps, self.E
+        step, env = idx // E, idx % E
+        nstep = (step + 1) % self.cap
+        flat = lambda t: t.reshape(self.cap * E, *t.shape[2:])
+        cont = (flat(self.done)[idx] == 0) & (nstep != self.pos_t) & (nstep < steps)
+        nidx = torch.where(cont, nstep * E + env, idx)
+        ok = flat(self.iter_ok)
+        return idx, ok[idx], nidx, ok[nidx]
 
 
 class BatchedTD3:
@@ -202,9 +233,16 @@ class BatchedTD3:
     def __init__(self, ocp, env, batch_size: int = 256, buffer_steps: int = 64, gamma: float = 0.99, tau: float = 0.005,
                  policy_delay: int = 2, action_noise: float = 0.1, target_noise: float = 0.2, noise_clip: float = 0.5,
                  lr_critic: float = 1e-3, lr_actor: float = 1e-4, reward_scale: float = -1.0, net_arch=(64, 64), device=None,
-                 group=None, seed: int = 0, learn_mask: Optional[torch.Tensor] = None, actor_factory=None):
+                 group=None, seed: int = 0, learn_mask: Optional[torch.Tensor] = None, actor_factory=None, replay_iterates: bool = False):
         """actor_factory(batch) -> an MPCActor-like object (default: MPCActor on the GPU).  The CPU tests of the loop's plumbing
-        (replay, critic update, the single all-reduce) pass a closed-form stand-in policy; the product path never does."""
+        (replay, critic update, the single all-reduce) pass a closed-form stand-in policy; the product path never does.
+        replay_iterates: keep, with every transition, the solver iterate the roll-out policy ended with (x, u, pi, bound multipliers and
+        slacks: 9.9 KB per cartpole transition, float64) and start the two replay solves of an update from it — the target actor's at
+        s' from the roll-out solution of the next step of that environment, the policy's at s from the roll-out solution at s —
+        instead of from the cold iterate.  theta' and theta differ from the roll-out's theta by a few small policy steps, so the stored
+        iterate is all but the answer: 0-4 SQP iterations instead of 6.6 on average and 22 for the slowest instance of a batch, which
+        is what a lock-step launch lasts for.  (The reference's SB3 loop never resets its one solver between replay samples either:
+        it warm-starts every solve from the previous — unrelated — sample's solution, rlmpc/td3/policies.py:186-213.)"""
         self.env, self.E, self.B = env, env.num_envs, batch_size
         make = actor_factory or (lambda batch: MPCActor(ocp, batch, device))
         self.actor = make(self.E)                               # roll-out: keeps one warm-start iterate per environment
@@ -226,7 +264,10 @@ class BatchedTD3:
         # (capturable: the step counter lives on the device, so that the optimiser step can be part of a replayed HIP graph)
         self.critic_opt = torch.optim.Adam(self.critic.parameters(), lr=lr_critic,
                                            **({"fused": True, "capturable": True} if dev.type == "cuda" else {}))
-        self.buffer = DeviceReplayBuffer(buffer_steps, self.E, ocp.nx, ocp.nu, dev)
+        self.replay_iterates = bool(replay_iterates)
+        nw_ = ocp.nx + ocp.nu
+        self.buffer = DeviceReplayBuffer(buffer_steps, self.E, ocp.nx, ocp.nu, dev, iterate_dims=(
+            (ocp.N + 1) * ocp.nx, ocp.N * ocp.nu, ocp.N * ocp.nx, 10 * (ocp.N + 1) * nw_) if self.replay_iterates else None)
         self.gamma, self.tau, self.policy_delay = gamma, tau, policy_delay
         self.action_noise, self.target_noise, self.noise_clip = action_noise, target_noise, noise_clip
         self.lr_actor, self.reward_scale, self.group = lr_actor, reward_scale, group
@@ -254,10 +295,13 @@ class BatchedTD3:
         nxt, rew, term, trunc = self.env.step(a.to(self.env.device))
         nxt, rew = nxt.to(self.device), rew.to(self.device)
         done = (term | trunc).to(self.device)
+        itk = {}
+        if self.replay_iterates:       # the iterate this solve ended with, next to its transition
+            itk = {"iterate": self.actor.mpc, "iterate_ok": u_ok & (r.status == 0)}
         if static:
-            self.buffer.add_at_device_pos(self.obs, nxt, a, self.reward_scale * rew, term.to(self.device))
+            self.buffer.add_at_device_pos(self.obs, nxt, a, self.reward_scale * rew, term.to(self.device), **itk)
         else:
-            self.buffer.add(self.obs, nxt, a, self.reward_scale * rew, term.to(self.device))
+            self.buffer.add(self.obs, nxt, a, self.reward_scale * rew, term.to(self.device), **itk)
         self._stats[0] += rew.sum()
         self._stats[1] += (r.status == 0).sum()
         self._stats[2] += done.sum()
@@ -313,7 +357,13 @@ class BatchedTD3:
         obs, nxt, act, rew, done = self.buffer.sample(self.B, self.gen)
         with torch.no_grad():
             noise = (self.target_noise * torch.randn(act.shape, device=self.device, generator=self.gen)).clamp(-self.noise_clip, self.noise_clip)
-            rt = self.target_mpc.mpc.solve(nxt.to(torch.float64), cold=True)               # actor_target(s'), one launch
+            if self.replay_iterates:
+                it_s, ok_s, it_n, ok_n = self.buffer.iterates_of_last_sample()
+                self._load_iterate(self.target_mpc.mpc, it_n)
+                # (a stored iterate of a failed roll-out solve is not a starting point: that instance starts cold)
+                rt = self.target_mpc.mpc.solve(nxt.to(torch.float64), cold_mask=~ok_n)     # actor_target(s'), one launch, warm
+            else:
+                rt = self.target_mpc.mpc.solve(nxt.to(torch.float64), cold=True)           # actor_target(s'), one launch
             # failed target solves are SELECTED out (a product with a 0 / 1 mask would keep their NaN: NaN * 0 = NaN), and so are
             # transitions whose stored observations are not finite
             # (one finiteness test over the whole transition: every separate test, fill and select is a launch of its own)
@@ -335,7 +385,11 @@ class BatchedTD3:
         flat = torch.zeros(self.n_crit + n_theta + 1, dtype=torch.float64, device=self.device)
         flat[: self.n_crit] = torch.cat([p.grad.reshape(-1) for p in self.critic.parameters()]).to(torch.float64) / world
         if do_policy:
-            rp = self.pi_mpc.mpc.solve(obs.to(torch.float64), sens_pi=True, cold=True)   # pi(s_i), dpi/dtheta_i: one launch
+            if self.replay_iterates:
+                self._load_iterate(self.pi_mpc.mpc, it_s)
+                rp = self.pi_mpc.mpc.solve(obs.to(torch.float64), sens_pi=True, cold_mask=~ok_s)   # pi(s_i), dpi/dtheta_i: one launch, warm
+            else:
+                rp = self.pi_mpc.mpc.solve(obs.to(torch.float64), sens_pi=True, cold=True)   # pi(s_i), dpi/dtheta_i: one launch
             okb = (rp.status == 0) & torch.isfinite(torch.cat([rp.u0.to(obs.dtype), obs], dim=1)).all(dim=1)
             u_pi = torch.where(okb[:, None], rp.u0, 0.0)
             a_pi = self.pi_mpc.scale_action(u_pi).to(torch.float32).detach().requires_grad_(True)
@@ -349,6 +403,9 @@ class BatchedTD3:
             flat[self.n_crit: self.n_crit + n_theta] = g.sum(0)
             flat[-1] = okp.sum()
         return flat, loss.detach()
+
+    def _load_iterate(self, mpc, rows) -> None:
+        mpc.set_iterate_rows(*self.buffer.iters, index=rows.contiguous())       # ONE launch: stored iterate i := table row rows[i]
 
     def _update_post(self, flat: torch.Tensor, do_policy: bool):
         """After the collective: the averaged critic gradients into the optimiser step; the policy step and the Polyak updates.
@@ -395,6 +452,10 @@ class BatchedTD3:
         return {"critic_loss": float(loss.item()) if loss is not None else 0.0,
                 "theta_step_norm": float(step.norm().item()) if step is not None else 0.0}
 
+    def _buffer_tensors(self):
+        b = self.buffer
+        return [b.obs, b.next_obs, b.act, b.rew, b.done] + ((b.iters + [b.iter_ok]) if b.iters is not None else [])
+
     # ------------------------------------------------------------------ HIP graphs
     def enable_graphs(self) -> None:
         """Captures the roll-out step and the two halves of an update (before / after the collective; with and without the policy
@@ -420,7 +481,13 @@ class BatchedTD3:
         rows = self.buffer.next_obs.reshape(-1, self.buffer.next_obs.shape[-1])
         rows = rows[torch.arange(self.B, device=self.device) * (rows.shape[0] // self.B if rows.shape[0] >= self.B else 1) % rows.shape[0]]
         rows = torch.where(torch.isfinite(rows), rows, torch.zeros_like(rows)).to(torch.float64).contiguous()
-        for _ in range(4):
+        if self.replay_iterates:
+            # warm replay solves: a handful of SQP rounds for a few instances, none for most — the plain launch shape (three instances per
+            # wavefront advance together, nobody parked) measured the same or better than the time-sliced one on such batches
+            # (0.24 vs 0.29 ms per 4096, profiles/r06_td3_replay_iterates.txt); no probe calls, the shape is fixed
+            self.target_mpc.mpc.set_launch_mode(-1)
+            self.pi_mpc.mpc.set_launch_mode(-1)
+        for _ in range(0 if self.replay_iterates else 4):
             self.target_mpc.mpc.solve(rows, cold=True)
             self.pi_mpc.mpc.solve(rows, sens_pi=True, cold=True)
             torch.cuda.synchronize(self.device)
@@ -435,7 +502,7 @@ class BatchedTD3:
                 "opt": copy.deepcopy(self.critic_opt.state_dict()), "theta": self.theta.clone(), "theta_target": self.theta_target.clone(),
                 "gens": [g.get_state() for g in gens], "obs": self.obs.clone(), "ended": self._ended.clone(), "stats": self._stats.clone(),
                 "env": (self.env.state.clone(), self.env.steps.clone()) if hasattr(self.env, "steps") else None,
-                "buf": [t.clone() for t in (self.buffer.obs, self.buffer.next_obs, self.buffer.act, self.buffer.rew, self.buffer.done)],
+                "buf": [t.clone() for t in self._buffer_tensors()],
                 "pos": (self.buffer.pos, self.buffer.full), "iter": self.actor.mpc.get_iterate() if hasattr(self.actor.mpc, "get_iterate") else None,
                 "iter_flags": (self.actor.mpc.has_iterate, self.actor.mpc.duals_valid)}
         side.wait_stream(torch.cuda.current_stream(self.device))
@@ -463,7 +530,7 @@ class BatchedTD3:
             self.obs.copy_(snap["obs"]), self._ended.copy_(snap["ended"]), self._stats.copy_(snap["stats"])
             if snap["env"] is not None:
                 self.env.state.copy_(snap["env"][0]), self.env.steps.copy_(snap["env"][1])
-            for t, old in zip((self.buffer.obs, self.buffer.next_obs, self.buffer.act, self.buffer.rew, self.buffer.done), snap["buf"]):
+            for t, old in zip(self._buffer_tensors(), snap["buf"]):
                 t.copy_(old)
             self.buffer.pos, self.buffer.full = snap["pos"]
             self.buffer.pos_t.fill_(self.buffer.pos)

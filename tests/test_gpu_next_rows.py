@@ -460,3 +460,106 @@ def test_sb3_shaped_td3_policy():
     pol.set_training_mode(False)
     assert not pol.critic.training and not pol.critic_target.training
     assert pol.actor.parameters().shape == (ocp.n_p,)
+
+
+@pytest.mark.gpu
+def test_iterate_rows_moves():
+    """mpcrl_get_iterate_rows / mpcrl_set_iterate_rows (ABI 120): whole iterates between a handle and caller-owned tables by row
+    index — what get_iterate + index_copy / index + set_iterate do in four passes, in one launch each."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    B, R = 96, 300
+    rng = np.random.default_rng(11)
+    x0 = np.zeros((B, 4))
+    x0[:, 2] = rng.uniform(0.9 * np.pi, 1.1 * np.pi, B)
+    a = MPCBatch(cartpole_ocp(), B)
+    ra = a.solve(x0, cold=True)
+    x, u, pi, bnd, _ = a.get_iterate()
+    lens = (21 * 4, 20 * 1, 20 * 4, 10 * 21 * 5)
+    tabs = [torch.full((R, n), -7.0, dtype=torch.float64, device="cuda") for n in lens]
+    rows = torch.as_tensor(rng.permutation(R)[:B], device="cuda")
+    a.get_iterate_rows(*tabs, index=rows)
+    for t, src in zip(tabs, (x, u, pi, bnd)):
+        assert torch.equal(t[rows], src.reshape(B, -1))
+        untouched = torch.ones(R, dtype=torch.bool, device="cuda")
+        untouched[rows] = False
+        assert bool((t[untouched] == -7.0).all())
+    # a second handle started from those rows (in another order) is converged at once: zero SQP iterations, same answer
+    order = torch.as_tensor(rng.permutation(B), device="cuda")
+    b = MPCBatch(cartpole_ocp(), B)
+    b.set_iterate_rows(*tabs, index=rows[order].contiguous())
+    rb = b.solve(torch.as_tensor(x0, device="cuda")[order])
+    assert int(rb.iters[:, 0].max()) == 0 and torch.equal(rb.u0, ra.u0[order]) and b.duals_valid
+    xb = b.get_iterate()[0]
+    assert torch.equal(xb, x[order])
+    # identity index, primal part only: next solve starts its interior point from the default point (as set_iterate(bnd=None))
+    c, d = MPCBatch(cartpole_ocp(), B), MPCBatch(cartpole_ocp(), B)
+    c.set_iterate_rows(x.reshape(B, -1), u.reshape(B, -1), pi.reshape(B, -1), None)
+    d.set_iterate(x, u, pi, None)
+    assert not c.duals_valid and not d.duals_valid
+    rc, rd = c.solve(x0), d.solve(x0)
+    assert torch.equal(rc.u0, rd.u0) and torch.equal(rc.iters, rd.iters)
+    with pytest.raises(ValueError):
+        a.get_iterate_rows(*tabs, index=rows.to(torch.int32))
+
+
+@pytest.mark.gpu
+def test_td3_replay_iterates():
+    """BatchedTD3(replay_iterates=True): every transition keeps the iterate the roll-out policy's solve ended with, and the two replay
+    solves of an update start from it instead of from the cold iterate (round 6).  (a) The stored rows ARE the roll-out solutions:
+    a fresh handle started from them at the stored observations is converged at once with the stored action.  (b) The target actor's
+    and the policy's answers on a sampled batch equal the cold solves' at 1e-6 (same KKT point, far fewer iterations).  (c) A few
+    closed-loop steps in eager and in graph mode: converged, finite, critic and theta move."""
+    from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedTD3, MPCBatch, cartpole_ocp
+    E = 512
+    ocp = cartpole_ocp()
+    env = BatchedCartPoleSwingUpEnv(E, device="cuda", seed=5, max_episode_steps=9)       # short episodes: done rows and resets in the buffer
+    agent = BatchedTD3(ocp, env, batch_size=E, buffer_steps=8, policy_delay=2, lr_actor=1e-4, seed=1, replay_iterates=True, action_noise=0.0)
+    agent.collect(8)
+    buf = agent.buffer
+    assert buf.full and bool(buf.iter_ok.float().mean() > 0.95)
+    # (a) slot 5: observations and their stored iterates
+    s = 5
+    rows = s * E + torch.arange(E, device="cuda")
+    m = MPCBatch(ocp, E)
+    m.set_iterate_rows(*buf.iters, index=rows)
+    r = m.solve(buf.obs[s].double())
+    ok = buf.iter_ok[s]
+    assert int(r.iters[ok][:, 0].max()) == 0
+    a_stored = buf.act[s][ok].double()                                            # action_noise = 0: the stored action is the policy's
+    assert float((agent.actor.scale_action(r.u0[ok]) - a_stored).abs().max()) < 1e-6
+    # (b) a sampled batch, warm from the stored iterates against cold
+    obs, nxt, act, rew, done = buf.sample(E, agent.gen)
+    i_s, ok_s, i_n, ok_n = buf.iterates_of_last_sample()
+    step, nstep = buf.last_idx // E, (buf.last_idx // E + 1) % buf.cap
+    cont = (done == 0) & (nstep != buf.pos)
+    assert torch.equal(i_n, torch.where(cont, nstep * E + buf.last_idx % E, buf.last_idx)) and bool(cont.any()) and bool((~cont).any())
+    for handle, states, rows_, okr in ((agent.target_mpc.mpc, nxt, i_n, ok_n), (agent.pi_mpc.mpc, obs, i_s, ok_s)):
+        states = states.double()
+        handle.set_iterate_rows(*buf.iters, index=rows_.contiguous())
+        rw = handle.solve(states, sens_pi=True, cold_mask=~okr)
+        rc = MPCBatch(ocp, E).solve(states, sens_pi=True, cold=True)
+        both = (rw.status == 0) & (rc.status == 0)
+        assert float(both.float().mean()) > 0.97
+        err = ((rw.u0 - rc.u0).abs() / rc.u0.abs().clamp(min=1.0))[both]
+        same = err[:, 0] < 1e-6                                                   # (a swing-up state can have two local minima: count, do not hide)
+        print("replay solve warm vs cold: same KKT point on %.4f of the batch, SQP iterations %.2f vs %.2f (max %d vs %d)" % (
+            float(same.float().mean()), float(rw.iters[:, 0].double().mean()), float(rc.iters[:, 0].double().mean()), int(rw.iters[:, 0].max()), int(rc.iters[:, 0].max())))
+        assert float(same.float().mean()) > 0.99 and float(rw.iters[:, 0].double().mean()) < 0.5 * float(rc.iters[:, 0].double().mean())
+        dw, dc = torch.nan_to_num(rw.dpi_dp[both][same][:, 0, :3]), torch.nan_to_num(rc.dpi_dp[both][same][:, 0, :3])
+        assert float(((dw - dc).abs() / dc.abs().amax(1, keepdim=True).clamp(min=1.0)).max()) < 1e-4
+    # (c) eager steps, then graph mode
+    th0 = agent.theta.clone()
+    crit = lambda: torch.cat([p.detach().reshape(-1) for p in agent.critic.parameters()]).clone()
+    c0 = crit()
+    agent.collect(2)
+    tr = agent.train(2)
+    assert np.isfinite(tr["critic_loss"]) and float((crit() - c0).abs().max()) > 0.0 and float((agent.theta - th0).abs().max()) > 0.0
+    agent.enable_graphs()
+    agent.collect(0)
+    for _ in range(6):
+        agent.collect(1, stats=False)
+        agent.train(1, stats=False)
+    torch.cuda.synchronize()
+    st = agent.last_stats()
+    assert st["converged_fraction"] > 0.95 and bool(torch.isfinite(agent.theta).all()) and bool(torch.isfinite(crit()).all())
+    assert int(buf.pos_t.item()) == buf.pos
