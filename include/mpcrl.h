@@ -212,7 +212,8 @@ int mpcrl_set_iterate(mpcrl_handle h, const double *x, const double *u, const do
  * rlmpc/td3/policies.py:186-213).  x [rows, (N+1) nx], u [rows, N nu], pi [rows, N nx], bnd [rows, 10 (N+1)(nu+nx)] device;
  * index [B] int64 device (NULL = identity).  get: table row index[i] := stored iterate of instance i (NULL arrays are skipped).
  * set: stored iterate of instance i := table row index[i]; bnd = NULL as in mpcrl_set_iterate (next solve: MPCRL_COLD_DUAL).
- * One launch each, no host synchronisation: capture-safe. */
+ * index[i] < 0: instance i is skipped (get: nothing written for it; set: it keeps its stored iterate — with bnd = NULL every
+ * instance's bound planes are reset, skipped or not).  One launch each, no host synchronisation: capture-safe. */
 int mpcrl_get_iterate_rows(mpcrl_handle h, double *x, double *u, double *pi, double *bnd, const int64_t *index, void *stream);
 int mpcrl_set_iterate_rows(mpcrl_handle h, const double *x, const double *u, const double *pi, const double *bnd, const int64_t *index, void *stream);
 /* L [B] device: the Lagrangian of the mirror NLP at the iterate the last solve returned, L = cost + pi'g + lam'h

@@ -23,12 +23,13 @@ __global__ void cold_iterate_kernel(const double *x0, int B, int N, int nx, int 
 
 // Row-indexed moves of whole iterates between the handle's stored-iterate arrays (H*, one row per instance) and caller-owned tables laid
 // out the same way with any number of rows (a replay buffer of solver iterates: mpcrl_get_iterate_rows / mpcrl_set_iterate_rows).
-// TO_HANDLE: H[i] = T[index[i]]; else T[index[i]] = H[i].  One 256-lane workgroup per instance, the four arrays back to back, 8-byte
+// TO_HANDLE: H[i] = T[index[i]]; else T[index[i]] = H[i]; index[i] < 0 skips instance i.  One 256-lane workgroup per instance, the four arrays back to back, 8-byte
 // elements, consecutive lanes on consecutive elements (a cartpole iterate is 9.9 KB: 40 MB per 4096 instances, one pass each way).
 template <bool TO_HANDLE>
 __global__ void __launch_bounds__(256) iterate_rows_kernel(double *HX, double *HU, double *HPI, double *HB, double *TX, double *TU, double *TPI, double *TB,
                                                            const long *index, int nX, int nU, int nP, int nB) {
     const long i = blockIdx.x, r = index ? index[i] : i;
+    if (r < 0) return;      // (a negative row: this instance is left alone / not recorded)
     auto move = [&](double *H, double *T, int n) {
         if (!H || !T) return;
         double *h = H + i * n, *t = T + r * n;

@@ -498,6 +498,17 @@ def test_iterate_rows_moves():
     assert not c.duals_valid and not d.duals_valid
     rc, rd = c.solve(x0), d.solve(x0)
     assert torch.equal(rc.u0, rd.u0) and torch.equal(rc.iters, rd.iters)
+    # a negative row skips the instance: set leaves its stored iterate alone, get records nothing for it
+    keep = torch.arange(B, device="cuda") % 2 == 0
+    e = MPCBatch(cartpole_ocp(), B)
+    e.solve(x0 * 0.99, cold=True)
+    xe = e.get_iterate()[0].clone()
+    e.set_iterate_rows(*tabs, index=torch.where(keep, -1, rows))
+    xe2 = e.get_iterate()[0]
+    assert torch.equal(xe2[keep], xe[keep]) and torch.equal(xe2[~keep], x[~keep])
+    tabs2 = [torch.full((R, n), -7.0, dtype=torch.float64, device="cuda") for n in lens]
+    a.get_iterate_rows(*tabs2, index=torch.where(keep, -1, rows))
+    assert bool((tabs2[0][rows[keep]] == -7.0).all()) and torch.equal(tabs2[0][rows[~keep]], x.reshape(B, -1)[~keep])
     with pytest.raises(ValueError):
         a.get_iterate_rows(*tabs, index=rows.to(torch.int32))
 
