@@ -51,7 +51,7 @@ def make_inputs(B, rank):
     return x0
 
 
-TRAFFIC_FILE = os.path.join("profiles", "r05_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r06_hbm_traffic.json")
 
 
 def csrc_hash():
@@ -204,6 +204,7 @@ def job_aggregate(elapsed_local, dist_mod, device):
 
 
 DRY = bool(os.environ.get("MPCRL_BENCH_DRYRUN"))
+STORE_BOUNDS = bool(os.environ.get("MPCRL_BENCH_STORE_BOUNDS"))      # linear workload: write the bound planes back as rounds 2-5 did (A/B of MPCRL_NO_BND_STORE)
 
 
 def timed_steps(step, args, dist_mod, dev, rank=0):
@@ -352,7 +353,7 @@ def small_measure(linear, B, sens, rti, steps, warmup, world, rank, dist, dev, s
         # cold start every step (MPC.reset semantics) so that every step does the same, full work
         # (linear system: every step starts cold, so nobody will warm-start an interior point from this solve's bound multipliers
         # and slacks — MPCRL_NO_BND_STORE leaves those ten planes of the stored iterate alone; x, u, pi are still written back)
-        r = mpc.solve(x0, sens_v=sens, sens_pi=sens, cold=not rti, rti=rti, store_bounds=not (linear and not rti))
+        r = mpc.solve(x0, sens_v=sens, sens_pi=sens, cold=not rti, rti=rti, store_bounds=not (linear and not rti and not STORE_BOUNDS))
         if dist is not None and sens:
             # data-parallel RL update: one all-reduce of [sum_i dV_i/dtheta, sum_i V_i, count]
             allreduce_weighted_grad(r.dV_dp[:, :n_theta], r.V)   # K5 reduction kernel + one all_reduce of 5 doubles
@@ -371,7 +372,7 @@ def small_measure(linear, B, sens, rti, steps, warmup, world, rank, dist, dev, s
     sweeps = float(iters[:, 1].mean()) + (1 + ocp.nu if sens else 0)
     fp64_tflops = sweeps * riccati_sweep_flops(ocp.N, ocp.nx, ocp.nu) * B / (kern_ms * 1e-3) / 1e12
     traffic, traffic_src = measured_traffic("linear" if linear else "cartpole", B, sens, rti)
-    name = "linear system N=40 nx=2 nu=1 (MPCRL_NO_BND_STORE)" if linear and not rti else ("linear system N=40 nx=2 nu=1" if linear else "cartpole N=20 nx=4 nu=1")
+    name = "linear system N=40 nx=2 nu=1 (MPCRL_NO_BND_STORE)" if linear and not rti and not STORE_BOUNDS else ("linear system N=40 nx=2 nu=1" if linear else "cartpole N=20 nx=4 nu=1")
     summ = {"value": B * world * steps / elapsed, "unit": "solves/s", "steps": steps, "warmup": warmup, "settle_steps": settle, "ms_per_step": 1e3 * elapsed / steps,
             "workload": ("%s, %d instances/GPU, %s" % (name, B, "RTI (1 SQP iteration, warm)" if rti else "cold-start full-step SQP to tol 1e-6"))
                         + (" + dV/dp + du0*/dp" if sens else ""),

@@ -7,7 +7,7 @@ tag=$1; steps=$2; warm=$3; shift 3
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pm_$c; rocprofv3 --kernel-trace --pmc $c -d /tmp/pm_$c -o run --output-format csv -- python $R/bench.py --steps $steps --warmup $warm --no-cpu --no-secondary "$@" > /tmp/pm_$c.out 2>&1
+  rm -rf /tmp/pm_$c; rocprofv3 --kernel-trace --pmc $c -d /tmp/pm_$c -o run --output-format csv -- python $R/bench.py --steps $steps --warmup $warm --no-cpu --no-secondary --settle 0 "$@" > /tmp/pm_$c.out 2>&1
 done
 python3 - "$tag" "$steps" "$warm" "$R" "$@" <<'PY'
 import csv, sys, glob, json, collections
