@@ -820,3 +820,28 @@ def test_hip_vs_third_party_cartpole_gradients_active_state_bound():
     e_pi = held(g["du0_d0"][:, :, 0], g["du0_d1"][:, :, 0], r.dpi_dp.cpu().numpy()[:, 0, :3])
     print("cartpole (active state bound / near upright) HIP vs third-party finite differences: dV/dp", e_v, "du0*/dp", e_pi)
     assert e_v < 1e-5 and e_pi < 1e-5
+
+
+def test_hip_vs_third_party_cartpole_gradients_96_states():
+    """G7c (tests/golden/make_thirdparty_grad3.py): the HIP path against certified third-party KKT points (MINPACK on the KKT equations) and
+    their finite differences at 94 cartpole states — u0*, V at 1e-6, dV/dp, du0*/dp at 1e-5."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    g = np.load(os.path.join(GOLD, "g7c_cartpole_grad.npz"))
+    n = len(g["x0"])
+    mpc = MPCBatch(cartpole_ocp(tol=1e-9), n)
+    r = mpc.solve(g["x0"], sens_v=True, sens_pi=True, cold=True)
+    assert bool((r.status == 0).all())
+    assert rel_err(r.u0.cpu().numpy(), g["u0"]) < RTOL and rel_err(r.V.cpu().numpy(), g["V"]) < RTOL
+
+    def held(fd0, fd1, mine):
+        fd0, fd1, mine = (np.asarray(a, float).reshape(len(fd0), -1) for a in (fd0, fd1, mine))
+        scale = np.maximum(np.abs(fd0).max(axis=1, keepdims=True), 1.0)
+        gg = fd0 - (fd1 - fd0) / 99.0
+        ok = np.abs(fd1 - fd0) / 99.0 <= 2e-6 * scale
+        assert ok.mean() >= 0.98, ok.mean()
+        return float(np.where(ok, np.abs(mine - gg) / scale, 0.0).max())
+
+    e_v = held(g["dV_d0"], g["dV_d1"], r.dV_dp.cpu().numpy()[:, :3])
+    e_pi = held(g["du0_d0"][:, :, 0], g["du0_d1"][:, :, 0], r.dpi_dp.cpu().numpy()[:, 0, :3])
+    print("cartpole, %d states, HIP vs third-party finite differences: dV/dp" % n, e_v, "du0*/dp", e_pi)
+    assert e_v < 1e-5 and e_pi < 1e-5

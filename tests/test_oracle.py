@@ -478,3 +478,24 @@ def test_third_party_cartpole_gradients_active_state_bound_vs_the_port(oracle_po
     e_pi, k_pi = _held_all(g["du0_d0"][:, :, 0], g["du0_d1"][:, :, 0], r.dpi[:, 0, :3])
     print("cartpole (active state bound / near upright) vs third-party finite differences: dV/dp %.2e (kept %.2f) du0*/dp %.2e (kept %.2f)" % (e_v, k_v, e_pi, k_pi))
     assert e_v < 1e-5 and e_pi < 1e-5
+
+
+def test_third_party_cartpole_gradients_96_states_vs_the_port(oracle_port):
+    """G7c (tests/golden/make_thirdparty_grad3.py, round 6): breadth — certified KKT points of the cartpole NLP found by MINPACK's hybrid
+    method on the KKT equations (not by any solver of this repository) at 96 drawn states (swing-up starts, near-upright states, a wider
+    box), their central differences over (M, m, l).  94 strictly complementary states are kept; 37 of them have u0* on its bound
+    (du0*/dp = 0 exactly, dV/dp not), 57 an interior u0*.  Port: u0*, V at 1e-6, dV/dp and du0*/dp at 1e-5, every entry."""
+    from oracle.problems import make_cartpole
+    g = np.load(os.path.join(GOLD, "g7c_cartpole_grad.npz"))
+    P = make_cartpole()
+    n = len(g["x0"])
+    assert n >= 90 and int(g["drawn"]) == 96 and g["kkt"][:, :2].max() < 1e-9 and g["kkt_d0"].max() < 1e-9
+    r = oracle_port.solve(P, g["x0"], tol=1e-9)
+    assert np.all(r.status == 0)
+    assert (np.abs(r.u0 - g["u0"]) / np.maximum(np.abs(g["u0"]), 1.0)).max() < 1e-6 and (np.abs(r.V - g["V"]) / np.maximum(np.abs(g["V"]), 1.0)).max() < 1e-6
+    e_v, k_v = _held_all(g["dV_d0"], g["dV_d1"], r.dV[:, :3], keep=0.98)
+    e_pi, k_pi = _held_all(g["du0_d0"][:, :, 0], g["du0_d1"][:, :, 0], r.dpi[:, 0, :3], keep=0.98)
+    sat = np.abs(g["u0"][:, 0]) > 29.999
+    assert np.abs(r.dpi[sat][:, 0, :3]).max() < 1e-9                      # a control that sits on its bound does not move with the parameters
+    print("cartpole, %d states (%d saturated) vs third-party finite differences: dV/dp %.2e (kept %.3f) du0*/dp %.2e (kept %.3f)" % (n, sat.sum(), e_v, k_v, e_pi, k_pi))
+    assert e_v < 1e-5 and e_pi < 1e-5
