@@ -25,7 +25,10 @@ from make_thirdparty_grad import cold, slsqp  # noqa: E402
 from oracle.problems import make_cartpole  # noqa: E402
 
 torch.set_num_threads(1)
-PARTS = "/tmp/g7b_parts"
+# G7B_METHOD=kkt: the same ten states through MINPACK's hybrid method on the KKT equations (make_thirdparty_chain_grad.kkt_root: seconds
+# per point where SLSQP needs 10-25 minutes per state and parameter) — the fixture records which method produced it ("method")
+METHOD = os.environ.get("G7B_METHOD", "slsqp")
+PARTS = "/tmp/g7b_parts" if METHOD == "slsqp" else "/tmp/g7b_parts_kkt"
 DELTA = (1e-5, 1e-4)
 # cart near the end of the track, moving outwards (found with the CPU port: position bound active on 1-4 stages, |u0*| <= 12)
 ACTIVE = np.array([[2.288, 1.838, -0.174, -0.525], [-1.952, -2.336, -0.241, 0.521], [2.231, 1.008, 0.25, 0.475], [-2.155, -2.153, 0.032, -0.182]])
@@ -45,7 +48,16 @@ def job(item):
     P = make_cartpole()
     x0, p0 = states()[i], P.p0.copy()
     nlp = Nlp(P, x0, p0)
-    zb, vb, _ = slsqp(nlp, cold(nlp, x0))
+    wb = None
+    if METHOD == "kkt":
+        from make_thirdparty_chain_grad import kkt_root
+        from oracle import cpu_port
+        r = cpu_port.solve(P, x0[None], tol=1e-9, flags=0)
+        assert r.status[0] == 0
+        zb, vb, wb, resb, _ = kkt_root(nlp, np.concatenate([r.U[0].ravel(), r.X[0, 1:].ravel()]))
+        assert resb < 1e-10
+    else:
+        zb, vb, _ = slsqp(nlp, cold(nlp, x0))
     kb = certify(nlp, zb)
     xs = zb[P.N * P.nu: P.N * P.nu + P.N * P.nx].reshape(P.N, P.nx)
     out = {"u0": zb[: P.nu].copy(), "V": vb, "kkt": [kb["stationarity"], kb["feasibility"], kb["min_multiplier"]], "n_active": kb["n_active"],
@@ -54,8 +66,13 @@ def job(item):
         pp, pm = p0.copy(), p0.copy()
         pp[j] *= 1.0 + d
         pm[j] *= 1.0 - d
-        zp, vp, _ = slsqp(Nlp(P, x0, pp), zb)
-        zm, vm, _ = slsqp(Nlp(P, x0, pm), zb)
+        if METHOD == "kkt":
+            zp, vp, _, rp, _ = kkt_root(Nlp(P, x0, pp), zb, wb)
+            zm, vm, _, rm, _ = kkt_root(Nlp(P, x0, pm), zb, wb)
+            assert max(rp, rm) < 1e-10
+        else:
+            zp, vp, _ = slsqp(Nlp(P, x0, pp), zb)
+            zm, vm, _ = slsqp(Nlp(P, x0, pm), zb)
         kp, km = certify(Nlp(P, x0, pp), zp), certify(Nlp(P, x0, pm), zm)
         out[d] = ((vp - vm) / (2 * d * p0[j]), (zp[: P.nu] - zm[: P.nu]) / (2 * d * p0[j]), max(kp["stationarity"], km["stationarity"]))
     print("cartpole state", i, "param", j, "u0", out["u0"], "max |s|", out["s_max"], {d: out[d][:2] for d in DELTA}, out["kkt"], flush=True)
@@ -76,7 +93,7 @@ def main(assemble_only=False, procs=int(os.environ.get("G7B_PROCS", "5"))):
                 print("done", it, flush=True)
     res = {it: pickle.load(open(os.path.join(PARTS, f"{it[0]}_{it[1]}.pkl"), "rb")) for it in items}
     n = len(X)
-    out = {"delta": np.array(DELTA), "x0": X, "u0": np.array([res[(i, 0)]["u0"] for i in range(n)]), "V": np.array([res[(i, 0)]["V"] for i in range(n)]),
+    out = {"method": np.array(METHOD), "delta": np.array(DELTA), "x0": X, "u0": np.array([res[(i, 0)]["u0"] for i in range(n)]), "V": np.array([res[(i, 0)]["V"] for i in range(n)]),
            "kkt": np.array([res[(i, 0)]["kkt"] for i in range(n)]), "s_max": np.array([res[(i, 0)]["s_max"] for i in range(n)]),
            "u_max": np.array([res[(i, 0)]["u_max"] for i in range(n)]), "n_active": np.array([res[(i, 0)]["n_active"] for i in range(n)])}
     for di, d in enumerate(DELTA):
@@ -86,7 +103,7 @@ def main(assemble_only=False, procs=int(os.environ.get("G7B_PROCS", "5"))):
     # what the fixture is for: u0* strictly inside its bounds everywhere, a state bound active on the first four
     assert np.all(np.abs(out["u0"]) < 29.0), out["u0"]
     assert np.all(np.abs(out["s_max"][: len(ACTIVE)] - 2.4) < 1e-7), out["s_max"]
-    assert out["kkt"][:, :2].max() < 1e-9 and out["kkt_d0"].max() < 1e-9
+    assert out["kkt"][:, :2].max() < 1e-9 and out["kkt_d0"].max() < 1e-9 and np.all(out["n_active"][: len(ACTIVE)] >= 1)
     np.savez(os.path.join(HERE, "g7b_cartpole_grad.npz"), **out)
     print("wrote g7b_cartpole_grad.npz: max |s| on the horizon", out["s_max"], "u0", out["u0"].ravel())
 
