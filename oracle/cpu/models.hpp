@@ -112,6 +112,7 @@ double val(const Dual<T, N> &a) { return val(a.v); }
 struct Cartpole {
     static constexpr int NX = 4, NU = 1, NP = 83, NTD = 3;
     static constexpr bool DISCRETE = false, SKIP_CORRECTOR = true;
+    static constexpr bool SENS_EXTRAP = true;    // adjoint solve of du0/dp: Richardson extrapolation in the stiffness cap where a STATE row is capped (mpc_oracle.cpp)
     static constexpr double TOL_MU_FACTOR = 0.1;
     static int td_index(int i) { return i; }
     // cost block of the full parameter vector p (nlp.py:969-989, column-major): W_0 (5x5) at 3, W at 28, W_e (4x4) at 53, yref_0 at 69,
@@ -188,6 +189,7 @@ struct Cartpole {
 struct Linear {
     static constexpr int NX = 2, NU = 1, NP = 12, NTD = 8;
     static constexpr bool DISCRETE = true, SKIP_CORRECTOR = false;
+    static constexpr bool SENS_EXTRAP = false;
     static constexpr double TOL_MU_FACTOR = 0.1;
     static int td_index(int i) { return i; }
     // consts: P (2x2 row-major) terminal DARE matrix
@@ -254,6 +256,7 @@ struct Chain {
                          OFF_W = OFF_R + NU * NU;
     static constexpr int NP = OFF_W + 3 * M, NTD = 10 * NL + 3 * M;
     static constexpr bool DISCRETE = false, SKIP_CORRECTOR = false;
+    static constexpr bool SENS_EXTRAP = false;
     // complementarity tolerance of an inexact QP = TOL_MU_FACTOR x its residual tolerance (1/10 elsewhere): with the cap itself the
     // n_mass 7 chain needs 15.8 instead of 18.8 interior-point iterations per solve, n_mass 3 / 5 and every SQP iteration count unchanged
     static constexpr double TOL_MU_FACTOR = 1.0;

@@ -613,10 +613,39 @@ struct Solver {
             return;
         }
         std::vector<double> zero(N * NX, 0.0), yx((N + 1) * NX), yu(N * NU), ypi(N * NX), yv(NW);
+        // Where the cap binds on a STATE row (an active state bound: lam / t ~ 1e20) the capped solve carries a bias c / W in the adjoint
+        // solution — 1.5e-6 ... 3.6e-6 of du0/dp on cartpole states with the cart at the end of its track (G7b) — which is linear in
+        // 1 / W down to W ~ 1e11, while the recursion's rounding grows with W.  Richardson in the cap removes it at W's rounding level:
+        // y = 2 y(W) - y(W / 2).  Per instance, only for the models whose kernels do the same (Mdl::SENS_EXTRAP), only where a state row is capped.
+        static_assert(!Mdl::SENS_EXTRAP || NU == 1, "the second factorisation below replaces the first: one adjoint solve only");
+        bool extrap = false;
+        if (Mdl::SENS_EXTRAP)
+            for (int e = 0; e < n; ++e)
+                if (e % NW >= NU)
+                    for (int sd = 0; sd < 2; ++sd)
+                        if (has[sd][e] && lam[LB + sd][e] / t[LB + sd][e] > SENS_W_MAX) extrap = true;
+        std::vector<double> yx2, yu2, ypi2;
         for (int iu = 0; iu < NU; ++iu) {
             std::fill(rt.begin(), rt.end(), 0.0);
             rt[iu] = -1.0;
             riccati_solve(rt.data(), zero.data(), yx.data(), yu.data(), ypi.data());
+            if (extrap) {
+                yx2.resize(yx.size()), yu2.resize(yu.size()), ypi2.resize(ypi.size());
+                for (int e = 0; e < n; ++e) {
+                    double d = 0;
+                    for (int sd = 0; sd < 2; ++sd)
+                        if (has[sd][e]) d += std::min(lam[LB + sd][e] / t[LB + sd][e], 0.5 * SENS_W_MAX);
+                    Dg[e] = d;
+                }
+                if (!riccati_factor(Hex.data(), Dg.data())) {
+                    for (int i = 0; i < NU * NP; ++i) dpi[i] = NAN;
+                    return;
+                }
+                riccati_solve(rt.data(), zero.data(), yx2.data(), yu2.data(), ypi2.data());
+                for (size_t i = 0; i < yx.size(); ++i) yx[i] = 2.0 * yx[i] - yx2[i];
+                for (size_t i = 0; i < yu.size(); ++i) yu[i] = 2.0 * yu[i] - yu2[i];
+                for (size_t i = 0; i < ypi.size(); ++i) ypi[i] = 2.0 * ypi[i] - ypi2[i];
+            }
             double *out = dpi + iu * NP;
             typedef Dual<double, 1> In;
             typedef Dual<In, NTD> D2;

@@ -223,6 +223,23 @@ def test_mirror_certifies_the_hip_iterate_cartpole():
     _check_certified(rq, mq.get_lagrangian(), outq, range(8), q_mode=True)
 
 
+def test_mirror_certifies_the_hip_iterate_cartpole_active_state_bound():
+    """The mirror of the reference's NLP (dense pivoted solve with the iterate's own lam / t ~ 1e20 on the active rows) at the four G7b states
+    whose cart reaches the end of the track: the position bound |s| <= 2.4 (config/cartpole.yaml:82-91) is active on the horizon, u0* is not
+    saturated.  Until round 6 the adjoint solve's stiffness cap left du0/dp 1.5e-6 ... 3.6e-6 off there; with the Richardson extrapolation
+    in the cap (SmallSolver::sensitivities) the 1e-6 bar holds against the reference-anchored leg as well."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g7b_cartpole_grad.npz"))
+    x0 = g["x0"][:4]
+    mpc = MPCBatch(cartpole_ocp(tol=1e-9), 4)
+    r = mpc.solve(x0, sens_v=True, sens_pi=True, cold=True)
+    assert bool((r.status == 0).all())
+    bnd = mpc.get_iterate()[3].cpu().numpy()
+    assert np.all(bnd[:, 0:2, 1:, 1:].reshape(4, -1).max(1) > 1e-3)            # a state row's multiplier is active on every one of them
+    out = _certify_batch("cartpole", {}, mpc, r, x0)
+    _check_certified(r, mpc.get_lagrangian(), out, range(4), strict_margin=1e-4)
+
+
 def test_mirror_certifies_the_hip_iterate_linear():
     from mpc4rl_amd import MPCBatch, linear_system_ocp
     rng = np.random.default_rng(12)

@@ -819,7 +819,7 @@ def test_hip_vs_third_party_cartpole_gradients_active_state_bound():
     e_v = held(g["dV_d0"], g["dV_d1"], r.dV_dp.cpu().numpy()[:, :3])
     e_pi = held(g["du0_d0"][:, :, 0], g["du0_d1"][:, :, 0], r.dpi_dp.cpu().numpy()[:, 0, :3])
     print("cartpole (active state bound / near upright) HIP vs third-party finite differences: dV/dp", e_v, "du0*/dp", e_pi)
-    assert e_v < 1e-5 and e_pi < 1e-5
+    assert e_v < 1e-6 and e_pi < 1e-6       # (the stiffness cap alone: 3.6e-6; with the Richardson extrapolation in the cap: 3e-9)
 
 
 def test_hip_vs_third_party_cartpole_gradients_96_states():

@@ -477,7 +477,9 @@ def test_third_party_cartpole_gradients_active_state_bound_vs_the_port(oracle_po
     e_v, k_v = _held_all(g["dV_d0"], g["dV_d1"], r.dV[:, :3])
     e_pi, k_pi = _held_all(g["du0_d0"][:, :, 0], g["du0_d1"][:, :, 0], r.dpi[:, 0, :3])
     print("cartpole (active state bound / near upright) vs third-party finite differences: dV/dp %.2e (kept %.2f) du0*/dp %.2e (kept %.2f)" % (e_v, k_v, e_pi, k_pi))
-    assert e_v < 1e-5 and e_pi < 1e-5
+    # (1e-6, the north_star bar: with the stiffness cap of the adjoint solve alone the four active-bound states were 1.5e-6 ... 3.6e-6 off;
+    # the Richardson extrapolation in the cap — port and kernels alike — brings them to 3e-9)
+    assert e_v < 1e-6 and e_pi < 1e-6
 
 
 def test_third_party_cartpole_gradients_96_states_vs_the_port(oracle_port):
