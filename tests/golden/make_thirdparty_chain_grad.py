@@ -66,7 +66,7 @@ def kkt_root(nlp, z_start, w_start=None, act_tol=1e-7):
     """KKT point of the NLP on the active set of z_start by scipy.optimize.root (MINPACK hybrj): unknowns w = [z; nu; mu_A]."""
     from scipy.optimize import root
     n = nlp.nz
-    lo_a, hi_a = np.where(z_start - nlp.lo < act_tol)[0], np.where(nlp.hi - z_start < act_tol)[0]
+    lo_a, hi_a = np.where(z_start - nlp.lo < act_tol)[0], np.where((nlp.hi - z_start < act_tol) & (nlp.hi > nlp.lo))[0]      # (a pinned variable, lo = hi, is ONE equality row)
     act = np.concatenate([lo_a, hi_a])
     bval = np.concatenate([nlp.lo[lo_a], nlp.hi[hi_a]])
     m = nlp.P.N * nlp.P.nx

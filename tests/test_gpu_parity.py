@@ -845,3 +845,23 @@ def test_hip_vs_third_party_cartpole_gradients_96_states():
     e_pi = held(g["du0_d0"][:, :, 0], g["du0_d1"][:, :, 0], r.dpi_dp.cpu().numpy()[:, 0, :3])
     print("cartpole, %d states, HIP vs third-party finite differences: dV/dp" % n, e_v, "du0*/dp", e_pi)
     assert e_v < 1e-5 and e_pi < 1e-5
+
+
+def test_hip_vs_third_party_q_mode_gradients():
+    """G7d: Q(s, a) and dQ/dp of the HIP path (u0_fixed of mpcrl_solve; MPC.q_update, mpc.py:52-96) at 31 cartpole (state, pinned u0) pairs
+    against certified third-party KKT points (MINPACK on the KKT equations with u_0 as an equality) and their central differences."""
+    from mpc4rl_amd import MPCBatch, cartpole_ocp
+    g = np.load(os.path.join(GOLD, "g7d_cartpole_qmode.npz"))
+    n = len(g["x0"])
+    mpc = MPCBatch(cartpole_ocp(tol=1e-9), n)
+    r = mpc.solve(g["x0"], g["u0"], sens_v=True, sens_pi=True, cold=True)
+    assert bool((r.status == 0).all()) and np.array_equal(r.u0.cpu().numpy(), g["u0"])
+    assert rel_err(r.V.cpu().numpy(), g["Q"]) < RTOL
+    fd0, fd1, mine = g["dQ_d0"], g["dQ_d1"], r.dV_dp.cpu().numpy()[:, :3]
+    scale = np.maximum(np.abs(fd0).max(axis=1, keepdims=True), 1.0)
+    gg = fd0 - (fd1 - fd0) / 99.0
+    ok = np.abs(fd1 - fd0) / 99.0 <= 2e-6 * scale
+    assert ok.mean() >= 0.98
+    e = float(np.where(ok, np.abs(mine - gg) / scale, 0.0).max())
+    print("cartpole Q-mode, %d pairs, HIP dQ/dp vs third-party finite differences:" % n, e)
+    assert e < 1e-6 and bool((r.dpi_dp == 0.0).all())

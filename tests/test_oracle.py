@@ -501,3 +501,18 @@ def test_third_party_cartpole_gradients_96_states_vs_the_port(oracle_port):
     assert np.abs(r.dpi[sat][:, 0, :3]).max() < 1e-9                      # a control that sits on its bound does not move with the parameters
     print("cartpole, %d states (%d saturated) vs third-party finite differences: dV/dp %.2e (kept %.3f) du0*/dp %.2e (kept %.3f)" % (n, sat.sum(), e_v, k_v, e_pi, k_pi))
     assert e_v < 1e-5 and e_pi < 1e-5
+
+
+def test_third_party_q_mode_gradients_vs_the_port(oracle_port):
+    """G7d (tests/golden/make_thirdparty_grad4.py, round 6): Q(s, a) and dQ/dp — MPC.q_update, mpc.py:52-96, what the reference's Q-learning
+    differentiates — at 31 cartpole (state, pinned u0) pairs against certified third-party KKT points and their central differences."""
+    from oracle.problems import make_cartpole
+    g = np.load(os.path.join(GOLD, "g7d_cartpole_qmode.npz"))
+    n = len(g["x0"])
+    assert n >= 28 and g["kkt"].max() < 1e-9 and g["kkt_d0"].max() < 1e-9
+    r = oracle_port.solve(make_cartpole(), g["x0"], u0fix=g["u0"], tol=1e-9)
+    assert np.all(r.status == 0) and np.array_equal(r.u0, g["u0"])
+    assert (np.abs(r.V - g["Q"]) / np.maximum(np.abs(g["Q"]), 1.0)).max() < 1e-6
+    e, kept = _held_all(g["dQ_d0"], g["dQ_d1"], r.dV[:, :3], keep=0.98)
+    print("cartpole Q-mode, %d pairs: dQ/dp vs third-party finite differences %.2e (kept %.3f)" % (n, e, kept))
+    assert e < 1e-6 and np.all(r.dpi == 0.0)
