@@ -372,6 +372,8 @@ def small_measure(linear, B, sens, rti, steps, warmup, world, rank, dist, dev, s
     sweeps = float(iters[:, 1].mean()) + (1 + ocp.nu if sens else 0)
     fp64_tflops = sweeps * riccati_sweep_flops(ocp.N, ocp.nx, ocp.nu) * B / (kern_ms * 1e-3) / 1e12
     traffic, traffic_src = measured_traffic("linear" if linear else "cartpole", B, sens, rti)
+    if linear and STORE_BOUNDS:
+        traffic, traffic_src = None, None      # (the committed counter pass is the MPCRL_NO_BND_STORE form)
     name = "linear system N=40 nx=2 nu=1 (MPCRL_NO_BND_STORE)" if linear and not rti and not STORE_BOUNDS else ("linear system N=40 nx=2 nu=1" if linear else "cartpole N=20 nx=4 nu=1")
     summ = {"value": B * world * steps / elapsed, "unit": "solves/s", "steps": steps, "warmup": warmup, "settle_steps": settle, "ms_per_step": 1e3 * elapsed / steps,
             "workload": ("%s, %d instances/GPU, %s" % (name, B, "RTI (1 SQP iteration, warm)" if rti else "cold-start full-step SQP to tol 1e-6"))
