@@ -91,12 +91,14 @@ enum {
                             (mpcrl_get_lagrangian stays current).  For callers that start every solve cold (a replay batch, the benchmark) or only ever
                             warm-start the primal iterate.  Honoured by the linear-system solve kernel (lq_solve_kernel); the
                             other kernels ignore it (they store, which is always allowed) */
-    MPCRL_EXACT_QP = 64  /* ABI 120, TEST-ONLY, cartpole, full SQP only (not with MPCRL_RTI; other models: MPCRL_E_ARG): every QP of
+    MPCRL_EXACT_QP = 64  /* ABI 120, TEST-ONLY, full SQP only (not with MPCRL_RTI, not with MPCRL_LINEAR_SPL=1: MPCRL_E_ARG): every QP of
                             the SQP is solved to the tight interior-point tolerance from a cold interior-point start, fixed
                             fraction to the boundary, no predictor-only steps — what acados + HPIPM do with the reference's
-                            options (config/cartpole.yaml:8-14) and what the oracle's frozen ORACLE_EXACT mode does.  Runs the
-                            plain launch shape of a separate kernel instantiation; tests/test_gpu_fullsize.py holds the shipped
-                            (inexact-SQP) iteration to it at 1e-6 on the benchmark's inputs.  ~5 x slower: never use it to time */
+                            options (config/cartpole.yaml:8-14, chain_mass/ocp_utils.py:308-312) and what the oracle's frozen
+                            ORACLE_EXACT mode does.  Cartpole: the plain launch shape of a separate kernel instantiation; chain of
+                            masses and the linear-system kernel: a wave-uniform switch at the SQP level.  tests/test_gpu_fullsize.py
+                            holds the shipped (inexact-SQP) iteration to it at 1e-6 on the benchmark's inputs.  Several times
+                            slower: never use it to time */
 };
 enum { MPCRL_E_ARG = -1, MPCRL_E_MODEL = -2, MPCRL_E_HIP = -3, MPCRL_E_NOMEM = -4 };
 

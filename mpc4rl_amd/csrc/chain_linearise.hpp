@@ -437,10 +437,13 @@ __global__ void __launch_bounds__(64, 1) chain_sqp_kernel(const LargeSpec sp, co
             }
         }
         if (status >= 0) break;
-        const double rr_ = fmin(1.0, rmax), ad_ = rmax < sp.tol ? 0.0 : IPM_ADAPT_C * rr_ * rr_;
+        // (MPCRL_EXACT_QP, test-only, wave-uniform: every QP to the tight tolerance from a cold interior-point start, fixed fraction to the boundary)
+        const bool exact_qp = (a.flags & 64) != 0;
+        const double rr_ = fmin(1.0, rmax), ad_ = (rmax < sp.tol || exact_qp) ? 0.0 : IPM_ADAPT_C * rr_ * rr_;
         const double tol_res = fmin(IPM_ADAPT_CAP, fmax(IPM_TOL_RES, ad_)), tol_mu = fmin(CHAIN_TOL_MU_FACTOR * IPM_ADAPT_CAP, fmax(IPM_TOL_MU, 1e-2 * ad_));
         const bool tight = tol_res <= IPM_TOL_RES && tol_mu <= IPM_TOL_MU;
-        const double warm_mu = stepn < 0.0 ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
+        const double warm_mu = (stepn < 0.0 || exact_qp) ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
+        S.frac_fixed = exact_qp;
         // the SQP Hessian: this lane's tiles of (R, Q) without c_k, in registers
         HessConst<M> hs;
         hs.th = S.th, hs.sck = S.sCK();

@@ -78,6 +78,7 @@ struct ChainSolver {
     int N, lane;
     const double *th;   // full parameter vector of this instance
     bool qmode;
+    bool frac_fixed = false;   // MPCRL_EXACT_QP (test-only): fixed fraction to the boundary
     // global (per instance)
     double *X, *U;
     WsArr NUv;             // NUv[k]: multiplier arriving at stage k, [(N+1)*NX] (index 0 unused)
@@ -1468,7 +1469,7 @@ struct ChainSolver {
                     const double ratio = mu > 0.0 ? mu_aff / mu : 0.0;
                     sigma_mu = ratio * ratio * ratio * mu;
                 } else
-                    alpha = fmin(1.0, fmax(IPM_FRAC, 1.0 - mu) * amax);   // fraction to the boundary -> 1 as mu -> 0
+                    alpha = fmin(1.0, fmax(IPM_FRAC, frac_fixed ? 0.0 : 1.0 - mu) * amax);   // fraction to the boundary -> 1 as mu -> 0
             }
             ph(5);
             if (fail) break;
@@ -1670,7 +1671,7 @@ struct ChainSolver {
                     sigma_mu = ratio * ratio * ratio * mu;
                     wave_sync();
                 } else
-                    alpha = fmin(1.0, fmax(IPM_FRAC, 1.0 - mu) * amax);   // fraction to the boundary -> 1 as mu -> 0
+                    alpha = fmin(1.0, fmax(IPM_FRAC, frac_fixed ? 0.0 : 1.0 - mu) * amax);   // fraction to the boundary -> 1 as mu -> 0
             }
             ph(5);
             if (fail) break;

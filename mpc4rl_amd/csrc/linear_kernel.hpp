@@ -1023,7 +1023,8 @@ __global__ void __launch_bounds__(64, 1) lq_solve_kernel(const SmallSpec sp, con
         const double tol_res = IPM_TOL_RES, tol_mu = IPM_TOL_MU;
         if (live) last_tight = true;
         if (!__any(live)) break;
-        const double warm_mu = stepn < 0.0 ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
+        // (MPCRL_EXACT_QP: the LQ model's QP is tight and its fraction to the boundary fixed anyway; the flag takes the interior-point warm start away)
+        const double warm_mu = (stepn < 0.0 || (a.flags & 64)) ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
         const bool ok = S.qp_solve(live, n_ipm, warm_mu, tol_res, tol_mu);
         if (live && !ok) status = 4, live = false;
         {

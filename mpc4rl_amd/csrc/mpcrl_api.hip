@@ -558,7 +558,9 @@ int mpcrl_solve(mpcrl_handle h, const double *x0, const double *u0_fixed, int fl
     if ((flags & MPCRL_SENS_PI) && !dpi_dp) return MPCRL_E_ARG;
     ON_DEVICE(h->device);
     hipStream_t st = (hipStream_t)stream;
-    if ((flags & MPCRL_EXACT_QP) && (h->model != MPCRL_MODEL_CARTPOLE || (flags & MPCRL_RTI))) return MPCRL_E_ARG;
+    // (test-only flag: cartpole through its own kernel instantiation, chain and lq_solve_kernel through a wave-uniform switch; not for RTI calls,
+    // not for the one-stage linear kernels)
+    if ((flags & MPCRL_EXACT_QP) && ((flags & MPCRL_RTI) || (h->model == MPCRL_MODEL_LINEAR && h->linear_spl == 1))) return MPCRL_E_ARG;
     if (!h->have_iterate) flags |= MPCRL_COLD;
     if (h->dual_cold) flags |= MPCRL_COLD_DUAL;
     SmallArgs a;
