@@ -233,7 +233,8 @@ class BatchedTD3:
     def __init__(self, ocp, env, batch_size: int = 256, buffer_steps: int = 64, gamma: float = 0.99, tau: float = 0.005,
                  policy_delay: int = 2, action_noise: float = 0.1, target_noise: float = 0.2, noise_clip: float = 0.5,
                  lr_critic: float = 1e-3, lr_actor: float = 1e-4, reward_scale: float = -1.0, net_arch=(64, 64), device=None,
-                 group=None, seed: int = 0, learn_mask: Optional[torch.Tensor] = None, actor_factory=None, replay_iterates: bool = False):
+                 group=None, seed: int = 0, learn_mask: Optional[torch.Tensor] = None, actor_factory=None, replay_iterates: bool = False,
+                 blas: Optional[str] = "cublas"):
         """actor_factory(batch) -> an MPCActor-like object (default: MPCActor on the GPU).  The CPU tests of the loop's plumbing
         (replay, critic update, the single all-reduce) pass a closed-form stand-in policy; the product path never does.
         replay_iterates: keep, with every transition, the solver iterate the roll-out policy ended with (x, u, pi, bound multipliers and
@@ -244,6 +245,12 @@ class BatchedTD3:
         is what a lock-step launch lasts for.  (The reference's SB3 loop never resets its one solver between replay samples either:
         it warm-starts every solve from the previous — unrelated — sample's solution, rlmpc/td3/policies.py:186-213.)"""
         self.env, self.E, self.B = env, env.num_envs, batch_size
+        if blas and torch.cuda.is_available() and actor_factory is None:
+            # The critics' GEMMs are tiny (batch x 64 by 64 x 64): torch's default on ROCm sends nn.Linear through hipBLASLt, whose
+            # kernels take 18 / 32 / 18 us for the forward / weight-gradient / input-gradient product at batch 4096 where rocBLAS
+            # ("cublas" in torch's naming) takes 8 / 15 / 7 us — ~30 such products per step: 1.68 -> 1.61 ms (profiles/r06_td3_replay_iterates.txt).
+            # A process-wide torch setting (blas=None leaves it alone).
+            torch.backends.cuda.preferred_blas_library(blas)
         make = actor_factory or (lambda batch: MPCActor(ocp, batch, device))
         self.actor = make(self.E)                               # roll-out: keeps one warm-start iterate per environment
         dev = self.actor.mpc.device
