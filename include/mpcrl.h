@@ -69,7 +69,7 @@ extern "C" {
  *        stopping test that is met within rounding can end an interior-point loop one iteration earlier or later (< 1 % of
  *        instances), or flip the status of an RTI call whose residual sits at the tolerance; outputs of such an instance then
  *        agree with the one-stage kernel and the oracle port to the QP tolerance (1e-4 ... 1e-3 on du0/dp), not to rounding
- *   120  round 6: mpcrl_solve flags MPCRL_NO_BND_STORE and MPCRL_EXACT_QP (test-only); mpcrl_get_iterate_rows / mpcrl_set_iterate_rows */
+ *   120  round 6: mpcrl_solve flags MPCRL_NO_BND_STORE and MPCRL_EXACT_QP (test-only); mpcrl_get_iterate_rows / mpcrl_set_iterate_rows; mpcrl_policy_action */
 #define MPCRL_ABI_VERSION 120
 
 enum { MPCRL_MODEL_CARTPOLE = 0, MPCRL_MODEL_LINEAR = 1, MPCRL_MODEL_CHAIN = 2 };
@@ -251,6 +251,15 @@ int mpcrl_env_cartpole_reset(int B, double *state, int64_t *steps, const uint8_t
  *   numbers of the caller; obs [B, 2] (may be NULL) = new state; cost [B] = 1/2 s's + 1/2 a'a + 100 per violated side of the box. */
 int mpcrl_env_linear_step(const double *par, int B, double *state, const double *action, const double *u01, void *obs, int obs_f32,
                           double *cost, void *stream);
+
+/* ABI 120.  The actor's output stage for a batch, one launch: what Actor.forward (rlmpc/td3/policies.py:186-213) and MPC.scale_action
+ * (rlmpc/mpc/common/mpc.py:290-301) do per observation, plus TD3's exploration / target-policy noise.  All device pointers:
+ *   u0 [B, nu] (mpcrl_solve's output), status [B]; noise [B, nu] float standard-normal draws of the caller or NULL; lo, hi [nu] = lbu, ubu;
+ *   ok_i = status_i == 0 (accept_status2: or == 2) and u0_i finite;  a_i = ok_i ? 2 (u0_i - lo) / (hi - lo) - 1 : 0   (scale = 0: u0_i);
+ *   noise given: a_i = clip(a_i + clip(sigma noise_i, +-noise_clip), -1, 1)   (noise_clip <= 0: the noise is not clipped);
+ *   action [B, nu] float; ok [B] uint8, may be NULL.  Handle-less like the environment kernels (launched on the device that owns `action`). */
+int mpcrl_policy_action(const double *u0, const int32_t *status, const float *noise, const double *lo, const double *hi, int B, int nu, int scale,
+                        double sigma, double noise_clip, int accept_status2, float *action, uint8_t *ok, void *stream);
 
 /* Bytes of device memory held by the handle; library version (MPCRL_ABI_VERSION of the header it was built from). */
 int64_t mpcrl_workspace_bytes(mpcrl_handle h);

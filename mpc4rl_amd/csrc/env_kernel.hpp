@@ -93,4 +93,30 @@ __global__ void __launch_bounds__(256) env_linear_step_kernel(const LinearEnvPar
     cost[i] = 0.5 * (s0 * s0 + s1 * s1) + 0.5 * (a * a) + lower + upper;
 }
 
+// The actor's output stage for a batch (round 6): what rlmpc/td3/policies.py:186-213 + MPC.scale_action (rlmpc/mpc/common/mpc.py:290-301) + TD3's
+// exploration / target-policy noise do per observation, one lane per instance:
+//     ok_i = status_i accepted (0, or also 2) and u0_i finite;   a_i = ok_i ? 2 (u0_i - lo) / (hi - lo) - 1 : 0   (scale = 0: a_i = u0_i)
+//     a_i  = clip(a_i + clip(sigma * noise_i, -noise_clip, noise_clip), -1, 1)      (noise = NULL: a_i as it is, unclipped)
+// The arithmetic keeps the order and types of the torch expressions it replaces (the scaling in fp64, then float; the noise product, its
+// clip, the sum and the final clip in float), so that a loop switched to it reproduces its numbers.
+__global__ void __launch_bounds__(256) policy_action_kernel(const double *u0, const int *status, const float *noise, const double *lo, const double *hi,
+                                                            int B, int nu, int scale, float sigma, float noise_clip, int accept2, float *action, uint8_t *ok) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const int st = status[i];
+    bool good = st == 0 || (accept2 && st == 2);
+    for (int j = 0; j < nu; ++j) good = good && isfinite(u0[(long)i * nu + j]);
+    for (int j = 0; j < nu; ++j) {
+        const double u = u0[(long)i * nu + j];
+        float a = !good ? 0.0f : (float)(scale ? 2.0 * ((u - lo[j]) / (hi[j] - lo[j])) - 1.0 : u);
+        if (noise) {
+            float n = sigma * noise[(long)i * nu + j];
+            if (noise_clip > 0.0f) n = fminf(fmaxf(n, -noise_clip), noise_clip);
+            a = fminf(fmaxf(a + n, -1.0f), 1.0f);
+        }
+        action[(long)i * nu + j] = a;
+    }
+    if (ok) ok[i] = good ? 1 : 0;
+}
+
 }  // namespace mpcrl

@@ -627,6 +627,17 @@ int mpcrl_env_cartpole_step(const double *par, int B, double *state, int64_t *st
     return 0;
 }
 
+int mpcrl_policy_action(const double *u0, const int32_t *status, const float *noise, const double *lo, const double *hi, int B, int nu, int scale,
+                        double sigma, double noise_clip, int accept_status2, float *action, uint8_t *ok, void *stream) {
+    if (!u0 || !status || !lo || !hi || !action || B < 0 || nu < 1) return MPCRL_E_ARG;
+    if (B == 0) return 0;
+    ON_DEVICE_OF(action);
+    hipLaunchKernelGGL(policy_action_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, u0, (const int *)status, noise, lo, hi, B, nu, scale,
+                       (float)sigma, (float)noise_clip, accept_status2, action, ok);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int mpcrl_env_linear_step(const double *par, int B, double *state, const double *action, const double *u01, void *obs, int obs_f32,
                           double *cost, void *stream) {
     if (!par || B < 0 || !state || !action || !u01 || !cost) return MPCRL_E_ARG;

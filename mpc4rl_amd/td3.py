@@ -8,6 +8,7 @@ grad_a Q from any torch critic.  (No reference behaviour to match for the update
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional
 
 import torch
@@ -55,6 +56,25 @@ class MPCActor:
 
     def scale_action(self, u):                                   # mpc.py:290-301
         return 2.0 * ((u - self.low) / (self.high - self.low)) - 1.0 if self.scale else u
+
+    def action(self, r, noise: Optional[torch.Tensor] = None, sigma: float = 0.0, noise_clip: float = 0.0, accept_status2: bool = False):
+        """(a [B, nu] float32, ok [B] bool): the policy's action of a solve result — scale_action where the solve succeeded (status 0, with
+        accept_status2 also 2: the closed loop applies what max_iter left) and u0 is finite, 0 elsewhere — plus
+        clip(sigma noise, +-noise_clip), the sum clipped to [-1, 1] when ``noise`` (standard-normal draws, float32) is given.  ONE launch
+        (mpcrl_policy_action) for what is ~15 elementwise launches in torch; the same arithmetic in the same order and types."""
+        from . import _lib
+        B, nu = r.u0.shape
+        a = torch.empty((B, nu), dtype=torch.float32, device=r.u0.device)
+        ok = torch.empty((B,), dtype=torch.uint8, device=r.u0.device)
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        if noise is not None and not (noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape == (B, nu)):
+            raise ValueError("noise: contiguous float32 [B, nu]")
+        with torch.cuda.device(r.u0.device):
+            rc = _lib.load().mpcrl_policy_action(ptr(r.u0), ptr(r.status), ptr(noise), ptr(self.low), ptr(self.high), B, nu, int(self.scale), float(sigma),
+                                                 float(noise_clip), int(accept_status2), ptr(a), ptr(ok), C.c_void_p(torch.cuda.current_stream(r.u0.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"mpcrl_policy_action failed with code {rc}")
+        return a, ok.bool()
 
     def forward(self, obs: torch.Tensor) -> torch.Tensor:        # Actor.forward, td3/policies.py:186-197 — ONE launch
         return self.scale_action(self.mpc.get_action(obs.to(torch.float64))).to(obs.dtype)
@@ -277,6 +297,7 @@ class BatchedTD3:
         self.critic_opt = torch.optim.Adam(self.critic.parameters(), lr=lr_critic,
                                            **({"fused": True, "capturable": True} if dev.type == "cuda" else {}))
         self.replay_iterates = bool(replay_iterates)
+        self._fused = actor_factory is None and dev.type == "cuda"      # the actors' output stage through mpcrl_policy_action (one launch)
         nw_ = ocp.nx + ocp.nu
         self.buffer = DeviceReplayBuffer(buffer_steps, self.E, ocp.nx, ocp.nu, dev, iterate_dims=(
             (ocp.N + 1) * ocp.nx, ocp.N * ocp.nu, ocp.N * ocp.nx, 10 * (ocp.N + 1) * nw_) if self.replay_iterates else None)
@@ -301,9 +322,13 @@ class BatchedTD3:
         # a solve that ended with status 1 / 4 may hand back a non-finite u0: such an environment gets the zero action (a
         # finite fallback; the reference raises instead, mpc.py:81-83).  The stored transition is the one that really happened
         # (action 0 was applied), so no NaN ever reaches the environment, the replay buffer or the critic
-        u_ok = torch.isfinite(r.u0).all(dim=1) & ((r.status == 0) | (r.status == 2))
-        a = torch.where(u_ok[:, None], self.actor.scale_action(torch.nan_to_num(r.u0)), torch.zeros_like(r.u0)).to(torch.float32)
-        a = (a + self.action_noise * torch.randn(a.shape, device=self.device, generator=self.gen)).clamp(-1.0, 1.0)
+        eps = torch.randn(r.u0.shape, dtype=torch.float32, device=self.device, generator=self.gen)
+        if self._fused:
+            a, u_ok = self.actor.action(r, eps, sigma=self.action_noise, accept_status2=True)
+        else:
+            u_ok = torch.isfinite(r.u0).all(dim=1) & ((r.status == 0) | (r.status == 2))
+            a = torch.where(u_ok[:, None], self.actor.scale_action(torch.nan_to_num(r.u0)), torch.zeros_like(r.u0)).to(torch.float32)
+            a = (a + self.action_noise * eps).clamp(-1.0, 1.0)
         nxt, rew, term, trunc = self.env.step(a.to(self.env.device))
         nxt, rew = nxt.to(self.device), rew.to(self.device)
         done = (term | trunc).to(self.device)
@@ -368,7 +393,7 @@ class BatchedTD3:
         world, n_theta = self._world(), self.theta.numel()
         obs, nxt, act, rew, done = self.buffer.sample(self.B, self.gen)
         with torch.no_grad():
-            noise = (self.target_noise * torch.randn(act.shape, device=self.device, generator=self.gen)).clamp(-self.noise_clip, self.noise_clip)
+            eps = torch.randn(act.shape, dtype=torch.float32, device=self.device, generator=self.gen)
             if self.replay_iterates:
                 it_s, ok_s, it_n, ok_n = self.buffer.iterates_of_last_sample()
                 self._load_iterate(self.target_mpc.mpc, it_n)
@@ -379,10 +404,16 @@ class BatchedTD3:
             # failed target solves are SELECTED out (a product with a 0 / 1 mask would keep their NaN: NaN * 0 = NaN), and so are
             # transitions whose stored observations are not finite
             # (one finiteness test over the whole transition: every separate test, fill and select is a launch of its own)
-            row = torch.cat([obs, nxt, act, rew[:, None], rt.u0.to(obs.dtype)], dim=1)
-            ok_b = (rt.status == 0) & torch.isfinite(row).all(dim=1)
-            u_next = torch.where(ok_b[:, None], rt.u0, 0.0)
-            a_next = (self.target_mpc.scale_action(u_next).to(torch.float32) + noise).clamp(-1.0, 1.0)
+            if self._fused:      # the target actor's output stage in one launch; the sampled rows are one packed tensor already
+                a_next, ok_u = self.target_mpc.action(rt, eps, sigma=self.target_noise, noise_clip=self.noise_clip)
+                row = self.buffer.last_rows
+                ok_b = ok_u & torch.isfinite(row).all(dim=1)
+            else:
+                noise = (self.target_noise * eps).clamp(-self.noise_clip, self.noise_clip)
+                row = torch.cat([obs, nxt, act, rew[:, None], rt.u0.to(obs.dtype)], dim=1)
+                ok_b = (rt.status == 0) & torch.isfinite(row).all(dim=1)
+                u_next = torch.where(ok_b[:, None], rt.u0, 0.0)
+                a_next = (self.target_mpc.scale_action(u_next).to(torch.float32) + noise).clamp(-1.0, 1.0)
             safe = torch.where(ok_b[:, None], row, 0.0)
             nx_ = obs.shape[1]
             obs_s, nxt_s, act_s = safe[:, :nx_], safe[:, nx_: 2 * nx_], safe[:, 2 * nx_: 2 * nx_ + act.shape[1]]
@@ -402,9 +433,14 @@ class BatchedTD3:
                 rp = self.pi_mpc.mpc.solve(obs.to(torch.float64), sens_pi=True, cold_mask=~ok_s)   # pi(s_i), dpi/dtheta_i: one launch, warm
             else:
                 rp = self.pi_mpc.mpc.solve(obs.to(torch.float64), sens_pi=True, cold=True)   # pi(s_i), dpi/dtheta_i: one launch
-            okb = (rp.status == 0) & torch.isfinite(torch.cat([rp.u0.to(obs.dtype), obs], dim=1)).all(dim=1)
-            u_pi = torch.where(okb[:, None], rp.u0, 0.0)
-            a_pi = self.pi_mpc.scale_action(u_pi).to(torch.float32).detach().requires_grad_(True)
+            if self._fused:
+                a_pi, ok_u = self.pi_mpc.action(rp)
+                okb = ok_u & torch.isfinite(obs).all(dim=1)
+                a_pi = a_pi.requires_grad_(True)
+            else:
+                okb = (rp.status == 0) & torch.isfinite(torch.cat([rp.u0.to(obs.dtype), obs], dim=1)).all(dim=1)
+                u_pi = torch.where(okb[:, None], rp.u0, 0.0)
+                a_pi = self.pi_mpc.scale_action(u_pi).to(torch.float32).detach().requires_grad_(True)
             # the policy branch has its own mask: obs_s above is zeroed where the TARGET solve failed, and dQ/da at obs = 0 paired
             # with pi(s) and dpi/dtheta of the real obs would bias the step for rows whose policy solve succeeded
             obs_p = torch.where(okb[:, None], obs, 0.0)

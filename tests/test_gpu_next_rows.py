@@ -574,3 +574,52 @@ def test_td3_replay_iterates():
     st = agent.last_stats()
     assert st["converged_fraction"] > 0.95 and bool(torch.isfinite(agent.theta).all()) and bool(torch.isfinite(crit()).all())
     assert int(buf.pos_t.item()) == buf.pos
+
+
+@pytest.mark.gpu
+def test_policy_action_kernel_and_fused_td3_glue():
+    """mpcrl_policy_action (round 6): the actor's output stage — scale_action (mpc.py:290-301), exploration / target-policy noise, clips,
+    the failed-solve mask — in one launch.  (a) Bit for bit the torch expressions it replaces, failed and non-finite rows included.
+    (b) A TD3 loop run with it (BatchedTD3._fused, the default on the GPU) reproduces the loop without it bit for bit: replay table,
+    critic losses, theta, critics."""
+    from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedTD3, MPCBatch, cartpole_ocp
+    from mpc4rl_amd.td3 import MPCActor
+    ocp = cartpole_ocp()
+    B = 300
+    rng = np.random.default_rng(8)
+    x0 = rng.uniform(-1, 1, (B, 4)) * np.array([2.0, 3.0, np.pi, 5.0])        # the whole box: some solves end with status 2 / 4
+    actor = MPCActor(ocp, B)
+    actor.mpc.set_options(max_iter=12)
+    r = actor.mpc.solve(x0, cold=True)
+    r.u0[5] = float("nan")
+    r.u0[6] = float("inf")
+    st = r.status
+    assert int((st == 0).sum()) > 0 and int((st != 0).sum()) > 0
+    eps = torch.randn(B, 1, device="cuda")
+    for sigma, clip, acc2 in ((0.1, 0.0, True), (0.2, 0.5, False)):
+        a, ok = actor.action(r, eps, sigma=sigma, noise_clip=clip, accept_status2=acc2)
+        ok_t = torch.isfinite(r.u0).all(dim=1) & ((st == 0) | (st == 2) if acc2 else (st == 0))
+        n = sigma * eps
+        if clip > 0:
+            n = n.clamp(-clip, clip)
+        a_t = (torch.where(ok_t[:, None], actor.scale_action(torch.nan_to_num(r.u0)), torch.zeros_like(r.u0)).to(torch.float32) + n).clamp(-1.0, 1.0)
+        assert torch.equal(ok, ok_t) and torch.equal(a, a_t)
+    a0, ok0 = actor.action(r)                                              # no noise: the scaled action itself, unclipped
+    assert torch.equal(a0, torch.where(ok0[:, None], actor.scale_action(torch.nan_to_num(r.u0)), torch.zeros_like(r.u0)).to(torch.float32))
+    with pytest.raises(ValueError):
+        actor.action(r, eps.double())
+    # (b)
+    res = {}
+    for fused in (False, True):
+        env = BatchedCartPoleSwingUpEnv(256, device="cuda", seed=0, max_episode_steps=7)
+        ag = BatchedTD3(ocp, env, batch_size=256, buffer_steps=6, policy_delay=2, lr_actor=1e-4, seed=0, replay_iterates=True)
+        assert ag._fused
+        ag._fused = fused
+        ag.collect(6)
+        losses = []
+        for _ in range(6):
+            ag.collect(1)
+            losses.append(ag.train(1)["critic_loss"])
+        res[fused] = (ag.buffer.data.clone(), losses, ag.theta.clone(), torch.cat([p.detach().reshape(-1) for p in ag.critic.parameters()]))
+    assert torch.equal(res[False][0], res[True][0]) and res[False][1] == res[True][1]
+    assert torch.equal(res[False][2], res[True][2]) and torch.equal(res[False][3], res[True][3])
