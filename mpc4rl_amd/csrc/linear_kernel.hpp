@@ -4,9 +4,9 @@
 // of its instructions — runs with ONE useful lane of 64.  Its SQ counters (profiles/r05_small_pmc.txt): 103 k wave-instructions per
 // instance, 66 % of the VALU issue floor of that stream: only instances SHARING wave-instructions can make it faster.  Here a lane
 // holds SPL = 3 consecutive stages (stage = 3 pos + j), an instance takes ceil((N + 1) / 3) = 14 lanes and a wavefront FOUR instances,
-// each in a DPP row (16 lanes) of its own (RL = 16; up to 8 lanes per instance: half rows, eight instances; more than 16: packed
-// segments and __shfl): 4096 instances are 1024
-// wavefronts, one per SIMD, one round.
+// each in a DPP row (16 lanes) of its own (RL = 16; up to 8 lanes per instance: half rows, eight instances; horizons whose three-stage
+// lanes would outgrow a row — N >= 48 — take FOUR stages per lane, SPL = 4, and fit a row again): 4096 instances are 1024 wavefronts,
+// one per SIMD, one round.
 //   * factor sweep: still N + 1 dependent stage steps, but every wave-instruction of it works for four instances and two of three
 //     steps take P_{k+1} out of the lane's own registers (one DPP shift per lane boundary);
 //   * vector sweeps: the lane composes its three affine stage maps, a Hillis-Steele scan over the row (4 steps of row_shr / row_shl
@@ -54,11 +54,12 @@ MPCRL_DI void row_reduce(double *mx, double *sm) {
 #undef MPCRL_ROW_STEP
 }
 
-// RL = 16 / 8: the instance owns one DPP row / half row (the live lanes first): reductions and scans by DPP moves; RL = 0: packed
-// segments of any length, __shfl
+// RL = 16 / 8: the instance owns one DPP row / half row (the live lanes first): reductions and scans by DPP moves.  (Round 5 also had
+// RL = 0, packed segments of any length with __shfl, for horizons whose three-stage lanes outgrow a row; round 6 runs those with four
+// stages per lane in rows — lq_solve_kernel<4, 16> — and the packed form is gone.)
 template <int SPL, int RL>
 struct LqSolver {
-    static constexpr bool ROW = RL != 0;
+    static_assert(RL == 8 || RL == 16, "an instance owns a DPP half row or row");
     static constexpr int NX = 2, NU = 1, NW = 3;
     const SmallSpec &sp;
     const int N, lpi, lpl, pos, base;   // lpi: lanes of the slot of the instance; lpl: the ones that hold live stages
@@ -93,10 +94,7 @@ struct LqSolver {
     // reductions over the lanes of the instance, result in all of them
     template <int NMAX, int NSUM>
     MPCRL_DI void red(double *mx, double *sm) const {
-        if constexpr (ROW)
-            row_reduce<NMAX, NSUM, RL>(mx, sm);
-        else
-            seg_reduce<NMAX, NSUM, true>(mx, sm, pos, lpi, base);
+        row_reduce<NMAX, NSUM, RL>(mx, sm);
     }
     MPCRL_DI double red_sum(double v) const {
         red<0, 1>(nullptr, &v);
@@ -350,24 +348,9 @@ struct LqSolver {
         for (int i = 0; i < 2; ++i) m.v[i] = valid ? n.v[i] : m.v[i];
     }
     MPCRL_DI void scan(Aff &m, bool down) const {
-        if constexpr (ROW) {      // row shifts (the lanes behind the live ones hold identity / constant maps)
-            scan_step<1>(m, down), scan_step<2>(m, down), scan_step<4>(m, down);
-            if constexpr (RL == 16) scan_step<8>(m, down);
-            return;
-        }
-        for (int sft = 1; sft < lpi; sft <<= 1) {
-            Aff o;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o.M[i] = down ? __shfl_down(m.M[i], sft) : __shfl_up(m.M[i], sft);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) o.v[i] = down ? __shfl_down(m.v[i], sft) : __shfl_up(m.v[i], sft);
-            const bool valid = down ? pos + sft < lpi : pos - sft >= 0;
-            const Aff n = compose(m, o);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) m.M[i] = valid ? n.M[i] : m.M[i];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) m.v[i] = valid ? n.v[i] : m.v[i];
-        }
+        // row shifts (the lanes behind the live ones hold identity / constant maps)
+        scan_step<1>(m, down), scan_step<2>(m, down), scan_step<4>(m, down);
+        if constexpr (RL == 16) scan_step<8>(m, down);
     }
 
     // ---- vector-only backward sweep on the stored factors (SmallSolver::backward_scan): p_k, kff_k for the right-hand side rt
@@ -889,7 +872,7 @@ __global__ void __launch_bounds__(64, 1) lq_solve_kernel(const SmallSpec sp, con
 #ifdef MPCRL_PROFILE_PHASES
     const unsigned long long rt0_ = wall_clock64();
 #endif
-    const int lane = threadIdx.x, N = sp.N, lpl = lq_lanes_per_instance<SPL>(N), lpi = RL ? RL : lpl, ipw = min(64 / lpi, MAXI);
+    const int lane = threadIdx.x, N = sp.N, lpl = lq_lanes_per_instance<SPL>(N), lpi = RL, ipw = min(64 / lpi, MAXI);
     const int slot = lane / lpi, pos = lane - slot * lpi, base = slot * lpi;
     long inst = (long)blockIdx.x * ipw + slot;
     const bool valid = slot < ipw && inst < a.B;
