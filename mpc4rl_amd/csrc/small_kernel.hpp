@@ -1636,6 +1636,9 @@ MPCRL_DI void small_sens_tail(SmallSolver<M> &S, const SmallArgs &a, long inst, 
     double hdd[M::NLD * (M::NLD + 1) / 2];
     if ((a.flags & 2) && a.dpi && !S.qmode) {   // wave-uniform
         S.template linearize<true>(xn, nun, hdd);
+#ifdef MPCRL_PROFILE_PHASES
+        { unsigned long long n_ = clock64(); if (S.pht) S.phw[9] += n_ - S.pht; S.pht = n_; }      // (phase profile of the sensitivity kernel)
+#endif
     } else {
 #pragma unroll
         for (int e = 0; e < M::NLD * (M::NLD + 1) / 2; ++e) hdd[e] = 0.0;
@@ -2495,7 +2498,14 @@ __global__ void __launch_bounds__(64) small_sens_kernel(const SmallSpec sp, cons
 #pragma unroll
     for (int i = 0; i < NW; ++i) S.lam[0][i] = bnd[0 * nb + i], S.lam[1][i] = bnd[1 * nb + i], S.t[0][i] = bnd[2 * nb + i], S.t[1][i] = bnd[3 * nb + i];
     // the dynamics Jacobians of the final iterate are needed by the adjoint Riccati sweep: linearised again inside the pass
+#ifdef MPCRL_PROFILE_PHASES
+    S.pht = clock64();
+#endif
     small_sens_tail<M>(S, a, inst, valid, a.status[inst]);
+#ifdef MPCRL_PROFILE_PHASES
+    { unsigned long long n_ = clock64(); S.phw[8] += n_ - S.pht; }
+    if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_phase_ticks[i_], S.phw[i_]);
+#endif
 }
 
 }  // namespace mpcrl
