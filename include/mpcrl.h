@@ -46,6 +46,9 @@
  *     of the three-stages-per-lane one.  Same iteration, sums associated differently: results equal to rounding EXCEPT where a
  *     stopping test is met within rounding — there the interior-point count can differ by one, an RTI call's status can differ,
  *     and the outputs agree to the QP tolerance only (see ABI 110 below).
+ *   - linear-system model, warm calls: an instance whose WARM-started interior point runs out of iterations (it can jam against the
+ *     rows a moved x0 activates) solves that QP once more from the cold interior point before status 4 is reported — the QP is convex,
+ *     the cold start solves it; its iteration count then includes both attempts (> 60).  No signature or output layout changes.
  *   - cartpole: a wavefront holds min(floor(64 / (N + 1)), 4) instances — four is the number of 4x4 blocks of the
  *     matrix-core sweeps — so horizons below N = 15 use fewer of its lanes than a lane-per-stage packing could.
  */

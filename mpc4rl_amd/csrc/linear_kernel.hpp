@@ -1008,7 +1008,19 @@ __global__ void __launch_bounds__(64, 1) lq_solve_kernel(const SmallSpec sp, con
         if (!__any(live)) break;
         // (MPCRL_EXACT_QP: the LQ model's QP is tight and its fraction to the boundary fixed anyway; the flag takes the interior-point warm start away)
         const double warm_mu = (stepn < 0.0 || (a.flags & 64)) ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
-        const bool ok = S.qp_solve(live, n_ipm, warm_mu, tol_res, tol_mu);
+        // A warm interior point can jam against rows that the moved x0 makes active, or settle into a two-cycle of mu (Mehrotra's sigma
+        // alternating), and run out of iterations; the QP of the LQ model is convex, so the cold start solves it: an instance whose WARM
+        // QP failed runs it once more from the cold interior point (same primal iterate; its iterations are counted on top).
+        bool ok = false, act = live;
+        double wm = warm_mu;
+#pragma nounroll
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const bool o = S.qp_solve(act, n_ipm, wm, tol_res, tol_mu);
+            if (act) ok = o;
+            act = act && !o && wm > 0.0;
+            if (!__any(act)) break;
+            wm = 0.0;
+        }
         if (live && !ok) status = 4, live = false;
         {
             double sl = 0.0;

@@ -1837,7 +1837,14 @@ __global__ void __launch_bounds__(64, M::DISCRETE ? MPCRL_LINEAR_OCC : MPCRL_CAR
         if (live) last_tight = tol_res <= IPM_TOL_RES && tol_mu <= IPM_TOL_MU;
         if (!__any(live)) break;
         const double warm_mu = (stepn < 0.0 || M::EXACT_QP) ? 0.0 : fmin(IPM_WARM_MAX, fmax(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
-        const bool ok = S.qp_solve(live, S.x0r, S.u0r, n_ipm, warm_mu, tol_res, tol_mu);
+        bool ok = S.qp_solve(live, S.x0r, S.u0r, n_ipm, warm_mu, tol_res, tol_mu);
+        if constexpr (M::DISCRETE) {      // (LQ model: a failed WARM QP once more from the cold interior point — see lq_solve_kernel)
+            const bool again = live && !ok && warm_mu > 0.0;
+            if (__any(again)) {
+                const bool o = S.qp_solve(again, S.x0r, S.u0r, n_ipm, 0.0, tol_res, tol_mu);
+                if (again) ok = o;
+            }
+        }
         if (live && !ok) status = 4, live = false;
         {
             double sl = 0.0;

@@ -560,6 +560,10 @@ struct Solver {
             bool ok;
             const double warm_mu = (stepn < 0.0 || exact) ? 0.0 : std::min(IPM_WARM_MAX, std::max(IPM_WARM_MIN, IPM_WARM_C * stepn * stepn));
             n_ipm += qp_solve(x0, u0fix, ok, warm_mu);
+            // (round 6, LQ model: a WARM interior point that ran out of iterations — jammed against rows the moved x0 activates
+            // (alpha 1e-13 ... 1e-6 for 15 iterations from mu 2e-8 under a residual of 2e-2), then a two-cycle of mu with sigma
+            // alternating 0.07 / 0.88 — once more from the cold interior point, which solves the convex QP; the kernels do the same)
+            if (!ok && warm_mu > 0.0 && Mdl::DISCRETE) n_ipm += qp_solve(x0, u0fix, ok, 0.0);
             if (!ok) return 4;
             stepn = 0.0;
             for (double v : dx) stepn = std::max(stepn, std::fabs(v));

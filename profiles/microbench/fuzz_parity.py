@@ -16,16 +16,19 @@ from oracle.problems import make_cartpole, make_chain_mass, make_linear_system  
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 rng = np.random.default_rng(seed)
 bad = 0
+DUMP = {}
 
 
 def rel(a, b):
+    if len(b) == 0:
+        return np.zeros(0)
     a, b = np.asarray(a, float).reshape(len(b), -1), np.asarray(b, float).reshape(len(b), -1)
     nn = np.isnan(a) & np.isnan(b)
     a, b = np.where(nn, 0, a), np.where(nn, 0, b)
     return (np.abs(a - b) / np.maximum(np.abs(b).max(1, keepdims=True), 1.0)).max(1)
 
 
-def check(tag, r, ref, dpi_tol=1e-5, unique=None):
+def check(tag, r, ref, dpi_tol=1e-5, unique=None, rti=False, among=None):
     """unique: for the convex linear-system QP — the port's solution of the same problem in its exact-QP mode from a cold start (ONE
     KKT point whatever the path): where the port's tuned iteration fails on a warm call (status 4: its re-evaluated residuals stall at
     their rounding level, or its interior point cycles on a degenerate QP — this box's rounding decides) or stops one interior-point
@@ -33,6 +36,21 @@ def check(tag, r, ref, dpi_tol=1e-5, unique=None):
     global bad
     st = r.status.cpu().numpy()
     it = r.iters.cpu().numpy()
+    both = (st == 0) & (ref.status == 0)
+    if among is not None:      # a chained call: only the instances both sides have solved so far start it from the same iterate
+        import dataclasses
+        ref = cpu_port.PortResult(*[getattr(ref, f.name)[among] if getattr(ref, f.name) is not None else None for f in dataclasses.fields(cpu_port.PortResult)])
+        class _Q: pass
+        rq = _Q()
+        kt = torch.as_tensor(among, device=r.status.device)
+        for n in ("u0", "V", "status", "iters", "dV_dp", "dpi_dp"):
+            v = getattr(r, n)
+            setattr(rq, n, v[kt] if v is not None else None)
+        r, st, it = rq, st[among], it[among]
+        if unique is not None:
+            unique = cpu_port.PortResult(*[getattr(unique, f.name)[among] if getattr(unique, f.name) is not None else None for f in dataclasses.fields(cpu_port.PortResult)])
+        if not among.any():
+            return both
     if unique is not None:
         apart = (ref.status != 0) | (it[:, 1] != ref.ipm_iter)
         if apart.any() and (unique.status[apart] == 0).all():
@@ -44,6 +62,11 @@ def check(tag, r, ref, dpi_tol=1e-5, unique=None):
             print("%-4s %s: %d instances where the port failed (%d) or stopped an interior-point iteration apart, held to the unique QP solution: u0 %.1e V %.1e dV %.1e, product converged on %d of them" % (
                 "FAIL" if f2 else "ok", tag, apart.sum(), (ref.status != 0).sum(), eu, eV, edV, g_ok.sum()), flush=True)
             bad += int(f2)
+            if f2 and os.environ.get("FUZZ_DUMP"):
+                idx = np.nonzero(apart)[0]
+                print("     apart instances", idx.tolist(), "product status", st[apart].tolist(), "iters", it[apart].tolist(), "port status", ref.status[apart].tolist(),
+                      "port ipm", ref.ipm_iter[apart].tolist(), flush=True)
+                np.savez(os.path.join(os.environ["FUZZ_DUMP"], "fuzz_%d_%s.npz" % (seed, tag.replace(" ", "_").replace("=", ""))), idx=idx, **DUMP)
         keep = ~apart
         import dataclasses
         ref = cpu_port.PortResult(*[getattr(ref, f.name)[keep] if getattr(ref, f.name) is not None else None for f in dataclasses.fields(cpu_port.PortResult)])
@@ -55,6 +78,8 @@ def check(tag, r, ref, dpi_tol=1e-5, unique=None):
             setattr(rr, n, v[kt] if v is not None else None)
         r, st, it = rr, st[keep], it[keep]
     ok = (st == 0) & (ref.status == 0)
+    if rti:       # one SQP iteration: status 2 is the regular outcome, the step taken is what is compared
+        ok = (st == ref.status) & ((st == 0) | (st == 2))
     e = {"u0": rel(r.u0.cpu().numpy()[ok], ref.u0[ok]), "V": rel(r.V.cpu().numpy()[ok], ref.V[ok])}
     if r.dV_dp is not None:
         e["dV"] = rel(r.dV_dp.cpu().numpy()[ok], ref.dV[ok])
@@ -69,6 +94,13 @@ def check(tag, r, ref, dpi_tol=1e-5, unique=None):
     print("%-4s %s: status equal %.4f, conv %.3f, |d sqp| <= %d, %s" % ("FAIL" if fail else "ok", tag, same, float((st == 0).mean()), dsqp,
           " ".join("%s %.1e" % kv for kv in worst.items())), flush=True)
     bad += int(fail)
+    if fail and os.environ.get("FUZZ_DUMP") and among is None:
+        for k, v in e.items():
+            if len(v):
+                j = int(np.argmax(v))
+                gi = np.nonzero(ok)[0][j] if k != "dpi" else -1
+                print("     worst %s %.2e at converged instance %d: iters product %s port (%d, %d)" % (k, v[j], gi, it[gi].tolist(), ref.sqp_iter[gi], ref.ipm_iter[gi]), flush=True)
+    return both
 
 
 for trial in range(int(os.environ.get("FUZZ_TRIALS", "24"))):
@@ -115,12 +147,30 @@ for trial in range(int(os.environ.get("FUZZ_TRIALS", "24"))):
     if fam == "linear":
         x1 = np.clip(x1, [0.05, -0.9], [0.95, 0.9])
     mask = rng.uniform(size=B) < 0.3
+    DUMP = dict(x0=x0, x1=x1, mask=mask, theta=theta, N=N, B=B, per=per)
     r1 = mpc.solve(x1, sens_v=True, sens_pi=True, cold_mask=torch.as_tensor(mask, device="cuda"))
     ref_c = cpu_port.solve(P, x1, p=theta if per else None)
     ref_w = cpu_port.solve(P, x1, p=theta if per else None, warm=ref)
     mix = cpu_port.PortResult(*[np.where(mask.reshape((-1,) + (1,) * (getattr(ref_c, f.name).ndim - 1)), getattr(ref_c, f.name), getattr(ref_w, f.name))
                                  if getattr(ref_c, f.name) is not None else None for f in __import__("dataclasses").fields(cpu_port.PortResult)])
     check(tag + " warm + cold mask", r1, mix, dpi_tol, unique=uq(x1) if uq else None)
+    # a closed loop from there: two more warm calls at larger moves, then one real-time iteration (FUZZ_CHAIN=0: skip)
+    if os.environ.get("FUZZ_CHAIN", "1") != "0":
+        xs, prev = x1, mix
+        solved = (r1.status.cpu().numpy() == 0) & (mix.status == 0)
+        for n, sc in enumerate((3.0, 1.0)):
+            xs = xs + rng.normal(0, 0.01 * sc * (0.3 if fam == "chain" else 1.0), xs.shape)
+            if fam == "linear":
+                xs = np.clip(xs, [0.05, -0.9], [0.95, 0.9])
+            DUMP = dict(x0=x0, x1=xs, mask=mask, theta=theta, N=N, B=B, per=per)
+            rn = mpc.solve(xs, sens_v=True, sens_pi=True)
+            prev = cpu_port.solve(P, xs, p=theta if per else None, warm=prev)
+            solved &= check(tag + " warm %d" % (n + 2), rn, prev, dpi_tol, unique=uq(xs) if uq else None, among=solved.copy())
+        if fam != "linear":      # (an RTI step of the LQ model is its solve)
+            xs = xs + rng.normal(0, 0.003, xs.shape)
+            rn = mpc.solve(xs, sens_pi=True, rti=True)
+            prev = cpu_port.solve(P, xs, p=theta if per else None, warm=prev, rti=True)
+            check(tag + " rti", rn, prev, dpi_tol, rti=True, among=solved.copy())
     # Q-mode
     lo, hi = np.asarray(ocp.lbu, float), np.asarray(ocp.ubu, float)
     u0 = rng.uniform(0.8 * lo, 0.8 * hi, (B, len(lo)))

@@ -865,3 +865,30 @@ def test_hip_vs_third_party_q_mode_gradients():
     e = float(np.where(ok, np.abs(mine - gg) / scale, 0.0).max())
     print("cartpole Q-mode, %d pairs, HIP dQ/dp vs third-party finite differences:" % n, e)
     assert e < 1e-6 and bool((r.dpi_dp == 0.0).all())
+
+
+@pytest.mark.parametrize("spl", ["3", "1"])
+def test_linear_warm_qp_failure_restarts_cold(spl, monkeypatch, oracle_port):
+    """LQ model, both kernel families: a WARM interior point that runs out of iterations (it jams against the rows the moved x0
+    activates, then cycles: tests/test_oracle.py WARM_QP_FAILS, found by profiles/microbench/fuzz_parity.py seed 7 as a status 4 of
+    the product AND the port) is run once more from the cold interior point.  Which side of 60 iterations a jammed interior point
+    ends on is decided by rounding, so the assertion is the result: status 0 and the ONE solution of the convex QP."""
+    from mpc4rl_amd import MPCBatch, linear_system_ocp
+    from oracle.problems import make_linear_system
+    WARM_QP_FAILS = np.array([[[0.8726968153298129, 0.5483649132524803], [0.8572483237722713, 0.5365310381189186]],
+                              [[0.11781405145159196, -0.5019479937647703], [0.12047207467889322, -0.4954152158824344]],
+                              [[0.8580657761160446, 0.5993274993476269], [0.8486730546864062, 0.6143373226840217]]])
+    monkeypatch.setenv("MPCRL_LINEAR_SPL", spl)
+    P = make_linear_system(gamma=0.9, N=23)
+    mpc = MPCBatch(linear_system_ocp(discount_factor=0.9, N=23), 3)
+    r0 = mpc.solve(WARM_QP_FAILS[:, 0], sens_v=True, cold=True)
+    r1 = mpc.solve(WARM_QP_FAILS[:, 1], sens_v=True)
+    first = oracle_port.solve(P, WARM_QP_FAILS[:, 0])
+    warm = oracle_port.solve(P, WARM_QP_FAILS[:, 1], warm=first)
+    cold = oracle_port.solve(P, WARM_QP_FAILS[:, 1])
+    print("interior-point iterations of the warm call:", r1.iters[:, 1].tolist(), "port", warm.ipm_iter.tolist())
+    assert torch.all(r0.status == 0) and torch.all(r1.status == 0)
+    assert rel_err(r1.u0.cpu().numpy(), cold.u0) < 1e-6 and rel_err(r1.V.cpu().numpy(), cold.V) < 1e-6
+    assert rel_err(r1.dV_dp.cpu().numpy(), cold.dV) < 1e-4
+    same = r1.iters[:, 1].cpu().numpy() == warm.ipm_iter
+    assert same.sum() >= 1 and rel_err(r1.dV_dp.cpu().numpy()[same], warm.dV[same]) < 1e-6

@@ -516,3 +516,24 @@ def test_third_party_q_mode_gradients_vs_the_port(oracle_port):
     e, kept = _held_all(g["dQ_d0"], g["dQ_d1"], r.dV[:, :3], keep=0.98)
     print("cartpole Q-mode, %d pairs: dQ/dp vs third-party finite differences %.2e (kept %.3f)" % (n, e, kept))
     assert e < 1e-6 and np.all(r.dpi == 0.0)
+
+
+# two (x0, moved x0) pairs of the linear-system OCP (gamma 0.9, N 23: profiles/microbench/fuzz_parity.py seed 7) whose warm QP runs out of
+# interior-point iterations, and one whose warm QP converges
+WARM_QP_FAILS = np.array([[[0.8726968153298129, 0.5483649132524803], [0.8572483237722713, 0.5365310381189186]],
+                          [[0.11781405145159196, -0.5019479937647703], [0.12047207467889322, -0.4954152158824344]],
+                          [[0.8580657761160446, 0.5993274993476269], [0.8486730546864062, 0.6143373226840217]]])
+
+
+def test_port_warm_qp_failure_restarts_cold(oracle_port):
+    """LQ model: a warm interior point that jams and then cycles (60 iterations, status 4 before round 6) is run once more from the cold
+    interior point; the answer is the one of a cold call (a convex QP has ONE solution)."""
+    from oracle.problems import make_linear_system
+    P = make_linear_system(gamma=0.9, N=23)
+    first = oracle_port.solve(P, WARM_QP_FAILS[:, 0])
+    warm = oracle_port.solve(P, WARM_QP_FAILS[:, 1], warm=first)
+    cold = oracle_port.solve(P, WARM_QP_FAILS[:, 1])
+    assert np.all(first.status == 0) and np.all(warm.status == 0) and np.all(cold.status == 0)
+    assert np.all(warm.ipm_iter[:2] > 60) and warm.ipm_iter[2] < 20          # the restart happened, and only where the warm QP failed
+    assert np.abs(warm.u0 - cold.u0).max() < 1e-6 and np.abs(warm.V - cold.V).max() < 1e-6
+    assert np.abs(warm.dV - cold.dV).max() < 1e-4 * max(1.0, np.abs(cold.dV).max())
