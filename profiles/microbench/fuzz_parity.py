@@ -95,6 +95,8 @@ def check(tag, r, ref, dpi_tol=1e-5, unique=None, rti=False, among=None):
           " ".join("%s %.1e" % kv for kv in worst.items())), flush=True)
     bad += int(fail)
     if fail and os.environ.get("FUZZ_DUMP") and among is None:
+        np.savez(os.path.join(os.environ["FUZZ_DUMP"], "fuzz_%d_%s.npz" % (seed, tag.replace(" ", "_").replace("=", ""))), ok=ok, st=st, it=it,
+                 u0=r.u0.cpu().numpy(), V=r.V.cpu().numpy(), dV=r.dV_dp.cpu().numpy() if r.dV_dp is not None else 0, **DUMP)
         for k, v in e.items():
             if len(v):
                 j = int(np.argmax(v))
@@ -121,19 +123,24 @@ for trial in range(int(os.environ.get("FUZZ_TRIALS", "24"))):
         x0 = np.column_stack([rng.uniform(0.1, 0.9, B), rng.uniform(-0.6, 0.6, B)])
         dpi_tol = 1e-3            # (weakly active soft rows: see tests/test_gpu_fullsize.py)
     else:
-        nm = int(rng.choice([3, 4, 5, 6]))
+        nm = int(rng.choice([3, 4, 5, 6, 7]))
         N = int(rng.choice([5, 17, 40, 50]))
-        B = int(rng.choice([1, 3, 17, 64]))
+        B = int(rng.choice([1, 3, 17, 64])) if nm < 7 else int(rng.choice([1, 3, 5]))
         ocp, P = chain_mass_ocp(n_mass=nm, N=N), make_chain_mass(n_mass=nm, N=N)
         M = nm - 2
         x0 = np.tile(ocp.x0, (B, 1))
         x0[:, 3 * (M + 1):] += rng.normal(0.0, 1e-2, (B, 3 * M))
         dpi_tol = 1e-5
-    per = bool(rng.integers(2))
+    per = int(rng.integers(3))      # 0: shared parameters; 1: the model block per instance; 2: every parameter per instance (cost blocks too)
     theta = np.tile(P.p0, (B, 1))
     nm_p = ocp.n_model_p if hasattr(ocp, "n_model_p") else 3
-    if per:
+    if per == 1:
         theta[:, :nm_p] *= rng.uniform(0.97, 1.03, (B, nm_p))
+    elif per == 2:
+        theta *= rng.uniform(0.97, 1.03, theta.shape)
+        if fam == "linear":
+            theta[:, 6:8] += rng.normal(0.0, 0.02, (B, 2))      # b
+            theta[:, 9:] += rng.normal(0.0, 0.05, (B, 3))       # f
     mpc = MPCBatch(ocp, B)
     if per:
         mpc.set_theta(torch.as_tensor(theta))
@@ -147,7 +154,7 @@ for trial in range(int(os.environ.get("FUZZ_TRIALS", "24"))):
     if fam == "linear":
         x1 = np.clip(x1, [0.05, -0.9], [0.95, 0.9])
     mask = rng.uniform(size=B) < 0.3
-    DUMP = dict(x0=x0, x1=x1, mask=mask, theta=theta, N=N, B=B, per=per)
+    DUMP = dict(x0=x0, x1=x1, mask=mask, theta=theta, N=N, B=B, per=per, g=g if fam == "linear" else 0.0)
     r1 = mpc.solve(x1, sens_v=True, sens_pi=True, cold_mask=torch.as_tensor(mask, device="cuda"))
     ref_c = cpu_port.solve(P, x1, p=theta if per else None)
     ref_w = cpu_port.solve(P, x1, p=theta if per else None, warm=ref)
