@@ -72,8 +72,10 @@ extern "C" {
  *        stopping test that is met within rounding can end an interior-point loop one iteration earlier or later (< 1 % of
  *        instances), or flip the status of an RTI call whose residual sits at the tolerance; outputs of such an instance then
  *        agree with the one-stage kernel and the oracle port to the QP tolerance (1e-4 ... 1e-3 on du0/dp), not to rounding
- *   120  round 6: mpcrl_solve flags MPCRL_NO_BND_STORE and MPCRL_EXACT_QP (test-only); mpcrl_get_iterate_rows / mpcrl_set_iterate_rows; mpcrl_policy_action */
-#define MPCRL_ABI_VERSION 120
+ *   120  round 6: mpcrl_solve flags MPCRL_NO_BND_STORE and MPCRL_EXACT_QP (test-only); mpcrl_get_iterate_rows / mpcrl_set_iterate_rows; mpcrl_policy_action
+ *   130  round 6: mpcrl_critic_td_grad / mpcrl_critic_workspace_bytes / mpcrl_critic_dq_da (the TD3 learner's critic step); linear system: a
+ *        failed WARM QP restarts cold (behaviour, see above) */
+#define MPCRL_ABI_VERSION 130
 
 enum { MPCRL_MODEL_CARTPOLE = 0, MPCRL_MODEL_LINEAR = 1, MPCRL_MODEL_CHAIN = 2 };
 /* how the stage-cost scaling c_k is built (rlmpc/mpc/nlp.py:1044-1055 vs 1083-1091) */
@@ -263,6 +265,33 @@ int mpcrl_env_linear_step(const double *par, int B, double *state, const double 
  *   action [B, nu] float; ok [B] uint8, may be NULL.  Handle-less like the environment kernels (launched on the device that owns `action`). */
 int mpcrl_policy_action(const double *u0, const int32_t *status, const float *noise, const double *lo, const double *hi, int B, int nu, int scale,
                         double sigma, double noise_clip, int accept_status2, float *action, uint8_t *ok, void *stream);
+
+/* ABI 130.  The critic side of one TD3 update, two launches (critic_kernel.hpp): what stable_baselines3's TD3.train (the reference's
+ * learner, pyproject.toml:10, around the critics of rlmpc/td3/policies.py:47-122) does between the target actor's action and the critic
+ * optimiser's step.  Critics: n_critics (1 or 2) MLPs [obs | action] -> 64 -> 64 -> 1 with ReLU, float; `params` / `params_target` hold them
+ * back to back in torch's parameter order, each W1 [64][nx + nu] | b1 [64] | W2 [64][64] | b2 [64] | W3 [64] | b3 [1] (row-major
+ * [out][in], what nn.Linear.weight is).  All device pointers:
+ *   rows [B][row_stride] float: obs (nx) | next obs (nx) | action (nu) | reward | done (the packed replay row), row_stride >= 2 nx + nu + 2;
+ *   a_next [B][nu] float: the target policy's action at the next obs;  ok_u [B] uint8 or NULL: 0 = leave the transition out;
+ *   ok_b   = ok_u[b] and the 2 nx + nu + 2 entries of the row and a_next[b] are finite;
+ *   y_b    = reward + gamma (1 - done) min_c Q'_c(next obs, a_next);   e_cb = ok_b ? Q_c(obs, action) - y_b : 0;
+ *   loss   = sum_c sum_b e_cb^2 / max(1, sum_b ok_b)   -> loss_out [1] float (may be NULL);
+ *   grad   [n_params] DOUBLE = out_scale * d loss / d params, in the order of `params` (n_params = n_critics (64 (nx + nu) + 4289));
+ *   ok_out [B] uint8 or NULL: ok_b.
+ *   workspace: mpcrl_critic_workspace_bytes(B, nx, nu, n_critics) bytes of device memory owned by the caller.
+ * The partial sums are reduced in a fixed order (no atomics): the same inputs give the same bits.  nx + nu <= 64, hidden width 64 only
+ * (MPCRL_E_ARG otherwise).  Handle-less (launched on the device that owns `grad`). */
+int64_t mpcrl_critic_workspace_bytes(int B, int nx, int nu, int n_critics);
+int mpcrl_critic_td_grad(const float *rows, int row_stride, int B, int nx, int nu, const float *a_next, const uint8_t *ok_u, const float *params,
+                         const float *params_target, int n_critics, double gamma, double out_scale, void *workspace, double *grad, float *loss_out,
+                         uint8_t *ok_out, void *stream);
+
+/* ABI 130.  dQ_1/da at (obs_b, act_b) for the deterministic policy gradient (autograd of ContinuousCritic.q1_forward,
+ * rlmpc/td3/policies.py:68-76), one launch: obs [B][obs_stride] float (first nx entries), act [B][nu] float, ok [B] uint8 or NULL,
+ * params: the FIRST critic in the layout above; dq_da [B][nu] float, 0 where ok[b] = 0 or an input is not finite; ok_out [B] uint8 or NULL:
+ * 1 where the row was used. */
+int mpcrl_critic_dq_da(const float *obs, int obs_stride, int B, int nx, int nu, const float *act, const uint8_t *ok, const float *params,
+                       float *dq_da, uint8_t *ok_out, void *stream);
 
 /* Bytes of device memory held by the handle; library version (MPCRL_ABI_VERSION of the header it was built from). */
 int64_t mpcrl_workspace_bytes(mpcrl_handle h);

@@ -16,6 +16,7 @@
 #include "order_kernel.hpp"
 #include "iterate_kernel.hpp"
 #include "env_kernel.hpp"
+#include "critic_kernel.hpp"
 
 using namespace mpcrl;
 
@@ -634,6 +635,42 @@ int mpcrl_policy_action(const double *u0, const int32_t *status, const float *no
     ON_DEVICE_OF(action);
     hipLaunchKernelGGL(policy_action_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, u0, (const int *)status, noise, lo, hi, B, nu, scale,
                        (float)sigma, (float)noise_clip, accept_status2, action, ok);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int64_t mpcrl_critic_workspace_bytes(int B, int nx, int nu, int n_critics) {
+    if (B < 0 || nx < 1 || nu < 1 || nx + nu > CRITIC_DMAX || n_critics < 1 || n_critics > 2) return MPCRL_E_ARG;
+    const int64_t n_blocks = (B + CRITIC_S - 1) / CRITIC_S, n_params = (int64_t)n_critics * (CRITIC_H * (nx + nu) + CRITIC_H * CRITIC_H + 3 * CRITIC_H + 1);
+    return n_blocks * (n_params + 2) * (int64_t)sizeof(float);
+}
+
+int mpcrl_critic_td_grad(const float *rows, int row_stride, int B, int nx, int nu, const float *a_next, const uint8_t *ok_u, const float *params,
+                         const float *params_target, int n_critics, double gamma, double out_scale, void *workspace, double *grad, float *loss_out,
+                         uint8_t *ok_out, void *stream) {
+    if (!rows || !a_next || !params || !params_target || !workspace || !grad || B < 1 || nx < 1 || nu < 1 || nx + nu > CRITIC_DMAX || n_critics < 1 ||
+        n_critics > 2 || row_stride < 2 * nx + nu + 2)
+        return MPCRL_E_ARG;
+    ON_DEVICE_OF(grad);
+    CriticArgs a;
+    a.rows = rows, a.row_stride = row_stride, a.row_len = 2 * nx + nu + 2, a.B = B, a.nx = nx, a.nu = nu, a.n_critics = n_critics;
+    a.a_next = a_next, a.ok_u = ok_u, a.params = params, a.params_target = params_target, a.gamma = (float)gamma;
+    a.partial = (float *)workspace, a.ok_out = ok_out;
+    const int n_blocks = (B + CRITIC_S - 1) / CRITIC_S, n_params = n_critics * (CRITIC_H * (nx + nu) + CRITIC_H * CRITIC_H + 3 * CRITIC_H + 1);
+    hipLaunchKernelGGL(critic_td_partial_kernel, dim3(n_blocks), dim3(128), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(critic_td_reduce_kernel, dim3((n_params + 1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float *)workspace, n_blocks, n_params,
+                       out_scale, grad, loss_out);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int mpcrl_critic_dq_da(const float *obs, int obs_stride, int B, int nx, int nu, const float *act, const uint8_t *ok, const float *params, float *dq_da,
+                       uint8_t *ok_out, void *stream) {
+    if (!obs || !act || !params || !dq_da || B < 1 || nx < 1 || nu < 1 || nx + nu > CRITIC_DMAX || obs_stride < nx) return MPCRL_E_ARG;
+    ON_DEVICE_OF(dq_da);
+    CriticDqdaArgs a;
+    a.obs = obs, a.obs_stride = obs_stride, a.B = B, a.nx = nx, a.nu = nu, a.act = act, a.ok = ok, a.params = params, a.dq_da = dq_da, a.ok_out = ok_out;
+    hipLaunchKernelGGL(critic_dqda_kernel, dim3((B + CRITIC_S - 1) / CRITIC_S), dim3(64), 0, (hipStream_t)stream, a);
     HIP_OK(hipGetLastError());
     return 0;
 }

@@ -40,6 +40,77 @@ class ContinuousCritic(nn.Module):
         return self.q_networks[0](torch.cat([obs, actions], dim=1))
 
 
+def flatten_parameters(module: nn.Module):
+    """(flat parameters, flat gradients): every parameter of ``module`` becomes a view into ONE contiguous float32 tensor, in
+    ``module.parameters()`` order, and gets a persistent ``.grad`` that is a view into a second one — the layout mpcrl_critic_td_grad
+    reads and writes.  In-place updates (fused Adam, load_state_dict, Polyak averaging) keep the views; nothing may rebind ``p.data``."""
+    params = list(module.parameters())
+    flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+    grad = torch.zeros_like(flat)
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.data = flat[off: off + n].view(p.shape)
+        p.grad = grad[off: off + n].view(p.shape)
+        off += n
+    return flat, grad
+
+
+def _as_u8(mask: torch.Tensor) -> torch.Tensor:
+    """a [B] mask as contiguous uint8 without a launch where it is bool already (one byte per entry, 0 / 1)"""
+    m = mask.contiguous()
+    return m.view(torch.uint8) if m.dtype == torch.bool else (m if m.dtype == torch.uint8 else m.to(torch.uint8))
+
+
+def critic_td_grad(rows, nx: int, nu: int, a_next, ok_u, params, params_target, n_critics: int, gamma: float, out_scale: float, grad_out,
+                   workspace=None):
+    """mpcrl_critic_td_grad (include/mpcrl.h): TD target, twin-critic loss and its gradient with respect to the flat critic parameters —
+    two launches.  rows [B, >= 2 nx + nu + 2] float32 (obs | next obs | action | reward | done), a_next [B, nu] float32, ok_u [B] bool /
+    uint8 or None; grad_out: float64 [n_params] (written).  Returns (loss [1] float32, ok [B] bool, workspace)."""
+    from . import _lib
+    lib = _lib.load()
+    B = rows.shape[0]
+    dev = rows.device
+    if not (rows.dtype == torch.float32 and rows.stride(1) == 1 and a_next.dtype == torch.float32 and a_next.is_contiguous()):
+        raise ValueError("rows / a_next: float32, unit inner stride")
+    need = lib.mpcrl_critic_workspace_bytes(B, nx, nu, n_critics)
+    if need < 0:
+        raise ValueError("mpcrl_critic_td_grad: nx + nu <= 64, n_critics 1 or 2")
+    if workspace is None or workspace.numel() * 4 < need:
+        workspace = torch.empty(need // 4, dtype=torch.float32, device=dev)
+    okb = None if ok_u is None else _as_u8(ok_u)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    ok = torch.empty(B, dtype=torch.uint8, device=dev)
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    with torch.cuda.device(dev):
+        rc = lib.mpcrl_critic_td_grad(ptr(rows), rows.stride(0), B, nx, nu, ptr(a_next), ptr(okb), ptr(params), ptr(params_target), n_critics,
+                                      float(gamma), float(out_scale), ptr(workspace), ptr(grad_out), ptr(loss), ptr(ok),
+                                      C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"mpcrl_critic_td_grad failed with code {rc}")
+    return loss, ok.view(torch.bool), workspace
+
+
+def critic_dq_da(obs, nx: int, act, ok_u, params):
+    """mpcrl_critic_dq_da: dQ_1/da at (obs[:, :nx], act), one launch; 0 where ok_u is 0 or an input is not finite.  Returns (dq_da [B, nu]
+    float32, ok [B] bool)."""
+    from . import _lib
+    B, nu = act.shape
+    dev = act.device
+    if not (obs.dtype == torch.float32 and obs.stride(1) == 1 and act.dtype == torch.float32 and act.is_contiguous()):
+        raise ValueError("obs / act: float32, unit inner stride")
+    okb = None if ok_u is None else _as_u8(ok_u)
+    out = torch.empty((B, nu), dtype=torch.float32, device=dev)
+    ok = torch.empty(B, dtype=torch.uint8, device=dev)
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    with torch.cuda.device(dev):
+        rc = _lib.load().mpcrl_critic_dq_da(ptr(obs), obs.stride(0), B, nx, nu, ptr(act), ptr(okb), ptr(params), ptr(out), ptr(ok),
+                                            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"mpcrl_critic_dq_da failed with code {rc}")
+    return out, ok.view(torch.bool)
+
+
 class MPCActor:
     """Deterministic policy a = scale(u0*(s; theta)) backed by an MPCBatch (td3/policies.py:125-222)."""
 
@@ -74,7 +145,7 @@ class MPCActor:
                                                  float(noise_clip), int(accept_status2), ptr(a), ptr(ok), C.c_void_p(torch.cuda.current_stream(r.u0.device).cuda_stream))
         if rc != 0:
             raise RuntimeError(f"mpcrl_policy_action failed with code {rc}")
-        return a, ok.bool()
+        return a, ok.view(torch.bool)        # (0 / 1 bytes: a view, not a launch)
 
     def forward(self, obs: torch.Tensor) -> torch.Tensor:        # Actor.forward, td3/policies.py:186-197 — ONE launch
         return self.scale_action(self.mpc.get_action(obs.to(torch.float64))).to(obs.dtype)
@@ -259,7 +330,7 @@ class BatchedTD3:
                  policy_delay: int = 2, action_noise: float = 0.1, target_noise: float = 0.2, noise_clip: float = 0.5,
                  lr_critic: float = 1e-3, lr_actor: float = 1e-4, reward_scale: float = -1.0, net_arch=(64, 64), device=None,
                  group=None, seed: int = 0, learn_mask: Optional[torch.Tensor] = None, actor_factory=None, replay_iterates: bool = False,
-                 blas: Optional[str] = "cublas"):
+                 blas: Optional[str] = "cublas", fused_critic: bool = True):
         """actor_factory(batch) -> an MPCActor-like object (default: MPCActor on the GPU).  The CPU tests of the loop's plumbing
         (replay, critic update, the single all-reduce) pass a closed-form stand-in policy; the product path never does.
         replay_iterates: keep, with every transition, the solver iterate the roll-out policy ended with (x, u, pi, bound multipliers and
@@ -298,6 +369,13 @@ class BatchedTD3:
                                            **({"fused": True, "capturable": True} if dev.type == "cuda" else {}))
         self.replay_iterates = bool(replay_iterates)
         self._fused = actor_factory is None and dev.type == "cuda"      # the actors' output stage through mpcrl_policy_action (one launch)
+        # the critic step through mpcrl_critic_td_grad / mpcrl_critic_dq_da (two launches + one, for ~60 + ~15 of the framework: 361 us of a
+        # 1.33 ms step at batch 4096) where the critics have the shape those kernels are written for; any other net_arch stays on autograd
+        self._fused_critic = fused_critic and self._fused and tuple(net_arch) == (64, 64) and ocp.nx + ocp.nu <= 64
+        if self._fused_critic:
+            self._crit_flat, self._crit_grad = flatten_parameters(self.critic)
+            self._crit_target_flat, _ = flatten_parameters(self.critic_target)
+            self._crit_ws = None
         nw_ = ocp.nx + ocp.nu
         self.buffer = DeviceReplayBuffer(buffer_steps, self.E, ocp.nx, ocp.nu, dev, iterate_dims=(
             (ocp.N + 1) * ocp.nx, ocp.N * ocp.nu, ocp.N * ocp.nx, 10 * (ocp.N + 1) * nw_) if self.replay_iterates else None)
@@ -407,34 +485,46 @@ class BatchedTD3:
             # (one finiteness test over the whole transition: every separate test, fill and select is a launch of its own)
             if self._fused:      # the target actor's output stage in one launch; the sampled rows are one packed tensor already
                 a_next, ok_u = self.target_mpc.action(rt, eps, sigma=self.target_noise, noise_clip=self.noise_clip)
-                row = self.buffer.last_rows
-                ok_b = ok_u & torch.isfinite(row).all(dim=1)
+                if not self._fused_critic:
+                    row = self.buffer.last_rows
+                    ok_b = ok_u & torch.isfinite(row).all(dim=1)
             else:
                 noise = (self.target_noise * eps).clamp(-self.noise_clip, self.noise_clip)
                 row = torch.cat([obs, nxt, act, rew[:, None], rt.u0.to(obs.dtype)], dim=1)
                 ok_b = (rt.status == 0) & torch.isfinite(row).all(dim=1)
                 u_next = torch.where(ok_b[:, None], rt.u0, 0.0)
                 a_next = (self.target_mpc.scale_action(u_next).to(torch.float32) + noise).clamp(-1.0, 1.0)
-            safe = torch.where(ok_b[:, None], row, 0.0)
             nx_ = obs.shape[1]
-            obs_s, nxt_s, act_s = safe[:, :nx_], safe[:, nx_: 2 * nx_], safe[:, 2 * nx_: 2 * nx_ + act.shape[1]]
-            q_next = torch.min(*self.critic_target(nxt_s, a_next)).squeeze(1)
-            ok_t = ok_b.to(torch.float32)
-            y = torch.where(ok_b, rew + self.gamma * (1.0 - done) * q_next, 0.0)
-        qs = self.critic(obs_s, act_s)
-        loss = sum((torch.where(ok_b, q.squeeze(1) - y, 0.0) ** 2).sum() for q in qs) / ok_t.sum().clamp(min=1.0)
-        self.critic_opt.zero_grad(set_to_none=True)
-        loss.backward()
-        # one flat message: critic gradients (already the local mean) | theta-gradient sum | sample count
-        flat = torch.zeros(self.n_crit + n_theta + 1, dtype=torch.float64, device=self.device)
-        flat[: self.n_crit] = torch.cat([p.grad.reshape(-1) for p in self.critic.parameters()]).to(torch.float64) / world
+            # one flat message: critic gradients (already the local mean) | theta-gradient sum | sample count
+            flat = torch.zeros(self.n_crit + n_theta + 1, dtype=torch.float64, device=self.device)
+            if self._fused_critic and not self._fused:
+                raise RuntimeError("BatchedTD3: fused_critic needs the fused actor output stage (_fused)")
+            if self._fused_critic:      # TD target, both critics' loss and its gradient into the message: two launches
+                loss, _, self._crit_ws = critic_td_grad(self.buffer.last_rows, nx_, act.shape[1], a_next, ok_u, self._crit_flat, self._crit_target_flat,
+                                                        len(self.critic.q_networks), self.gamma, 1.0 / world, flat, self._crit_ws)
+                loss = loss[0]
+        if not self._fused_critic:
+            with torch.no_grad():
+                safe = torch.where(ok_b[:, None], row, 0.0)
+                obs_s, nxt_s, act_s = safe[:, :nx_], safe[:, nx_: 2 * nx_], safe[:, 2 * nx_: 2 * nx_ + act.shape[1]]
+                q_next = torch.min(*self.critic_target(nxt_s, a_next)).squeeze(1)
+                ok_t = ok_b.to(torch.float32)
+                y = torch.where(ok_b, rew + self.gamma * (1.0 - done) * q_next, 0.0)
+            qs = self.critic(obs_s, act_s)
+            loss = sum((torch.where(ok_b, q.squeeze(1) - y, 0.0) ** 2).sum() for q in qs) / ok_t.sum().clamp(min=1.0)
+            self.critic_opt.zero_grad(set_to_none=True)
+            loss.backward()
+            flat[: self.n_crit] = torch.cat([p.grad.reshape(-1) for p in self.critic.parameters()]).to(torch.float64) / world
         if do_policy:
             if self.replay_iterates:
                 self._load_iterate(self.pi_mpc.mpc, it_s)
                 rp = self.pi_mpc.mpc.solve(obs.to(torch.float64), sens_pi=True, cold_mask=~ok_s, reorder=False)   # pi(s_i), dpi/dtheta_i: one launch, warm
             else:
                 rp = self.pi_mpc.mpc.solve(obs.to(torch.float64), sens_pi=True, cold=True)   # pi(s_i), dpi/dtheta_i: one launch
-            if self._fused:
+            if self._fused_critic:
+                a_pi, ok_u = self.pi_mpc.action(rp)
+                dq_da, okb = critic_dq_da(self.buffer.last_rows, nx_, a_pi, ok_u, self._crit_flat)     # dQ_1/da at (s, pi(s)): one launch
+            elif self._fused:
                 a_pi, ok_u = self.pi_mpc.action(rp)
                 okb = ok_u & torch.isfinite(obs).all(dim=1)
                 a_pi = a_pi.requires_grad_(True)
@@ -444,8 +534,9 @@ class BatchedTD3:
                 a_pi = self.pi_mpc.scale_action(u_pi).to(torch.float32).detach().requires_grad_(True)
             # the policy branch has its own mask: obs_s above is zeroed where the TARGET solve failed, and dQ/da at obs = 0 paired
             # with pi(s) and dpi/dtheta of the real obs would bias the step for rows whose policy solve succeeded
-            obs_p = torch.where(okb[:, None], obs, 0.0)
-            (dq_da,) = torch.autograd.grad(self.critic.q1_forward(obs_p, a_pi).sum(), a_pi)
+            if not self._fused_critic:
+                obs_p = torch.where(okb[:, None], obs, 0.0)
+                (dq_da,) = torch.autograd.grad(self.critic.q1_forward(obs_p, a_pi).sum(), a_pi)
             chain = (2.0 / (self.pi_mpc.high - self.pi_mpc.low)) if self.pi_mpc.scale else torch.ones_like(self.pi_mpc.low)
             okp = okb.to(torch.float64)
             g = torch.einsum("bu,bup->bp", torch.where(okb[:, None], dq_da.to(torch.float64) * chain, 0.0), torch.nan_to_num(rp.dpi_dp))
@@ -461,11 +552,14 @@ class BatchedTD3:
         All parameter tensors are updated IN PLACE (their addresses are what a captured graph and the solver handles hold)."""
         n_theta = self.theta.numel()
         params = list(self.critic.parameters())
-        g32, off, views = flat[: self.n_crit].to(params[0].dtype), 0, []
-        for p in params:
-            views.append(g32[off: off + p.numel()].view(p.shape))
-            off += p.numel()
-        torch._foreach_copy_([p.grad for p in params], views)
+        if self._fused_critic:
+            self._crit_grad.copy_(flat[: self.n_crit])        # every p.grad is a view of it: one launch
+        else:
+            g32, off, views = flat[: self.n_crit].to(params[0].dtype), 0, []
+            for p in params:
+                views.append(g32[off: off + p.numel()].view(p.shape))
+                off += p.numel()
+            torch._foreach_copy_([p.grad for p in params], views)
         self.critic_opt.step()
         step = None
         if do_policy:
@@ -476,9 +570,12 @@ class BatchedTD3:
                 m.theta = th
                 m.mpc.set_theta(th)
             with torch.no_grad():
-                pts = list(self.critic_target.parameters())
-                torch._foreach_mul_(pts, 1.0 - self.tau)
-                torch._foreach_add_(pts, params, alpha=self.tau)
+                if self._fused_critic:
+                    self._crit_target_flat.mul_(1.0 - self.tau).add_(self._crit_flat, alpha=self.tau)
+                else:
+                    pts = list(self.critic_target.parameters())
+                    torch._foreach_mul_(pts, 1.0 - self.tau)
+                    torch._foreach_add_(pts, params, alpha=self.tau)
         return step
 
     def train(self, n_updates: int, stats: bool = True) -> dict:

@@ -612,8 +612,8 @@ def test_policy_action_kernel_and_fused_td3_glue():
     res = {}
     for fused in (False, True):
         env = BatchedCartPoleSwingUpEnv(256, device="cuda", seed=0, max_episode_steps=7)
-        ag = BatchedTD3(ocp, env, batch_size=256, buffer_steps=6, policy_delay=2, lr_actor=1e-4, seed=0, replay_iterates=True)
-        assert ag._fused
+        ag = BatchedTD3(ocp, env, batch_size=256, buffer_steps=6, policy_delay=2, lr_actor=1e-4, seed=0, replay_iterates=True, fused_critic=False)
+        assert ag._fused and not ag._fused_critic
         ag._fused = fused
         ag.collect(6)
         losses = []
@@ -623,3 +623,101 @@ def test_policy_action_kernel_and_fused_td3_glue():
         res[fused] = (ag.buffer.data.clone(), losses, ag.theta.clone(), torch.cat([p.detach().reshape(-1) for p in ag.critic.parameters()]))
     assert torch.equal(res[False][0], res[True][0]) and res[False][1] == res[True][1]
     assert torch.equal(res[False][2], res[True][2]) and torch.equal(res[False][3], res[True][3])
+
+
+def _critic_reference(critic, target, rows, nx, nu, a_next, ok_u, gamma, dtype):
+    """the torch expressions of BatchedTD3._update_pre (autograd) in ``dtype``: (loss, flat gradient, ok_b)"""
+    import copy
+    cr, tg = copy.deepcopy(critic).to(dtype), copy.deepcopy(target).to(dtype)
+    row = rows[:, : 2 * nx + nu + 2]
+    ok_b = ok_u & torch.isfinite(row).all(dim=1) & torch.isfinite(a_next).all(dim=1)
+    safe = torch.where(ok_b[:, None], row, 0.0).to(dtype)
+    an = torch.where(ok_b[:, None], a_next, 0.0).to(dtype)
+    obs_s, nxt_s, act_s, rew, done = safe[:, :nx], safe[:, nx: 2 * nx], safe[:, 2 * nx: 2 * nx + nu], safe[:, 2 * nx + nu], safe[:, 2 * nx + nu + 1]
+    with torch.no_grad():
+        qn = tg(nxt_s, an)
+        q_next = (torch.min(*qn) if len(qn) > 1 else qn[0]).squeeze(1)
+        y = torch.where(ok_b, rew + gamma * (1.0 - done) * q_next, 0.0)
+    qs = cr(obs_s, act_s)
+    loss = sum((torch.where(ok_b, q.squeeze(1) - y, 0.0) ** 2).sum() for q in qs) / ok_b.to(dtype).sum().clamp(min=1.0)
+    loss.backward()
+    return loss.detach(), torch.cat([p.grad.reshape(-1) for p in cr.parameters()]), ok_b
+
+
+@pytest.mark.parametrize("B,nx,nu,n_critics", [(4096, 4, 1, 2), (257, 4, 1, 2), (37, 9, 3, 1), (16, 2, 1, 2), (5, 33, 3, 2)])
+def test_critic_td_grad_and_dq_da_vs_autograd(B, nx, nu, n_critics):
+    """mpcrl_critic_td_grad / mpcrl_critic_dq_da (round 6, ABI 130): the TD target, the twin-critic loss, its gradient with respect to the
+    critics' parameters and dQ_1/da — hand-written forward and backward passes of the [obs | action] -> 64 -> 64 -> 1 MLPs — against torch
+    autograd of the same expressions.  The yardstick is the float64 evaluation: the kernels (fp32 FMAs, fp64 reduction over the batch) must
+    be as close to it as torch's own fp32 path is (1e-6 of the largest gradient entry, and within 4 x torch's error).  Rows with a non-finite entry, rows whose target
+    solve failed and a ragged last workgroup are part of every case; the selected-out rows are reported back (ok)."""
+    from mpc4rl_amd.td3 import ContinuousCritic, critic_dq_da, critic_td_grad, flatten_parameters
+    torch.manual_seed(B + nx)
+    dev = torch.device("cuda")
+    critic, target = ContinuousCritic(nx, nu, n_critics=n_critics).to(dev), ContinuousCritic(nx, nu, n_critics=n_critics).to(dev)
+    flat, grad = flatten_parameters(critic)
+    flat_t, _ = flatten_parameters(target)
+    assert all(p.data_ptr() >= flat.data_ptr() and p.grad.data_ptr() >= grad.data_ptr() for p in critic.parameters())
+    rows = torch.randn(B, 2 * nx + nu + 2 + 3, device=dev)[:, : 2 * nx + nu + 2]            # a row stride larger than the row
+    rows[:, -1] = (torch.rand(B, device=dev) < 0.1).float()
+    a_next = torch.randn(B, nu, device=dev).clamp(-1, 1)
+    ok_u = torch.rand(B, device=dev) < 0.9
+    if B > 4:
+        rows[1, 0], rows[2, nx + 1], rows[3, 2 * nx] = float("nan"), float("inf"), float("-inf")
+        a_next[4, 0] = float("nan")
+    gamma = 0.99
+    out = torch.full((flat.numel() + 7,), -1.0, dtype=torch.float64, device=dev)
+    loss, ok, ws = critic_td_grad(rows, nx, nu, a_next, ok_u, flat, flat_t, n_critics, gamma, 0.5, out)
+    l64, g64, ok64 = _critic_reference(critic, target, rows, nx, nu, a_next, ok_u, gamma, torch.float64)
+    l32, g32, _ = _critic_reference(critic, target, rows, nx, nu, a_next, ok_u, gamma, torch.float32)
+    assert torch.equal(ok, ok64) and bool((out[flat.numel():] == -1.0).all())
+    scale = float(g64.abs().max())
+    err_k = float((2.0 * out[: flat.numel()] - g64).abs().max()) / scale
+    err_t = float((g32.double() - g64).abs().max()) / scale
+    print(f"B {B} nx {nx} nu {nu} critics {n_critics}: gradient against float64 — kernels {err_k:.1e}, torch float32 {err_t:.1e}; loss {abs(float(loss) - float(l64)) / float(l64):.1e}")
+    assert err_k < 1e-6 and err_k < 4.0 * err_t and abs(float(loss) - float(l64)) < 1e-6 * float(l64)
+    # the same call again: the same bits (fixed-order reduction), the workspace reused
+    out2 = torch.zeros_like(out)
+    loss2, _, ws2 = critic_td_grad(rows, nx, nu, a_next, ok_u, flat, flat_t, n_critics, gamma, 0.5, out2, ws)
+    assert ws2 is ws and torch.equal(out2[: flat.numel()], out[: flat.numel()]) and torch.equal(loss, loss2)
+    # dQ_1/da
+    act = torch.randn(B, nu, device=dev).clamp(-1, 1)
+    dq, okq = critic_dq_da(rows, nx, act, ok_u, flat)
+    okr = ok_u & torch.isfinite(rows[:, :nx]).all(dim=1)
+    a64 = act.double().requires_grad_(True)
+    import copy
+    c64 = copy.deepcopy(critic).double()
+    (ref,) = torch.autograd.grad(c64.q1_forward(torch.where(okr[:, None], rows[:, :nx], 0.0).double(), a64).sum(), a64)
+    ref = torch.where(okr[:, None], ref, 0.0)
+    assert torch.equal(okq, okr)
+    assert float((dq.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    with pytest.raises(ValueError):
+        critic_td_grad(rows.double(), nx, nu, a_next, ok_u, flat, flat_t, n_critics, gamma, 1.0, out)
+
+
+def test_td3_loop_with_the_critic_kernels():
+    """BatchedTD3 with the critic step on mpcrl_critic_td_grad / mpcrl_critic_dq_da (the default on the GPU for 64 x 64 critics) against the
+    same loop on autograd: the same replay table bit for bit (the roll-out does not see the critics), critic losses, critics and theta
+    equal to fp32 rounding after six updates — eager and graph-replayed."""
+    from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedTD3, cartpole_ocp
+    ocp = cartpole_ocp()
+    res = {}
+    for mode in ("autograd", "kernels", "kernels+graphs"):
+        env = BatchedCartPoleSwingUpEnv(256, device="cuda", seed=0, max_episode_steps=7)
+        ag = BatchedTD3(ocp, env, batch_size=256, buffer_steps=6, policy_delay=2, lr_actor=1e-4, seed=0, replay_iterates=True, fused_critic=mode != "autograd")
+        assert ag._fused_critic == (mode != "autograd")
+        ag.collect(6)
+        if mode.endswith("graphs"):
+            ag.enable_graphs()
+        losses = []
+        for _ in range(6):
+            ag.collect(1)
+            losses.append(ag.train(1)["critic_loss"])
+        res[mode] = (ag.buffer.data.clone(), np.array(losses), ag.theta.clone(), torch.cat([p.detach().reshape(-1) for p in ag.critic.parameters()]),
+                     torch.cat([p.detach().reshape(-1) for p in ag.critic_target.parameters()]))
+    a, k = res["autograd"], res["kernels"]
+    assert torch.equal(a[0], k[0])
+    assert np.abs(a[1] - k[1]).max() < 1e-4 * np.abs(a[1]).max()
+    assert float((a[2] - k[2]).abs().max()) < 1e-9 and float((a[3] - k[3]).abs().max()) < 2e-5 and float((a[4] - k[4]).abs().max()) < 2e-6
+    g = res["kernels+graphs"]      # (enable_graphs fills the replay table on its own: compared with itself being finite and learning)
+    assert np.isfinite(g[1]).all() and bool(torch.isfinite(g[3]).all())
