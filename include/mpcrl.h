@@ -73,7 +73,7 @@ extern "C" {
  *        instances), or flip the status of an RTI call whose residual sits at the tolerance; outputs of such an instance then
  *        agree with the one-stage kernel and the oracle port to the QP tolerance (1e-4 ... 1e-3 on du0/dp), not to rounding
  *   120  round 6: mpcrl_solve flags MPCRL_NO_BND_STORE and MPCRL_EXACT_QP (test-only); mpcrl_get_iterate_rows / mpcrl_set_iterate_rows; mpcrl_policy_action
- *   130  round 6: mpcrl_critic_td_grad / mpcrl_critic_workspace_bytes / mpcrl_critic_dq_da (the TD3 learner's critic step); linear system: a
+ *   130  round 6: mpcrl_critic_td_grad / mpcrl_critic_workspace_bytes / mpcrl_critic_dq_da (the TD3 learner's critic step); mpcrl_replay_sample; linear system: a
  *        failed WARM QP restarts cold (behaviour, see above) */
 #define MPCRL_ABI_VERSION 130
 
@@ -292,6 +292,18 @@ int mpcrl_critic_td_grad(const float *rows, int row_stride, int B, int nx, int n
  * 1 where the row was used. */
 int mpcrl_critic_dq_da(const float *obs, int obs_stride, int B, int nx, int nu, const float *act, const uint8_t *ok, const float *params,
                        float *dq_da, uint8_t *ok_out, void *stream);
+
+/* ABI 130.  A replay batch in one launch (replay_kernel.hpp): the sampled transitions gathered, their states widened for the two replay
+ * solves, and — with iter_ok — the rows of the caller's iterate tables (mpcrl_set_iterate_rows) those solves start from.  Device pointers:
+ *   table [cap * E][row_len] float: obs (nx) | next obs (nx) | action | reward | done (last entry), row = step * E + env;
+ *   idx [B] int64: the sampled rows (the caller draws them);  pos_t [1] int64: the slot the roll-out writes next;  steps: slots written;
+ *   rows [B][row_len] float = table[idx];  obs64 / nxt64 [B][nx] double;
+ *   iter_ok [cap * E] uint8 or NULL (then the four outputs below are not written):
+ *     row_s = idx;  row_n = the row of the NEXT step of the same environment if done == 0 and that slot is written and is not pos_t,
+ *     else idx;  cold_s / cold_n [B] int32 = 1 where iter_ok[row] == 0 (mpcrl_set_cold_mask takes them as they are). */
+int mpcrl_replay_sample(const float *table, int row_len, int nx, int E, int cap, int steps, const int64_t *idx, int B, const int64_t *pos_t,
+                        const uint8_t *iter_ok, float *rows, double *obs64, double *nxt64, int64_t *row_s, int32_t *cold_s, int64_t *row_n,
+                        int32_t *cold_n, void *stream);
 
 /* Bytes of device memory held by the handle; library version (MPCRL_ABI_VERSION of the header it was built from). */
 int64_t mpcrl_workspace_bytes(mpcrl_handle h);

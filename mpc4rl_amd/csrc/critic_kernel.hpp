@@ -46,63 +46,95 @@ __device__ inline float wave_sum64(float v) {
 }
 
 __global__ void __launch_bounds__(128) critic_td_partial_kernel(const CriticArgs a) {
-    constexpr int H = CRITIC_H, S = CRITIC_S;
+    constexpr int H = CRITIC_H, S = CRITIC_S, RMAX = 2 * CRITIC_DMAX + 2;
+    constexpr int DR = 16;      // first-layer inputs whose weights (and weight gradients) a lane keeps in registers; the rest goes through LDS
     const int D = a.nx + a.nu, c = threadIdx.x >> 6, j = threadIdx.x & 63, b0 = blockIdx.x * S;
     const int npn = critic_params_per_net(D), n_params = npn * a.n_critics;
-    __shared__ float xt[S][CRITIC_DMAX], xo[S][CRITIC_DMAX];      // inputs of the target pass (s', a') and of the online pass (s, a)
+    __shared__ float rowb[S][RMAX], anb[S][CRITIC_DMAX];          // the workgroup's transitions as stored, the target actions
+    __shared__ __attribute__((aligned(16))) float xt[S][CRITIC_DMAX], xo[S][CRITIC_DMAX];      // inputs of the target pass (s', a') and of the online pass (s, a)
     __shared__ float rew[S], dn[S], ys[S], okf[S];
     __shared__ float qn[2][S];
     __shared__ __attribute__((aligned(16))) float h1s[2][S][H];    // first-layer activations, per critic
     __shared__ float ps[2][S][H + 1];                              // per-lane pieces of the output sum
-    __shared__ __attribute__((aligned(16))) float g2s[2][S][H];    // the second layer's pre-activation gradient
+    __shared__ __attribute__((aligned(16))) float g2s[2][S][H];    // second-layer activations (forward), then the second layer's pre-activation gradient
     __shared__ float w1s[2][H][CRITIC_DMAX + 1];                   // first-layer weight of the pass at hand; then its gradient accumulator
-    // ---- the workgroup's transitions
+    __shared__ float w2s[2][2][H][H + 1];                          // second-layer weights, [target / online][critic] (read by rows and by columns)
+    // ---- the workgroup's transitions: every load in flight at once (128 lanes), then one lane per transition looks at them in LDS
+    for (int e = threadIdx.x; e < S * a.row_len; e += 128) {
+        const int s = e / a.row_len, i = e - s * a.row_len, b = b0 + s;
+        rowb[s][i] = b < a.B ? a.rows[(long)b * a.row_stride + i] : 0.0f;
+    }
+    for (int e = threadIdx.x; e < S * a.nu; e += 128) {
+        const int s = e / a.nu, i = e - s * a.nu, b = b0 + s;
+        anb[s][i] = b < a.B ? a.a_next[(long)b * a.nu + i] : 0.0f;
+    }
+    __syncthreads();
     if (threadIdx.x < S) {
         const int s = threadIdx.x, b = b0 + s;
         bool ok = b < a.B && (!a.ok_u || a.ok_u[b]);
-        if (b < a.B) {
-            const float *r = a.rows + (long)b * a.row_stride;
-            for (int i = 0; i < a.row_len; ++i) ok = ok && isfinite(r[i]);
-            for (int i = 0; i < a.nu; ++i) ok = ok && isfinite(a.a_next[(long)b * a.nu + i]);
-            if (a.ok_out) a.ok_out[b] = ok ? 1 : 0;
-        }
+        for (int i = 0; i < a.row_len; ++i) ok = ok & (bool)isfinite(rowb[s][i]);
+        for (int i = 0; i < a.nu; ++i) ok = ok & (bool)isfinite(anb[s][i]);
+        if (a.ok_out && b < a.B) a.ok_out[b] = ok ? 1 : 0;
         okf[s] = ok ? 1.0f : 0.0f;
-        const float *r = a.rows + (long)(b < a.B ? b : 0) * a.row_stride;
-        rew[s] = ok ? r[2 * a.nx + a.nu] : 0.0f, dn[s] = ok ? r[2 * a.nx + a.nu + 1] : 0.0f;
+        rew[s] = ok ? rowb[s][2 * a.nx + a.nu] : 0.0f, dn[s] = ok ? rowb[s][2 * a.nx + a.nu + 1] : 0.0f;
         for (int d = 0; d < D; ++d) {
-            xo[s][d] = !ok ? 0.0f : (d < a.nx ? r[d] : r[2 * a.nx + (d - a.nx)]);
-            xt[s][d] = !ok ? 0.0f : (d < a.nx ? r[a.nx + d] : a.a_next[(long)b * a.nu + (d - a.nx)]);
+            xo[s][d] = !ok ? 0.0f : (d < a.nx ? rowb[s][d] : rowb[s][2 * a.nx + (d - a.nx)]);
+            xt[s][d] = !ok ? 0.0f : (d < a.nx ? rowb[s][a.nx + d] : anb[s][d - a.nx]);
         }
+        for (int d = D; d < DR; ++d) xo[s][d] = xt[s][d] = 0.0f;
     }
     const bool live = c < a.n_critics;      // (n_critics = 1: the second wavefront only keeps the barriers company)
-    float w2r[H], h2r[S];
+    float w2r[H];
     float b1 = 0.0f, b2 = 0.0f, w3 = 0.0f, b3 = 0.0f;
-    auto load_net = [&](const float *p) {
-        const float *W1 = p, *B1 = W1 + H * D, *W2 = B1 + H, *B2 = W2 + H * H, *W3 = B2 + H, *B3 = W3 + H;
-        for (int d = 0; d < D; ++d) w1s[c][j][d] = W1[j * D + d];
+    // Both nets' weights are asked for at once, up front (W2 in coalesced rows: lane j gets W2[i][j], through LDS, back as row j in
+    // registers when its pass begins); the first DR columns of W1 live in registers, the rest in LDS
+    float w1r[DR];
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float *W2 = (k ? a.params : a.params_target) + (long)c * npn + H * D + H;
+#pragma unroll
+            for (int i = 0; i < H; ++i) w2s[k][c][i][j] = W2[i * H + j];
+        }
+    }
+    auto load_net = [&](int k) {
+        const float *p = (k ? a.params : a.params_target) + (long)(live ? c : 0) * npn;
+        const float *W1 = p, *B1 = W1 + H * D, *B2 = B1 + H + H * H, *W3 = B2 + H, *B3 = W3 + H;
+#pragma unroll
+        for (int d = 0; d < DR; ++d) w1r[d] = d < D ? W1[j * D + d] : 0.0f;
+        for (int d = DR; d < D; ++d) w1s[c][j][d] = W1[j * D + d];
         b1 = B1[j], b2 = B2[j], w3 = W3[j], b3 = B3[0];
 #pragma unroll
-        for (int i = 0; i < H; ++i) w2r[i] = W2[j * H + i];      // (a net is an odd number of floats: no vector alignment to rely on)
+        for (int i = 0; i < H; ++i) w2r[i] = w2s[k][c][j][i];
     };
-    // forward pass of the net at hand over the S transitions: h1 to LDS, h2 to registers, the output's per-lane pieces to LDS
+    // forward pass of the net at hand over the S transitions: h1, h2 and the output's per-lane pieces to LDS
     auto forward = [&](const float (*x)[CRITIC_DMAX]) {
-#pragma unroll 4
+        // (the loops over the transitions stay rolled: straight-line code that runs once is paid in instruction fetches)
+#pragma unroll 2
         for (int s = 0; s < S; ++s) {
             float z = b1;
-            for (int d = 0; d < D; ++d) z = fmaf(w1s[c][j][d], x[s][d], z);
+#pragma unroll
+            for (int d = 0; d < DR; d += 4) {
+                if (d >= D) break;      // (uniform)
+                const float4 v = *(const float4 *)&x[s][d];
+                z = fmaf(w1r[d], v.x, z), z = fmaf(w1r[d + 1], v.y, z), z = fmaf(w1r[d + 2], v.z, z), z = fmaf(w1r[d + 3], v.w, z);
+            }
+            for (int d = DR; d < D; ++d) z = fmaf(w1s[c][j][d], x[s][d], z);
             h1s[c][s][j] = fmaxf(z, 0.0f);
         }
         __syncthreads();
-#pragma unroll
+#pragma unroll 2
         for (int s = 0; s < S; ++s) {
-            float z = b2;
+            float z0 = b2, z1 = 0.0f;
 #pragma unroll
-            for (int i = 0; i < H; i += 4) {
-                const float4 h = *(const float4 *)&h1s[c][s][i];
-                z = fmaf(w2r[i], h.x, z), z = fmaf(w2r[i + 1], h.y, z), z = fmaf(w2r[i + 2], h.z, z), z = fmaf(w2r[i + 3], h.w, z);
+            for (int i = 0; i < H; i += 8) {
+                const float4 h = *(const float4 *)&h1s[c][s][i], k = *(const float4 *)&h1s[c][s][i + 4];
+                z0 = fmaf(w2r[i], h.x, z0), z0 = fmaf(w2r[i + 1], h.y, z0), z0 = fmaf(w2r[i + 2], h.z, z0), z0 = fmaf(w2r[i + 3], h.w, z0);
+                z1 = fmaf(w2r[i + 4], k.x, z1), z1 = fmaf(w2r[i + 5], k.y, z1), z1 = fmaf(w2r[i + 6], k.z, z1), z1 = fmaf(w2r[i + 7], k.w, z1);
             }
-            h2r[s] = fmaxf(z, 0.0f);
-            ps[c][s][j] = w3 * h2r[s];
+            const float h2 = fmaxf(z0 + z1, 0.0f);
+            g2s[c][s][j] = h2;
+            ps[c][s][j] = w3 * h2;
         }
         __syncthreads();
     };
@@ -118,7 +150,7 @@ __global__ void __launch_bounds__(128) critic_td_partial_kernel(const CriticArgs
     };
     __syncthreads();
     // ---- target critics: y
-    if (live) load_net(a.params_target + (long)c * npn);
+    load_net(0);
     forward(xt);
     {
         const float q = output();
@@ -132,7 +164,7 @@ __global__ void __launch_bounds__(128) critic_td_partial_kernel(const CriticArgs
     }
     __syncthreads();
     // ---- online critics: error, loss
-    if (live) load_net(a.params + (long)c * npn);
+    load_net(1);
     forward(xo);
     float loss = 0.0f;
     {
@@ -146,21 +178,21 @@ __global__ void __launch_bounds__(128) critic_td_partial_kernel(const CriticArgs
     // ---- backward
     // second layer's pre-activation gradient g2[s][j] to LDS, the output layer's gradients on the way
     float dw3 = 0.0f, db3 = 0.0f, db2 = 0.0f;
-#pragma unroll
+#pragma unroll 1
     for (int s = 0; s < S; ++s) {
-        const float dq = qn[c][s];
-        const float g2 = h2r[s] > 0.0f ? dq * w3 : 0.0f;
-        dw3 = fmaf(dq, h2r[s], dw3), db3 += dq, db2 += g2;
+        const float dq = qn[c][s], h2 = g2s[c][s][j];
+        const float g2 = h2 > 0.0f ? dq * w3 : 0.0f;
+        dw3 = fmaf(dq, h2, dw3), db3 += dq, db2 += g2;
         g2s[c][s][j] = g2;
     }
-    // column j of W2 (coalesced over the lanes), and the first layer's gradient accumulator in place of its weight
+    // column j of W2 (still in LDS), and the first layer's gradient accumulator in place of its weight
     float w2c[H];
-    {
-        const float *W2 = a.params + (long)(live ? c : 0) * npn + H * D + H;
 #pragma unroll
-        for (int i = 0; i < H; ++i) w2c[i] = W2[i * H + j];
-    }
-    for (int d = 0; d < D; ++d) w1s[c][j][d] = 0.0f;
+    for (int i = 0; i < H; ++i) w2c[i] = w2s[1][c][i][j];
+    float dw1[DR];
+#pragma unroll
+    for (int d = 0; d < DR; ++d) dw1[d] = 0.0f;
+    for (int d = DR; d < D; ++d) w1s[c][j][d] = 0.0f;
     __syncthreads();
     float dw2[H];
 #pragma unroll
@@ -169,27 +201,37 @@ __global__ void __launch_bounds__(128) critic_td_partial_kernel(const CriticArgs
 #pragma unroll 2
     for (int s = 0; s < S; ++s) {
         const float g2 = g2s[c][s][j];
-        float g1 = 0.0f;
+        float g1a = 0.0f, g1b = 0.0f;
 #pragma unroll
         for (int i = 0; i < H; i += 4) {
             const float4 h = *(const float4 *)&h1s[c][s][i], g = *(const float4 *)&g2s[c][s][i];
             dw2[i] = fmaf(g2, h.x, dw2[i]), dw2[i + 1] = fmaf(g2, h.y, dw2[i + 1]), dw2[i + 2] = fmaf(g2, h.z, dw2[i + 2]), dw2[i + 3] = fmaf(g2, h.w, dw2[i + 3]);
-            g1 = fmaf(w2c[i], g.x, g1), g1 = fmaf(w2c[i + 1], g.y, g1), g1 = fmaf(w2c[i + 2], g.z, g1), g1 = fmaf(w2c[i + 3], g.w, g1);
+            g1a = fmaf(w2c[i], g.x, g1a), g1b = fmaf(w2c[i + 1], g.y, g1b), g1a = fmaf(w2c[i + 2], g.z, g1a), g1b = fmaf(w2c[i + 3], g.w, g1b);
         }
-        g1 = h1s[c][s][j] > 0.0f ? g1 : 0.0f;
+        const float g1 = h1s[c][s][j] > 0.0f ? g1a + g1b : 0.0f;
         db1 += g1;
-        for (int d = 0; d < D; ++d) w1s[c][j][d] = fmaf(g1, xo[s][d], w1s[c][j][d]);
+#pragma unroll
+        for (int d = 0; d < DR; d += 4) {
+            if (d >= D) break;      // (uniform)
+            const float4 v = *(const float4 *)&xo[s][d];
+            dw1[d] = fmaf(g1, v.x, dw1[d]), dw1[d + 1] = fmaf(g1, v.y, dw1[d + 1]), dw1[d + 2] = fmaf(g1, v.z, dw1[d + 2]), dw1[d + 3] = fmaf(g1, v.w, dw1[d + 3]);
+        }
+        for (int d = DR; d < D; ++d) w1s[c][j][d] = fmaf(g1, xo[s][d], w1s[c][j][d]);
     }
-    // ---- the workgroup's partial
+    // ---- the workgroup's partial: a net's parameters in order, EXCEPT that the 64 x 64 block is stored transposed (lane j writes
+    // d W2[j][i] to [i][j]: coalesced; critic_td_reduce_kernel puts it back)
     float *out = a.partial + (long)blockIdx.x * (n_params + 2);
     if (live) {
         float *o = out + (long)c * npn;
-        for (int d = 0; d < D; ++d) o[j * D + d] = w1s[c][j][d];
+#pragma unroll
+        for (int d = 0; d < DR; ++d)
+            if (d < D) o[j * D + d] = dw1[d];
+        for (int d = DR; d < D; ++d) o[j * D + d] = w1s[c][j][d];
         o += H * D;
         o[j] = db1;
         o += H;
 #pragma unroll
-        for (int i = 0; i < H; ++i) o[j * H + i] = dw2[i];
+        for (int i = 0; i < H; ++i) o[i * H + j] = dw2[i];
         o += H * H;
         o[j] = db2;
         o += H;
@@ -208,8 +250,9 @@ __global__ void __launch_bounds__(128) critic_td_partial_kernel(const CriticArgs
     }
 }
 
-// grad[t] = out_scale / max(1, n_ok) * sum_blocks partial[block][t]  (fp64), loss = sum / max(1, n_ok)
-__global__ void __launch_bounds__(256) critic_td_reduce_kernel(const float *partial, int n_blocks, int n_params, double out_scale, double *grad, float *loss_out) {
+// grad[t] = out_scale / max(1, n_ok) * sum_blocks partial[block][t]  (fp64), loss = sum / max(1, n_ok).  A workgroup takes 64 entries; its
+// four wavefronts take a quarter of the blocks each (16 loads in flight per lane) and are added in a fixed order.
+__global__ void __launch_bounds__(256) critic_td_reduce_kernel(const float *partial, int n_blocks, int n_params, int D, double out_scale, double *grad, float *loss_out) {
     __shared__ double red[256];
     const int stride = n_params + 2;
     double n = 0.0;
@@ -221,13 +264,32 @@ __global__ void __launch_bounds__(256) critic_td_reduce_kernel(const float *part
         __syncthreads();
     }
     const double cnt = red[0] > 1.0 ? red[0] : 1.0;
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    __syncthreads();
+    const int p = threadIdx.x & 63, sl = threadIdx.x >> 6, t = blockIdx.x * 64 + p;
+    const int per = (n_blocks + 3) / 4, lo = sl * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
+    double acc = 0.0;
     if (t <= n_params) {
-        double acc = 0.0;
-        for (int b = 0; b < n_blocks; ++b) acc += partial[(long)b * stride + t];
-        if (t < n_params)
-            grad[t] = acc * out_scale / cnt;
-        else if (loss_out)
+        int b = lo;
+        for (; b + 16 <= hi; b += 16) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = partial[(long)(b + k) * stride + t];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc += (double)v[k];
+        }
+        for (; b < hi; ++b) acc += (double)partial[(long)b * stride + t];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (sl == 0 && t <= n_params) {
+        acc = ((red[p] + red[64 + p]) + red[128 + p]) + red[192 + p];
+        if (t < n_params) {
+            // where the entry lives in torch's order: the 64 x 64 block of a net comes in transposed
+            const int npn = critic_params_per_net(D), net = t / npn, l = t - net * npn, w2 = CRITIC_H * D + CRITIC_H;
+            int dst = t;
+            if (l >= w2 && l < w2 + CRITIC_H * CRITIC_H) dst = net * npn + w2 + ((l - w2) & 63) * CRITIC_H + ((l - w2) >> 6);
+            grad[dst] = acc * out_scale / cnt;
+        } else if (loss_out)
             *loss_out = (float)(acc / cnt);
     }
 }
@@ -263,7 +325,7 @@ __global__ void __launch_bounds__(64) critic_dqda_kernel(const CriticDqdaArgs a)
         for (int d = 0; d < D; ++d) x[j][d] = !ok ? 0.0f : (d < a.nx ? a.obs[(long)b * a.obs_stride + d] : a.act[(long)b * a.nu + (d - a.nx)]);
     }
     const float *W1 = a.params, *B1 = W1 + H * D, *W2 = B1 + H, *B2 = W2 + H * H, *W3 = B2 + H;
-    float w2r[H], w2c[H], h2r[S];
+    float w2r[H], w2c[H];
 #pragma unroll
     for (int i = 0; i < H; ++i) w2r[i] = W2[j * H + i], w2c[i] = W2[i * H + j];
     const float b1 = B1[j], b2 = B2[j], w3 = W3[j];
@@ -274,7 +336,7 @@ __global__ void __launch_bounds__(64) critic_dqda_kernel(const CriticDqdaArgs a)
         h1s[s][j] = fmaxf(z, 0.0f);
     }
     __syncthreads();
-#pragma unroll
+#pragma unroll 1
     for (int s = 0; s < S; ++s) {
         float z = b2;
 #pragma unroll
@@ -285,7 +347,7 @@ __global__ void __launch_bounds__(64) critic_dqda_kernel(const CriticDqdaArgs a)
         g2s[s][j] = z > 0.0f ? w3 : 0.0f;            // d q / d z2_j
     }
     __syncthreads();
-#pragma unroll 2
+#pragma unroll 1
     for (int s = 0; s < S; ++s) {
         float g1 = 0.0f;
 #pragma unroll

@@ -17,6 +17,7 @@
 #include "iterate_kernel.hpp"
 #include "env_kernel.hpp"
 #include "critic_kernel.hpp"
+#include "replay_kernel.hpp"
 
 using namespace mpcrl;
 
@@ -639,6 +640,20 @@ int mpcrl_policy_action(const double *u0, const int32_t *status, const float *no
     return 0;
 }
 
+int mpcrl_replay_sample(const float *table, int row_len, int nx, int E, int cap, int steps, const int64_t *idx, int B, const int64_t *pos_t,
+                        const uint8_t *iter_ok, float *rows, double *obs64, double *nxt64, int64_t *row_s, int32_t *cold_s, int64_t *row_n,
+                        int32_t *cold_n, void *stream) {
+    if (!table || !idx || !rows || !obs64 || !nxt64 || B < 1 || nx < 1 || row_len < 2 * nx + 2 || E < 1 || cap < 1 || steps < 1 || steps > cap) return MPCRL_E_ARG;
+    if (iter_ok && (!pos_t || !row_s || !cold_s || !row_n || !cold_n)) return MPCRL_E_ARG;
+    ON_DEVICE_OF(rows);
+    ReplaySampleArgs a;
+    a.table = table, a.row_len = row_len, a.nx = nx, a.B = B, a.E = E, a.cap = cap, a.steps = steps, a.idx = idx, a.pos_t = pos_t, a.iter_ok = iter_ok;
+    a.rows = rows, a.obs64 = obs64, a.nxt64 = nxt64, a.row_s = row_s, a.row_n = row_n, a.cold_s = cold_s, a.cold_n = cold_n;
+    hipLaunchKernelGGL(replay_sample_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int64_t mpcrl_critic_workspace_bytes(int B, int nx, int nu, int n_critics) {
     if (B < 0 || nx < 1 || nu < 1 || nx + nu > CRITIC_DMAX || n_critics < 1 || n_critics > 2) return MPCRL_E_ARG;
     const int64_t n_blocks = (B + CRITIC_S - 1) / CRITIC_S, n_params = (int64_t)n_critics * (CRITIC_H * (nx + nu) + CRITIC_H * CRITIC_H + 3 * CRITIC_H + 1);
@@ -658,8 +673,8 @@ int mpcrl_critic_td_grad(const float *rows, int row_stride, int B, int nx, int n
     a.partial = (float *)workspace, a.ok_out = ok_out;
     const int n_blocks = (B + CRITIC_S - 1) / CRITIC_S, n_params = n_critics * (CRITIC_H * (nx + nu) + CRITIC_H * CRITIC_H + 3 * CRITIC_H + 1);
     hipLaunchKernelGGL(critic_td_partial_kernel, dim3(n_blocks), dim3(128), 0, (hipStream_t)stream, a);
-    hipLaunchKernelGGL(critic_td_reduce_kernel, dim3((n_params + 1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float *)workspace, n_blocks, n_params,
-                       out_scale, grad, loss_out);
+    hipLaunchKernelGGL(critic_td_reduce_kernel, dim3((n_params + 1 + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float *)workspace, n_blocks, n_params,
+                       nx + nu, out_scale, grad, loss_out);
     HIP_OK(hipGetLastError());
     return 0;
 }

@@ -292,6 +292,36 @@ class DeviceReplayBuffer:
         nx, nu = self._nx, self._nu
         return rows[:, :nx], rows[:, nx: 2 * nx], rows[:, 2 * nx: 2 * nx + nu], rows[:, -2], rows[:, -1]
 
+    def sample_fused(self, n: int, gen: Optional[torch.Generator] = None):
+        """sample() + iterates_of_last_sample() + the float64 copies of obs / next_obs the replay solves read, through
+        mpcrl_replay_sample: the same draw (torch.randint on ``gen``), then ONE launch.  Returns (obs, next_obs, act, rew, done) as
+        sample() does — views of ``last_rows`` — and sets ``last_x64`` = (obs, next_obs) in float64 and, with iterate tables,
+        ``last_starts`` = (rows for obs, cold mask, rows for next_obs, cold mask), masks as int32 (1 = start cold)."""
+        from . import _lib
+        steps = self.cap if self.full else self.pos
+        if steps == 0:
+            raise RuntimeError("DeviceReplayBuffer.sample: the buffer is empty (call collect() / add() first)")
+        dev = self.data.device
+        idx = torch.randint(0, steps * self.E, (n,), device=dev, generator=gen)
+        L, nx, nu = self.data.shape[-1], self._nx, self._nu
+        rows = torch.empty((n, L), dtype=torch.float32, device=dev)
+        x64 = torch.empty((2, n, nx), dtype=torch.float64, device=dev)
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        st = None
+        if self.iters is not None:
+            r64 = torch.empty((2, n), dtype=torch.int64, device=dev)
+            c32 = torch.empty((2, n), dtype=torch.int32, device=dev)
+            st = (r64[0], c32[0], r64[1], c32[1])
+        with torch.cuda.device(dev):
+            rc = _lib.load().mpcrl_replay_sample(ptr(self.data), L, nx, self.E, self.cap, steps, ptr(idx), n, ptr(self.pos_t),
+                                                 ptr(self.iter_ok) if st else None, ptr(rows), ptr(x64[0]), ptr(x64[1]),
+                                                 ptr(st[0]) if st else None, ptr(st[1]) if st else None, ptr(st[2]) if st else None,
+                                                 ptr(st[3]) if st else None, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"mpcrl_replay_sample failed with code {rc}")
+        self.last_idx, self.last_steps, self.last_rows, self.last_x64, self.last_starts = idx, steps, rows, (x64[0], x64[1]), st
+        return rows[:, :nx], rows[:, nx: 2 * nx], rows[:, 2 * nx: 2 * nx + nu], rows[:, -2], rows[:, -1]
+
     def iterates_of_last_sample(self):
         """For the transitions of the last sample(): (rows for obs, ok, rows for next_obs, ok) — row numbers into ``iters``.  The
         iterate for obs is the roll-out policy's own solution there.  For next_obs it is the roll-out solution of the NEXT step of the
@@ -372,6 +402,7 @@ class BatchedTD3:
         # the critic step through mpcrl_critic_td_grad / mpcrl_critic_dq_da (two launches + one, for ~60 + ~15 of the framework: 361 us of a
         # 1.33 ms step at batch 4096) where the critics have the shape those kernels are written for; any other net_arch stays on autograd
         self._fused_critic = fused_critic and self._fused and tuple(net_arch) == (64, 64) and ocp.nx + ocp.nu <= 64
+        self._fused_sample = self._fused      # the replay batch through mpcrl_replay_sample (one launch after the draw)
         if self._fused_critic:
             self._crit_flat, self._crit_grad = flatten_parameters(self.critic)
             self._crit_target_flat, _ = flatten_parameters(self.critic_target)
@@ -469,17 +500,26 @@ class BatchedTD3:
         gradients, (every policy_delay-th update) the policy's batched solve with du0*/dtheta and the theta-gradient sum.
         Returns (flat message, loss)."""
         world, n_theta = self._world(), self.theta.numel()
-        obs, nxt, act, rew, done = self.buffer.sample(self.B, self.gen)
+        if self._fused_sample:      # the draw, then ONE launch for the gather, the index arithmetic, the masks and the float64 states
+            obs, nxt, act, rew, done = self.buffer.sample_fused(self.B, self.gen)
+            obs64, nxt64 = self.buffer.last_x64
+        else:
+            obs, nxt, act, rew, done = self.buffer.sample(self.B, self.gen)
+            obs64 = nxt64 = None
         with torch.no_grad():
             eps = torch.randn(act.shape, dtype=torch.float32, device=self.device, generator=self.gen)
             if self.replay_iterates:
-                it_s, ok_s, it_n, ok_n = self.buffer.iterates_of_last_sample()
+                if self._fused_sample:
+                    it_s, cold_s, it_n, cold_n = self.buffer.last_starts
+                else:
+                    it_s, ok_s, it_n, ok_n = self.buffer.iterates_of_last_sample()
+                    cold_s, cold_n = ~ok_s, ~ok_n
                 self._load_iterate(self.target_mpc.mpc, it_n)
                 # (a stored iterate of a failed roll-out solve is not a starting point: that instance starts cold)
                 # (no packing order: nearly every instance is converged at its start, there is no difficulty to group by — 14 us of order kernel)
-                rt = self.target_mpc.mpc.solve(nxt.to(torch.float64), cold_mask=~ok_n, reorder=False)     # actor_target(s'), one launch, warm
+                rt = self.target_mpc.mpc.solve(nxt.to(torch.float64) if nxt64 is None else nxt64, cold_mask=cold_n, reorder=False)     # actor_target(s'), one launch, warm
             else:
-                rt = self.target_mpc.mpc.solve(nxt.to(torch.float64), cold=True)           # actor_target(s'), one launch
+                rt = self.target_mpc.mpc.solve(nxt.to(torch.float64) if nxt64 is None else nxt64, cold=True)           # actor_target(s'), one launch
             # failed target solves are SELECTED out (a product with a 0 / 1 mask would keep their NaN: NaN * 0 = NaN), and so are
             # transitions whose stored observations are not finite
             # (one finiteness test over the whole transition: every separate test, fill and select is a launch of its own)
@@ -518,9 +558,9 @@ class BatchedTD3:
         if do_policy:
             if self.replay_iterates:
                 self._load_iterate(self.pi_mpc.mpc, it_s)
-                rp = self.pi_mpc.mpc.solve(obs.to(torch.float64), sens_pi=True, cold_mask=~ok_s, reorder=False)   # pi(s_i), dpi/dtheta_i: one launch, warm
+                rp = self.pi_mpc.mpc.solve(obs.to(torch.float64) if obs64 is None else obs64, sens_pi=True, cold_mask=cold_s, reorder=False)   # pi(s_i), dpi/dtheta_i: one launch, warm
             else:
-                rp = self.pi_mpc.mpc.solve(obs.to(torch.float64), sens_pi=True, cold=True)   # pi(s_i), dpi/dtheta_i: one launch
+                rp = self.pi_mpc.mpc.solve(obs.to(torch.float64) if obs64 is None else obs64, sens_pi=True, cold=True)   # pi(s_i), dpi/dtheta_i: one launch
             if self._fused_critic:
                 a_pi, ok_u = self.pi_mpc.action(rp)
                 dq_da, okb = critic_dq_da(self.buffer.last_rows, nx_, a_pi, ok_u, self._crit_flat)     # dQ_1/da at (s, pi(s)): one launch

@@ -580,8 +580,8 @@ def test_td3_replay_iterates():
 def test_policy_action_kernel_and_fused_td3_glue():
     """mpcrl_policy_action (round 6): the actor's output stage — scale_action (mpc.py:290-301), exploration / target-policy noise, clips,
     the failed-solve mask — in one launch.  (a) Bit for bit the torch expressions it replaces, failed and non-finite rows included.
-    (b) A TD3 loop run with it (BatchedTD3._fused, the default on the GPU) reproduces the loop without it bit for bit: replay table,
-    critic losses, theta, critics."""
+    (b) A TD3 loop run with it and with mpcrl_replay_sample (BatchedTD3._fused / _fused_sample, the defaults on the GPU) reproduces the
+    loop on the framework's own launches bit for bit: replay table, critic losses, theta, critics."""
     from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedTD3, MPCBatch, cartpole_ocp
     from mpc4rl_amd.td3 import MPCActor
     ocp = cartpole_ocp()
@@ -613,8 +613,8 @@ def test_policy_action_kernel_and_fused_td3_glue():
     for fused in (False, True):
         env = BatchedCartPoleSwingUpEnv(256, device="cuda", seed=0, max_episode_steps=7)
         ag = BatchedTD3(ocp, env, batch_size=256, buffer_steps=6, policy_delay=2, lr_actor=1e-4, seed=0, replay_iterates=True, fused_critic=False)
-        assert ag._fused and not ag._fused_critic
-        ag._fused = fused
+        assert ag._fused and ag._fused_sample and not ag._fused_critic
+        ag._fused = ag._fused_sample = fused
         ag.collect(6)
         losses = []
         for _ in range(6):
