@@ -73,7 +73,7 @@ extern "C" {
  *        instances), or flip the status of an RTI call whose residual sits at the tolerance; outputs of such an instance then
  *        agree with the one-stage kernel and the oracle port to the QP tolerance (1e-4 ... 1e-3 on du0/dp), not to rounding
  *   120  round 6: mpcrl_solve flags MPCRL_NO_BND_STORE and MPCRL_EXACT_QP (test-only); mpcrl_get_iterate_rows / mpcrl_set_iterate_rows; mpcrl_policy_action
- *   130  round 6: mpcrl_critic_td_grad / mpcrl_critic_workspace_bytes / mpcrl_critic_dq_da (the TD3 learner's critic step); mpcrl_replay_sample; linear system: a
+ *   130  round 6: mpcrl_critic_td_grad / mpcrl_critic_workspace_bytes / mpcrl_critic_dq_da (the TD3 learner's critic step); mpcrl_replay_sample; mpcrl_dpg_grad / mpcrl_dpg_workspace_bytes; linear system: a
  *        failed WARM QP restarts cold (behaviour, see above) */
 #define MPCRL_ABI_VERSION 130
 
@@ -304,6 +304,16 @@ int mpcrl_critic_dq_da(const float *obs, int obs_stride, int B, int nx, int nu, 
 int mpcrl_replay_sample(const float *table, int row_len, int nx, int E, int cap, int steps, const int64_t *idx, int B, const int64_t *pos_t,
                         const uint8_t *iter_ok, float *rows, double *obs64, double *nxt64, int64_t *row_s, int32_t *cold_s, int64_t *row_n,
                         int32_t *cold_n, void *stream);
+
+/* ABI 130.  The contraction of the deterministic policy gradient, one launch: out[p] = sum_b ok_b sum_u dq_da[b][u] chain_u dpi_dp[b][u][p]
+ * (p < n_p), out[n_p] = sum_b ok_b, chain_u = 2 / (hi_u - lo_u) with scale != 0 (the derivative of MPC.scale_action,
+ * rlmpc/mpc/common/mpc.py:290-301), else 1.  dq_da [B][nu] float (mpcrl_critic_dq_da), ok [B] uint8 or NULL, dpi_dp [B][nu][n_p] double
+ * (mpcrl_solve's output; entries of rows that are left in are read as nan_to_num would), lo / hi [nu] double, out [n_p + 1] double.
+ * workspace: mpcrl_dpg_workspace_bytes(B, n_p) bytes of device memory, ZERO before the first call (the call leaves its counter zero);
+ * fixed summation order: the same inputs give the same bits.  nu <= 8. */
+int64_t mpcrl_dpg_workspace_bytes(int B, int n_p);
+int mpcrl_dpg_grad(const float *dq_da, const uint8_t *ok, const double *dpi_dp, int B, int nu, int n_p, const double *lo, const double *hi, int scale,
+                   void *workspace, double *out, void *stream);
 
 /* Bytes of device memory held by the handle; library version (MPCRL_ABI_VERSION of the header it was built from). */
 int64_t mpcrl_workspace_bytes(mpcrl_handle h);

@@ -654,6 +654,23 @@ int mpcrl_replay_sample(const float *table, int row_len, int nx, int E, int cap,
     return 0;
 }
 
+int64_t mpcrl_dpg_workspace_bytes(int B, int n_p) {
+    if (B < 1 || n_p < 1) return MPCRL_E_ARG;
+    return 16 + (int64_t)((B + DPG_ROWS - 1) / DPG_ROWS) * (n_p + 1) * (int64_t)sizeof(double);
+}
+
+int mpcrl_dpg_grad(const float *dq_da, const uint8_t *ok, const double *dpi_dp, int B, int nu, int n_p, const double *lo, const double *hi, int scale,
+                   void *workspace, double *out, void *stream) {
+    if (!dq_da || !dpi_dp || !workspace || !out || B < 1 || nu < 1 || nu > 8 || n_p < 1 || (scale && (!lo || !hi))) return MPCRL_E_ARG;
+    ON_DEVICE_OF(out);
+    DpgArgs a;
+    a.dq_da = dq_da, a.ok = ok, a.dpi_dp = dpi_dp, a.B = B, a.nu = nu, a.n_p = n_p, a.scale = scale, a.lo = lo, a.hi = hi;
+    a.ticket = (unsigned int *)workspace, a.partial = (double *)((char *)workspace + 16), a.out = out;
+    hipLaunchKernelGGL(dpg_grad_kernel, dim3((B + DPG_ROWS - 1) / DPG_ROWS), dim3(128), 0, (hipStream_t)stream, a);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int64_t mpcrl_critic_workspace_bytes(int B, int nx, int nu, int n_critics) {
     if (B < 0 || nx < 1 || nu < 1 || nx + nu > CRITIC_DMAX || n_critics < 1 || n_critics > 2) return MPCRL_E_ARG;
     const int64_t n_blocks = (B + CRITIC_S - 1) / CRITIC_S, n_params = (int64_t)n_critics * (CRITIC_H * (nx + nu) + CRITIC_H * CRITIC_H + 3 * CRITIC_H + 1);

@@ -39,4 +39,68 @@ __global__ void __launch_bounds__(256) replay_sample_kernel(const ReplaySampleAr
     }
 }
 
+// The deterministic policy gradient's contraction (round 6): out[p] = sum_b ok_b sum_u dq_da[b][u] chain_u dpi_dp[b][u][p], out[n_p] = sum_b ok_b
+// with chain_u = 2 / (hi_u - lo_u) (the derivative of MPC.scale_action, rlmpc/mpc/common/mpc.py:290-301; 1 without scaling) — the step
+// the reference leaves as a stub (rlmpc/td3/policies.py:332).  ~14 framework launches, the batch sum of [4096 x 83] doubles alone 48 us,
+// in ONE: every workgroup sums DPG_ROWS rows into its partial; the LAST workgroup to finish (a ticket counter) adds the partials in
+// block order — no floating-point atomics, the same bits whatever the scheduling.  Non-finite sensitivities are read as nan_to_num does.
+constexpr int DPG_ROWS = 32;
+
+struct DpgArgs {
+    const float *dq_da;      // [B][nu]
+    const uint8_t *ok;       // [B] or nullptr
+    const double *dpi_dp;    // [B][nu][n_p]
+    int B, nu, n_p, scale;
+    const double *lo, *hi;   // [nu]
+    double *partial;         // [n_blocks][n_p + 1]
+    unsigned int *ticket;    // [1], zero before the first launch (the kernel leaves it zero)
+    double *out;             // [n_p + 1]
+};
+
+__device__ inline double nan_to_num_d(double v) {
+    return v != v ? 0.0 : (v > 1.7976931348623157e308 ? 1.7976931348623157e308 : (v < -1.7976931348623157e308 ? -1.7976931348623157e308 : v));
+}
+
+__global__ void __launch_bounds__(128) dpg_grad_kernel(const DpgArgs a) {
+    __shared__ double w[DPG_ROWS][8];      // the rows' weights (nu <= 8), 0 for a row that is left out
+    __shared__ double cnt;
+    __shared__ bool last;
+    const int b0 = blockIdx.x * DPG_ROWS, P1 = a.n_p + 1;
+    for (int e = threadIdx.x; e < DPG_ROWS * a.nu; e += 128) {
+        const int r = e / a.nu, u = e - r * a.nu, b = b0 + r;
+        const bool ok = b < a.B && (!a.ok || a.ok[b]);
+        const double chain = a.scale ? 2.0 / (a.hi[u] - a.lo[u]) : 1.0;
+        w[r][u] = ok ? (double)a.dq_da[(long)b * a.nu + u] * chain : 0.0;
+    }
+    if (threadIdx.x == 0) {
+        double n = 0.0;
+        for (int r = 0; r < DPG_ROWS; ++r) n += (b0 + r < a.B && (!a.ok || a.ok[b0 + r])) ? 1.0 : 0.0;
+        cnt = n;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < a.n_p; p += 128) {
+        double acc = 0.0;
+        for (int r = 0; r < DPG_ROWS && b0 + r < a.B; ++r)
+            for (int u = 0; u < a.nu; ++u) {
+                const double wt = w[r][u];
+                if (wt != 0.0) acc = fma(wt, nan_to_num_d(a.dpi_dp[((long)(b0 + r) * a.nu + u) * a.n_p + p]), acc);
+            }
+        a.partial[(long)blockIdx.x * P1 + p] = acc;
+    }
+    if (threadIdx.x == 0) a.partial[(long)blockIdx.x * P1 + a.n_p] = cnt;
+    // the last workgroup to get here adds the partials up, in block order
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    for (int p = threadIdx.x; p < P1; p += 128) {
+        double acc = 0.0;
+        for (int k = 0; k < (int)gridDim.x; ++k) acc += __builtin_nontemporal_load(&a.partial[(long)k * P1 + p]);
+        a.out[p] = acc;
+    }
+    if (threadIdx.x == 0) *a.ticket = 0u;
+}
+
 }  // namespace mpcrl

@@ -111,6 +111,27 @@ def critic_dq_da(obs, nx: int, act, ok_u, params):
     return out, ok.view(torch.bool)
 
 
+def dpg_grad(dq_da, ok, dpi_dp, low, high, scale: bool, out, workspace=None):
+    """mpcrl_dpg_grad: out[:n_p] = sum_b ok_b sum_u dq_da[b, u] chain_u dpi_dp[b, u, :], out[n_p] = sum_b ok_b — one launch, fixed summation
+    order.  out: float64 [n_p + 1] (written; may be a slice of a larger message).  Returns the workspace to pass again."""
+    from . import _lib
+    lib = _lib.load()
+    B, nu, n_p = dpi_dp.shape
+    dev = dpi_dp.device
+    if not (dq_da.dtype == torch.float32 and dq_da.is_contiguous() and dpi_dp.dtype == torch.float64 and dpi_dp.is_contiguous() and out.is_contiguous()):
+        raise ValueError("dq_da: contiguous float32 [B, nu]; dpi_dp, out: contiguous float64")
+    need = lib.mpcrl_dpg_workspace_bytes(B, n_p)
+    if workspace is None or workspace.numel() * 8 < need:
+        workspace = torch.zeros((need + 7) // 8, dtype=torch.float64, device=dev)       # (zero once: the kernel leaves its counter zero)
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    with torch.cuda.device(dev):
+        rc = lib.mpcrl_dpg_grad(ptr(dq_da), ptr(None if ok is None else _as_u8(ok)), ptr(dpi_dp), B, nu, n_p, ptr(low), ptr(high), int(scale),
+                                ptr(workspace), ptr(out), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"mpcrl_dpg_grad failed with code {rc}")
+    return workspace
+
+
 class MPCActor:
     """Deterministic policy a = scale(u0*(s; theta)) backed by an MPCBatch (td3/policies.py:125-222)."""
 
@@ -406,7 +427,7 @@ class BatchedTD3:
         if self._fused_critic:
             self._crit_flat, self._crit_grad = flatten_parameters(self.critic)
             self._crit_target_flat, _ = flatten_parameters(self.critic_target)
-            self._crit_ws = None
+            self._crit_ws = self._dpg_ws = None
         nw_ = ocp.nx + ocp.nu
         self.buffer = DeviceReplayBuffer(buffer_steps, self.E, ocp.nx, ocp.nu, dev, iterate_dims=(
             (ocp.N + 1) * ocp.nx, ocp.N * ocp.nu, ocp.N * ocp.nx, 10 * (ocp.N + 1) * nw_) if self.replay_iterates else None)
@@ -561,6 +582,7 @@ class BatchedTD3:
                 rp = self.pi_mpc.mpc.solve(obs.to(torch.float64) if obs64 is None else obs64, sens_pi=True, cold_mask=cold_s, reorder=False)   # pi(s_i), dpi/dtheta_i: one launch, warm
             else:
                 rp = self.pi_mpc.mpc.solve(obs.to(torch.float64) if obs64 is None else obs64, sens_pi=True, cold=True)   # pi(s_i), dpi/dtheta_i: one launch
+            ocp_nu = act.shape[1]
             if self._fused_critic:
                 a_pi, ok_u = self.pi_mpc.action(rp)
                 dq_da, okb = critic_dq_da(self.buffer.last_rows, nx_, a_pi, ok_u, self._crit_flat)     # dQ_1/da at (s, pi(s)): one launch
@@ -577,11 +599,14 @@ class BatchedTD3:
             if not self._fused_critic:
                 obs_p = torch.where(okb[:, None], obs, 0.0)
                 (dq_da,) = torch.autograd.grad(self.critic.q1_forward(obs_p, a_pi).sum(), a_pi)
-            chain = (2.0 / (self.pi_mpc.high - self.pi_mpc.low)) if self.pi_mpc.scale else torch.ones_like(self.pi_mpc.low)
-            okp = okb.to(torch.float64)
-            g = torch.einsum("bu,bup->bp", torch.where(okb[:, None], dq_da.to(torch.float64) * chain, 0.0), torch.nan_to_num(rp.dpi_dp))
-            flat[self.n_crit: self.n_crit + n_theta] = g.sum(0)
-            flat[-1] = okp.sum()
+            if self._fused_critic and ocp_nu <= 8:      # the contraction with dpi/dtheta and the count into the message: one launch
+                self._dpg_ws = dpg_grad(dq_da, okb, rp.dpi_dp, self.pi_mpc.low, self.pi_mpc.high, self.pi_mpc.scale, flat[self.n_crit:], self._dpg_ws)
+            else:
+                chain = (2.0 / (self.pi_mpc.high - self.pi_mpc.low)) if self.pi_mpc.scale else torch.ones_like(self.pi_mpc.low)
+                okp = okb.to(torch.float64)
+                g = torch.einsum("bu,bup->bp", torch.where(okb[:, None], dq_da.to(torch.float64) * chain, 0.0), torch.nan_to_num(rp.dpi_dp))
+                flat[self.n_crit: self.n_crit + n_theta] = g.sum(0)
+                flat[-1] = okp.sum()
         return flat, loss.detach()
 
     def _load_iterate(self, mpc, rows) -> None:

@@ -693,6 +693,26 @@ def test_critic_td_grad_and_dq_da_vs_autograd(B, nx, nu, n_critics):
     assert float((dq.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
     with pytest.raises(ValueError):
         critic_td_grad(rows.double(), nx, nu, a_next, ok_u, flat, flat_t, n_critics, gamma, 1.0, out)
+    # the policy gradient's contraction with dpi/dtheta (mpcrl_dpg_grad): torch's expressions in float64, non-finite sensitivities on rows
+    # that are left in and on rows that are left out
+    from mpc4rl_amd.td3 import dpg_grad
+    n_p = 83
+    dpi = torch.randn(B, nu, n_p, dtype=torch.float64, device=dev)
+    dpi[0, 0, 3] = float("nan")
+    if B > 4:
+        dpi[1] = float("nan")
+        dpi[4, nu - 1, 7] = float("inf")
+    lo, hi = -torch.rand(nu, dtype=torch.float64, device=dev) - 0.5, torch.rand(nu, dtype=torch.float64, device=dev) + 0.5
+    for scale in (True, False):
+        msg = torch.full((5 + n_p + 1,), -1.0, dtype=torch.float64, device=dev)
+        wsd = dpg_grad(dq, okq, dpi, lo, hi, scale, msg[5:])
+        chain = 2.0 / (hi - lo) if scale else torch.ones_like(lo)
+        g = torch.einsum("bu,bup->bp", torch.where(okq[:, None], dq.double() * chain, 0.0), torch.nan_to_num(dpi)).sum(0)
+        assert bool((msg[:5] == -1.0).all()) and float(msg[-1]) == float(okq.sum())
+        fin = g.abs() < 1e300
+        assert float((msg[5:-1][fin] - g[fin]).abs().max()) <= 1e-12 * max(1.0, float(g[fin].abs().max())) and bool((msg[5:-1][~fin].abs() > 1e300).all())
+        msg2 = torch.zeros_like(msg)
+        assert dpg_grad(dq, okq, dpi, lo, hi, scale, msg2[5:], wsd) is wsd and torch.equal(msg2[5:], msg[5:])      # counter left at zero, same bits
 
 
 def test_td3_loop_with_the_critic_kernels():
