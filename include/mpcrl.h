@@ -73,7 +73,7 @@ extern "C" {
  *        instances), or flip the status of an RTI call whose residual sits at the tolerance; outputs of such an instance then
  *        agree with the one-stage kernel and the oracle port to the QP tolerance (1e-4 ... 1e-3 on du0/dp), not to rounding
  *   120  round 6: mpcrl_solve flags MPCRL_NO_BND_STORE and MPCRL_EXACT_QP (test-only); mpcrl_get_iterate_rows / mpcrl_set_iterate_rows; mpcrl_policy_action
- *   130  round 6: mpcrl_critic_td_grad / mpcrl_critic_workspace_bytes / mpcrl_critic_dq_da (the TD3 learner's critic step); mpcrl_replay_sample; mpcrl_dpg_grad / mpcrl_dpg_workspace_bytes; linear system: a
+ *   130  round 6: mpcrl_critic_td_grad / mpcrl_critic_workspace_bytes / mpcrl_critic_dq_da (the TD3 learner's critic step); mpcrl_replay_sample; mpcrl_dpg_grad / mpcrl_dpg_workspace_bytes; mpcrl_td3_cartpole_collect; linear system: a
  *        failed WARM QP restarts cold (behaviour, see above) */
 #define MPCRL_ABI_VERSION 130
 
@@ -314,6 +314,20 @@ int mpcrl_replay_sample(const float *table, int row_len, int nx, int E, int cap,
 int64_t mpcrl_dpg_workspace_bytes(int B, int n_p);
 int mpcrl_dpg_grad(const float *dq_da, const uint8_t *ok, const double *dpi_dp, int B, int nu, int n_p, const double *lo, const double *hi, int scale,
                    void *workspace, double *out, void *stream);
+
+/* ABI 130.  The roll-out side of one TD3 step after the policy's solve, one launch (td3_kernel.hpp), cartpole environment, nu = 1: the
+ * actor's output stage with exploration noise (mpcrl_policy_action with accept_status2), mpcrl_env_cartpole_step, the replay row
+ * [obs | next obs | action | reward_scale * reward | terminated] (float, 11 entries) written at slot pos[0] of table [cap][E][11], the flag
+ * of the stored iterate (iter_ok[pos][env] = solve converged and u0 finite; may be NULL), the statistics (stats[0..2] += sum of rewards,
+ * converged solves, episodes ended), the reset of the environments that ended (mpcrl_env_cartpole_reset with u01), the next observation
+ * obs [E][4] double (in: the observation of this solve) and ended [E] int32 (the cold mask of the next solve).  The last workgroup
+ * advances pos[0] to (pos + 1) % cap; iter_rows [E] int64 (may be NULL) receives the rows of this step in the caller's iterate tables,
+ * pos * E + env (what mpcrl_get_iterate_rows is then called with).
+ * par: the nine doubles of mpcrl_env_cartpole_step.  workspace: 16 + 24 * ceil(E / 256) bytes, ZERO before the first call.  The
+ * arithmetic is that of the three kernels it stands for (shared device functions): a loop switched to it reproduces its numbers. */
+int mpcrl_td3_cartpole_collect(const double *par, int E, double *state, int64_t *steps, const double *u0, const int32_t *status, const float *eps,
+                               const double *u01, double lo, double hi, int scale, double sigma, double *obs, int32_t *ended, float *table, int cap,
+                               double reward_scale, int64_t *pos, uint8_t *iter_ok, int64_t *iter_rows, double *stats, void *workspace, void *stream);
 
 /* Bytes of device memory held by the handle; library version (MPCRL_ABI_VERSION of the header it was built from). */
 int64_t mpcrl_workspace_bytes(mpcrl_handle h);

@@ -25,27 +25,39 @@ __device__ __forceinline__ void store_obs4(OBS *obs, int i, double a, double b, 
         reinterpret_cast<float4 *>(obs)[i] = make_float4((float)a, (float)b, (float)c, (float)d);
 }
 
+// one environment's step (shared by env_cartpole_step_kernel and the fused roll-out kernel of td3_kernel.hpp: the same expressions, the same bits)
+struct CartpoleStepOut {
+    double nx, nxd, nth, nthd, reward;
+    bool terminated;
+};
+__device__ __forceinline__ CartpoleStepOut cartpole_env_step(const CartpoleEnvPar &p, double x, double xd, double th, double thd, double action) {
+    const double total_mass = p.masspole + p.masscart, pml = p.masspole * p.length;
+    const double force = action * p.force_mag;
+    const double c = cos(th), s = sin(th);
+    const double temp = (force + pml * (thd * thd) * s) / total_mass;
+    const double thacc = (p.gravity * s - c * temp) / (p.length * (4.0 / 3.0 - p.masspole * (c * c) / total_mass));
+    const double xacc = temp - pml * thacc * c / total_mass;
+    CartpoleStepOut o;
+    o.nx = x + p.tau * xd, o.nxd = xd + p.tau * xacc, o.nth = th + p.tau * thd, o.nthd = thd + p.tau * thacc;
+    o.reward = o.nx * o.nx + o.nth * o.nth;
+    o.terminated = fabs(o.nx) < p.x_threshold && fabs(o.nxd) < 0.1 && fabs(o.nth) < p.theta_threshold && fabs(o.nthd) < 0.1;
+    return o;
+}
+
 template <class OBS>
 __global__ void __launch_bounds__(256) env_cartpole_step_kernel(const CartpoleEnvPar p, int B, double *state, int64_t *steps, const double *action,
                                                                 OBS *obs, double *reward, uint8_t *terminated, uint8_t *truncated) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B) return;
     const double2 s01 = reinterpret_cast<const double2 *>(state)[2 * i], s23 = reinterpret_cast<const double2 *>(state)[2 * i + 1];
-    const double x = s01.x, xd = s01.y, th = s23.x, thd = s23.y;
-    const double total_mass = p.masspole + p.masscart, pml = p.masspole * p.length;
-    const double force = action[i] * p.force_mag;
-    const double c = cos(th), s = sin(th);
-    const double temp = (force + pml * (thd * thd) * s) / total_mass;
-    const double thacc = (p.gravity * s - c * temp) / (p.length * (4.0 / 3.0 - p.masspole * (c * c) / total_mass));
-    const double xacc = temp - pml * thacc * c / total_mass;
-    const double nx = x + p.tau * xd, nxd = xd + p.tau * xacc, nth = th + p.tau * thd, nthd = thd + p.tau * thacc;
-    reinterpret_cast<double2 *>(state)[2 * i] = make_double2(nx, nxd);
-    reinterpret_cast<double2 *>(state)[2 * i + 1] = make_double2(nth, nthd);
-    if (obs) store_obs4(obs, i, nx, nxd, nth, nthd);
+    const CartpoleStepOut o = cartpole_env_step(p, s01.x, s01.y, s23.x, s23.y, action[i]);
+    reinterpret_cast<double2 *>(state)[2 * i] = make_double2(o.nx, o.nxd);
+    reinterpret_cast<double2 *>(state)[2 * i + 1] = make_double2(o.nth, o.nthd);
+    if (obs) store_obs4(obs, i, o.nx, o.nxd, o.nth, o.nthd);
     const int64_t n = steps[i] + 1;
     steps[i] = n;
-    reward[i] = nx * nx + nth * nth;
-    terminated[i] = fabs(nx) < p.x_threshold && fabs(nxd) < 0.1 && fabs(nth) < p.theta_threshold && fabs(nthd) < 0.1;
+    reward[i] = o.reward;
+    terminated[i] = o.terminated;
     truncated[i] = n >= p.max_episode_steps;
 }
 
@@ -99,6 +111,17 @@ __global__ void __launch_bounds__(256) env_linear_step_kernel(const LinearEnvPar
 //     a_i  = clip(a_i + clip(sigma * noise_i, -noise_clip, noise_clip), -1, 1)      (noise = NULL: a_i as it is, unclipped)
 // The arithmetic keeps the order and types of the torch expressions it replaces (the scaling in fp64, then float; the noise product, its
 // clip, the sum and the final clip in float), so that a loop switched to it reproduces its numbers.
+__device__ __forceinline__ float policy_action_one(double u, bool good, double lo, double hi, int scale, const float *noise, float sigma, float noise_clip) {
+    float a = !good ? 0.0f : (float)(scale ? 2.0 * ((u - lo) / (hi - lo)) - 1.0 : u);
+    if (noise) {
+#pragma clang fp contract(off)      // the product and the sum stay two roundings, as in the torch expressions, wherever this is inlined
+        float n = sigma * *noise;
+        if (noise_clip > 0.0f) n = fminf(fmaxf(n, -noise_clip), noise_clip);
+        a = fminf(fmaxf(a + n, -1.0f), 1.0f);
+    }
+    return a;
+}
+
 __global__ void __launch_bounds__(256) policy_action_kernel(const double *u0, const int *status, const float *noise, const double *lo, const double *hi,
                                                             int B, int nu, int scale, float sigma, float noise_clip, int accept2, float *action, uint8_t *ok) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -106,16 +129,8 @@ __global__ void __launch_bounds__(256) policy_action_kernel(const double *u0, co
     const int st = status[i];
     bool good = st == 0 || (accept2 && st == 2);
     for (int j = 0; j < nu; ++j) good = good && isfinite(u0[(long)i * nu + j]);
-    for (int j = 0; j < nu; ++j) {
-        const double u = u0[(long)i * nu + j];
-        float a = !good ? 0.0f : (float)(scale ? 2.0 * ((u - lo[j]) / (hi[j] - lo[j])) - 1.0 : u);
-        if (noise) {
-            float n = sigma * noise[(long)i * nu + j];
-            if (noise_clip > 0.0f) n = fminf(fmaxf(n, -noise_clip), noise_clip);
-            a = fminf(fmaxf(a + n, -1.0f), 1.0f);
-        }
-        action[(long)i * nu + j] = a;
-    }
+    for (int j = 0; j < nu; ++j)
+        action[(long)i * nu + j] = policy_action_one(u0[(long)i * nu + j], good, lo[j], hi[j], scale, noise ? noise + (long)i * nu + j : nullptr, sigma, noise_clip);
     if (ok) ok[i] = good ? 1 : 0;
 }
 

@@ -18,6 +18,7 @@
 #include "env_kernel.hpp"
 #include "critic_kernel.hpp"
 #include "replay_kernel.hpp"
+#include "td3_kernel.hpp"
 
 using namespace mpcrl;
 
@@ -650,6 +651,23 @@ int mpcrl_replay_sample(const float *table, int row_len, int nx, int E, int cap,
     a.table = table, a.row_len = row_len, a.nx = nx, a.B = B, a.E = E, a.cap = cap, a.steps = steps, a.idx = idx, a.pos_t = pos_t, a.iter_ok = iter_ok;
     a.rows = rows, a.obs64 = obs64, a.nxt64 = nxt64, a.row_s = row_s, a.row_n = row_n, a.cold_s = cold_s, a.cold_n = cold_n;
     hipLaunchKernelGGL(replay_sample_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int mpcrl_td3_cartpole_collect(const double *par, int E, double *state, int64_t *steps, const double *u0, const int32_t *status, const float *eps,
+                               const double *u01, double lo, double hi, int scale, double sigma, double *obs, int32_t *ended, float *table, int cap,
+                               double reward_scale, int64_t *pos, uint8_t *iter_ok, int64_t *iter_rows, double *stats, void *workspace, void *stream) {
+    if (!par || E < 1 || !state || !steps || !u0 || !status || !eps || !u01 || !obs || !ended || !table || cap < 1 || !pos || !stats || !workspace)
+        return MPCRL_E_ARG;
+    ON_DEVICE_OF(state);
+    Td3CollectArgs a;
+    a.par.gravity = par[0], a.par.masscart = par[1], a.par.masspole = par[2], a.par.length = par[3], a.par.force_mag = par[4], a.par.tau = par[5];
+    a.par.x_threshold = par[6], a.par.theta_threshold = par[7], a.par.max_episode_steps = (long)par[8];
+    a.E = E, a.state = state, a.steps = steps, a.u0 = u0, a.status = (const int *)status, a.eps = eps, a.u01 = u01, a.lo = lo, a.hi = hi, a.scale = scale;
+    a.sigma = (float)sigma, a.obs = obs, a.ended = ended, a.table = table, a.cap = cap, a.reward_scale = reward_scale, a.pos = pos, a.iter_ok = iter_ok;
+    a.iter_rows = iter_rows, a.stats = stats, a.ticket = (unsigned int *)workspace, a.partial = (double *)((char *)workspace + 16);
+    hipLaunchKernelGGL(td3_cartpole_collect_kernel, dim3((E + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     HIP_OK(hipGetLastError());
     return 0;
 }

@@ -424,6 +424,10 @@ class BatchedTD3:
         # 1.33 ms step at batch 4096) where the critics have the shape those kernels are written for; any other net_arch stays on autograd
         self._fused_critic = fused_critic and self._fused and tuple(net_arch) == (64, 64) and ocp.nx + ocp.nu <= 64
         self._fused_sample = self._fused      # the replay batch through mpcrl_replay_sample (one launch after the draw)
+        # the roll-out after the solve through mpcrl_td3_cartpole_collect (one launch for ~36) where the environment is the library's cartpole
+        from .envs import BatchedCartPoleSwingUpEnv
+        self._fused_collect = (self._fused and isinstance(env, BatchedCartPoleSwingUpEnv) and env._native() and env.dtype == torch.float64
+                               and ocp.nu == 1 and ocp.nx == 4 and env.state.device == self.theta.device)
         if self._fused_critic:
             self._crit_flat, self._crit_grad = flatten_parameters(self.critic)
             self._crit_target_flat, _ = flatten_parameters(self.critic_target)
@@ -439,6 +443,12 @@ class BatchedTD3:
         self.n_updates = 0
         self.obs = self.env.reset().to(dev)
         self._ended = None
+        if self._fused_collect:
+            self.obs = self.obs.to(torch.float64).contiguous()
+            self._ended = torch.zeros(self.E, dtype=torch.int32, device=dev)      # updated in place: the cold mask of the next roll-out solve
+            self._iter_rows = torch.zeros(self.E, dtype=torch.int64, device=dev) if self.replay_iterates else None
+            self._collect_ws = torch.zeros(2 + 3 * ((self.E + 255) // 256), dtype=torch.float64, device=dev)
+            self._lo_hi = (float(ocp.lbu[0]), float(ocp.ubu[0]))
         self._stats = torch.zeros(3, dtype=torch.float64, device=dev)    # reward sum, converged solves, episodes ended (since the last read)
         self._stats_steps = 0
         self._graphs = None
@@ -448,6 +458,8 @@ class BatchedTD3:
     def _collect_step(self, static: bool = False):
         """One closed-loop step of all E environments.  static: the form that can be captured into a HIP graph and replayed — the
         replay write position is read on the device, the running observation / ended mask / statistics are updated in place."""
+        if self._fused_collect:
+            return self._collect_step_fused(static)
         r = self.actor.mpc.solve(self.obs.to(torch.float64), cold_mask=self._ended)   # ONE launch for E policies
         # a solve that ended with status 1 / 4 may hand back a non-finite u0: such an environment gets the zero action (a
         # finite fallback; the reference raises instead, mpc.py:81-83).  The stored transition is the one that really happened
@@ -484,6 +496,30 @@ class BatchedTD3:
             any_done = bool(done.any())      # an episode end changes the control flow: one host synchronisation per step
             self.obs = self.env.reset(done.to(self.env.device)).to(self.device) if any_done else nxt
             self._ended = done if any_done else None
+
+    def _collect_step_fused(self, static: bool) -> None:
+        """_collect_step on mpcrl_td3_cartpole_collect: the solve, the two draws (the generators stay torch's), ONE launch for the actor's
+        output stage, the environment step, the replay row, the statistics, the resets, the next observation and cold mask — all in
+        place, so eager and graph-replayed steps are the same launches — and the move of the iterates into the replay tables."""
+        from . import _lib
+        from .batch import _ptr
+        env, buf, dev = self.env, self.buffer, self.device
+        r = self.actor.mpc.solve(self.obs, cold_mask=self._ended)
+        eps = torch.randn(r.u0.shape, dtype=torch.float32, device=dev, generator=self.gen)
+        u01 = torch.rand(self.E, generator=env.gen, dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.load().mpcrl_td3_cartpole_collect(
+                env._par(), self.E, _ptr(env.state), _ptr(env.steps), _ptr(r.u0), _ptr(r.status), _ptr(eps), _ptr(u01), self._lo_hi[0],
+                self._lo_hi[1], int(bool(self.actor.scale)), float(self.action_noise), _ptr(self.obs), _ptr(self._ended), _ptr(buf.data),
+                buf.cap, float(self.reward_scale), _ptr(buf.pos_t), _ptr(buf.iter_ok) if self.replay_iterates else None,
+                _ptr(self._iter_rows) if self.replay_iterates else None, _ptr(self._stats), _ptr(self._collect_ws),
+                torch.cuda.current_stream(dev).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"mpcrl_td3_cartpole_collect failed with code {rc}")
+        if self.replay_iterates:
+            self.actor.mpc.get_iterate_rows(*buf.iters, index=self._iter_rows)
+        if not static:
+            buf._advance()
 
     def collect(self, n_steps: int, stats: bool = True) -> dict:
         """n_steps closed-loop steps of all E environments; returns roll-out statistics (device tensors -> python floats once;

@@ -580,8 +580,9 @@ def test_td3_replay_iterates():
 def test_policy_action_kernel_and_fused_td3_glue():
     """mpcrl_policy_action (round 6): the actor's output stage — scale_action (mpc.py:290-301), exploration / target-policy noise, clips,
     the failed-solve mask — in one launch.  (a) Bit for bit the torch expressions it replaces, failed and non-finite rows included.
-    (b) A TD3 loop run with it and with mpcrl_replay_sample (BatchedTD3._fused / _fused_sample, the defaults on the GPU) reproduces the
-    loop on the framework's own launches bit for bit: replay table, critic losses, theta, critics."""
+    (b) A TD3 loop run with it, with mpcrl_replay_sample and with mpcrl_td3_cartpole_collect (BatchedTD3._fused / _fused_sample /
+    _fused_collect, the defaults on the GPU) reproduces the loop on the framework's own launches bit for bit: replay table, iterate
+    tables and flags, environment state, critic losses, theta, critics; the statistics to rounding (another summation order)."""
     from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedTD3, MPCBatch, cartpole_ocp
     from mpc4rl_amd.td3 import MPCActor
     ocp = cartpole_ocp()
@@ -613,16 +614,23 @@ def test_policy_action_kernel_and_fused_td3_glue():
     for fused in (False, True):
         env = BatchedCartPoleSwingUpEnv(256, device="cuda", seed=0, max_episode_steps=7)
         ag = BatchedTD3(ocp, env, batch_size=256, buffer_steps=6, policy_delay=2, lr_actor=1e-4, seed=0, replay_iterates=True, fused_critic=False)
-        assert ag._fused and ag._fused_sample and not ag._fused_critic
-        ag._fused = ag._fused_sample = fused
+        assert ag._fused and ag._fused_sample and ag._fused_collect and not ag._fused_critic
+        ag._fused = ag._fused_sample = ag._fused_collect = fused
         ag.collect(6)
         losses = []
         for _ in range(6):
             ag.collect(1)
             losses.append(ag.train(1)["critic_loss"])
-        res[fused] = (ag.buffer.data.clone(), losses, ag.theta.clone(), torch.cat([p.detach().reshape(-1) for p in ag.critic.parameters()]))
+        st = ag.last_stats()
+        res[fused] = (ag.buffer.data.clone(), losses, ag.theta.clone(), torch.cat([p.detach().reshape(-1) for p in ag.critic.parameters()]),
+                      [t.clone() for t in ag.buffer.iters] + [ag.buffer.iter_ok.clone(), env.state.clone(), env.steps.clone(), ag.obs.clone().double(),
+                                                              ag.buffer.pos_t.clone()], st, (ag.buffer.pos, ag.buffer.full))
     assert torch.equal(res[False][0], res[True][0]) and res[False][1] == res[True][1]
     assert torch.equal(res[False][2], res[True][2]) and torch.equal(res[False][3], res[True][3])
+    assert all(torch.equal(x, y) for x, y in zip(res[False][4], res[True][4])) and res[False][6] == res[True][6]
+    sa, sb = res[False][5], res[True][5]
+    assert abs(sa["mean_reward"] - sb["mean_reward"]) < 1e-12 * abs(sa["mean_reward"]) and sa["converged_fraction"] == sb["converged_fraction"]
+    assert sa["episodes_ended"] == sb["episodes_ended"]
 
 
 def _critic_reference(critic, target, rows, nx, nu, a_next, ok_u, gamma, dtype):
@@ -741,3 +749,54 @@ def test_td3_loop_with_the_critic_kernels():
     assert float((a[2] - k[2]).abs().max()) < 1e-9 and float((a[3] - k[3]).abs().max()) < 2e-5 and float((a[4] - k[4]).abs().max()) < 2e-6
     g = res["kernels+graphs"]      # (enable_graphs fills the replay table on its own: compared with itself being finite and learning)
     assert np.isfinite(g[1]).all() and bool(torch.isfinite(g[3]).all())
+
+
+def test_td3_cartpole_collect_kernel_vs_the_kernels_it_stands_for():
+    """mpcrl_td3_cartpole_collect (round 6): the roll-out side of a TD3 step after the solve in one launch, against the launches it
+    stands for on the same inputs — mpcrl_policy_action, mpcrl_env_cartpole_step, the replay row, mpcrl_env_cartpole_reset — bit for
+    bit (failed solves, non-finite controls, terminated and truncated episodes included), the statistics and the device-side write
+    position over two calls (wrap-around of a two-slot table)."""
+    from mpc4rl_amd import BatchedCartPoleSwingUpEnv, _lib
+    from mpc4rl_amd.batch import _ptr
+    lib, dev, E = _lib.load(), torch.device("cuda:0"), 1000
+    torch.manual_seed(0)
+    env = BatchedCartPoleSwingUpEnv(E, device="cuda", seed=0, max_episode_steps=3)
+    env.reset()
+    env.state.copy_(torch.randn(E, 4, dtype=torch.float64, device=dev) * torch.tensor([0.5, 1.0, 3.0, 2.0], device=dev, dtype=torch.float64))
+    env.state[:50] *= 0.01                                   # some inside the terminal box after the step
+    env.steps.copy_(torch.randint(0, 3, (E,), device=dev))
+    lo, hi = torch.tensor([-30.0], dtype=torch.float64, device=dev), torch.tensor([30.0], dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    state1, steps1 = env.state.clone(), env.steps.clone()
+    obs, ended = env.state.clone(), torch.zeros(E, dtype=torch.int32, device=dev)
+    table, pos = torch.zeros(2, E, 11, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
+    iter_ok, rows = torch.zeros(2, E, dtype=torch.uint8, device=dev), torch.zeros(E, dtype=torch.int64, device=dev)
+    stats, ws = torch.zeros(3, dtype=torch.float64, device=dev), torch.zeros(2 + 3 * 4, dtype=torch.float64, device=dev)
+    ref_stats = torch.zeros(3, dtype=torch.float64, device=dev)
+    for call in range(3):
+        u0 = torch.randn(E, 1, dtype=torch.float64, device=dev) * 20
+        u0[7], u0[8] = float("nan"), float("inf")
+        status = torch.randint(0, 5, (E,), device=dev, dtype=torch.int32)
+        eps, u01 = torch.randn(E, 1, device=dev), torch.rand(E, dtype=torch.float64, device=dev)
+        u0[:50], eps[:50], status[:50] = 0.0, 0.0, 0                 # (no force: the near-origin states stay in the terminal box)
+        # the launches it stands for
+        a, ok = torch.empty(E, 1, device=dev), torch.empty(E, dtype=torch.uint8, device=dev)
+        assert lib.mpcrl_policy_action(_ptr(u0), _ptr(status), _ptr(eps), _ptr(lo), _ptr(hi), E, 1, 1, 0.1, 0.0, 1, _ptr(a), _ptr(ok), st) == 0
+        obs_before = env.state.clone()
+        nxt, rew, term, trunc = env.step(a)
+        done = term | trunc
+        m8, new_obs = done.to(torch.uint8), torch.empty(E, 4, dtype=torch.float64, device=dev)
+        assert lib.mpcrl_env_cartpole_reset(E, _ptr(env.state), _ptr(env.steps), _ptr(m8), _ptr(u01), _ptr(new_obs), 0, st) == 0
+        ref_stats += torch.stack([rew.sum(), (status == 0).sum().double(), done.sum().double()])
+        # the one launch
+        rc = lib.mpcrl_td3_cartpole_collect(env._par(), E, _ptr(state1), _ptr(steps1), _ptr(u0), _ptr(status), _ptr(eps), _ptr(u01), -30.0, 30.0, 1, 0.1, _ptr(obs),
+                                            _ptr(ended), _ptr(table), 2, -1.0, _ptr(pos), _ptr(iter_ok), _ptr(rows), _ptr(stats), _ptr(ws), st)
+        assert rc == 0
+        slot = call % 2
+        row = torch.cat([obs_before.float(), nxt.float(), a, (-1.0 * rew).float()[:, None], term.float()[:, None]], dim=1)
+        assert torch.equal(table[slot], row) and int(pos) == (call + 1) % 2
+        assert torch.equal(state1, env.state) and torch.equal(steps1, env.steps) and torch.equal(obs, new_obs) and torch.equal(ended.bool(), done)
+        assert torch.equal(iter_ok[slot].bool(), ok.bool() & (status == 0)) and torch.equal(rows, slot * E + torch.arange(E, device=dev))
+        assert int(done.sum()) > 0 and (call > 0 or int(term.sum()) > 0)
+    assert float((stats - ref_stats).abs().max()) < 1e-9 * float(ref_stats.abs().max()) and torch.equal(stats[1:], ref_stats[1:])
+    assert float(ws[0]) == 0.0
