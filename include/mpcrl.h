@@ -73,7 +73,7 @@ extern "C" {
  *        instances), or flip the status of an RTI call whose residual sits at the tolerance; outputs of such an instance then
  *        agree with the one-stage kernel and the oracle port to the QP tolerance (1e-4 ... 1e-3 on du0/dp), not to rounding
  *   120  round 6: mpcrl_solve flags MPCRL_NO_BND_STORE and MPCRL_EXACT_QP (test-only); mpcrl_get_iterate_rows / mpcrl_set_iterate_rows; mpcrl_policy_action
- *   130  round 6: mpcrl_critic_td_grad / mpcrl_critic_workspace_bytes / mpcrl_critic_dq_da (the TD3 learner's critic step); mpcrl_replay_sample; mpcrl_dpg_grad / mpcrl_dpg_workspace_bytes; mpcrl_td3_cartpole_collect; linear system: a
+ *   130  round 6: mpcrl_critic_td_grad / mpcrl_critic_workspace_bytes / mpcrl_critic_dq_da (the TD3 learner's critic step); mpcrl_replay_sample; mpcrl_dpg_grad / mpcrl_dpg_workspace_bytes; mpcrl_td3_cartpole_collect; mpcrl_td3_policy_post; linear system: a
  *        failed WARM QP restarts cold (behaviour, see above) */
 #define MPCRL_ABI_VERSION 130
 
@@ -328,6 +328,12 @@ int mpcrl_dpg_grad(const float *dq_da, const uint8_t *ok, const double *dpi_dp, 
 int mpcrl_td3_cartpole_collect(const double *par, int E, double *state, int64_t *steps, const double *u0, const int32_t *status, const float *eps,
                                const double *u01, double lo, double hi, int scale, double sigma, double *obs, int32_t *ended, float *table, int cap,
                                double reward_scale, int64_t *pos, uint8_t *iter_ok, int64_t *iter_rows, double *stats, void *workspace, void *stream);
+
+/* ABI 130.  The policy half of a TD3 update after the collective, one launch: msg [n_theta + 1] double = the all-reduced theta-gradient
+ * sum and sample count;  step = lr * mask * msg / max(1, count) -> step_out;  theta += step;  theta_target = (1 - tau) theta_target +
+ * tau theta;  crit_target = (1 - tau) crit_target + tau crit (float [n_crit], the flat critic parameters; n_crit may be 0). */
+int mpcrl_td3_policy_post(const double *msg, int n_theta, double lr, const double *mask, double tau, double *theta, double *theta_target,
+                          double *step_out, const float *crit, float *crit_target, int n_crit, void *stream);
 
 /* Bytes of device memory held by the handle; library version (MPCRL_ABI_VERSION of the header it was built from). */
 int64_t mpcrl_workspace_bytes(mpcrl_handle h);

@@ -31,7 +31,7 @@ class ProblemSpec(C.Structure):
 
 
 EXPORTS = ["mpcrl_create", "mpcrl_destroy", "mpcrl_set_theta", "mpcrl_set_gamma", "mpcrl_set_options", "mpcrl_set_exit_rule", "mpcrl_set_order", "mpcrl_set_bounds", "mpcrl_set_cold_mask", "mpcrl_reset",
-           "mpcrl_solve", "mpcrl_get_iterate", "mpcrl_set_iterate", "mpcrl_get_iterate_rows", "mpcrl_set_iterate_rows", "mpcrl_get_lagrangian", "mpcrl_weighted_grad_sum", "mpcrl_env_cartpole_step", "mpcrl_env_cartpole_reset", "mpcrl_env_linear_step", "mpcrl_policy_action", "mpcrl_critic_workspace_bytes", "mpcrl_critic_td_grad", "mpcrl_critic_dq_da", "mpcrl_replay_sample", "mpcrl_dpg_workspace_bytes", "mpcrl_dpg_grad", "mpcrl_td3_cartpole_collect", "mpcrl_auto_order", "mpcrl_query_time_sliced", "mpcrl_set_launch_mode", "mpcrl_get_launch_times", "mpcrl_workspace_bytes", "mpcrl_version"]
+           "mpcrl_solve", "mpcrl_get_iterate", "mpcrl_set_iterate", "mpcrl_get_iterate_rows", "mpcrl_set_iterate_rows", "mpcrl_get_lagrangian", "mpcrl_weighted_grad_sum", "mpcrl_env_cartpole_step", "mpcrl_env_cartpole_reset", "mpcrl_env_linear_step", "mpcrl_policy_action", "mpcrl_critic_workspace_bytes", "mpcrl_critic_td_grad", "mpcrl_critic_dq_da", "mpcrl_replay_sample", "mpcrl_dpg_workspace_bytes", "mpcrl_dpg_grad", "mpcrl_td3_cartpole_collect", "mpcrl_td3_policy_post", "mpcrl_auto_order", "mpcrl_query_time_sliced", "mpcrl_set_launch_mode", "mpcrl_get_launch_times", "mpcrl_workspace_bytes", "mpcrl_version"]
 
 _lib = None
 
@@ -86,6 +86,7 @@ def load():
     lib.mpcrl_dpg_grad.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp]
     lib.mpcrl_td3_cartpole_collect.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_double, vp, vp, vp, C.c_int,
                                                C.c_double, vp, vp, vp, vp, vp, vp]
+    lib.mpcrl_td3_policy_post.argtypes = [vp, C.c_int, C.c_double, vp, C.c_double, vp, vp, vp, vp, vp, C.c_int, vp]
     lib.mpcrl_workspace_bytes.argtypes = [vp]
     lib.mpcrl_workspace_bytes.restype = C.c_int64
     for name in EXPORTS:

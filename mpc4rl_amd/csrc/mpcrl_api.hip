@@ -672,6 +672,17 @@ int mpcrl_td3_cartpole_collect(const double *par, int E, double *state, int64_t 
     return 0;
 }
 
+int mpcrl_td3_policy_post(const double *msg, int n_theta, double lr, const double *mask, double tau, double *theta, double *theta_target,
+                          double *step_out, const float *crit, float *crit_target, int n_crit, void *stream) {
+    if (!msg || n_theta < 1 || !mask || !theta || !theta_target || !step_out || n_crit < 0 || (n_crit > 0 && (!crit || !crit_target))) return MPCRL_E_ARG;
+    ON_DEVICE_OF(theta);
+    const int n = n_theta > n_crit ? n_theta : n_crit;
+    hipLaunchKernelGGL(td3_policy_post_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, msg, n_theta, lr, mask, tau, theta, theta_target,
+                       step_out, crit, crit_target, n_crit);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int64_t mpcrl_dpg_workspace_bytes(int B, int n_p) {
     if (B < 1 || n_p < 1) return MPCRL_E_ARG;
     return 16 + (int64_t)((B + DPG_ROWS - 1) / DPG_ROWS) * (n_p + 1) * (int64_t)sizeof(double);

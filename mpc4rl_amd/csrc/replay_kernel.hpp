@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256) replay_sample_kernel(const ReplaySampleAr
 // the reference leaves as a stub (rlmpc/td3/policies.py:332).  ~14 framework launches, the batch sum of [4096 x 83] doubles alone 48 us,
 // in ONE: every workgroup sums DPG_ROWS rows into its partial; the LAST workgroup to finish (a ticket counter) adds the partials in
 // block order — no floating-point atomics, the same bits whatever the scheduling.  Non-finite sensitivities are read as nan_to_num does.
-constexpr int DPG_ROWS = 32;
+constexpr int DPG_ROWS = 32, DPG_PMAX = 256;
 
 struct DpgArgs {
     const float *dq_da;      // [B][nu]
@@ -65,6 +65,7 @@ __global__ void __launch_bounds__(128) dpg_grad_kernel(const DpgArgs a) {
     __shared__ double w[DPG_ROWS][8];      // the rows' weights (nu <= 8), 0 for a row that is left out
     __shared__ double cnt;
     __shared__ bool last;
+    __shared__ double fin[4][DPG_PMAX];
     const int b0 = blockIdx.x * DPG_ROWS, P1 = a.n_p + 1;
     for (int e = threadIdx.x; e < DPG_ROWS * a.nu; e += 128) {
         const int r = e / a.nu, u = e - r * a.nu, b = b0 + r;
@@ -78,13 +79,21 @@ __global__ void __launch_bounds__(128) dpg_grad_kernel(const DpgArgs a) {
         cnt = n;
     }
     __syncthreads();
+    // (a row that is left out has weight 0 and is read all the same — nan_to_num makes every entry finite, 0 x finite = 0: no branch,
+    // eight loads in flight per lane)
+    const int nr = (a.B - b0 < DPG_ROWS ? a.B - b0 : DPG_ROWS) * a.nu;      // (row, control) pairs of this workgroup
+    const double *base = a.dpi_dp + (long)b0 * a.nu * a.n_p;
     for (int p = threadIdx.x; p < a.n_p; p += 128) {
         double acc = 0.0;
-        for (int r = 0; r < DPG_ROWS && b0 + r < a.B; ++r)
-            for (int u = 0; u < a.nu; ++u) {
-                const double wt = w[r][u];
-                if (wt != 0.0) acc = fma(wt, nan_to_num_d(a.dpi_dp[((long)(b0 + r) * a.nu + u) * a.n_p + p]), acc);
-            }
+        int k = 0;
+        for (; k + 8 <= nr; k += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = base[(long)(k + q) * a.n_p + p];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = fma((&w[0][0])[((k + q) / a.nu) * 8 + (k + q) % a.nu], nan_to_num_d(v[q]), acc);
+        }
+        for (; k < nr; ++k) acc = fma((&w[0][0])[(k / a.nu) * 8 + k % a.nu], nan_to_num_d(base[(long)k * a.n_p + p]), acc);
         a.partial[(long)blockIdx.x * P1 + p] = acc;
     }
     if (threadIdx.x == 0) a.partial[(long)blockIdx.x * P1 + a.n_p] = cnt;
@@ -95,10 +104,29 @@ __global__ void __launch_bounds__(128) dpg_grad_kernel(const DpgArgs a) {
     __syncthreads();
     if (!last) return;
     __threadfence();
-    for (int p = threadIdx.x; p < P1; p += 128) {
-        double acc = 0.0;
-        for (int k = 0; k < (int)gridDim.x; ++k) acc += __builtin_nontemporal_load(&a.partial[(long)k * P1 + p]);
-        a.out[p] = acc;
+    // (a dependent chain of loads over the blocks would cost their latency each: four slices of the blocks per entry, eight loads in flight,
+    // the slices added in order)
+    const int nb = gridDim.x, per = (nb + 3) / 4;
+    for (int p0 = 0; p0 < P1; p0 += DPG_PMAX) {
+        const int np = P1 - p0 < DPG_PMAX ? P1 - p0 : DPG_PMAX;
+        for (int e = threadIdx.x; e < 4 * np; e += 128) {
+            const int sl = e / np, p = p0 + e - sl * np;
+            const int lo = sl * per, hi = lo + per < nb ? lo + per : nb;
+            double acc = 0.0;
+            int k = lo;
+            for (; k + 8 <= hi; k += 8) {
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = a.partial[(long)(k + q) * P1 + p];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += v[q];
+            }
+            for (; k < hi; ++k) acc += a.partial[(long)k * P1 + p];
+            fin[sl][e - sl * np] = acc;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < np; e += 128) a.out[p0 + e] = ((fin[0][e] + fin[1][e]) + fin[2][e]) + fin[3][e];
+        __syncthreads();
     }
     if (threadIdx.x == 0) *a.ticket = 0u;
 }

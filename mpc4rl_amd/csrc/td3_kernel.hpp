@@ -95,4 +95,20 @@ __global__ void __launch_bounds__(256) td3_cartpole_collect_kernel(const Td3Coll
     if (threadIdx.x == 0) a.pos[0] = npos, *a.ticket = 0u;
 }
 
+// After the collective, every policy_delay-th update (BatchedTD3._update_post): the policy step from the all-reduced message
+//     step = lr * mask * g / max(1, count);  theta += step;  theta' = (1 - tau) theta' + tau theta
+// and the Polyak update of the target critics, critic' = (1 - tau) critic' + tau critic — nine framework launches — in one.
+__global__ void __launch_bounds__(256) td3_policy_post_kernel(const double *msg, int n_theta, double lr, const double *mask, double tau, double *theta,
+                                                              double *theta_target, double *step_out, const float *crit, float *crit_target, int n_crit) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_theta) {
+        const double cnt = msg[n_theta] > 1.0 ? msg[n_theta] : 1.0;
+        const double st = lr * mask[i] * msg[i] / cnt;
+        const double th = theta[i] + st;
+        theta[i] = th, step_out[i] = st;
+        theta_target[i] = theta_target[i] * (1.0 - tau) + tau * th;
+    }
+    if (i < n_crit) crit_target[i] = crit_target[i] * (float)(1.0 - tau) + (float)tau * crit[i];
+}
+
 }  // namespace mpcrl

@@ -663,7 +663,20 @@ class BatchedTD3:
             torch._foreach_copy_([p.grad for p in params], views)
         self.critic_opt.step()
         step = None
-        if do_policy:
+        if do_policy and self._fused_critic:      # the policy step, theta' and the target critics' Polyak update: one launch
+            from . import _lib
+            from .batch import _ptr
+            step = torch.empty_like(self.theta)
+            with torch.cuda.device(self.device), torch.no_grad():
+                rc = _lib.load().mpcrl_td3_policy_post(C.c_void_p(flat.data_ptr() + 8 * self.n_crit), n_theta, float(self.lr_actor), _ptr(self.learn_mask),
+                                                       float(self.tau), _ptr(self.theta), _ptr(self.theta_target), _ptr(step), _ptr(self._crit_flat),
+                                                       _ptr(self._crit_target_flat), self.n_crit, torch.cuda.current_stream(self.device).cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"mpcrl_td3_policy_post failed with code {rc}")
+            for m, th in ((self.actor, self.theta), (self.pi_mpc, self.theta), (self.target_mpc, self.theta_target)):
+                m.theta = th
+                m.mpc.set_theta(th)
+        elif do_policy:
             step = self.lr_actor * self.learn_mask * flat[self.n_crit: self.n_crit + n_theta] / flat[-1].clamp(min=1.0)
             self.theta.add_(step)
             self.theta_target.mul_(1.0 - self.tau).add_(self.theta, alpha=self.tau)
