@@ -45,26 +45,31 @@ __device__ inline float wave_sum64(float v) {
     return v;
 }
 
-__global__ void __launch_bounds__(128) critic_td_partial_kernel(const CriticArgs a) {
-    constexpr int H = CRITIC_H, S = CRITIC_S, RMAX = 2 * CRITIC_DMAX + 2;
+// HV = 2 (nx + nu <= 16): FOUR wavefronts per workgroup — each critic's 16 transitions are split between two of them (all four SIMDs of
+// the CU issue; the halves' gradients are added through LDS before the partial is written, the target and the online weights are
+// fetched by one half each).  HV = 1: two wavefronts, any nx + nu <= 64.
+template <int HV>
+__global__ void __launch_bounds__(128 * HV) critic_td_partial_kernel(const CriticArgs a) {
+    constexpr int H = CRITIC_H, S = CRITIC_S, RMAX = 2 * CRITIC_DMAX + 2, NT = 128 * HV, SH = S / HV;
     constexpr int DR = 16;      // first-layer inputs whose weights (and weight gradients) a lane keeps in registers; the rest goes through LDS
-    const int D = a.nx + a.nu, c = threadIdx.x >> 6, j = threadIdx.x & 63, b0 = blockIdx.x * S;
+    const int D = a.nx + a.nu, w = threadIdx.x >> 6, c = w & 1, half = w >> 1, j = threadIdx.x & 63, b0 = blockIdx.x * S;
+    const int s0 = half * SH, s1 = s0 + SH;      // this wavefront's transitions
     const int npn = critic_params_per_net(D), n_params = npn * a.n_critics;
     __shared__ float rowb[S][RMAX], anb[S][CRITIC_DMAX];          // the workgroup's transitions as stored, the target actions
     __shared__ __attribute__((aligned(16))) float xt[S][CRITIC_DMAX], xo[S][CRITIC_DMAX];      // inputs of the target pass (s', a') and of the online pass (s, a)
     __shared__ float rew[S], dn[S], ys[S], okf[S];
-    __shared__ float qn[2][S];
+    __shared__ float qn[2][S], lossw[4];
     __shared__ __attribute__((aligned(16))) float h1s[2][S][H];    // first-layer activations, per critic
     __shared__ float ps[2][S][H + 1];                              // per-lane pieces of the output sum
     __shared__ __attribute__((aligned(16))) float g2s[2][S][H];    // second-layer activations (forward), then the second layer's pre-activation gradient
     __shared__ float w1s[2][H][CRITIC_DMAX + 1];                   // first-layer weight of the pass at hand; then its gradient accumulator
     __shared__ float w2s[2][2][H][H + 1];                          // second-layer weights, [target / online][critic] (read by rows and by columns)
     // ---- the workgroup's transitions: every load in flight at once (128 lanes), then one lane per transition looks at them in LDS
-    for (int e = threadIdx.x; e < S * a.row_len; e += 128) {
+    for (int e = threadIdx.x; e < S * a.row_len; e += NT) {
         const int s = e / a.row_len, i = e - s * a.row_len, b = b0 + s;
         rowb[s][i] = b < a.B ? a.rows[(long)b * a.row_stride + i] : 0.0f;
     }
-    for (int e = threadIdx.x; e < S * a.nu; e += 128) {
+    for (int e = threadIdx.x; e < S * a.nu; e += NT) {
         const int s = e / a.nu, i = e - s * a.nu, b = b0 + s;
         anb[s][i] = b < a.B ? a.a_next[(long)b * a.nu + i] : 0.0f;
     }
@@ -92,6 +97,7 @@ __global__ void __launch_bounds__(128) critic_td_partial_kernel(const CriticArgs
     if (live) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
+            if (HV == 2 && k != half) continue;
             const float *W2 = (k ? a.params : a.params_target) + (long)c * npn + H * D + H;
 #pragma unroll
             for (int i = 0; i < H; ++i) w2s[k][c][i][j] = W2[i * H + j];
@@ -111,7 +117,7 @@ __global__ void __launch_bounds__(128) critic_td_partial_kernel(const CriticArgs
     auto forward = [&](const float (*x)[CRITIC_DMAX]) {
         // (the loops over the transitions stay rolled: straight-line code that runs once is paid in instruction fetches)
 #pragma unroll 2
-        for (int s = 0; s < S; ++s) {
+        for (int s = s0; s < s1; ++s) {
             float z = b1;
 #pragma unroll
             for (int d = 0; d < DR; d += 4) {
@@ -124,7 +130,7 @@ __global__ void __launch_bounds__(128) critic_td_partial_kernel(const CriticArgs
         }
         __syncthreads();
 #pragma unroll 2
-        for (int s = 0; s < S; ++s) {
+        for (int s = s0; s < s1; ++s) {
             float z0 = b2, z1 = 0.0f;
 #pragma unroll
             for (int i = 0; i < H; i += 8) {
@@ -171,7 +177,10 @@ __global__ void __launch_bounds__(128) critic_td_partial_kernel(const CriticArgs
         const int s = j >> 2;
         const float q = output();
         const float e = okf[s] != 0.0f ? q - ys[s] : 0.0f;
-        if ((j & 3) == 0) qn[c][s] = 2.0f * e, loss = e * e;      // dq of the unscaled loss (the count divides in the reduction)
+        if ((j & 3) == 0) {
+            qn[c][s] = 2.0f * e;      // dq of the unscaled loss (the count divides in the reduction); both halves write the same value
+            if (s >= s0 && s < s1) loss = e * e;
+        }
     }
     loss = wave_sum64(loss);
     __syncthreads();
@@ -179,7 +188,7 @@ __global__ void __launch_bounds__(128) critic_td_partial_kernel(const CriticArgs
     // second layer's pre-activation gradient g2[s][j] to LDS, the output layer's gradients on the way
     float dw3 = 0.0f, db3 = 0.0f, db2 = 0.0f;
 #pragma unroll 1
-    for (int s = 0; s < S; ++s) {
+    for (int s = s0; s < s1; ++s) {
         const float dq = qn[c][s], h2 = g2s[c][s][j];
         const float g2 = h2 > 0.0f ? dq * w3 : 0.0f;
         dw3 = fmaf(dq, h2, dw3), db3 += dq, db2 += g2;
@@ -199,7 +208,7 @@ __global__ void __launch_bounds__(128) critic_td_partial_kernel(const CriticArgs
     for (int i = 0; i < H; ++i) dw2[i] = 0.0f;
     float db1 = 0.0f;
 #pragma unroll 2
-    for (int s = 0; s < S; ++s) {
+    for (int s = s0; s < s1; ++s) {
         const float g2 = g2s[c][s][j];
         float g1a = 0.0f, g1b = 0.0f;
 #pragma unroll
@@ -220,8 +229,26 @@ __global__ void __launch_bounds__(128) critic_td_partial_kernel(const CriticArgs
     }
     // ---- the workgroup's partial: a net's parameters in order, EXCEPT that the 64 x 64 block is stored transposed (lane j writes
     // d W2[j][i] to [i][j]: coalesced; critic_td_reduce_kernel puts it back)
+    if (HV == 2) {      // the second half's sums through LDS (regions no pass reads any more), added by the first
+        __syncthreads();
+        if (half == 1) {
+#pragma unroll
+            for (int i = 0; i < H; ++i) w2s[0][c][i][j] = dw2[i];
+#pragma unroll
+            for (int d = 0; d < DR; ++d) h1s[c][d][j] = dw1[d];
+            ps[c][0][j] = db1, ps[c][1][j] = db2, ps[c][2][j] = dw3, ps[c][3][j] = db3;
+        }
+        __syncthreads();
+        if (half == 0) {
+#pragma unroll
+            for (int i = 0; i < H; ++i) dw2[i] += w2s[0][c][i][j];
+#pragma unroll
+            for (int d = 0; d < DR; ++d) dw1[d] += h1s[c][d][j];
+            db1 += ps[c][0][j], db2 += ps[c][1][j], dw3 += ps[c][2][j], db3 += ps[c][3][j];
+        }
+    }
     float *out = a.partial + (long)blockIdx.x * (n_params + 2);
-    if (live) {
+    if (live && half == 0) {
         float *o = out + (long)c * npn;
 #pragma unroll
         for (int d = 0; d < DR; ++d)
@@ -240,10 +267,10 @@ __global__ void __launch_bounds__(128) critic_td_partial_kernel(const CriticArgs
         if (j == 0) o[0] = db3;
     }
     // loss partial (both critics), ok count
-    if (j == 0) qn[c][0] = live ? loss : 0.0f;
+    if (j == 0) lossw[w] = live ? loss : 0.0f;
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[n_params] = qn[0][0] + qn[1][0];
+        out[n_params] = HV == 2 ? (lossw[0] + lossw[2]) + (lossw[1] + lossw[3]) : lossw[0] + lossw[1];
         float n = 0.0f;
         for (int s = 0; s < S; ++s) n += okf[s];
         out[n_params + 1] = n;
@@ -296,7 +323,7 @@ __global__ void __launch_bounds__(256) critic_td_reduce_kernel(const float *part
 
 // dQ_1/da at (s_b, a_b) for the deterministic policy gradient (what autograd of ContinuousCritic.q1_forward, rlmpc/td3/policies.py:68-76,
 // gives): forward of the first critic, then back through the two ReLU layers to the action inputs.  Rows with ok[b] = 0 get 0 (their
-// inputs are read as 0, like the torch expression that selects them out).  One workgroup of one wavefront per 16 rows.
+// inputs are read as 0, like the torch expression that selects them out).  One workgroup of one wavefront per 4 rows.
 struct CriticDqdaArgs {
     const float *obs;     // [B][obs_stride]: the first nx entries
     int obs_stride, B, nx, nu;
@@ -308,7 +335,7 @@ struct CriticDqdaArgs {
 };
 
 __global__ void __launch_bounds__(64) critic_dqda_kernel(const CriticDqdaArgs a) {
-    constexpr int H = CRITIC_H, S = CRITIC_S;
+    constexpr int H = CRITIC_H, S = 4;      // four rows per single-wavefront workgroup: 1024 workgroups at batch 4096
     const int D = a.nx + a.nu, j = threadIdx.x, b0 = blockIdx.x * S;
     __shared__ float x[S][CRITIC_DMAX], okf[S];
     __shared__ __attribute__((aligned(16))) float h1s[S][H], g2s[S][H];
@@ -358,13 +385,15 @@ __global__ void __launch_bounds__(64) critic_dqda_kernel(const CriticDqdaArgs a)
         g1s[s][j] = h1s[s][j] > 0.0f ? g1 : 0.0f;    // d q / d z1_j
     }
     __syncthreads();
-    // dq/da_u = sum_i W1[i][nx + u] g1_i: lane = (row s, quarter k)
-    const int s = j >> 2, k = j & 3, b = b0 + s;
+    // dq/da_u = sum_i W1[i][nx + u] g1_i: lane = (row s, sixteenth k)
+    const int s = j >> 4, k = j & 15, b = b0 + s;
     for (int u = 0; u < a.nu; ++u) {
         float v = 0.0f;
-        for (int i = 0; i < 16; ++i) v = fmaf(W1[(k * 16 + i) * D + a.nx + u], g1s[s][k * 16 + i], v);
+        for (int i = 0; i < 4; ++i) v = fmaf(W1[(k * 4 + i) * D + a.nx + u], g1s[s][k * 4 + i], v);
         v += __shfl_xor(v, 1, 64);
         v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
         if (k == 0 && b < a.B) a.dq_da[(long)b * a.nu + u] = okf[s] != 0.0f ? v : 0.0f;
     }
 }

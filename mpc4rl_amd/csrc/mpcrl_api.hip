@@ -718,7 +718,10 @@ int mpcrl_critic_td_grad(const float *rows, int row_stride, int B, int nx, int n
     a.a_next = a_next, a.ok_u = ok_u, a.params = params, a.params_target = params_target, a.gamma = (float)gamma;
     a.partial = (float *)workspace, a.ok_out = ok_out;
     const int n_blocks = (B + CRITIC_S - 1) / CRITIC_S, n_params = n_critics * (CRITIC_H * (nx + nu) + CRITIC_H * CRITIC_H + 3 * CRITIC_H + 1);
-    hipLaunchKernelGGL(critic_td_partial_kernel, dim3(n_blocks), dim3(128), 0, (hipStream_t)stream, a);
+    if (nx + nu <= 16)
+        hipLaunchKernelGGL(critic_td_partial_kernel<2>, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(critic_td_partial_kernel<1>, dim3(n_blocks), dim3(128), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(critic_td_reduce_kernel, dim3((n_params + 1 + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float *)workspace, n_blocks, n_params,
                        nx + nu, out_scale, grad, loss_out);
     HIP_OK(hipGetLastError());
@@ -731,7 +734,7 @@ int mpcrl_critic_dq_da(const float *obs, int obs_stride, int B, int nx, int nu, 
     ON_DEVICE_OF(dq_da);
     CriticDqdaArgs a;
     a.obs = obs, a.obs_stride = obs_stride, a.B = B, a.nx = nx, a.nu = nu, a.act = act, a.ok = ok, a.params = params, a.dq_da = dq_da, a.ok_out = ok_out;
-    hipLaunchKernelGGL(critic_dqda_kernel, dim3((B + CRITIC_S - 1) / CRITIC_S), dim3(64), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(critic_dqda_kernel, dim3((B + 3) / 4), dim3(64), 0, (hipStream_t)stream, a);
     HIP_OK(hipGetLastError());
     return 0;
 }

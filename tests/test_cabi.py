@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "mpcrl.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(mpcrl_[a-z_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(mpcrl_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_header_declares_the_boundary():
