@@ -514,8 +514,7 @@ def td3_measure(E, steps, warmup, graphs, world, rank, dist, dev, settle, replay
         agent.enable_graphs()              # fills the replay buffer, then captures the roll-out step and the update into HIP graphs
 
     def step():                            # no host synchronisation inside the timed region: statistics are read after it
-        agent.collect(1, stats=False)
-        agent.train(1, stats=False)
+        agent.step()                       # = collect(1) + train(1); with graphs on one rank: one graph replay
 
     # the warm-up steps run here: the roll-out statistics are zeroed where the timed region starts
     for _ in range(settle + warmup):
@@ -523,7 +522,7 @@ def td3_measure(E, steps, warmup, graphs, world, rank, dist, dev, settle, replay
     agent.collect(0)                       # zero the roll-out statistics
     elapsed, _, _ = timed_steps(step, argparse.Namespace(steps=steps, warmup=0), dist, dev, rank)
     st = agent.last_stats()
-    tr = {"critic_loss": float(agent._graphs["update"][True]["loss"].item())} if agent._graphs else agent.train(1)
+    tr = {"critic_loss": agent.last_critic_loss()} if agent._graphs else agent.train(1)
     solves = world * steps * (E + E + E / agent.policy_delay)
     summ = {"value": world * E * steps / elapsed, "unit": "env-steps/s", "steps": steps, "warmup": warmup, "settle_steps": settle,
             "ms_per_step": 1e3 * elapsed / steps,

@@ -707,10 +707,29 @@ class BatchedTD3:
                 flat, loss = self._update_pre(do_policy)
                 flat = self._allreduce(flat)
                 step = self._update_post(flat, do_policy)
+            self._last_loss = loss
         if not stats:
             return {}
         return {"critic_loss": float(loss.item()) if loss is not None else 0.0,
                 "theta_step_norm": float(step.norm().item()) if step is not None else 0.0}
+
+    def step(self, n_steps: int = 1) -> None:
+        """n closed-loop steps, each collect(1) + train(1) without statistics (read them with last_stats() / last_critic_loss()).  With
+        graphs on a single rank a step is ONE graph replay."""
+        for _ in range(n_steps):
+            if self._graphs is not None and "full" in self._graphs:
+                self.n_updates += 1
+                gp = self._graphs["full"][self.n_updates % self.policy_delay == 0]
+                gp["graph"].replay()
+                self.buffer._advance()
+                self._stats_steps += 1
+                self._last_loss = gp["loss"]
+            else:
+                self.collect(1, stats=False)
+                self.train(1, stats=False)
+
+    def last_critic_loss(self) -> float:
+        return float(self._last_loss.item()) if getattr(self, "_last_loss", None) is not None else float("nan")
 
     def _buffer_tensors(self):
         b = self.buffer
@@ -822,5 +841,17 @@ class BatchedTD3:
             g_post, step = capture(lambda: self._update_post(flat, dp))
             graphs["update"][dp] = {"pre": g_pre, "post": g_post, "flat": flat, "loss": loss, "step": step}
         graphs["collect"], _ = capture(lambda: self._collect_step(static=True))
+        if self._world() == 1:
+            # one rank: nothing has to happen between the halves of an update, so a whole closed-loop step — roll-out, update before and
+            # after the (absent) collective — is ONE graph per kind of update (step()): two graph boundaries and the generator-state
+            # fills of two replays less per step
+            def whole(dp):
+                self._collect_step(static=True)
+                flat, loss = self._update_pre(dp)
+                return loss, self._update_post(flat, dp)
+            graphs["full"] = {}
+            for dp in (False, True):
+                g, (loss, step) = capture(lambda: whole(dp))
+                graphs["full"][dp] = {"graph": g, "loss": loss, "step": step}
         torch.cuda.synchronize(self.device)
         self._graphs = graphs

@@ -730,25 +730,30 @@ def test_td3_loop_with_the_critic_kernels():
     from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedTD3, cartpole_ocp
     ocp = cartpole_ocp()
     res = {}
-    for mode in ("autograd", "kernels", "kernels+graphs"):
+    for mode in ("autograd", "kernels", "kernels+graphs", "kernels+graphs, step()"):
         env = BatchedCartPoleSwingUpEnv(256, device="cuda", seed=0, max_episode_steps=7)
         ag = BatchedTD3(ocp, env, batch_size=256, buffer_steps=6, policy_delay=2, lr_actor=1e-4, seed=0, replay_iterates=True, fused_critic=mode != "autograd")
         assert ag._fused_critic == (mode != "autograd")
         ag.collect(6)
-        if mode.endswith("graphs"):
+        if "graphs" in mode:
             ag.enable_graphs()
         losses = []
         for _ in range(6):
-            ag.collect(1)
-            losses.append(ag.train(1)["critic_loss"])
+            if mode.endswith("step()"):      # one graph replay per closed-loop step (single rank)
+                ag.step()
+                losses.append(ag.last_critic_loss())
+            else:
+                ag.collect(1)
+                losses.append(ag.train(1)["critic_loss"])
         res[mode] = (ag.buffer.data.clone(), np.array(losses), ag.theta.clone(), torch.cat([p.detach().reshape(-1) for p in ag.critic.parameters()]),
                      torch.cat([p.detach().reshape(-1) for p in ag.critic_target.parameters()]))
     a, k = res["autograd"], res["kernels"]
     assert torch.equal(a[0], k[0])
     assert np.abs(a[1] - k[1]).max() < 1e-4 * np.abs(a[1]).max()
     assert float((a[2] - k[2]).abs().max()) < 1e-9 and float((a[3] - k[3]).abs().max()) < 2e-5 and float((a[4] - k[4]).abs().max()) < 2e-6
-    g = res["kernels+graphs"]      # (enable_graphs fills the replay table on its own: compared with itself being finite and learning)
+    g, h = res["kernels+graphs"], res["kernels+graphs, step()"]      # (enable_graphs fills the replay table on its own: the two graph forms against each other)
     assert np.isfinite(g[1]).all() and bool(torch.isfinite(g[3]).all())
+    assert torch.equal(g[0], h[0]) and np.array_equal(g[1], h[1]) and all(torch.equal(x, y) for x, y in zip(g[2:], h[2:]))
 
 
 def test_td3_cartpole_collect_kernel_vs_the_kernels_it_stands_for():
