@@ -427,6 +427,8 @@ def secondary_lines(world, rank, dist, dev):
                         wins.append(td3_measure(B_PER_GPU, steps, warmup, True, world, rank, dist, dev, SETTLE["td3"])[1])
                         if len(wins) == SECONDARY_WINDOWS:      # one window of the rounds 2-5 form (cold replay solves) beside it
                             cold_ms = td3_measure(B_PER_GPU, steps, warmup, True, world, rank, dist, dev, SETTLE["td3"], replay_iterates=False)[1]["ms_per_step"]
+                            # and one of the opt-in pipelined loop (the update beside the roll-out step, one rank: BatchedTD3(pipeline=True))
+                            pipe_ms = td3_measure(B_PER_GPU, steps, warmup, True, world, rank, dist, dev, SETTLE["td3"], pipeline=True)[1]["ms_per_step"] if world == 1 else None
                     else:
                         wins.append(chain_measure(int(wl[5:]), 1024, True, steps, warmup, world, rank, dist, dev)[2])
                 wins.sort(key=lambda w: w["ms_per_step"])
@@ -435,6 +437,7 @@ def secondary_lines(world, rank, dist, dev):
                 out[wl]["statistic"] = "median of %d windows of %d steps" % (SECONDARY_WINDOWS, steps)
                 if wl == "td3":
                     out[wl]["cold_replay_ms_per_step"] = cold_ms
+                    out[wl]["pipelined_ms_per_step"] = pipe_ms
         except Exception as e:   # the headline line must still come out
             out[wl] = {"value": None, "error": repr(e)}
     return out
@@ -501,14 +504,14 @@ def count_ranks(dist_mod, dev):
     return int(round(float(one.item())))
 
 
-def td3_measure(E, steps, warmup, graphs, world, rank, dist, dev, settle, replay_iterates=True):
+def td3_measure(E, steps, warmup, graphs, world, rank, dist, dev, settle, replay_iterates=True, pipeline=False):
     """One TD3 closed-loop measurement through timed_steps: (job seconds, summary dict).  A step = one environment step of all E
     environments + one TD3 update (batch E per rank); MPC solves per step and rank: E warm (roll-out actor) + E cold (target actor)
     + E / policy_delay cold with du0*/dtheta (policy gradient)."""
     from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedTD3, cartpole_ocp
     env = BatchedCartPoleSwingUpEnv(E, device=dev, seed=rank)
     agent = BatchedTD3(cartpole_ocp(), env, batch_size=E, buffer_steps=64, policy_delay=2, lr_actor=1e-6, seed=0, device=dev,
-                       replay_iterates=replay_iterates)
+                       replay_iterates=replay_iterates, pipeline=pipeline and graphs and world == 1)
     agent.collect(4)                       # something to sample from
     if graphs:
         agent.enable_graphs()              # fills the replay buffer, then captures the roll-out step and the update into HIP graphs
@@ -531,9 +534,11 @@ def td3_measure(E, steps, warmup, graphs, world, rank, dist, dev, settle, replay
                         + (f"+ {E} (target actor) + {E // 2} with du0*/dtheta (policy gradient), both started from the roll-out "
                            f"policy's stored iterate of the sampled transition (replay_iterates); " if replay_iterates else
                            f"+ {E} cold (target actor) + {E // 2} cold with du0*/dtheta (policy gradient); ")
-                        + ("roll-out step and update replayed as HIP graphs" if graphs else "eager launches"),
+                        + ("roll-out step and update replayed as HIP graphs" if graphs else "eager launches")
+                        + ("; PIPELINED (opt-in): the update runs beside the roll-out step of the same call and samples the replay table "
+                           "without the slot being written" if agent.pipeline else ""),
             "mpc_solves_per_s": solves / elapsed, "converged_fraction": st["converged_fraction"], "critic_loss": tr["critic_loss"],
-            "replay_iterates": bool(replay_iterates),
+            "replay_iterates": bool(replay_iterates), "pipeline": bool(agent.pipeline),
             # launch shape of the solves (mpcrl_set_launch_mode 0): probe times in ms of the two shapes and the one in use
             "replay_launch_shape": {"target_actor": list(agent.target_mpc.mpc.launch_times()), "policy": list(agent.pi_mpc.mpc.launch_times()),
                                     "rollout_warm": list(agent.actor.mpc.launch_times(warm=True))}}
@@ -556,7 +561,7 @@ def td3_bench(args):
         return finish_ranks(dist)
     settle = SETTLE["td3"] if SETTLE_OVERRIDE is None else SETTLE_OVERRIDE
     elapsed, summ = td3_measure(args.batch, args.steps, args.warmup, not args.no_graph, world, rank, dist, dev, settle,
-                                replay_iterates=not args.cold_replay)
+                                replay_iterates=not args.cold_replay, pipeline=args.td3_pipeline)
     if rank == 0:
         print(json.dumps({
             "metric": metric, "value": summ["value"],
@@ -585,6 +590,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="headline run: skip the chain5 / chain7 / linear figures measured after "
                     "the headline's timed region and attached to the line as `secondary`")
     ap.add_argument("--no-graph", action="store_true", help="td3 workload: eager launches instead of replayed HIP graphs")
+    ap.add_argument("--td3-pipeline", action="store_true", help="td3 workload, one rank, graphs on: BatchedTD3(pipeline=True) — the update runs beside the "
+                    "roll-out step of the same call (pipelined actor / learner: the sampler leaves out the slot being written; same work per step)")
     ap.add_argument("--cold-replay", action="store_true", help="td3 workload: the two replay solves of an update start cold (rounds 2-5) "
                     "instead of from the roll-out policy's stored iterates")
     ap.add_argument("--workload", default="cartpole", choices=["cartpole", "linear", "chain5", "chain7", "td3"],

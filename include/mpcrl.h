@@ -300,10 +300,12 @@ int mpcrl_critic_dq_da(const float *obs, int obs_stride, int B, int nx, int nu, 
  *   rows [B][row_len] float = table[idx];  obs64 / nxt64 [B][nx] double;
  *   iter_ok [cap * E] uint8 or NULL (then the four outputs below are not written):
  *     row_s = idx;  row_n = the row of the NEXT step of the same environment if done == 0 and that slot is written and is not pos_t,
- *     else idx;  cold_s / cold_n [B] int32 = 1 where iter_ok[row] == 0 (mpcrl_set_cold_mask takes them as they are). */
+ *     else idx;  cold_s / cold_n [B] int32 = 1 where iter_ok[row] == 0 (mpcrl_set_cold_mask takes them as they are).
+ *   exclude_pos != 0 (a full table only): slot pos_t is being written while the batch is drawn (a roll-out running beside the update):
+ *     idx [B] in [0, (cap - 1) E) then counts the rows of the other slots, slot (pos_t + 1 + idx / E) % cap. */
 int mpcrl_replay_sample(const float *table, int row_len, int nx, int E, int cap, int steps, const int64_t *idx, int B, const int64_t *pos_t,
-                        const uint8_t *iter_ok, float *rows, double *obs64, double *nxt64, int64_t *row_s, int32_t *cold_s, int64_t *row_n,
-                        int32_t *cold_n, void *stream);
+                        int exclude_pos, const uint8_t *iter_ok, float *rows, double *obs64, double *nxt64, int64_t *row_s, int32_t *cold_s,
+                        int64_t *row_n, int32_t *cold_n, void *stream);
 
 /* ABI 130.  The contraction of the deterministic policy gradient, one launch: out[p] = sum_b ok_b sum_u dq_da[b][u] chain_u dpi_dp[b][u][p]
  * (p < n_p), out[n_p] = sum_b ok_b, chain_u = 2 / (hi_u - lo_u) with scale != 0 (the derivative of MPC.scale_action,

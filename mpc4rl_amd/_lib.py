@@ -80,7 +80,7 @@ def load():
     lib.mpcrl_critic_workspace_bytes.restype = C.c_int64
     lib.mpcrl_critic_td_grad.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_double, C.c_double, vp, vp, vp, vp, vp]
     lib.mpcrl_critic_dq_da.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
-    lib.mpcrl_replay_sample.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.mpcrl_replay_sample.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.mpcrl_dpg_workspace_bytes.argtypes = [C.c_int, C.c_int]
     lib.mpcrl_dpg_workspace_bytes.restype = C.c_int64
     lib.mpcrl_dpg_grad.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp]

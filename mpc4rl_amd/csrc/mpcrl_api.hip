@@ -642,13 +642,14 @@ int mpcrl_policy_action(const double *u0, const int32_t *status, const float *no
 }
 
 int mpcrl_replay_sample(const float *table, int row_len, int nx, int E, int cap, int steps, const int64_t *idx, int B, const int64_t *pos_t,
-                        const uint8_t *iter_ok, float *rows, double *obs64, double *nxt64, int64_t *row_s, int32_t *cold_s, int64_t *row_n,
-                        int32_t *cold_n, void *stream) {
+                        int exclude_pos, const uint8_t *iter_ok, float *rows, double *obs64, double *nxt64, int64_t *row_s, int32_t *cold_s,
+                        int64_t *row_n, int32_t *cold_n, void *stream) {
     if (!table || !idx || !rows || !obs64 || !nxt64 || B < 1 || nx < 1 || row_len < 2 * nx + 2 || E < 1 || cap < 1 || steps < 1 || steps > cap) return MPCRL_E_ARG;
     if (iter_ok && (!pos_t || !row_s || !cold_s || !row_n || !cold_n)) return MPCRL_E_ARG;
+    if (exclude_pos && (!pos_t || steps != cap || cap < 2)) return MPCRL_E_ARG;
     ON_DEVICE_OF(rows);
     ReplaySampleArgs a;
-    a.table = table, a.row_len = row_len, a.nx = nx, a.B = B, a.E = E, a.cap = cap, a.steps = steps, a.idx = idx, a.pos_t = pos_t, a.iter_ok = iter_ok;
+    a.table = table, a.row_len = row_len, a.nx = nx, a.B = B, a.E = E, a.cap = cap, a.steps = steps, a.idx = idx, a.pos_t = pos_t, a.exclude = exclude_pos, a.iter_ok = iter_ok;
     a.rows = rows, a.obs64 = obs64, a.nxt64 = nxt64, a.row_s = row_s, a.row_n = row_n, a.cold_s = cold_s, a.cold_n = cold_n;
     hipLaunchKernelGGL(replay_sample_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     HIP_OK(hipGetLastError());

@@ -13,6 +13,7 @@ struct ReplaySampleArgs {
     int row_len, nx, B, E, cap, steps;
     const int64_t *idx;       // [B] sampled rows (step * E + env)
     const int64_t *pos_t;     // [1] the slot the roll-out writes next
+    int exclude;              // != 0: that slot is being written WHILE this batch is drawn (pipelined loop): idx counts the rows of the other cap - 1 slots
     const uint8_t *iter_ok;   // [cap * E] or nullptr: the roll-out solve stored with the transition converged
     float *rows;              // [B][row_len]
     double *obs64, *nxt64;    // [B][nx]
@@ -23,7 +24,11 @@ struct ReplaySampleArgs {
 __global__ void __launch_bounds__(256) replay_sample_kernel(const ReplaySampleArgs a) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= a.B) return;
-    const int64_t i = a.idx[b];
+    int64_t i = a.idx[b];
+    if (a.exclude) {      // row of the k-th slot after the excluded one
+        const int64_t st = i / a.E;
+        i = ((a.pos_t[0] + 1 + st) % a.cap) * a.E + (i - st * a.E);
+    }
     const float *r = a.table + i * a.row_len;
     float *o = a.rows + (long)b * a.row_len;
     for (int k = 0; k < a.row_len; ++k) o[k] = r[k];

@@ -313,7 +313,7 @@ class DeviceReplayBuffer:
         nx, nu = self._nx, self._nu
         return rows[:, :nx], rows[:, nx: 2 * nx], rows[:, 2 * nx: 2 * nx + nu], rows[:, -2], rows[:, -1]
 
-    def sample_fused(self, n: int, gen: Optional[torch.Generator] = None):
+    def sample_fused(self, n: int, gen: Optional[torch.Generator] = None, exclude_pos: Optional[torch.Tensor] = None):
         """sample() + iterates_of_last_sample() + the float64 copies of obs / next_obs the replay solves read, through
         mpcrl_replay_sample: the same draw (torch.randint on ``gen``), then ONE launch.  Returns (obs, next_obs, act, rew, done) as
         sample() does — views of ``last_rows`` — and sets ``last_x64`` = (obs, next_obs) in float64 and, with iterate tables,
@@ -323,7 +323,11 @@ class DeviceReplayBuffer:
         if steps == 0:
             raise RuntimeError("DeviceReplayBuffer.sample: the buffer is empty (call collect() / add() first)")
         dev = self.data.device
-        idx = torch.randint(0, steps * self.E, (n,), device=dev, generator=gen)
+        # exclude_pos [1] int64 (a full table): that slot is being written by a roll-out that runs beside this update — the draw is
+        # over the rows of the other slots and the slot stands in for the write position in the choice of the iterate for next_obs
+        if exclude_pos is not None and not (self.full and self.cap >= 2):
+            raise RuntimeError("DeviceReplayBuffer.sample_fused(exclude_pos): the table must be full")
+        idx = torch.randint(0, (steps - (exclude_pos is not None)) * self.E, (n,), device=dev, generator=gen)
         L, nx, nu = self.data.shape[-1], self._nx, self._nu
         rows = torch.empty((n, L), dtype=torch.float32, device=dev)
         x64 = torch.empty((2, n, nx), dtype=torch.float64, device=dev)
@@ -334,7 +338,8 @@ class DeviceReplayBuffer:
             c32 = torch.empty((2, n), dtype=torch.int32, device=dev)
             st = (r64[0], c32[0], r64[1], c32[1])
         with torch.cuda.device(dev):
-            rc = _lib.load().mpcrl_replay_sample(ptr(self.data), L, nx, self.E, self.cap, steps, ptr(idx), n, ptr(self.pos_t),
+            rc = _lib.load().mpcrl_replay_sample(ptr(self.data), L, nx, self.E, self.cap, steps, ptr(idx), n,
+                                                 ptr(self.pos_t if exclude_pos is None else exclude_pos), int(exclude_pos is not None),
                                                  ptr(self.iter_ok) if st else None, ptr(rows), ptr(x64[0]), ptr(x64[1]),
                                                  ptr(st[0]) if st else None, ptr(st[1]) if st else None, ptr(st[2]) if st else None,
                                                  ptr(st[3]) if st else None, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
@@ -381,7 +386,7 @@ class BatchedTD3:
                  policy_delay: int = 2, action_noise: float = 0.1, target_noise: float = 0.2, noise_clip: float = 0.5,
                  lr_critic: float = 1e-3, lr_actor: float = 1e-4, reward_scale: float = -1.0, net_arch=(64, 64), device=None,
                  group=None, seed: int = 0, learn_mask: Optional[torch.Tensor] = None, actor_factory=None, replay_iterates: bool = False,
-                 blas: Optional[str] = "cublas", fused_critic: bool = True):
+                 blas: Optional[str] = "cublas", fused_critic: bool = True, pipeline: bool = False):
         """actor_factory(batch) -> an MPCActor-like object (default: MPCActor on the GPU).  The CPU tests of the loop's plumbing
         (replay, critic update, the single all-reduce) pass a closed-form stand-in policy; the product path never does.
         replay_iterates: keep, with every transition, the solver iterate the roll-out policy ended with (x, u, pi, bound multipliers and
@@ -424,6 +429,12 @@ class BatchedTD3:
         # 1.33 ms step at batch 4096) where the critics have the shape those kernels are written for; any other net_arch stays on autograd
         self._fused_critic = fused_critic and self._fused and tuple(net_arch) == (64, 64) and ocp.nx + ocp.nu <= 64
         self._fused_sample = self._fused      # the replay batch through mpcrl_replay_sample (one launch after the draw)
+        # pipeline (opt-in; step() with graphs on one rank): the update runs BESIDE the roll-out step of the same call instead of after
+        # it — a pipelined actor / learner.  The update then samples the replay table without the slot the roll-out is writing (its
+        # newest data are one step older) and the roll-out uses the policy parameters of before this call's update; the work per step
+        # is the same.  What it buys: a lock-step solve lasts as long as its hardest instance, and the other solves fill the idle chip.
+        self.pipeline = bool(pipeline)
+        self._pipe_pos = None       # [1] int64 while a pipelined step is being captured: the slot the concurrent roll-out writes
         # the roll-out after the solve through mpcrl_td3_cartpole_collect (one launch for ~36) where the environment is the library's cartpole
         from .envs import BatchedCartPoleSwingUpEnv
         self._fused_collect = (self._fused and isinstance(env, BatchedCartPoleSwingUpEnv) and env._native() and env.dtype == torch.float64
@@ -558,7 +569,7 @@ class BatchedTD3:
         Returns (flat message, loss)."""
         world, n_theta = self._world(), self.theta.numel()
         if self._fused_sample:      # the draw, then ONE launch for the gather, the index arithmetic, the masks and the float64 states
-            obs, nxt, act, rew, done = self.buffer.sample_fused(self.B, self.gen)
+            obs, nxt, act, rew, done = self.buffer.sample_fused(self.B, self.gen, exclude_pos=self._pipe_pos)
             obs64, nxt64 = self.buffer.last_x64
         else:
             obs, nxt, act, rew, done = self.buffer.sample(self.B, self.gen)
@@ -648,7 +659,12 @@ class BatchedTD3:
     def _load_iterate(self, mpc, rows) -> None:
         mpc.set_iterate_rows(*self.buffer.iters, index=rows.contiguous())       # ONE launch: stored iterate i := table row rows[i]
 
-    def _update_post(self, flat: torch.Tensor, do_policy: bool):
+    def _push_theta(self) -> None:
+        for m, th in ((self.actor, self.theta), (self.pi_mpc, self.theta), (self.target_mpc, self.theta_target)):
+            m.theta = th
+            m.mpc.set_theta(th)
+
+    def _update_post(self, flat: torch.Tensor, do_policy: bool, push_theta: bool = True):
         """After the collective: the averaged critic gradients into the optimiser step; the policy step and the Polyak updates.
         All parameter tensors are updated IN PLACE (their addresses are what a captured graph and the solver handles hold)."""
         n_theta = self.theta.numel()
@@ -673,16 +689,14 @@ class BatchedTD3:
                                                        _ptr(self._crit_target_flat), self.n_crit, torch.cuda.current_stream(self.device).cuda_stream)
             if rc != 0:
                 raise RuntimeError(f"mpcrl_td3_policy_post failed with code {rc}")
-            for m, th in ((self.actor, self.theta), (self.pi_mpc, self.theta), (self.target_mpc, self.theta_target)):
-                m.theta = th
-                m.mpc.set_theta(th)
+            if push_theta:
+                self._push_theta()
         elif do_policy:
             step = self.lr_actor * self.learn_mask * flat[self.n_crit: self.n_crit + n_theta] / flat[-1].clamp(min=1.0)
             self.theta.add_(step)
             self.theta_target.mul_(1.0 - self.tau).add_(self.theta, alpha=self.tau)
-            for m, th in ((self.actor, self.theta), (self.pi_mpc, self.theta), (self.target_mpc, self.theta_target)):
-                m.theta = th
-                m.mpc.set_theta(th)
+            if push_theta:
+                self._push_theta()
             with torch.no_grad():
                 if self._fused_critic:
                     self._crit_target_flat.mul_(1.0 - self.tau).add_(self._crit_flat, alpha=self.tau)
@@ -845,10 +859,33 @@ class BatchedTD3:
             # one rank: nothing has to happen between the halves of an update, so a whole closed-loop step — roll-out, update before and
             # after the (absent) collective — is ONE graph per kind of update (step()): two graph boundaries and the generator-state
             # fills of two replays less per step
+            pipe = self.pipeline and self._fused_collect and self._fused_sample
+            if self.pipeline and not pipe:
+                raise RuntimeError("BatchedTD3(pipeline=True) needs the library's cartpole environment on the GPU (the fused roll-out and replay kernels)")
+            if pipe:
+                self._pipe_pos_t = torch.zeros(1, dtype=torch.int64, device=self.device)
+                self._pipe_stream = torch.cuda.Stream(device=self.device)
+
             def whole(dp):
+                if not pipe:
+                    self._collect_step(static=True)
+                    flat, loss = self._update_pre(dp)
+                    return loss, self._update_post(flat, dp)
+                # pipelined: [update on the table without the slot being written] beside [roll-out step]; the handles take the new theta
+                # after both (the roll-out solve reads its handle's parameters while it runs)
+                self._pipe_pos_t.copy_(self.buffer.pos_t)
+                cur = torch.cuda.current_stream(self.device)
+                self._pipe_stream.wait_stream(cur)
+                with torch.cuda.stream(self._pipe_stream):
+                    self._pipe_pos = self._pipe_pos_t
+                    flat, loss = self._update_pre(dp)
+                    self._pipe_pos = None
+                    out = loss, self._update_post(flat, dp, push_theta=False)
                 self._collect_step(static=True)
-                flat, loss = self._update_pre(dp)
-                return loss, self._update_post(flat, dp)
+                cur.wait_stream(self._pipe_stream)
+                if dp:
+                    self._push_theta()
+                return out
             graphs["full"] = {}
             for dp in (False, True):
                 g, (loss, step) = capture(lambda: whole(dp))

@@ -805,3 +805,62 @@ def test_td3_cartpole_collect_kernel_vs_the_kernels_it_stands_for():
         assert int(done.sum()) > 0 and (call > 0 or int(term.sum()) > 0)
     assert float((stats - ref_stats).abs().max()) < 1e-9 * float(ref_stats.abs().max()) and torch.equal(stats[1:], ref_stats[1:])
     assert float(ws[0]) == 0.0
+
+
+def test_replay_sample_excluding_the_slot_being_written():
+    """mpcrl_replay_sample with exclude_pos (the pipelined TD3 loop: a roll-out writes slot pos while the batch is drawn): the rows of the
+    other cap - 1 slots in the order after pos, the excluded slot never touched, and pos standing in for the write position in the choice
+    of the iterate for next_obs — against the index expressions in torch."""
+    from mpc4rl_amd.td3 import DeviceReplayBuffer
+    dev, E, cap, nx, nu, n = torch.device("cuda"), 37, 5, 4, 1, 4000
+    buf = DeviceReplayBuffer(cap, E, nx, nu, dev, iterate_dims=(3, 2, 2, 4))
+    buf.data.copy_(torch.randn_like(buf.data))
+    buf.data[..., -1] = (torch.rand(cap, E, device=dev) < 0.3).float()
+    buf.iter_ok.copy_(torch.rand(cap, E, device=dev) < 0.8)
+    buf.pos, buf.full = 2, True
+    buf.pos_t.fill_(2)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    for pos in (0, 3, 4):
+        ex = torch.tensor([pos], dtype=torch.int64, device=dev)
+        st = gen.get_state()
+        obs, nxt, act, rew, done = buf.sample_fused(n, gen, exclude_pos=ex)
+        gen.set_state(st)
+        idx = torch.randint(0, (cap - 1) * E, (n,), device=dev, generator=gen)
+        step, env = (pos + 1 + idx // E) % cap, idx % E
+        assert int((step == pos).sum()) == 0 and set(step.unique().tolist()) == set(range(cap)) - {pos}
+        rows = buf.data[step, env]
+        assert torch.equal(buf.last_rows, rows) and torch.equal(buf.last_x64[0], rows[:, :nx].double()) and torch.equal(buf.last_x64[1], rows[:, nx: 2 * nx].double())
+        row_s, cold_s, row_n, cold_n = buf.last_starts
+        nstep = (step + 1) % cap
+        cont = (rows[:, -1] == 0) & (nstep != pos)
+        rn = torch.where(cont, nstep * E + env, step * E + env)
+        ok = buf.iter_ok.reshape(-1)
+        assert torch.equal(row_s, step * E + env) and torch.equal(row_n, rn) and int(cont.sum()) > 0 and int((~cont).sum()) > 0
+        assert torch.equal(cold_s.bool(), ~ok[row_s]) and torch.equal(cold_n.bool(), ~ok[rn])
+    with pytest.raises(RuntimeError):
+        buf.full = False
+        buf.sample_fused(n, gen, exclude_pos=ex)
+
+
+def test_td3_pipelined_loop():
+    """BatchedTD3(pipeline=True), step() with graphs on one rank: the update runs beside the roll-out step of the same call.  Another
+    loop than the sequential one (the sampler leaves out the slot being written, the draws come in another order), so what is asserted
+    is what must hold for it on its own: two runs are bit-identical (nothing depends on how the two branches interleave), every
+    solve's result is used (finite tables, critics, theta), the write position and the table advance as in the sequential loop, and it
+    learns on the same scale (critic loss within a factor of two of the sequential loop's after the same number of steps)."""
+    from mpc4rl_amd import BatchedCartPoleSwingUpEnv, BatchedTD3, cartpole_ocp
+    ocp, res = cartpole_ocp(), []
+    for pipe in (True, True, False):
+        env = BatchedCartPoleSwingUpEnv(512, device="cuda", seed=0, max_episode_steps=9)
+        ag = BatchedTD3(ocp, env, batch_size=512, buffer_steps=6, policy_delay=2, lr_actor=1e-4, seed=0, replay_iterates=True, pipeline=pipe)
+        ag.collect(2)
+        ag.enable_graphs()
+        ag.step(14)
+        res.append((ag.buffer.data.clone(), torch.cat([p.detach().reshape(-1) for p in ag.critic.parameters()]), ag.theta.clone(), env.state.clone(),
+                    ag.buffer.pos_t.clone(), ag.buffer.iter_ok.clone(), ag.last_critic_loss(), (ag.buffer.pos, ag.buffer.full)))
+    a, b, c = res
+    assert all(torch.equal(x, y) for x, y in zip(a[:6], b[:6])) and a[6] == b[6]
+    assert all(bool(torch.isfinite(t).all()) for t in a[:4]) and float((a[2] - torch.as_tensor(ocp.p0, device="cuda")).abs().max()) > 0.0
+    assert int(a[4]) == int(c[4]) and a[7] == c[7] and int(a[4]) == a[7][0]
+    assert 0.5 < a[6] / c[6] < 2.0
+    assert float((a[0] != c[0]).float().mean()) > 0.0      # (it IS another loop)
